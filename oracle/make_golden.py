@@ -1,0 +1,185 @@
+"""Generate tests/golden/*.npz by running the LIVE reference (/root/reference) on CPU.
+
+TEST INFRASTRUCTURE.  Run in the build container only (the GPU box has no
+/root/reference):   python oracle/make_golden.py
+
+For every case we run the reference's real ImplicitFactorizationModel.fit()
+(spotlight/factorization/implicit.py:184-252) with recording hooks patched around
+`shuffle`, `sample_items`, the loss function and `optimizer.step`, and store:
+initial parameters, per-epoch shuffled ids, per-minibatch negatives and losses,
+the summed gradients of the very first minibatch, final parameters, final optimizer
+state and the final numpy RandomState.  The same script then replays each case
+through oracle/slk_oracle.c and asserts parity, so the oracle is pinned against the
+reference itself, not just against its own fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import spotlight.factorization.implicit as ref_implicit  # noqa: E402
+from spotlight.interactions import Interactions  # noqa: E402
+
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def optimizer_factory(kind):
+    if kind == 'adam_default':
+        return None
+    if kind in ('adagrad', 'adagrad_sparse'):
+        return lambda params: torch.optim.Adagrad(params, lr=0.05)
+    if kind == 'sparse_adam':
+        return lambda params: torch.optim.SparseAdam(list(params), lr=0.01)
+    if kind == 'adagrad_dense_wd':
+        return lambda params: torch.optim.Adagrad(params, lr=0.05, weight_decay=1e-3)
+    raise ValueError(kind)
+
+
+def run_reference(case):
+    rs = np.random.RandomState(case['data_seed'])
+    users = rs.randint(0, case['U'], case['N']).astype(np.int32)
+    items = rs.randint(0, case['I'], case['N']).astype(np.int32)
+    inter = Interactions(users, items, num_users=case['U'], num_items=case['I'])
+
+    model_rs = np.random.RandomState(case['seed'])
+    model = ref_implicit.ImplicitFactorizationModel(
+        loss=case['loss'], embedding_dim=case['D'], n_iter=case['n_iter'],
+        batch_size=case['B'], l2=case.get('l2', 0.0), learning_rate=case.get('lr', 1e-2),
+        optimizer_func=optimizer_factory(case['opt']),
+        sparse=case['opt'] in ('adagrad_sparse', 'sparse_adam'),
+        random_state=model_rs, num_negative_samples=case.get('n_neg', 5))
+    model._initialize(inter)
+    names = ['user_embeddings.weight', 'item_embeddings.weight', 'user_biases.weight',
+             'item_biases.weight']
+    params = dict(model._net.named_parameters())
+    rec = {'init_%d' % t: params[nm].detach().numpy().copy() for t, nm in enumerate(names)}
+    rec['rng_key_before_fit'] = model_rs.get_state()[1].copy()
+    rec['rng_pos_before_fit'] = np.int64(model_rs.get_state()[2])
+
+    shuffled, negatives, losses, first_grads = [], [], [], []
+
+    orig_shuffle, orig_sample = ref_implicit.shuffle, ref_implicit.sample_items
+
+    def rec_shuffle(*arrays, **kw):
+        out = orig_shuffle(*arrays, **kw)
+        shuffled.append([np.asarray(o).copy() for o in out])
+        return out
+
+    def rec_sample(*a, **kw):
+        out = orig_sample(*a, **kw)
+        negatives.append(np.asarray(out).copy().ravel())
+        return out
+
+    orig_loss = model._loss_func
+
+    def rec_loss(*a, **kw):
+        out = orig_loss(*a, **kw)
+        losses.append(float(out.item()))
+        return out
+
+    orig_step = model._optimizer.step
+
+    def rec_step(*a, **kw):
+        if not first_grads:
+            for nm in names:
+                g = params[nm].grad
+                first_grads.append((g.to_dense() if g.is_sparse else g).detach().numpy().copy())
+        return orig_step(*a, **kw)
+
+    ref_implicit.shuffle, ref_implicit.sample_items = rec_shuffle, rec_sample
+    model._loss_func = rec_loss
+    model._optimizer.step = rec_step
+    try:
+        model.fit(inter)
+    finally:
+        ref_implicit.shuffle, ref_implicit.sample_items = orig_shuffle, orig_sample
+
+    rec['users'], rec['items'] = users, items
+    rec['shuffled_users'] = np.stack([s[0] for s in shuffled])
+    rec['shuffled_items'] = np.stack([s[1] for s in shuffled])
+    rec['negatives'] = np.concatenate(negatives)
+    rec['losses'] = np.array(losses, dtype=np.float32)
+    for t in range(4):
+        rec['grad0_%d' % t] = first_grads[t]
+        rec['final_%d' % t] = params[names[t]].detach().numpy().copy()
+    st = model._optimizer.state
+    for t, nm in enumerate(names):
+        s = st[params[nm]]
+        if 'sum' in s:
+            rec['state1_%d' % t] = s['sum'].detach().numpy().copy()
+        else:
+            rec['state1_%d' % t] = s['exp_avg'].detach().numpy().copy()
+            rec['state2_%d' % t] = s['exp_avg_sq'].detach().numpy().copy()
+    rec['rng_key_after_fit'] = model_rs.get_state()[1].copy()
+    rec['rng_pos_after_fit'] = np.int64(model_rs.get_state()[2])
+    # a few predictions from the trained reference model
+    rec['predict_user3_all'] = model.predict(3)
+    pu = np.arange(0, min(case['U'], 20), dtype=np.int64)
+    pi = (pu * 7 + 1) % case['I']
+    rec['predict_pairs_u'], rec['predict_pairs_i'] = pu, pi
+    rec['predict_pairs'] = model.predict(pu, pi)
+    for k, v in case.items():
+        rec['case_' + k] = np.array(v)
+    return rec
+
+
+from oracle.replay import replay_with_oracle  # noqa: E402
+
+
+def cases():
+    out = []
+    for loss in ('pointwise', 'bpr', 'hinge', 'adaptive_hinge'):
+        for opt in ('adam_default', 'adagrad', 'adagrad_sparse', 'sparse_adam'):
+            out.append(dict(name='%s_%s' % (loss, opt), loss=loss, opt=opt, U=30, I=40, N=200, D=8,
+                            B=32, n_iter=2, seed=42, data_seed=7, l2=1e-6, lr=1e-2, n_neg=3))
+    # MovieLens-100K-shaped slice of config C1 (tests/factorization/test_implicit.py:40-57 kwargs)
+    out.append(dict(name='c1_bpr_adam', loss='bpr', opt='adam_default', U=94, I=168, N=3000, D=32,
+                    B=1024, n_iter=3, seed=42, data_seed=42, l2=1e-6, lr=1e-2))
+    out.append(dict(name='c1_bpr_adagrad', loss='bpr', opt='adagrad_sparse', U=94, I=168, N=3000,
+                    D=32, B=1024, n_iter=3, seed=42, data_seed=42))
+    out.append(dict(name='d64_bpr_adagrad', loss='bpr', opt='adagrad', U=200, I=150, N=1500, D=64,
+                    B=256, n_iter=2, seed=1, data_seed=0))
+    out.append(dict(name='d64_adaptive_sparse_adam', loss='adaptive_hinge', opt='sparse_adam', U=200,
+                    I=150, N=1500, D=64, B=256, n_iter=2, seed=1, data_seed=0, n_neg=5))
+    out.append(dict(name='d12_pointwise_adagrad_wd', loss='pointwise', opt='adagrad_dense_wd', U=50,
+                    I=33, N=300, D=12, B=64, n_iter=2, seed=3, data_seed=5))
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    worst = 0.0
+    for case in cases():
+        rec = run_reference(case)
+        errs, fr = replay_with_oracle(case, rec)
+        m = max(errs.values())
+        worst = max(worst, m)
+        step_keys = [k for k in errs if k.startswith('grad0') or k == 'loss']
+        m_step = max(errs[k] for k in step_keys)
+        print('%-34s single-step err %.2e | trajectory err %.2e (%s)'
+              % (case['name'], m_step, m, max(errs, key=errs.get)))
+        # single minibatch (identical inputs): loss/grad within 1e-5 rel.  Whole-run
+        # trajectories (9-21 optimizer steps) are only conditionally stable: Adagrad's first
+        # step is lr*sign(g) and Adam normalises by sqrt(v), so an element whose gradient is
+        # pure cancellation noise (an item that is positive in one interaction and negative in
+        # another at equal scores; the pointwise user bias) moves by O(lr) in a direction set
+        # by summation order -- and torch's own order is unspecified (unstable sort inside
+        # coalesce).  Trajectories are therefore judged by the fraction of elements outside
+        # 2e-4 of the tensor's inf-norm (<= 2 %), not by the worst element.
+        assert m_step < 1e-5, errs
+        assert errs['loss'] < 1e-4 and max(fr.values()) <= 0.02, (errs, fr)
+        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **rec)
+    print('all cases pinned; worst %.2e' % worst)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,101 @@
+"""Replay of a recorded reference run (tests/golden/*.npz) through the C oracle.
+
+TEST INFRASTRUCTURE (see oracle/slk_oracle.c).  Shared by oracle/make_golden.py (which
+records the runs from the live reference) and tests/test_oracle.py (which re-checks the
+committed fixtures where /root/reference does not exist).
+"""
+import numpy as np
+
+from oracle.oracle import BilinearOracle, Rng
+
+ORACLE_OPT = {'adam_default': 'adam_dense', 'adagrad': 'adagrad', 'adagrad_sparse': 'adagrad',
+              'sparse_adam': 'sparse_adam', 'adagrad_dense_wd': 'adagrad_dense'}
+
+
+def oracle_hparams(case):
+    hp = _oracle_hparams(case)
+    hp['sparse_grads'] = case['opt'] in ('adagrad_sparse', 'sparse_adam')
+    return hp
+
+
+def _oracle_hparams(case):
+    opt = case['opt']
+    if opt == 'adam_default':
+        return dict(lr=case.get('lr', 1e-2), weight_decay=case.get('l2', 0.0))
+    if opt == 'adagrad_dense_wd':
+        return dict(lr=0.05, weight_decay=1e-3)
+    if opt == 'sparse_adam':
+        return dict(lr=0.01)
+    return dict(lr=0.05)
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def frac_outside(a, b, tol=2e-4):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) > tol * max(np.abs(b).max(), 1e-30)).mean())
+
+
+def replay_with_oracle(case, rec, tol=1e-5):
+    """Replays the recorded run through the C oracle; returns max parity errors."""
+    o = BilinearOracle(rec['init_0'], rec['init_1'], rec['init_2'], rec['init_3'],
+                       opt=ORACLE_OPT[case['opt']], **oracle_hparams(case))
+    rng = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    nn = case.get('n_neg', 5) if case['loss'] == 'adaptive_hinge' else 1
+    losses, negs = [], []
+    users64, items64 = rec['users'].astype(np.int64), rec['items'].astype(np.int64)
+    errs = {}
+    for e in range(case['n_iter']):
+        perm = rng.shuffle_perm(case['N'])
+        su, si = users64[perm], items64[perm]
+        assert (su == rec['shuffled_users'][e]).all() and (si == rec['shuffled_items'][e]).all()
+        if e == 0:
+            # first minibatch gradients via a throw-away copy
+            o2 = BilinearOracle(rec['init_0'], rec['init_1'], rec['init_2'], rec['init_3'],
+                                opt=ORACLE_OPT[case['opt']], **oracle_hparams(case))
+            B0 = min(case['B'], case['N'])
+            _, dg = o2.step(su[:B0], si[:B0], rec['negatives'][:B0 * nn], loss=case['loss'],
+                            n_neg=nn, want_grads=True)
+            # bias-gradient scale: user-bias gradients are sums of +g/-g terms that cancel
+            # (exactly for bpr/hinge), so both bias tables are judged against their joint norm
+            bscale = max(np.abs(rec['grad0_2']).max(), np.abs(rec['grad0_3']).max())
+            for t in range(4):
+                ref = rec['grad0_%d' % t]
+                if t < 2:
+                    errs['grad0_%d' % t] = rel_inf(dg[t].reshape(ref.shape), ref)
+                else:
+                    errs['grad0_%d' % t] = np.abs(dg[t].reshape(ref.shape) - ref).max() / bscale
+        l, ng = o.train(rng, su, si, case['B'], loss=case['loss'], n_neg=nn, want_negs=True)
+        losses.append(l)
+        negs.append(ng)
+    negs = np.concatenate(negs)
+    assert (negs == rec['negatives']).all(), 'negative ids differ'
+    errs['loss'] = np.max(np.abs(np.concatenate(losses) - rec['losses']) / np.abs(rec['losses']))
+    for t in range(4):
+        errs['final_%d' % t] = rel_inf(o.p[t].reshape(rec['final_%d' % t].shape), rec['final_%d' % t])
+        errs['state1_%d' % t] = rel_inf(o.s1[t].reshape(rec['state1_%d' % t].shape), rec['state1_%d' % t])
+        if 'state2_%d' % t in rec:
+            errs['state2_%d' % t] = rel_inf(o.s2[t].reshape(rec['state2_%d' % t].shape),
+                                            rec['state2_%d' % t])
+    st = rng.get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    fr = {}
+    for t in range(4):
+        fr['final_%d' % t] = frac_outside(o.p[t].reshape(rec['final_%d' % t].shape), rec['final_%d' % t])
+    errs['predict_all'] = rel_inf(o.predict(3), rec['predict_user3_all'])
+    errs['predict_pairs'] = rel_inf(o.predict(rec['predict_pairs_u'], rec['predict_pairs_i']),
+                                    rec['predict_pairs'])
+    return errs, fr
+
+
+def case_from_rec(rec):
+    """Rebuilds the case dict stored alongside a fixture."""
+    case = {}
+    for k in rec.files if hasattr(rec, 'files') else rec.keys():
+        if k.startswith('case_'):
+            v = rec[k]
+            case[k[5:]] = v.item() if v.shape == () else v
+    return case
