@@ -1,0 +1,150 @@
+/*
+ * spotlight_hip.h -- C ABI of libspotlight_hip.so, the MI355X (gfx950) engine behind
+ * spotlight_amd's drop-in ImplicitFactorizationModel.fit()/predict().
+ *
+ * The reference (maciejkula/spotlight, pure Python) has no FFI seam; this boundary is
+ * created INSIDE its fit()/predict().  Each entry point names the
+ * reference code it replaces.  Conventions:
+ *   - plain C, no torch / C++ types; every function returns 0 or a negative errno-style
+ *     code (SLK_EINVAL bad argument/shape, SLK_ERANGE id >= table rows, SLK_ENOMEM,
+ *     SLK_EIO HIP failure); text via slk_last_error().
+ *   - pointers named d_* are DEVICE pointers owned by the caller (torch tensors'
+ *     data_ptr()); h_* are host pointers.  The library owns only the opaque ctx and
+ *     its scratch.  No caller pointer is retained across calls.
+ *   - all work is enqueued on the caller's hipStream_t (`stream`, passed as void*);
+ *     calls return without synchronising unless stated.
+ *   - a ctx is bound to one device and is not thread-safe.
+ *   - all tables are row-major fp32, rows contiguous (stride == dim); ids are int64 as on
+ *     the reference path (factorization/implicit.py:202-203); tables have < 2^31 rows.
+ */
+#ifndef SPOTLIGHT_HIP_H
+#define SPOTLIGHT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLK_ABI_VERSION 1
+
+#define SLK_OK 0
+#define SLK_EIO (-5)
+#define SLK_ENOMEM (-12)
+#define SLK_EINVAL (-22)
+#define SLK_ERANGE (-34)
+
+typedef struct slk_ctx slk_ctx;
+
+/* spotlight/losses.py: pointwise_loss :18-50, bpr_loss :53-90, hinge_loss :93-124,
+ * adaptive_hinge_loss :127-166 */
+enum slk_loss {
+    SLK_LOSS_POINTWISE = 0,
+    SLK_LOSS_BPR = 1,
+    SLK_LOSS_HINGE = 2,
+    SLK_LOSS_ADAPTIVE_HINGE = 3
+};
+
+/* Optimizers the reference can instantiate (factorization/implicit.py:143-150):
+ *  ADAGRAD       torch.optim.Adagrad, weight_decay == 0: row-sparse update of looked-up rows
+ *                (== dense Adagrad, zero grad => zero update; == sparse=True path)
+ *  SPARSE_ADAM   torch.optim.SparseAdam (sparse=True): looked-up rows only, stale moments
+ *  ADAM_DENSE    torch.optim.Adam (+weight_decay=l2), the reference default: every step
+ *                sweeps every row of all four tables
+ *  ADAGRAD_DENSE torch.optim.Adagrad with weight_decay != 0: full sweep */
+enum slk_opt {
+    SLK_OPT_ADAGRAD = 0,
+    SLK_OPT_SPARSE_ADAM = 1,
+    SLK_OPT_ADAM_DENSE = 2,
+    SLK_OPT_ADAGRAD_DENSE = 3
+};
+
+/* Table order everywhere = BilinearNet parameter creation order
+ * (factorization/representations.py:46-59):
+ *   0 user_embeddings.weight [num_users, dim]   1 item_embeddings.weight [num_items, dim]
+ *   2 user_biases.weight     [num_users, 1]     3 item_biases.weight     [num_items, 1] */
+typedef struct slk_tables {
+    float *d_param[4];
+    int64_t num_users;
+    int64_t num_items;
+    int32_t dim;
+    int32_t reserved;
+} slk_tables;
+
+/* Optimizer hyper-parameters are doubles because torch keeps them as Python floats and
+ * forms 1-beta, bias corrections and step sizes in double before rounding to fp32. */
+typedef struct slk_optim {
+    int32_t kind; /* enum slk_opt */
+    int32_t reserved;
+    int64_t step; /* optimizer steps already taken (torch state['step']); advanced by the
+                     number of minibatches processed */
+    double lr, eps, beta1, beta2, weight_decay, lr_decay;
+    float *d_state1[4]; /* Adagrad: state['sum'];  Adam/SparseAdam: state['exp_avg']   */
+    float *d_state2[4]; /* Adam/SparseAdam: state['exp_avg_sq']; unused for Adagrad      */
+} slk_optim;
+
+int slk_abi_version(void);
+
+/* One ctx per model per device (replaces nothing in the reference: it is the home of the
+ * scratch torch would allocate per op, and of the on-device MT19937 state). */
+int slk_ctx_create(slk_ctx **out, int device_id);
+void slk_ctx_destroy(slk_ctx *ctx);
+const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference
+ * draws shuffles and negatives from (torch_utils.py:46-47, sampling.py:34).  h_key is
+ * uint32[624].  get_state synchronises the stream last used by this ctx. */
+int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos);
+int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
+
+/* spotlight/sampling.py:8-36 sample_items(num_items, shape, random_state): `count` uniform
+ * ids in [0, num_items) by numpy's masked rejection over the ctx's MT19937 stream,
+ * bit-exact, written row-major as int64 to d_out.  1 <= num_items <= 2^32. */
+int slk_sample_items(slk_ctx *ctx, int64_t num_items, int64_t count, int64_t *d_out, void *stream);
+
+/* The minibatch loop of one epoch of ImplicitFactorizationModel.fit() after the shuffle
+ * (factorization/implicit.py:223-243): contiguous minibatches of `batch_size` over the n
+ * (user, item) pairs (short last batch); per minibatch: negatives (drawn from the ctx RNG
+ * exactly as _get_negative_prediction / _get_multiple_negative_predictions do, :254-275,
+ * or taken from d_neg_in), BilinearNet forward for positives and negatives
+ * (representations.py:61-91), the loss (losses.py), backward with duplicate rows summed,
+ * and the optimizer update (torch.optim.*), in place on tables/optimizer state.
+ *   d_neg_in   NULL, or n*nn int64 negatives to use instead of sampling (nn = n_neg for
+ *              adaptive hinge, else 1), minibatch-major in the reference's draw order
+ *   d_neg_out  NULL, or receives the n*nn negatives used
+ *   d_mb_loss  float[ceil(n / batch_size)]: loss.item() of every minibatch (:240)
+ * optim->step is advanced on return.  ids are NOT range-checked here (the reference checks
+ * on the host, :161-182; so does spotlight_amd). */
+int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                       const int64_t *d_users, const int64_t *d_items, int64_t n,
+                       int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
+                       int64_t *d_neg_out, float *d_mb_loss, void *stream);
+
+/* ImplicitFactorizationModel.predict (factorization/implicit.py:277-311 with
+ * _components.py:8-25): d_out[k] = score(user_k, item_k); n_users == 1 broadcasts the user;
+ * d_items == NULL means items 0..n-1. */
+int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_users,
+                         int64_t n_users, const int64_t *d_items, int64_t n, float *d_out,
+                         void *stream);
+
+/* Measurement support (the reference has none; examples/bloom_embeddings/performance.py
+ * times fit() with time.time()): when enabled, every launch of the engine's kernels is
+ * bracketed by hipEvents on the launch stream.  slk_profile_read synchronises and returns,
+ * per kernel class, the number of launches and the summed duration since the last reset. */
+enum slk_kernel_class {
+    SLK_K_SAMPLE = 0,   /* MT19937 generate + rejection compaction */
+    SLK_K_PREP = 1,     /* key build + radix sorts + pack          */
+    SLK_K_USER_PASS = 2,
+    SLK_K_ITEM_PASS = 3,
+    SLK_K_DENSE_SWEEP = 4,
+    SLK_K_SCORE = 5,    /* adaptive-hinge score/select; predict    */
+    SLK_K_COUNT = 6
+};
+int slk_profile_enable(slk_ctx *ctx, int32_t on);
+int slk_profile_read(slk_ctx *ctx, int32_t kernel_class, int64_t *launches, double *total_ms);
+int slk_profile_reset(slk_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPOTLIGHT_HIP_H */

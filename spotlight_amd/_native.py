@@ -1,0 +1,182 @@
+"""ctypes binding of include/spotlight_hip.h (libspotlight_hip.so, gfx950).
+
+There is deliberately no fallback: if the HIP library is missing or fails to load, every
+entry point of spotlight_amd that needs it raises.  `bind()` is split out so that the test
+harness can bind the same prototypes onto its emulator build of the same sources
+(tests/emu) -- spotlight_amd itself only ever loads csrc/libspotlight_hip.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
+
+SLK_ABI_VERSION = 1
+SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
+
+LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
+OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
+KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5}
+
+
+class SlkTables(C.Structure):
+    _fields_ = [('d_param', C.c_void_p * 4), ('num_users', C.c_int64), ('num_items', C.c_int64),
+                ('dim', C.c_int32), ('reserved', C.c_int32)]
+
+
+class SlkOptim(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('reserved', C.c_int32), ('step', C.c_int64),
+                ('lr', C.c_double), ('eps', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('weight_decay', C.c_double), ('lr_decay', C.c_double),
+                ('d_state1', C.c_void_p * 4), ('d_state2', C.c_void_p * 4)]
+
+
+_PROTOTYPES = {
+    'slk_abi_version': (C.c_int, []),
+    'slk_ctx_create': (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    'slk_ctx_destroy': (None, [C.c_void_p]),
+    'slk_last_error': (C.c_char_p, [C.c_void_p]),
+    'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    'slk_sample_items': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
+    'slk_profile_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    'slk_profile_reset': (C.c_int, [C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))
+
+
+def bind(cdll):
+    """Attach the prototypes of include/spotlight_hip.h to a loaded library."""
+    for name, (res, args) in _PROTOTYPES.items():
+        fn = getattr(cdll, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if cdll.slk_abi_version() != SLK_ABI_VERSION:
+        raise ImportError('libspotlight_hip ABI %d != expected %d'
+                          % (cdll.slk_abi_version(), SLK_ABI_VERSION))
+    return cdll
+
+
+_LIB = None
+
+
+def load():
+    """Loads csrc/libspotlight_hip.so; raises ImportError (never falls back) if it is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s not found: build it with `python -m spotlight_amd.build` '
+                              '(hipcc --offload-arch=gfx950).  spotlight_amd has no CPU fallback.'
+                              % LIB_PATH)
+        _LIB = bind(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+class SlkError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, 'libspotlight_hip error %d: %s' % (code, text))
+        self.code = code
+
+
+class Engine(object):
+    """One slk_ctx.  All pointer arguments are raw integer addresses of device memory
+    (torch `tensor.data_ptr()`), `stream` is a raw hipStream_t (0 = default stream)."""
+
+    def __init__(self, device_id=0, lib=None):
+        self._lib = lib if lib is not None else load()
+        ctx = C.c_void_p()
+        rc = self._lib.slk_ctx_create(C.byref(ctx), int(device_id))
+        if rc != SLK_OK:
+            raise SlkError(rc, (self._lib.slk_last_error(None) or b'').decode())
+        self._ctx = ctx
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.slk_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != SLK_OK:
+            raise SlkError(rc, (self._lib.slk_last_error(self._ctx) or b'').decode())
+
+    # -- numpy RandomState hand-over ---------------------------------------------------
+    def rng_set_state(self, state):
+        """`state` = numpy RandomState.get_state() tuple."""
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        assert key.shape == (624,)
+        self._check(self._lib.slk_rng_set_state(self._ctx, key.ctypes.data, int(state[2])))
+
+    def rng_get_state(self):
+        key = np.empty(624, dtype=np.uint32)
+        pos = C.c_int32()
+        self._check(self._lib.slk_rng_get_state(self._ctx, key.ctypes.data, C.byref(pos)))
+        return ('MT19937', key, int(pos.value), 0, 0.0)
+
+    def sample_items(self, num_items, count, d_out, stream=0):
+        self._check(self._lib.slk_sample_items(self._ctx, int(num_items), int(count), d_out, stream))
+
+    # -- training / prediction ---------------------------------------------------------
+    def bilinear_train(self, tables, optim, d_users, d_items, n, batch_size, loss, n_neg,
+                       d_mb_loss, d_neg_in=None, d_neg_out=None, stream=0):
+        self._check(self._lib.slk_bilinear_train(
+            self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, int(n), int(batch_size),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), d_neg_in, d_neg_out,
+            d_mb_loss, stream))
+
+    def bilinear_predict(self, tables, d_users, n_users, d_items, n, d_out, stream=0):
+        self._check(self._lib.slk_bilinear_predict(self._ctx, C.byref(tables), d_users, int(n_users),
+                                                   d_items, int(n), d_out, stream))
+
+    # -- measurement -------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.slk_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.slk_profile_reset(self._ctx))
+
+    def profile_read(self):
+        out = {}
+        for name, cls in KERNEL_CLASSES.items():
+            n, ms = C.c_int64(), C.c_double()
+            self._check(self._lib.slk_profile_read(self._ctx, cls, C.byref(n), C.byref(ms)))
+            out[name] = (int(n.value), float(ms.value))
+        return out
+
+
+def make_tables(ptrs, num_users, num_items, dim):
+    t = SlkTables()
+    for i in range(4):
+        t.d_param[i] = ptrs[i]
+    t.num_users, t.num_items, t.dim = int(num_users), int(num_items), int(dim)
+    return t
+
+
+def make_optim(kind, state1, state2=None, lr=1e-2, eps=None, betas=(0.9, 0.999), weight_decay=0.0,
+               lr_decay=0.0, step=0):
+    o = SlkOptim()
+    o.kind = OPT_KINDS[kind] if isinstance(kind, str) else int(kind)
+    if eps is None:
+        eps = 1e-10 if o.kind in (0, 3) else 1e-8
+    o.step = int(step)
+    o.lr, o.eps, o.beta1, o.beta2 = float(lr), float(eps), float(betas[0]), float(betas[1])
+    o.weight_decay, o.lr_decay = float(weight_decay), float(lr_decay)
+    for i in range(4):
+        o.d_state1[i] = state1[i]
+        o.d_state2[i] = state2[i] if state2 is not None else None
+    return o

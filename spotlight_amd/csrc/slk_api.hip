@@ -1,0 +1,149 @@
+// slk_api.hip -- ctx lifetime, error text, scratch, event-based kernel timing.
+#include <stdarg.h>
+
+#include "slk_common.h"
+
+static char g_create_err[512] = {0};
+
+int slk_fail(slk_ctx *ctx, int code, const char *fmt, ...) {
+    char *dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int slk_ensure(slk_ctx *ctx, slk_buf &b, size_t bytes) {
+    if (bytes <= b.cap) return SLK_OK;
+    if (b.p) {
+        // hipFree waits for outstanding work that may still read the old block
+        SLK_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return slk_fail(ctx, SLK_ENOMEM, "hipMalloc of %zu scratch bytes failed", want);
+    }
+    b.p = p;
+    b.cap = want;
+    return SLK_OK;
+}
+
+void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s) {
+    if (!ctx->prof_on) return;
+    slk_prof_span sp;
+    sp.cls = cls;
+    for (hipEvent_t *e : {&sp.a, &sp.b}) {
+        if (!ctx->ev_pool.empty()) {
+            *e = ctx->ev_pool.back();
+            ctx->ev_pool.pop_back();
+        } else {
+            (void)hipEventCreate(e);
+        }
+    }
+    (void)hipEventRecord(sp.a, s);
+    ctx->spans.push_back(sp);
+}
+
+void slk_prof_end(slk_ctx *ctx, hipStream_t s) {
+    if (!ctx->prof_on) return;
+    (void)hipEventRecord(ctx->spans.back().b, s);
+    if (ctx->spans.size() >= 8192) slk_prof_drain(ctx);
+}
+
+int slk_prof_drain(slk_ctx *ctx) {
+    for (slk_prof_span &sp : ctx->spans) {
+        SLK_HIP(ctx, hipEventSynchronize(sp.b));
+        float ms = 0.0f;
+        SLK_HIP(ctx, hipEventElapsedTime(&ms, sp.a, sp.b));
+        ctx->prof_launches[sp.cls] += 1;
+        ctx->prof_ms[sp.cls] += (double)ms;
+        ctx->ev_pool.push_back(sp.a);
+        ctx->ev_pool.push_back(sp.b);
+    }
+    ctx->spans.clear();
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_abi_version(void) { return SLK_ABI_VERSION; }
+
+SLK_EXPORT int slk_ctx_create(slk_ctx **out, int device_id) {
+    if (!out) return slk_fail(nullptr, SLK_EINVAL, "slk_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return slk_fail(nullptr, SLK_EIO, "slk_ctx_create: no HIP device visible");
+    }
+    if (device_id < 0 || device_id >= ndev)
+        return slk_fail(nullptr, SLK_EINVAL, "slk_ctx_create: device %d out of range (%d devices)",
+                        device_id, ndev);
+    slk_ctx *ctx = new slk_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) {
+        delete ctx;
+        return slk_fail(nullptr, SLK_EIO, "slk_ctx_create: hipSetDevice(%d) failed", device_id);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cus = prop.multiProcessorCount;
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_rng), sizeof(slk_rng_dev)) != hipSuccess) {
+        delete ctx;
+        return slk_fail(nullptr, SLK_ENOMEM, "slk_ctx_create: hipMalloc(rng) failed");
+    }
+    // numpy's RandomState(0)-independent default: an all-zero key with pos = 624 is a valid
+    // (if degenerate) state; callers are expected to slk_rng_set_state() before sampling.
+    (void)hipMemset(ctx->d_rng, 0, sizeof(slk_rng_dev));
+    int32_t pos = 624;
+    (void)hipMemcpy(&ctx->d_rng->pos, &pos, sizeof(pos), hipMemcpyHostToDevice);
+    *out = ctx;
+    return SLK_OK;
+}
+
+SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    slk_prof_drain(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    slk_buf *bufs[] = {&ctx->raw, &ctx->cnt, &ctx->neg32, &ctx->ukey[0], &ctx->ukey[1], &ctx->uval[0],
+                       &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
+                       &ctx->ipay[1], &ctx->gbuf, &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
+                       &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3]};
+    for (slk_buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->d_rng) (void)hipFree(ctx->d_rng);
+    delete ctx;
+}
+
+SLK_EXPORT const char *slk_last_error(const slk_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+SLK_EXPORT int slk_profile_enable(slk_ctx *ctx, int32_t on) {
+    if (!ctx) return SLK_EINVAL;
+    if (!on) slk_prof_drain(ctx);
+    ctx->prof_on = on != 0;
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_profile_read(slk_ctx *ctx, int32_t cls, int64_t *launches, double *total_ms) {
+    if (!ctx || cls < 0 || cls >= SLK_K_COUNT) return SLK_EINVAL;
+    int rc = slk_prof_drain(ctx);
+    if (rc) return rc;
+    if (launches) *launches = ctx->prof_launches[cls];
+    if (total_ms) *total_ms = ctx->prof_ms[cls];
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_profile_reset(slk_ctx *ctx) {
+    if (!ctx) return SLK_EINVAL;
+    int rc = slk_prof_drain(ctx);
+    for (int i = 0; i < SLK_K_COUNT; ++i) {
+        ctx->prof_launches[i] = 0;
+        ctx->prof_ms[i] = 0.0;
+    }
+    return rc;
+}

@@ -1,0 +1,784 @@
+// slk_bilinear.hip -- the fused negative-sampled BilinearNet training step for gfx950.
+//
+// Replaces the minibatch body of ImplicitFactorizationModel.fit()
+// (spotlight/factorization/implicit.py:229-243): 2x BilinearNet.forward
+// (factorization/representations.py:61-91), the loss (losses.py:18-166), autograd's
+// embedding backward (duplicate rows SUMMED before the non-linear optimizer update) and
+// torch.optim.{Adagrad,SparseAdam,Adam}.step().
+//
+// Exactness constraint that shapes the design (hard part 1): within a minibatch
+// every forward reads pre-step parameters, and every row receives the SUM of its gradient
+// contributions before one optimizer update.  So per minibatch:
+//
+//   prep (per chunk of minibatches, slk_prep): radix-sort the interactions by
+//        (minibatch, user) and the (interaction, item) occurrences by (minibatch, item).
+//        Sorted order makes each unique row the property of exactly ONE row group, turns
+//        row traffic into ascending-address streams, and needs no atomics.
+//   USER PASS  one row group (G = dim/4 lanes, 16 B per lane, a D=64 row = one 256-B line)
+//        per unique user: gathers U[u], V[pos], V[neg] and the biases, wave-shuffle dot
+//        products, loss + dL/dscore, accumulates the user-row gradient over the user's
+//        occurrences, snapshots the pre-step user row (coalesced, position-indexed) for the
+//        item pass, writes dL/dscore per occurrence, then applies the optimizer to U[u] in
+//        place.
+//   ITEM PASS  one row group per unique item: sums g * snapshot(user row) over the item's
+//        occurrences (positive or negative), then applies the optimizer to V[i] in place.
+//
+// The path is HBM-bound (0.2 flop/B): no MFMA, no LDS tiling of rows -- each row is touched
+// once per pass by the lanes that own it.
+#include <math.h>
+
+#include "slk_common.h"
+
+// ---------------------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------------------
+struct slk_pass_args {
+    float *P[4];   // tables (user_emb, item_emb, user_bias, item_bias)
+    float *S1[4];  // optimizer state 1 / dense gradient buffer in *_DENSE modes
+    float *S2[4];
+    int D;
+    int NP;                  // score pairs per interaction: 1 positive + nn negatives
+    uint32_t begin, end;     // this minibatch's window in the user-sorted arrays
+    const uint32_t *ukey;    // (minibatch << ubits) | user, sorted
+    uint32_t umask;
+    const uint32_t *uit;     // [pos*NP + s] item of pair s at sorted position pos
+    const uint32_t *uk;      // sorted position -> chunk-local interaction index (PRE mode)
+    const float *gk;         // PRE mode: dL/dscore per (interaction, pair)
+    float *sk;               // PRE mode: scores per (interaction, pair)
+    float *gbuf;             // [pos*NP + s] dL/dscore, written by the user pass
+    float *snap;             // [(pos - begin)*D] pre-step user rows
+    const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
+    uint32_t imask;
+    const uint32_t *ipay;    // occurrence -> pos*NP + s
+    double *loss_partial;    // per-block partial loss sums
+    int n_loss_partial;
+    float *mb_loss_out;      // this minibatch's loss.item()
+    int loss_kind;
+    float inv_b;             // 1 / (minibatch size)
+    // optimizer coefficients, rounded from double on the host exactly as torch does
+    float c_lr;    // Adagrad: clr.  SparseAdam: step_size.
+    float c_eps;
+    float c_omb1, c_omb2;  // 1-beta1, 1-beta2
+};
+
+enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
+
+// Row update for the elements one lane owns.  GRAD_ONLY stores the summed gradient into the
+// dense gradient buffer (aliased on S1) for the full-table sweep.
+template <int VEC, int UPD>
+__device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
+                                              const slk_vec<VEC> &g) {
+    if (UPD == SLK_UPD_ADAGRAD) {
+        // torch/optim/adagrad.py:360-385: sum += g^2; p += -clr * (g / (sqrt(sum) + eps))
+        slk_vec<VEC> s = slk_vload<VEC>(a.S1[t] + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s.v[i] += g.v[i] * g.v[i];
+            p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
+        }
+        slk_vstore<VEC>(a.S1[t] + off, s);
+        slk_vstore<VEC>(a.P[t] + off, p);
+    } else if (UPD == SLK_UPD_SPARSE_ADAM) {
+        // torch/optim/_functional.py:61-84
+        slk_vec<VEC> m = slk_vload<VEC>(a.S1[t] + off);
+        slk_vec<VEC> v = slk_vload<VEC>(a.S2[t] + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float mu = (g.v[i] - m.v[i]) * a.c_omb1;
+            const float vu = (g.v[i] * g.v[i] - v.v[i]) * a.c_omb2;
+            m.v[i] = mu + m.v[i];
+            v.v[i] = vu + v.v[i];
+            p.v[i] += -a.c_lr * (m.v[i] / (sqrtf(v.v[i]) + a.c_eps));
+        }
+        slk_vstore<VEC>(a.S1[t] + off, m);
+        slk_vstore<VEC>(a.S2[t] + off, v);
+        slk_vstore<VEC>(a.P[t] + off, p);
+    } else {
+        slk_vstore<VEC>(a.S1[t] + off, g);
+    }
+}
+
+template <int UPD>
+__device__ __forceinline__ void slk_apply_bias(const slk_pass_args &a, int t, size_t row, float g) {
+    slk_vec<1> gv;
+    gv.v[0] = g;
+    if (UPD == SLK_UPD_ADAGRAD && g == 0.0f) return;  // exact no-op: sum += 0, p -= 0
+    slk_vec<1> p = slk_vload<1>(a.P[t] + row);
+    slk_apply_vec<1, UPD>(a, t, row, p, gv);
+}
+
+__device__ __forceinline__ float slk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// USER PASS
+// ---------------------------------------------------------------------------------------
+template <int VEC, int G, int UPD, bool PRE>
+__global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
+    __shared__ double red[256];
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t stride = gridDim.x * GPB;
+    float loss_acc = 0.0f;
+
+    for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
+        const uint32_t key = a.ukey[p];
+        if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
+        const uint32_t user = key & a.umask;
+        const size_t uoff = (size_t)user * D + d0;
+        slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
+        const float bu = a.P[2][user];
+        slk_vec<VEC> gu = slk_vzero<VEC>();
+        float gbu = 0.0f;
+        uint32_t q = p;
+        do {
+            if (on) slk_vstore<VEC>(a.snap + (size_t)(q - a.begin) * D + d0, u);
+            if (!PRE) {
+                const uint32_t ip = a.uit[2 * (size_t)q], in = a.uit[2 * (size_t)q + 1];
+                const slk_vec<VEC> vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
+                const slk_vec<VEC> vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
+                const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.P[3][ip];
+                const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.P[3][in];
+                float l, gp, gn;
+                if (a.loss_kind == SLK_LOSS_BPR) {  // losses.py:82-90
+                    const float s = slk_sigmoid(sp - sn);
+                    l = 1.0f - s;
+                    gp = -(s * (1.0f - s)) * a.inv_b;
+                    gn = -gp;
+                } else if (a.loss_kind == SLK_LOSS_HINGE) {  // losses.py:115-124
+                    const float x = sn - sp + 1.0f;
+                    l = x > 0.0f ? x : 0.0f;
+                    gn = x >= 0.0f ? a.inv_b : 0.0f;  // clamp backward is inclusive at 0
+                    gp = -gn;
+                } else {  // pointwise, losses.py:40-50
+                    const float sa = slk_sigmoid(sp), sb = slk_sigmoid(sn);
+                    l = (1.0f - sa) + sb;
+                    gp = -(sa * (1.0f - sa)) * a.inv_b;
+                    gn = (sb * (1.0f - sb)) * a.inv_b;
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
+                gbu += gp + gn;
+                if (lane == 0) {
+                    a.gbuf[2 * (size_t)q] = gp;
+                    a.gbuf[2 * (size_t)q + 1] = gn;
+                    loss_acc += l;
+                }
+            } else {
+                const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
+                for (int s = 0; s < a.NP; ++s) {
+                    const float g = a.gk[kb + s];
+                    if (lane == 0) a.gbuf[qb + s] = g;
+                    if (g != 0.0f) {
+                        const uint32_t it = a.uit[qb + s];
+                        const slk_vec<VEC> v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
+                        slk_vaxpy<VEC>(gu, g, v);
+                        gbu += g;
+                    }
+                }
+            }
+            ++q;
+        } while (q < a.end && a.ukey[q] == key);
+
+        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu);
+        if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
+    }
+    if (!PRE) {
+        const double tot = slk_block_sum_256((double)loss_acc, red);
+        if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ITEM PASS
+// ---------------------------------------------------------------------------------------
+template <int VEC, int G, int UPD>
+__global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
+    __shared__ double red[256];
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t stride = gridDim.x * GPB;
+    const uint32_t ibegin = a.begin * a.NP, iend = a.end * a.NP;
+
+    if (blockIdx.x == 0) {
+        // loss.item() of this minibatch: mean over the minibatch of the per-interaction loss
+        double x = 0.0;
+        for (int i = threadIdx.x; i < a.n_loss_partial; i += 256) x += a.loss_partial[i];
+        const double tot = slk_block_sum_256(x, red);
+        if (threadIdx.x == 0) *a.mb_loss_out = (float)(tot * (double)a.inv_b);
+    }
+
+    for (uint32_t p = ibegin + blockIdx.x * GPB + grp; p < iend; p += stride) {
+        const uint32_t key = a.ikey[p];
+        if (p > ibegin && a.ikey[p - 1] == key) continue;
+        const uint32_t item = key & a.imask;
+        slk_vec<VEC> gv = slk_vzero<VEC>();
+        float gb = 0.0f;
+        bool any = false;
+        uint32_t q = p;
+        do {
+            const uint32_t r = a.ipay[q];
+            const float g = a.gbuf[r];
+            if (g != 0.0f) {
+                const uint32_t pos = (a.NP == 2) ? (r >> 1) : (r / (uint32_t)a.NP);
+                const slk_vec<VEC> u =
+                    on ? slk_vload<VEC>(a.snap + (size_t)(pos - a.begin) * D + d0) : slk_vzero<VEC>();
+                slk_vaxpy<VEC>(gv, g, u);
+                gb += g;
+                any = true;
+            }
+            ++q;
+        } while (q < iend && a.ikey[q] == key);
+
+        // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
+        // moments of every looked-up row (torch coalesces zero-valued rows too).
+        if (UPD == SLK_UPD_ADAGRAD && !any) continue;
+        if (UPD == SLK_UPD_GRAD_ONLY && !any) continue;
+        const size_t voff = (size_t)item * D + d0;
+        if (on) {
+            slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
+            slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
+        }
+        if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// adaptive hinge: scores for every (interaction, pair), then the per-column selection of
+// _get_multiple_negative_predictions' view(n, B) layout (factorization/implicit.py:266-275)
+// ---------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t stride = gridDim.x * GPB;
+    for (uint32_t q = a.begin + blockIdx.x * GPB + grp; q < a.end; q += stride) {
+        const uint32_t user = a.ukey[q] & a.umask;
+        const slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + (size_t)user * D + d0) : slk_vzero<VEC>();
+        const float bu = a.P[2][user];
+        const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
+        for (int s = 0; s < a.NP; ++s) {
+            const uint32_t it = a.uit[qb + s];
+            const slk_vec<VEC> v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
+            const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v)) + bu + a.P[3][it];
+            if (lane == 0) a.sk[kb + s] = sc;
+        }
+    }
+}
+
+// one thread per column c of the [n, B] candidate matrix; k0 = chunk-local index of the
+// minibatch's first interaction.  gk must be zero on entry for this minibatch.
+__global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float *gk, uint32_t k0, uint32_t bm,
+                                                         int nn, float inv_b, double *loss_partial) {
+    __shared__ double red[256];
+    const int NP = nn + 1;
+    double lsum = 0.0;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < bm; c += gridDim.x * 256) {
+        const float sp = sk[(size_t)(k0 + c) * NP];
+        float best = 0.0f;
+        size_t best_at = 0;
+        for (int r = 0; r < nn; ++r) {
+            const uint32_t f = (uint32_t)r * bm + c;  // flat index into the n*B draws
+            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
+            const float sc = sk[at];
+            if (r == 0 || sc > best) {  // torch.max(dim=0): first maximum wins ties
+                best = sc;
+                best_at = at;
+            }
+        }
+        const float x = best - sp + 1.0f;
+        lsum += (double)(x > 0.0f ? x : 0.0f);
+        const float g = x >= 0.0f ? inv_b : 0.0f;
+        gk[(size_t)(k0 + c) * NP] = -g;
+        gk[best_at] = g;
+    }
+    const double tot = slk_block_sum_256(lsum, red);
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense sweeps (reference default optimizer: Adam with weight_decay = l2 over EVERY row)
+// ---------------------------------------------------------------------------------------
+struct slk_sweep_args {
+    float *p, *s1, *s2, *g;
+    size_t numel;
+    float wd, w1, beta2, omb2, step_size, bc2_sqrt, eps, clr;
+};
+
+__global__ __launch_bounds__(256) void k_adam_dense_sweep(slk_sweep_args a) {
+    // torch/optim/adam.py:414-546 (single-tensor): g += wd*p; m.lerp_(g, 1-b1);
+    // v = b2*v + (1-b2) g^2; p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < a.numel; e += (size_t)gridDim.x * 256) {
+        const float gv = a.g[e] + a.wd * a.p[e];
+        a.g[e] = 0.0f;
+        const float m = a.s1[e] + a.w1 * (gv - a.s1[e]);
+        const float v = a.s2[e] * a.beta2 + a.omb2 * (gv * gv);
+        a.s1[e] = m;
+        a.s2[e] = v;
+        a.p[e] += -a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_adagrad_dense_sweep(slk_sweep_args a) {
+    // torch/optim/adagrad.py:350-385 dense branch with weight_decay
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < a.numel; e += (size_t)gridDim.x * 256) {
+        const float gv = a.g[e] + a.wd * a.p[e];
+        a.g[e] = 0.0f;
+        const float s = a.s1[e] + gv * gv;
+        a.s1[e] = s;
+        a.p[e] += -a.clr * (gv / (sqrtf(s) + a.eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// prep kernels
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_i64_to_u32(const int64_t *in, uint32_t *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (uint32_t)in[i];
+}
+
+__global__ __launch_bounds__(256) void k_u32_to_i64(const uint32_t *in, int64_t *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (int64_t)in[i];
+}
+
+// key = (minibatch-in-chunk << ubits) | user.  FAT (one negative): value = (neg << 32) | pos so
+// the sorted values ARE the user pass's item pairs; otherwise value = interaction index.
+template <bool FAT>
+__global__ __launch_bounds__(256) void k_build_user_keys(const int64_t *users, const int64_t *items,
+                                                         const uint32_t *neg32, uint32_t nc, uint32_t bsz,
+                                                         unsigned ubits, uint32_t *key, void *val) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
+        key[k] = ((k / bsz) << ubits) | (uint32_t)users[k];
+        if (FAT)
+            ((uint64_t *)val)[k] = ((uint64_t)neg32[k] << 32) | (uint64_t)(uint32_t)items[k];
+        else
+            ((uint32_t *)val)[k] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_items(const uint32_t *uk, const int64_t *items,
+                                                    const uint32_t *neg32, uint32_t nc, int nn, uint32_t *uit) {
+    const int NP = nn + 1;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nc; q += gridDim.x * 256) {
+        const uint32_t k = uk[q];
+        uit[(size_t)q * NP] = (uint32_t)items[k];
+        for (int r = 0; r < nn; ++r) uit[(size_t)q * NP + 1 + r] = neg32[(size_t)k * nn + r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build_item_keys(const uint32_t *uit, uint32_t nocc, int NP,
+                                                         uint32_t bsz, unsigned ibits, uint32_t *key,
+                                                         uint32_t *val) {
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nocc; r += gridDim.x * 256) {
+        const uint32_t q = r / (uint32_t)NP;
+        key[r] = ((q / bsz) << ibits) | uit[r];
+        val[r] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// predict
+// ---------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void k_predict(const float *U, const float *V, const float *bu,
+                                                 const float *bi, int D, const int64_t *users,
+                                                 int64_t n_users, const int64_t *items, int64_t n, float *out) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    for (int64_t k = (int64_t)blockIdx.x * GPB + grp; k < n; k += (int64_t)gridDim.x * GPB) {
+        const int64_t u = users[n_users == 1 ? 0 : k];
+        const int64_t i = items ? items[k] : k;
+        const slk_vec<VEC> a = on ? slk_vload<VEC>(U + (size_t)u * D + d0) : slk_vzero<VEC>();
+        const slk_vec<VEC> b = on ? slk_vload<VEC>(V + (size_t)i * D + d0) : slk_vzero<VEC>();
+        const float s = slk_group_sum<G>(slk_vdot<VEC>(a, b)) + bu[u] + bi[i];
+        if (lane == 0) out[k] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static unsigned grid_for(const slk_ctx *ctx, size_t work_items, unsigned per_block) {
+    size_t blocks = (work_items + per_block - 1) / per_block;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// (VEC, G) layout for an embedding dim: 16 B per lane when dim % 4 == 0.
+static bool pick_layout(int D, int *vec, int *g) {
+    if (D <= 0) return false;
+    if (D % 4 == 0 && D <= 256) {
+        *vec = 4;
+        int need = D / 4, G = 1;
+        while (G < need) G <<= 1;
+        *g = G;
+        return true;
+    }
+    if (D <= 64) {
+        *vec = 1;
+        int G = 1;
+        while (G < D) G <<= 1;
+        *g = G;
+        return true;
+    }
+    return false;
+}
+
+#define SLK_FOR_LAYOUT(vec, g, MACRO)                                                 \
+    do {                                                                              \
+        if ((vec) == 4) {                                                             \
+            switch (g) {                                                              \
+                case 1: MACRO(4, 1); break;                                           \
+                case 2: MACRO(4, 2); break;                                           \
+                case 4: MACRO(4, 4); break;                                           \
+                case 8: MACRO(4, 8); break;                                           \
+                case 16: MACRO(4, 16); break;                                         \
+                case 32: MACRO(4, 32); break;                                         \
+                default: MACRO(4, 64); break;                                         \
+            }                                                                         \
+        } else {                                                                      \
+            switch (g) {                                                              \
+                case 1: MACRO(1, 1); break;                                           \
+                case 2: MACRO(1, 2); break;                                           \
+                case 4: MACRO(1, 4); break;                                           \
+                case 8: MACRO(1, 8); break;                                           \
+                case 16: MACRO(1, 16); break;                                         \
+                case 32: MACRO(1, 32); break;                                         \
+                default: MACRO(1, 64); break;                                         \
+            }                                                                         \
+        }                                                                             \
+    } while (0)
+
+typedef void (*pass_fn)(slk_pass_args);
+
+template <int VEC, int G>
+static pass_fn user_pass_fn(int upd, bool pre) {
+    if (pre) {
+        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, true>;
+        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, true>;
+        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, true>;
+    }
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, false>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, false>;
+    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, false>;
+}
+
+template <int VEC, int G>
+static pass_fn item_pass_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM>;
+    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY>;
+}
+
+static int check_tables(slk_ctx *ctx, const slk_tables *t, int *vec, int *g) {
+    if (!t) return slk_fail(ctx, SLK_EINVAL, "tables is NULL");
+    for (int i = 0; i < 4; ++i)
+        if (!t->d_param[i]) return slk_fail(ctx, SLK_EINVAL, "tables->d_param[%d] is NULL", i);
+    if (t->num_users < 1 || t->num_items < 1 || t->num_users >= ((int64_t)1 << 31) ||
+        t->num_items >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "table rows must be in [1, 2^31): users %lld items %lld",
+                        (long long)t->num_users, (long long)t->num_items);
+    if (!pick_layout(t->dim, vec, g))
+        return slk_fail(ctx, SLK_EINVAL,
+                        "embedding dim %d unsupported (need dim %% 4 == 0 and <= 256, or dim <= 64)", t->dim);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_users,
+                                    int64_t n_users, const int64_t *d_items, int64_t n, float *d_out,
+                                    void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = check_tables(ctx, tables, &vec, &g))) return rc;
+    if (n < 0 || !d_users || (n > 0 && !d_out)) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_predict: bad arguments");
+    if (n_users != 1 && n_users != n)
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_predict: n_users must be 1 or n (%lld vs %lld)",
+                        (long long)n_users, (long long)n);
+    if (n == 0) return SLK_OK;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    slk_prof_begin(ctx, SLK_K_SCORE, s);
+#define SLK_PREDICT(V_, G_)                                                                          \
+    hipLaunchKernelGGL((k_predict<V_, G_>), dim3(grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
+                       (const float *)tables->d_param[0], (const float *)tables->d_param[1],          \
+                       (const float *)tables->d_param[2], (const float *)tables->d_param[3],          \
+                       (int)tables->dim, d_users, n_users, d_items, n, d_out)
+    SLK_FOR_LAYOUT(vec, g, SLK_PREDICT);
+#undef SLK_PREDICT
+    SLK_LAUNCH_CHECK(ctx, "k_predict");
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                                  const int64_t *d_users, const int64_t *d_items, int64_t n,
+                                  int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
+                                  int64_t *d_neg_out, float *d_mb_loss, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = check_tables(ctx, tables, &vec, &g))) return rc;
+    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    if (n < 0 || batch_size < 1) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: n %lld batch_size %lld",
+                                                 (long long)n, (long long)batch_size);
+    if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_ADAPTIVE_HINGE)
+        return slk_fail(ctx, SLK_EINVAL, "unknown loss kind %d", loss);
+    if (optim->kind < SLK_OPT_ADAGRAD || optim->kind > SLK_OPT_ADAGRAD_DENSE)
+        return slk_fail(ctx, SLK_EINVAL, "unknown optimizer kind %d", optim->kind);
+    const bool adaptive = loss == SLK_LOSS_ADAPTIVE_HINGE;
+    const int nn = adaptive ? n_neg : 1;
+    if (nn < 1 || nn > 1024) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", nn);
+    const int NP = nn + 1;
+    const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    const bool need_s2 = optim->kind == SLK_OPT_SPARSE_ADAM || optim->kind == SLK_OPT_ADAM_DENSE;
+    for (int i = 0; i < 4; ++i) {
+        if (!optim->d_state1[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state1[%d] is NULL", i);
+        if (need_s2 && !optim->d_state2[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state2[%d] is NULL", i);
+    }
+    if (optim->kind == SLK_OPT_ADAGRAD && optim->weight_decay != 0.0)
+        return slk_fail(ctx, SLK_EINVAL, "row-sparse Adagrad requires weight_decay == 0 (use ADAGRAD_DENSE)");
+    if (n == 0) return SLK_OK;
+    if (!d_users || !d_items || !d_mb_loss) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: NULL id/loss pointer");
+    if (batch_size * (int64_t)NP >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "batch_size * (1 + negatives) must be < 2^31");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+
+    const int D = tables->dim;
+    const unsigned ubits = slk_bits_for((uint64_t)tables->num_users - 1);
+    const unsigned ibits = slk_bits_for((uint64_t)tables->num_items - 1);
+    const unsigned idbits = ubits > ibits ? ubits : ibits;
+    // minibatches per chunk: keys must fit 32 bits, occurrences must fit 2^31, and scratch
+    // stays bounded (~8M interactions).
+    const int64_t bsz = batch_size < n ? batch_size : n;
+    int64_t mb_per_chunk = (int64_t)1 << (32 - idbits);
+    const int64_t cap_inter = (int64_t)1 << 23;
+    if (mb_per_chunk * bsz > cap_inter) mb_per_chunk = cap_inter / bsz;
+    while (mb_per_chunk > 1 && mb_per_chunk * bsz * NP >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
+    if (mb_per_chunk < 1) mb_per_chunk = 1;
+    const int64_t chunk_cap = mb_per_chunk * bsz;
+
+    // scratch
+    const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
+    if ((rc = slk_ensure(ctx, ctx->neg32, nc_max * nn * 4))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = slk_ensure(ctx, ctx->ukey[b], nc_max * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->uval[b], nc_max * 8))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->ikey[b], nc_max * NP * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->ipay[b], nc_max * NP * 4))) return rc;
+    }
+    if ((rc = slk_ensure(ctx, ctx->gbuf, nc_max * NP * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * D * 4))) return rc;
+    const unsigned max_grid = (unsigned)ctx->num_cus * 8;
+    if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
+    if (adaptive) {
+        if ((rc = slk_ensure(ctx, ctx->uit, nc_max * NP * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
+    }
+    if (dense) {
+        const size_t elems[4] = {(size_t)tables->num_users * D, (size_t)tables->num_items * D,
+                                 (size_t)tables->num_users, (size_t)tables->num_items};
+        for (int t = 0; t < 4; ++t) {
+            if (ctx->dgrad_elems[t] != elems[t] || !ctx->dgrad[t].p) {
+                if ((rc = slk_ensure(ctx, ctx->dgrad[t], elems[t] * 4))) return rc;
+                SLK_HIP(ctx, hipMemsetAsync(ctx->dgrad[t].p, 0, elems[t] * 4, s));
+                ctx->dgrad_elems[t] = elems[t];
+            }
+        }
+    }
+
+    const int upd = dense ? SLK_UPD_GRAD_ONLY
+                          : (optim->kind == SLK_OPT_ADAGRAD ? SLK_UPD_ADAGRAD : SLK_UPD_SPARSE_ADAM);
+    pass_fn upass = nullptr, ipass = nullptr, spass = nullptr;
+#define SLK_PICK(V_, G_)                                  \
+    do {                                                  \
+        upass = user_pass_fn<V_, G_>(upd, adaptive);      \
+        ipass = item_pass_fn<V_, G_>(upd);                \
+        spass = k_score_pass<V_, G_>;                     \
+    } while (0)
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK);
+#undef SLK_PICK
+    const unsigned gpb = 256u / (unsigned)g;
+
+    int64_t mb_global = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
+        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const uint32_t nocc = nc * (uint32_t)NP;
+        const int64_t *cu = d_users + c0, *ci = d_items + c0;
+        uint32_t *neg32 = (uint32_t *)ctx->neg32.p;
+
+        // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
+        if (d_neg_in) {
+            slk_prof_begin(ctx, SLK_K_SAMPLE, s);
+            hipLaunchKernelGGL(k_i64_to_u32, dim3(grid_for(ctx, (size_t)nc * nn, 256)), dim3(256), 0, s,
+                               d_neg_in + c0 * nn, neg32, (size_t)nc * nn);
+            SLK_LAUNCH_CHECK(ctx, "k_i64_to_u32");
+            if (d_neg_out)
+                SLK_HIP(ctx, hipMemcpyAsync(d_neg_out + c0 * nn, d_neg_in + c0 * nn, (size_t)nc * nn * 8,
+                                            hipMemcpyDeviceToDevice, s));
+            slk_prof_end(ctx, s);
+        } else {
+            if ((rc = slk_sample_u32(ctx, tables->num_items, (int64_t)nc * nn, neg32,
+                                     d_neg_out ? d_neg_out + c0 * nn : nullptr, s)))
+                return rc;
+        }
+
+        // ---- prep: sort interactions by (minibatch, user), occurrences by (minibatch, item)
+        slk_prof_begin(ctx, SLK_K_PREP, s);
+        const unsigned mbbits = slk_bits_for((uint64_t)((nc - 1) / (uint32_t)bsz));
+        uint32_t *ukey_in = (uint32_t *)ctx->ukey[0].p, *ukey = (uint32_t *)ctx->ukey[1].p;
+        const uint32_t *uit, *uk = nullptr;
+        if (!adaptive) {
+            hipLaunchKernelGGL((k_build_user_keys<true>), dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
+                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
+            if ((rc = slk_sort_pairs_u32_u64(ctx, ukey_in, ukey, (const uint64_t *)ctx->uval[0].p,
+                                             (uint64_t *)ctx->uval[1].p, nc, ubits + mbbits, s)))
+                return rc;
+            uit = (const uint32_t *)ctx->uval[1].p;  // little-endian (pos, neg) pairs
+        } else {
+            hipLaunchKernelGGL((k_build_user_keys<false>), dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
+                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, ukey_in, ukey, (const uint32_t *)ctx->uval[0].p,
+                                             (uint32_t *)ctx->uval[1].p, nc, ubits + mbbits, s)))
+                return rc;
+            uk = (const uint32_t *)ctx->uval[1].p;
+            hipLaunchKernelGGL(k_pack_items, dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, ci,
+                               (const uint32_t *)neg32, nc, nn, (uint32_t *)ctx->uit.p);
+            SLK_LAUNCH_CHECK(ctx, "k_pack_items");
+            uit = (const uint32_t *)ctx->uit.p;
+        }
+        hipLaunchKernelGGL(k_build_item_keys, dim3(grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
+                           (uint32_t)bsz, ibits, (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+        SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
+        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
+                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
+                                         ibits + mbbits, s)))
+            return rc;
+        slk_prof_end(ctx, s);
+
+        // ---- minibatches, in order
+        for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
+            const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
+            const uint32_t bm = b1 - b0;
+            const double step = (double)(optim->step + 1);
+            slk_pass_args a;
+            memset(&a, 0, sizeof(a));
+            for (int t = 0; t < 4; ++t) {
+                a.P[t] = tables->d_param[t];
+                a.S1[t] = dense ? (float *)ctx->dgrad[t].p : optim->d_state1[t];
+                a.S2[t] = optim->d_state2[t];
+            }
+            a.D = D;
+            a.NP = NP;
+            a.begin = b0;
+            a.end = b1;
+            a.ukey = ukey;
+            a.umask = (uint32_t)((1ull << ubits) - 1);
+            a.uit = uit;
+            a.uk = uk;
+            a.gk = (const float *)ctx->gk.p;
+            a.sk = (float *)ctx->sk.p;
+            a.gbuf = (float *)ctx->gbuf.p;
+            a.snap = (float *)ctx->snap.p;
+            a.ikey = (const uint32_t *)ctx->ikey[1].p;
+            a.imask = (uint32_t)((1ull << ibits) - 1);
+            a.ipay = (const uint32_t *)ctx->ipay[1].p;
+            a.loss_partial = (double *)ctx->losspart.p;
+            a.mb_loss_out = d_mb_loss + mb_global;
+            a.loss_kind = loss;
+            a.inv_b = 1.0f / (float)bm;
+            a.c_eps = (float)optim->eps;
+            if (optim->kind == SLK_OPT_ADAGRAD) {
+                a.c_lr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
+            } else if (optim->kind == SLK_OPT_SPARSE_ADAM) {
+                const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
+                a.c_lr = (float)(optim->lr * sqrt(bc2) / bc1);
+                a.c_omb1 = (float)(1.0 - optim->beta1);
+                a.c_omb2 = (float)(1.0 - optim->beta2);
+            }
+            const unsigned ugrid = grid_for(ctx, bm, gpb);
+            const unsigned igrid = grid_for(ctx, (size_t)bm * NP, gpb);
+
+            if (adaptive) {
+                slk_prof_begin(ctx, SLK_K_SCORE, s);
+                SLK_HIP(ctx, hipMemsetAsync((float *)ctx->gk.p + (size_t)b0 * NP, 0, (size_t)bm * NP * 4, s));
+                hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_score_pass");
+                const unsigned sgrid = grid_for(ctx, bm, 256);
+                hipLaunchKernelGGL(k_adaptive_select, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
+                                   (float *)ctx->gk.p, b0, bm, nn, a.inv_b, (double *)ctx->losspart.p);
+                SLK_LAUNCH_CHECK(ctx, "k_adaptive_select");
+                a.n_loss_partial = (int)sgrid;
+                slk_prof_end(ctx, s);
+            } else {
+                a.n_loss_partial = (int)ugrid;
+            }
+
+            slk_prof_begin(ctx, SLK_K_USER_PASS, s);
+            hipLaunchKernelGGL(upass, dim3(ugrid), dim3(256), 0, s, a);
+            SLK_LAUNCH_CHECK(ctx, "k_user_pass");
+            slk_prof_end(ctx, s);
+
+            slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
+            hipLaunchKernelGGL(ipass, dim3(igrid), dim3(256), 0, s, a);
+            SLK_LAUNCH_CHECK(ctx, "k_item_pass");
+            slk_prof_end(ctx, s);
+
+            if (dense) {
+                slk_prof_begin(ctx, SLK_K_DENSE_SWEEP, s);
+                slk_sweep_args w;
+                memset(&w, 0, sizeof(w));
+                w.wd = (float)optim->weight_decay;
+                w.eps = (float)optim->eps;
+                if (optim->kind == SLK_OPT_ADAM_DENSE) {
+                    const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
+                    w.w1 = (float)(1.0 - optim->beta1);
+                    w.beta2 = (float)optim->beta2;
+                    w.omb2 = (float)(1.0 - optim->beta2);
+                    w.step_size = (float)(optim->lr / bc1);
+                    w.bc2_sqrt = (float)sqrt(bc2);
+                } else {
+                    w.clr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
+                }
+                for (int t = 0; t < 4; ++t) {
+                    w.p = tables->d_param[t];
+                    w.s1 = optim->d_state1[t];
+                    w.s2 = optim->d_state2[t];
+                    w.g = (float *)ctx->dgrad[t].p;
+                    w.numel = ctx->dgrad_elems[t];
+                    const unsigned wgrid = grid_for(ctx, w.numel, 256);
+                    if (optim->kind == SLK_OPT_ADAM_DENSE)
+                        hipLaunchKernelGGL(k_adam_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
+                    else
+                        hipLaunchKernelGGL(k_adagrad_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
+                    SLK_LAUNCH_CHECK(ctx, "dense sweep");
+                }
+                slk_prof_end(ctx, s);
+            }
+            optim->step += 1;
+        }
+    }
+    return SLK_OK;
+}

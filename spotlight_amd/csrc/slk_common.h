@@ -1,0 +1,173 @@
+// slk_common.h -- internal declarations shared by the gfx950 engine's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/spotlight_hip.h"
+
+#define SLK_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------------------
+// ctx
+// ---------------------------------------------------------------------------------------
+struct slk_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// On-device RNG block (numpy RandomState layout: key[624] + pos) plus sampler bookkeeping.
+struct slk_rng_dev {
+    uint32_t key[624];
+    int32_t pos;
+    int32_t insufficient;     // sticky: a sampling call ran out of generated words
+    unsigned long long t_last;  // stream index of the word that produced the last output
+    unsigned long long accepted;
+};
+
+struct slk_prof_span {
+    int cls;
+    hipEvent_t a, b;
+};
+
+struct slk_ctx {
+    int device = 0;
+    int num_cus = 256;
+    char err[512] = {0};
+    hipStream_t last_stream = nullptr;
+    slk_rng_dev *d_rng = nullptr;
+
+    // scratch (grown on demand, freed in slk_ctx_destroy)
+    slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gbuf, gk, sk, snap, losspart,
+        sort_tmp, dgrad[4];
+    size_t dgrad_elems[4] = {0, 0, 0, 0};
+
+    // profiling
+    bool prof_on = false;
+    std::vector<slk_prof_span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    int64_t prof_launches[SLK_K_COUNT] = {0};
+    double prof_ms[SLK_K_COUNT] = {0};
+};
+
+int slk_fail(slk_ctx *ctx, int code, const char *fmt, ...);
+int slk_ensure(slk_ctx *ctx, slk_buf &b, size_t bytes);
+void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s);
+void slk_prof_end(slk_ctx *ctx, hipStream_t s);
+int slk_prof_drain(slk_ctx *ctx);
+
+#define SLK_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return slk_fail((ctx), SLK_EIO, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define SLK_LAUNCH_CHECK(ctx, what)                                                          \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess)                                                                \
+            return slk_fail((ctx), SLK_EIO, "launch of %s failed: %s", (what), hipGetErrorString(e_)); \
+    } while (0)
+
+// sampler (slk_rng.hip): `count` negatives into ctx->neg32 (uint32) [+ int64 copy to d_out64]
+int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,
+                   hipStream_t s);
+
+// sort wrapper (slk_sort.hip)
+int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                           uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
+                           uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+
+static inline unsigned slk_bits_for(uint64_t max_value) {
+    unsigned b = 1;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+
+// Sum over the G lanes that share one embedding row (G = 1..64, power of two); every lane
+// receives the total.  A row group never straddles a wavefront.
+template <int G>
+__device__ __forceinline__ float slk_group_sum(float x) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, G);
+    return x;
+}
+
+// VEC consecutive fp32 of an embedding row held by one lane: VEC == 4 moves 16 B per lane
+// (a D=64 row = 16 lanes x 16 B = one 256-B line), VEC == 1 is the odd-dim fallback.
+template <int VEC>
+struct slk_vec {
+    float v[VEC];
+};
+
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_vzero() {
+    slk_vec<VEC> r;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r.v[i] = 0.0f;
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_vload(const float *p);
+template <>
+__device__ __forceinline__ slk_vec<4> slk_vload<4>(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    slk_vec<4> r;
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    return r;
+}
+template <>
+__device__ __forceinline__ slk_vec<1> slk_vload<1>(const float *p) {
+    slk_vec<1> r;
+    r.v[0] = *p;
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void slk_vstore(float *p, const slk_vec<VEC> &x);
+template <>
+__device__ __forceinline__ void slk_vstore<4>(float *p, const slk_vec<4> &x) {
+    *reinterpret_cast<float4 *>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+template <>
+__device__ __forceinline__ void slk_vstore<1>(float *p, const slk_vec<1> &x) {
+    *p = x.v[0];
+}
+
+template <int VEC>
+__device__ __forceinline__ float slk_vdot(const slk_vec<VEC> &a, const slk_vec<VEC> &b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += a.v[i] * b.v[i];
+    return s;
+}
+
+// acc += g * x
+template <int VEC>
+__device__ __forceinline__ void slk_vaxpy(slk_vec<VEC> &acc, float g, const slk_vec<VEC> &x) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] += g * x.v[i];
+}
+
+// Block-wide sum of one double per thread (256 threads); result valid in thread 0.
+__device__ __forceinline__ double slk_block_sum_256(double x, double *red /*[256] LDS*/) {
+    const int t = threadIdx.x;
+    red[t] = x;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    return red[0];
+}

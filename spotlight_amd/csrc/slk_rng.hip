@@ -1,0 +1,268 @@
+// slk_rng.hip -- on-GPU, bit-exact numpy legacy RandomState.randint(0, num_items, ...).
+//
+// Replaces spotlight/sampling.py:8-36 (sample_items) + the per-minibatch H2D copy at
+// spotlight/factorization/implicit.py:256-260.  numpy draws each output by masked
+// rejection over the raw MT19937 32-bit stream: v = next32() & mask until v <= num_items-1.
+// The k-th accepted word is the k-th output, so the whole draw is
+//     raw stream  ->  temper  ->  mask/accept  ->  order-preserving stream compaction.
+//   k_mt_generate   one workgroup advances the 624-word state block by block (the twist has
+//                   227-way parallelism: words [0,227) need only old words, [227,454) need
+//                   the first round, [454,624) the second) and streams the UNTEMPERED blocks
+//                   to HBM;
+//   k_accept_count / k_scan_counts / k_accept_scatter   all CUs temper, test and compact;
+//   k_rng_finalize  restores (key, pos) to exactly what numpy would hold after the draw:
+//                   the state block containing the last CONSUMED word, pos = offset + 1.
+#include <math.h>
+
+#include "slk_common.h"
+
+#define SLK_MT_N 624
+#define SLK_TILE 2048  // words per block in the compaction kernels (256 threads x 8)
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// raw[0..624) = current key block; raw[b*624 ..] = state after b regenerations.
+__global__ __launch_bounds__(256) void k_mt_generate(const slk_rng_dev *st, uint32_t *raw, int nblocks) {
+    __shared__ uint32_t s[2][SLK_MT_N];
+    const int t = threadIdx.x;
+    for (int i = t; i < SLK_MT_N; i += 256) {
+        const uint32_t k = st->key[i];
+        s[0][i] = k;
+        raw[i] = k;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int b = 1; b < nblocks; ++b) {
+        const uint32_t *o = s[cur];
+        uint32_t *n = s[cur ^ 1];
+        if (t < 227) n[t] = mt_twist(o[t], o[t + 1], o[t + 397]);
+        __syncthreads();
+        if (t < 227) {
+            const int i = t + 227;
+            n[i] = mt_twist(o[i], o[i + 1], n[i - 227]);
+        }
+        __syncthreads();
+        if (t < 170) {
+            const int i = t + 454;
+            const uint32_t nx = (i == SLK_MT_N - 1) ? n[0] : o[i + 1];
+            n[i] = mt_twist(o[i], nx, n[i - 227]);
+        }
+        __syncthreads();
+        uint32_t *dst = raw + (size_t)b * SLK_MT_N;
+        for (int i = t; i < SLK_MT_N; i += 256) dst[i] = n[i];
+        cur ^= 1;
+    }
+}
+
+struct slk_accept_args {
+    const uint32_t *raw;
+    const slk_rng_dev *st;
+    unsigned long long total_words;  // words generated (nblocks * 624)
+    uint32_t mask, rng;
+};
+
+__device__ __forceinline__ bool accept_word(const slk_accept_args &a, unsigned long long t, int pos0,
+                                            uint32_t *v) {
+    if (t < (unsigned long long)pos0 || t >= a.total_words) return false;
+    *v = mt_temper(a.raw[t]) & a.mask;
+    return *v <= a.rng;
+}
+
+__global__ __launch_bounds__(256) void k_accept_count(slk_accept_args a, uint32_t *cnt) {
+    __shared__ double red[256];
+    const int pos0 = a.st->pos;
+    const unsigned long long base = (unsigned long long)blockIdx.x * SLK_TILE + (unsigned long long)threadIdx.x * 8;
+    unsigned c = 0;
+    for (int j = 0; j < 8; ++j) {
+        uint32_t v;
+        c += accept_word(a, base + j, pos0, &v) ? 1u : 0u;
+    }
+    const double tot = slk_block_sum_256((double)c, red);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (uint32_t)tot;
+}
+
+// exclusive scan of cnt[nb] in place -> block offsets (64-bit); total -> st->accepted
+__global__ __launch_bounds__(256) void k_scan_counts(const uint32_t *cnt, unsigned long long *off, int nb,
+                                                     slk_rng_dev *st) {
+    __shared__ unsigned long long s[256];
+    __shared__ unsigned long long carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + t;
+        const unsigned long long v = (i < nb) ? cnt[i] : 0ull;
+        s[t] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const unsigned long long x = (t >= d) ? s[t - d] : 0ull;
+            __syncthreads();
+            s[t] += x;
+            __syncthreads();
+        }
+        if (i < nb) off[i] = carry + s[t] - v;
+        __syncthreads();
+        if (t == 255) carry += s[255];
+        __syncthreads();
+    }
+    if (t == 0) st->accepted = carry;
+}
+
+__global__ __launch_bounds__(256) void k_accept_scatter(slk_accept_args a, const unsigned long long *off,
+                                                        unsigned long long count, uint32_t *out32,
+                                                        int64_t *out64, slk_rng_dev *st) {
+    __shared__ unsigned s[256];
+    const int t = threadIdx.x;
+    const int pos0 = a.st->pos;
+    const unsigned long long base = (unsigned long long)blockIdx.x * SLK_TILE + (unsigned long long)t * 8;
+    uint32_t v[8];
+    bool ok[8];
+    unsigned c = 0;
+    for (int j = 0; j < 8; ++j) {
+        ok[j] = accept_word(a, base + j, pos0, &v[j]);
+        c += ok[j] ? 1u : 0u;
+    }
+    s[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned x = (t >= d) ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += x;
+        __syncthreads();
+    }
+    unsigned long long rank = off[blockIdx.x] + (unsigned long long)(s[t] - c);
+    for (int j = 0; j < 8; ++j) {
+        if (!ok[j]) continue;
+        if (rank < count) {
+            if (out32) out32[rank] = v[j];
+            if (out64) out64[rank] = (int64_t)v[j];
+            if (rank == count - 1) st->t_last = base + j;
+        }
+        ++rank;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rng_finalize(slk_rng_dev *st, const uint32_t *raw,
+                                                      unsigned long long count) {
+    __shared__ int enough;
+    if (threadIdx.x == 0) {
+        enough = st->accepted >= count;
+        if (!enough) st->insufficient = 1;
+    }
+    __syncthreads();
+    if (!enough) return;
+    const unsigned long long tl = st->t_last;
+    const unsigned long long blk = tl / SLK_MT_N;
+    for (int i = threadIdx.x; i < SLK_MT_N; i += 256) st->key[i] = raw[blk * SLK_MT_N + i];
+    __syncthreads();
+    if (threadIdx.x == 0) st->pos = (int32_t)(tl % SLK_MT_N) + 1;
+}
+
+__global__ __launch_bounds__(256) void k_fill_zero(uint32_t *out32, int64_t *out64, unsigned long long n) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        if (out32) out32[i] = 0;
+        if (out64) out64[i] = 0;
+    }
+}
+
+int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,
+                   hipStream_t s) {
+    if (num_items < 1 || num_items > (int64_t)1 << 32)
+        return slk_fail(ctx, SLK_EINVAL, "slk_sample_items: num_items %lld outside [1, 2^32]", (long long)num_items);
+    if (count < 0) return slk_fail(ctx, SLK_EINVAL, "slk_sample_items: negative count");
+    if (count == 0) return SLK_OK;
+    ctx->last_stream = s;
+    slk_prof_begin(ctx, SLK_K_SAMPLE, s);
+    if (num_items == 1) {
+        // numpy: rng == 0 returns zeros and consumes nothing
+        hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, d_out32, d_out64,
+                           (unsigned long long)count);
+        SLK_LAUNCH_CHECK(ctx, "k_fill_zero");
+        slk_prof_end(ctx, s);
+        return SLK_OK;
+    }
+    const uint32_t rng = (uint32_t)(num_items - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const double p = ((double)rng + 1.0) / ((double)mask + 1.0);
+    // words needed: mean count/p plus 12 sigma of the negative-binomial spread plus slack;
+    // the first block (current key) may contribute nothing when pos == 624.
+    double need = (double)count / p + 12.0 * sqrt((double)count * (1.0 - p)) / p + 64.0;
+    if (p == 1.0) need = (double)count;
+    const unsigned long long nblocks = 1ull + (unsigned long long)((need + SLK_MT_N - 1) / SLK_MT_N);
+    const unsigned long long total_words = nblocks * SLK_MT_N;
+    if (nblocks > 0x7fffffffull) return slk_fail(ctx, SLK_EINVAL, "slk_sample_items: count too large for one call");
+    const unsigned long long nb = (total_words + SLK_TILE - 1) / SLK_TILE;
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->cnt, nb * 4 + nb * 8 + 64))) return rc;
+    uint32_t *raw = (uint32_t *)ctx->raw.p;
+    unsigned long long *off = (unsigned long long *)ctx->cnt.p;
+    uint32_t *cnt = (uint32_t *)(off + nb);
+
+    hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, s, (const slk_rng_dev *)ctx->d_rng, raw, (int)nblocks);
+    SLK_LAUNCH_CHECK(ctx, "k_mt_generate");
+    slk_accept_args a;
+    a.raw = raw;
+    a.st = ctx->d_rng;
+    a.total_words = total_words;
+    a.mask = mask;
+    a.rng = rng;
+    hipLaunchKernelGGL(k_accept_count, dim3((unsigned)nb), dim3(256), 0, s, a, cnt);
+    SLK_LAUNCH_CHECK(ctx, "k_accept_count");
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb, ctx->d_rng);
+    SLK_LAUNCH_CHECK(ctx, "k_scan_counts");
+    hipLaunchKernelGGL(k_accept_scatter, dim3((unsigned)nb), dim3(256), 0, s, a, (const unsigned long long *)off,
+                       (unsigned long long)count, d_out32, d_out64, ctx->d_rng);
+    SLK_LAUNCH_CHECK(ctx, "k_accept_scatter");
+    hipLaunchKernelGGL(k_rng_finalize, dim3(1), dim3(256), 0, s, ctx->d_rng, (const uint32_t *)raw,
+                       (unsigned long long)count);
+    SLK_LAUNCH_CHECK(ctx, "k_rng_finalize");
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos) {
+    if (!ctx || !h_key) return SLK_EINVAL;
+    if (pos < 0 || pos > SLK_MT_N) return slk_fail(ctx, SLK_EINVAL, "slk_rng_set_state: pos %d outside [0, 624]", pos);
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_stream) SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    slk_rng_dev h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.key, h_key, sizeof(h.key));
+    h.pos = pos;
+    SLK_HIP(ctx, hipMemcpy(ctx->d_rng, &h, sizeof(h), hipMemcpyHostToDevice));
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
+    if (!ctx || !h_key || !pos) return SLK_EINVAL;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->last_stream) SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    slk_rng_dev h;
+    SLK_HIP(ctx, hipMemcpy(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.insufficient)
+        return slk_fail(ctx, SLK_EIO, "sampler ran out of generated words (rejection tail > 12 sigma)");
+    memcpy(h_key, h.key, sizeof(h.key));
+    *pos = h.pos;
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_sample_items(slk_ctx *ctx, int64_t num_items, int64_t count, int64_t *d_out, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (!d_out && count > 0) return slk_fail(ctx, SLK_EINVAL, "slk_sample_items: d_out is NULL");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    return slk_sample_u32(ctx, num_items, count, nullptr, d_out, (hipStream_t)stream);
+}

@@ -1,0 +1,30 @@
+// slk_sort.hip -- the one place the engine calls a ROCm library: rocPRIM's device radix sort
+// (keys: (minibatch, row id) packed in 32 bits; only the bits in use are sorted).
+#include <cstring>  // rocPRIM's texture iterator header needs host memset declared first
+
+#include <rocprim/rocprim.hpp>
+
+#include "slk_common.h"
+
+template <class V>
+static int sort_impl(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
+                     unsigned end_bit, hipStream_t s) {
+    if (n == 0) return SLK_OK;
+    if (end_bit > 32) end_bit = 32;
+    size_t tmp = 0;
+    SLK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
+    int rc = slk_ensure(ctx, ctx->sort_tmp, tmp);
+    if (rc) return rc;
+    SLK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
+    return SLK_OK;
+}
+
+int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                           uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
+    return sort_impl<uint32_t>(ctx, kin, kout, vin, vout, n, end_bit, s);
+}
+
+int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
+                           uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
+    return sort_impl<uint64_t>(ctx, kin, kout, vin, vout, n, end_bit, s);
+}

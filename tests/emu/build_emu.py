@@ -1,0 +1,37 @@
+"""TEST HARNESS: compiles the UNMODIFIED engine sources (spotlight_amd/csrc/*.hip) with g++
+against the fiber emulator (tests/emu/hip/hip_runtime.h) into tests/emu/_build/libspotlight_emu.so.
+Never used by spotlight_amd itself."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, 'spotlight_amd', 'csrc')
+OUT = os.path.join(HERE, '_build')
+LIB = os.path.join(OUT, 'libspotlight_emu.so')
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    deps = srcs + [os.path.join(CSRC, 'slk_common.h'), os.path.join(ROOT, 'include', 'spotlight_hip.h'),
+                   os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'),
+                   os.path.join(HERE, 'rocprim', 'rocprim.hpp')]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objs, procs = [], []
+    for s in srcs + [os.path.join(HERE, 'emu_runtime.cpp')]:
+        o = os.path.join(OUT, os.path.basename(s) + '.o')
+        objs.append(o)
+        cmd = ['g++', '-std=c++17', '-O1', '-g', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
+               '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas', '-I', HERE, '-x', 'c++', '-c', s, '-o', o]
+        procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('g++ failed on %s' % s)
+    subprocess.check_call(['g++', '-shared', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True))
