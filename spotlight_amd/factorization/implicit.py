@@ -1,0 +1,282 @@
+"""ImplicitFactorizationModel -- drop-in for spotlight/factorization/implicit.py:22-311.
+
+Same constructor, fit(), predict(), error messages and random-state behaviour as the
+reference; everything inside the epoch loop (negative sampling, both forward passes, loss,
+backward, optimizer update) is one C-ABI call into csrc/libspotlight_hip.so per epoch.
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from spotlight_amd import _native
+from spotlight_amd.factorization._components import _predict_process_ids
+from spotlight_amd.factorization.representations import BilinearNet
+from spotlight_amd.helpers import _repr_model
+from spotlight_amd.layers import ScaledEmbedding, ZeroEmbedding
+from spotlight_amd.torch_utils import set_seed, shuffle
+
+_ENGINES = {}
+
+
+def _engine_for(device):
+    """One slk_ctx per (process, HIP device)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index not in _ENGINES:
+        _ENGINES[index] = _native.Engine(index)
+    return _ENGINES[index]
+
+
+def _stream_for(device):
+    """Raw hipStream_t of torch's current stream on `device`."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _model_device():
+    """The HIP device models live on.  (The GPU-less test harness substitutes these three
+    hooks to drive the same host logic through its emulator build of the kernels.)"""
+    if not torch.cuda.is_available():
+        raise RuntimeError('spotlight_amd needs a HIP device (MI355X): torch.cuda.is_available() '
+                           'is False and there is no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _state_tensor(state, key, like):
+    if key not in state:
+        state[key] = torch.zeros_like(like, memory_format=torch.preserve_format)
+    return state[key]
+
+
+class _OptimizerBinding(object):
+    """Maps a torch.optim object onto slk_optim.  The torch optimizer stays the owner of
+    hyper-parameters and state tensors (so state_dict / pickle / resuming fit() behave as
+    in the reference); the kernels update those tensors in place."""
+
+    def __init__(self, optimizer, params, sparse):
+        self.optimizer = optimizer
+        self.params = params
+        groups = optimizer.param_groups
+        if len(groups) != 1:
+            raise NotImplementedError('spotlight_amd supports a single optimizer param group')
+        g = groups[0]
+        if g.get('maximize', False):
+            raise NotImplementedError('maximize=True is not supported')
+        st = optimizer.state
+        if isinstance(optimizer, optim.Adagrad):
+            wd = g['weight_decay']
+            if sparse and wd != 0:
+                # torch/optim/adagrad.py:355-358
+                raise RuntimeError('weight_decay option is not compatible with sparse gradients')
+            self.kind = 'adagrad_dense' if wd != 0 else 'adagrad'
+            self.hp = dict(lr=g['lr'], eps=g['eps'], weight_decay=wd, lr_decay=g['lr_decay'])
+            self.s1 = [st[p]['sum'] for p in params]
+            self.s2 = None
+        elif isinstance(optimizer, optim.SparseAdam):
+            if not sparse:
+                raise RuntimeError('SparseAdam does not support dense gradients, please consider '
+                                   'Adam instead')
+            self.kind = 'sparse_adam'
+            self.hp = dict(lr=g['lr'], eps=g['eps'], betas=g['betas'])
+            for p in params:
+                st[p].setdefault('step', 0)
+            self.s1 = [_state_tensor(st[p], 'exp_avg', p) for p in params]
+            self.s2 = [_state_tensor(st[p], 'exp_avg_sq', p) for p in params]
+        elif type(optimizer) is optim.Adam:
+            if sparse:
+                raise RuntimeError('Adam does not support sparse gradients, please consider '
+                                   'SparseAdam instead')
+            if g.get('amsgrad', False):
+                raise NotImplementedError('amsgrad=True is not supported')
+            self.kind = 'adam_dense'
+            self.hp = dict(lr=g['lr'], eps=g['eps'], betas=g['betas'], weight_decay=g['weight_decay'])
+            for p in params:
+                if 'step' not in st[p]:
+                    st[p]['step'] = torch.tensor(0.0, dtype=torch.float32)
+            self.s1 = [_state_tensor(st[p], 'exp_avg', p) for p in params]
+            self.s2 = [_state_tensor(st[p], 'exp_avg_sq', p) for p in params]
+        else:
+            raise NotImplementedError(
+                'optimizer {} has no fused gfx950 update; supported: Adam (default), Adagrad, '
+                'SparseAdam'.format(type(optimizer).__name__))
+        for t in self.s1 + (self.s2 or []):
+            if not t.is_contiguous():
+                raise RuntimeError('optimizer state must be contiguous')
+
+    def steps_taken(self):
+        step = self.optimizer.state[self.params[0]].get('step', 0)
+        return int(step.item()) if torch.is_tensor(step) else int(step)
+
+    def as_struct(self):
+        return _native.make_optim(self.kind, [t.data_ptr() for t in self.s1],
+                                  [t.data_ptr() for t in self.s2] if self.s2 else None,
+                                  step=self.steps_taken(), **self.hp)
+
+    def store_steps(self, step):
+        for p in self.params:
+            s = self.optimizer.state[p]
+            if torch.is_tensor(s.get('step')):
+                s['step'].fill_(float(step))
+            else:
+                s['step'] = int(step)
+
+
+class ImplicitFactorizationModel(object):
+    """Implicit-feedback matrix factorization trained by negative sampling.
+
+    Parameters and semantics follow spotlight/factorization/implicit.py:76-88.  Two
+    notes specific to this implementation:
+
+    * `use_cuda` is accepted for signature compatibility; the model always lives on the HIP
+      device (there is no CPU path).
+    * `representation` may be a :class:`BilinearNet`; arbitrary modules have no fused kernel
+      and raise NotImplementedError.
+    """
+
+    def __init__(self, loss='pointwise', embedding_dim=32, n_iter=10, batch_size=256, l2=0.0,
+                 learning_rate=1e-2, optimizer_func=None, use_cuda=False, representation=None,
+                 sparse=False, random_state=None, num_negative_samples=5):
+
+        assert loss in ('pointwise', 'bpr', 'hinge', 'adaptive_hinge')
+
+        self._loss = loss
+        self._embedding_dim = embedding_dim
+        self._n_iter = n_iter
+        self._learning_rate = learning_rate
+        self._batch_size = batch_size
+        self._l2 = l2
+        self._use_cuda = use_cuda
+        self._representation = representation
+        self._sparse = sparse
+        self._optimizer_func = optimizer_func
+        self._random_state = random_state or np.random.RandomState()
+        self._num_negative_samples = num_negative_samples
+
+        self._num_users = None
+        self._num_items = None
+        self._net = None
+        self._optimizer = None
+        self._loss_func = None
+        self._binding = None
+
+        # consumes one draw of the stream, like the reference (implicit.py:114-115)
+        set_seed(self._random_state.randint(-10**8, 10**8), cuda=self._use_cuda)
+
+    def __repr__(self):
+        return _repr_model(self)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_binding'] = None  # holds raw pointers; rebuilt on the next fit()
+        return state
+
+    @property
+    def _initialized(self):
+        return self._net is not None
+
+    def _initialize(self, interactions):
+        self._num_users, self._num_items = interactions.num_users, interactions.num_items
+        if self._representation is not None:
+            net = self._representation
+            if not isinstance(net, BilinearNet):
+                raise NotImplementedError('only BilinearNet representations have a fused gfx950 path')
+        else:
+            net = BilinearNet(self._num_users, self._num_items, self._embedding_dim,
+                              sparse=self._sparse)
+        for layer in (net.user_embeddings, net.item_embeddings):
+            if not isinstance(layer, ScaledEmbedding) and type(layer) is not torch.nn.Embedding:
+                raise NotImplementedError('embedding layer {} has no fused gfx950 path yet'
+                                          .format(type(layer).__name__))
+        assert isinstance(net.user_biases, (ZeroEmbedding, torch.nn.Embedding))
+        self._net = net.to(_model_device())
+
+        if self._optimizer_func is None:
+            self._optimizer = optim.Adam(self._net.parameters(), weight_decay=self._l2,
+                                         lr=self._learning_rate)
+        else:
+            self._optimizer = self._optimizer_func(self._net.parameters())
+        self._loss_func = self._loss  # the loss is fused into the kernel; kept for introspection
+        self._binding = None
+
+    def _bind(self):
+        if self._binding is None:
+            tables = self._net.tables()
+            for t in tables:
+                if not (t.device.type == _model_device().type and t.is_contiguous()
+                        and t.dtype == torch.float32):
+                    raise RuntimeError('model tables must be contiguous fp32 tensors on the HIP device')
+            self._binding = _OptimizerBinding(self._optimizer, tables, self._sparse)
+        return self._binding
+
+    def _check_input(self, user_ids, item_ids, allow_items_none=False):
+        user_id_max = user_ids if isinstance(user_ids, int) else user_ids.max()
+        if user_id_max >= self._num_users:
+            raise ValueError('Maximum user id greater than number of users in model.')
+        if allow_items_none and item_ids is None:
+            return
+        item_id_max = item_ids if isinstance(item_ids, int) else item_ids.max()
+        if item_id_max >= self._num_items:
+            raise ValueError('Maximum item id greater than number of items in model.')
+
+    def _slk_tables(self):
+        w = self._net.tables()
+        return _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0], w[0].shape[1])
+
+    def fit(self, interactions, verbose=False):
+        """Fit the model; repeated calls resume from the current parameters and optimizer
+        state (implicit.py:184-252)."""
+        user_ids = interactions.user_ids.astype(np.int64)
+        item_ids = interactions.item_ids.astype(np.int64)
+
+        if not self._initialized:
+            self._initialize(interactions)
+
+        self._check_input(user_ids, item_ids)
+
+        binding = self._bind()
+        device = self._net.tables()[0].device
+        engine = _engine_for(device)
+        stream = _stream_for(device)
+        tables = self._slk_tables()
+        n = len(user_ids)
+        n_minibatches = (n + self._batch_size - 1) // self._batch_size
+        mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
+
+        for epoch_num in range(self._n_iter):
+            # host shuffle: numpy Fisher-Yates on the model's RandomState (torch_utils.py:35-52)
+            users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
+            d_users = torch.from_numpy(users).to(device)
+            d_items = torch.from_numpy(items).to(device)
+
+            # the negatives continue the same MT19937 stream on the GPU
+            engine.rng_set_state(self._random_state.get_state())
+            ostruct = binding.as_struct()
+            engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
+                                  self._batch_size, self._loss, self._num_negative_samples,
+                                  mb_loss.data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
+
+            # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch
+            epoch_loss = float(mb_loss.double().mean().item())
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def predict(self, user_ids, item_ids=None):
+        """Scores for one user against all/some items, or for explicit (user, item) pairs;
+        returns a flat np.float32 array (implicit.py:277-311)."""
+        self._check_input(user_ids, item_ids, allow_items_none=True)
+        self._net.train(False)
+
+        users, items, n = _predict_process_ids(user_ids, item_ids, self._num_items)
+        device = self._net.tables()[0].device
+        engine = _engine_for(device)
+        d_users = torch.from_numpy(users).to(device)
+        d_items = torch.from_numpy(items).to(device) if items is not None else None
+        out = torch.empty(n, dtype=torch.float32, device=device)
+        engine.bilinear_predict(self._slk_tables(), d_users.data_ptr(), users.size,
+                                d_items.data_ptr() if d_items is not None else None, n,
+                                out.data_ptr(), _stream_for(device))
+        return out.cpu().numpy().flatten()

@@ -1,0 +1,52 @@
+"""BilinearNet (mirrors spotlight/factorization/representations.py:10-91).
+
+A parameter holder: four embedding tables created in the reference's order (so that
+state_dict keys, repr and the torch-generator initialisation match).  Scoring, training
+and the optimizer update are done by csrc/slk_bilinear.hip directly on these tensors'
+storage; `forward` is provided for API parity and runs the same predict kernel.
+"""
+import torch
+import torch.nn as nn
+
+from spotlight_amd.layers import ScaledEmbedding, ZeroEmbedding
+
+
+class BilinearNet(nn.Module):
+
+    def __init__(self, num_users, num_items, embedding_dim=32, user_embedding_layer=None,
+                 item_embedding_layer=None, sparse=False):
+        super(BilinearNet, self).__init__()
+        self.embedding_dim = embedding_dim
+        if user_embedding_layer is not None:
+            self.user_embeddings = user_embedding_layer
+        else:
+            self.user_embeddings = ScaledEmbedding(num_users, embedding_dim, sparse=sparse)
+        if item_embedding_layer is not None:
+            self.item_embeddings = item_embedding_layer
+        else:
+            self.item_embeddings = ScaledEmbedding(num_items, embedding_dim, sparse=sparse)
+        self.user_biases = ZeroEmbedding(num_users, 1, sparse=sparse)
+        self.item_biases = ZeroEmbedding(num_items, 1, sparse=sparse)
+
+    def tables(self):
+        """The four fp32 tables in the C ABI's order (include/spotlight_hip.h: slk_tables)."""
+        return [self.user_embeddings.weight, self.item_embeddings.weight,
+                self.user_biases.weight, self.item_biases.weight]
+
+    def forward(self, user_ids, item_ids):
+        """score[k] = <U[user_k], V[item_k]> + bu[user_k] + bi[item_k]  (no autograd: the
+        backward of this model lives in the fused training kernels)."""
+        from spotlight_amd.factorization import implicit as host
+        w = self.tables()
+        if w[0].device.type != host._model_device().type:
+            raise RuntimeError('BilinearNet.forward runs on the HIP device only (no CPU path)')
+        users = user_ids.reshape(-1).to(device=w[0].device, dtype=torch.int64).contiguous()
+        items = item_ids.reshape(-1).to(device=w[0].device, dtype=torch.int64).contiguous()
+        out = torch.empty(items.numel(), dtype=torch.float32, device=w[0].device)
+        eng = host._engine_for(w[0].device)
+        from spotlight_amd import _native
+        tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0],
+                                     w[0].shape[1])
+        eng.bilinear_predict(tables, users.data_ptr(), users.numel(), items.data_ptr(), items.numel(),
+                             out.data_ptr(), host._stream_for(w[0].device))
+        return out

@@ -1,7 +1,8 @@
 """TEST HARNESS: drives the engine's C ABI through the fiber-emulator build of the same
 sources (tests/emu), with numpy arrays standing in for device memory.  This checks kernel
 indexing / sort-key / segment logic and the host control flow on a box without a GPU; the
-`-m gpu` tests run the real gfx950 library through the very same checks."""
+`-m gpu` tests run the real gfx950 library through the very same checks
+(tests/hip_backend.py)."""
 import ctypes as C
 import os
 import sys
@@ -24,19 +25,35 @@ def emu_lib():
     return _EMU
 
 
-def ptr(a):
-    return a.ctypes.data if a is not None else None
+class _Model(object):
+    def __init__(self, be, params, opt='adagrad', **hp):
+        f = lambda x: be.alloc(np.array(x, dtype=np.float32, order='C'))
+        self.p = [f(params[0]), f(params[1]), f(np.asarray(params[2]).reshape(-1)), f(np.asarray(params[3]).reshape(-1))]
+        self.s1 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
+        self.s2 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
+        U, D = be.get(self.p[0]).shape
+        I = be.get(self.p[1]).shape[0]
+        self.tables = _native.make_tables([be.ptr(x) for x in self.p], U, I, D)
+        self.optim = _native.make_optim(opt, [be.ptr(x) for x in self.s1], [be.ptr(x) for x in self.s2], **hp)
 
 
-class HostModel(object):
-    """fp32 numpy tables + optimizer state laid out for the C ABI (emulator: host memory)."""
+class EmuBackend(object):
+    stream = 0
 
-    def __init__(self, params, opt='adagrad', state1=None, state2=None, **hp):
-        self.p = [np.array(x, dtype=np.float32, order='C', copy=True) for x in params]
-        self.p[2] = self.p[2].reshape(-1)
-        self.p[3] = self.p[3].reshape(-1)
-        self.s1 = [np.array(s, np.float32, copy=True) for s in state1] if state1 else [np.zeros_like(x) for x in self.p]
-        self.s2 = [np.array(s, np.float32, copy=True) for s in state2] if state2 else [np.zeros_like(x) for x in self.p]
-        U, D = self.p[0].shape
-        self.tables = _native.make_tables([ptr(x) for x in self.p], U, self.p[1].shape[0], D)
-        self.optim = _native.make_optim(opt, [ptr(x) for x in self.s1], [ptr(x) for x in self.s2], **hp)
+    def __init__(self):
+        self.engine = _native.Engine(0, lib=emu_lib())
+
+    def alloc(self, a):
+        return np.array(a, order='C', copy=True)
+
+    def ptr(self, a):
+        return a.ctypes.data if a is not None else None
+
+    def get(self, a):
+        return a
+
+    def model(self, params, opt='adagrad', **hp):
+        return _Model(self, params, opt, **hp)
+
+    def close(self):
+        self.engine.close()

@@ -1,0 +1,173 @@
+"""Backend-agnostic parity checks of the engine's C ABI against the CPU oracle / numpy /
+the golden vectors.  `be` is a backend: tests/emu_backend.EmuBackend (fiber emulator, numpy
+memory; runs anywhere) or tests/hip_backend.HipBackend (the real gfx950 library, torch device
+memory; `-m gpu`)."""
+import os
+
+import numpy as np
+
+from oracle.oracle import BilinearOracle, Rng
+from oracle.replay import ORACLE_OPT, oracle_hparams
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def check_sampler_bit_exact(be, num_items, counts=(1, 5, 700, 3000)):
+    eng = be.engine
+    rs = np.random.RandomState(1234)
+    rs.randint(0, 10, 77)  # start mid-block
+    eng.rng_set_state(rs.get_state())
+    for count in counts:
+        out = be.alloc(np.full(count, -1, dtype=np.int64))
+        eng.sample_items(num_items, count, be.ptr(out), be.stream)
+        want = rs.randint(0, num_items, count, dtype=np.int64)
+        assert (be.get(out) == want).all()
+        got, ref = eng.rng_get_state(), rs.get_state()
+        assert (got[1] == ref[1]).all() and got[2] == ref[2]
+
+
+def check_sampler_block_boundaries(be):
+    eng = be.engine
+    rs = np.random.RandomState(42)  # pos == 624: regenerate-on-first-draw
+    eng.rng_set_state(rs.get_state())
+    for count in (624, 1, 623, 1248):
+        out = be.alloc(np.empty(count, dtype=np.int64))
+        eng.sample_items(2 ** 32, count, be.ptr(out), be.stream)  # every word accepted
+        assert (be.get(out) == rs.randint(0, 2 ** 32, count, dtype=np.int64)).all()
+        got, ref = eng.rng_get_state(), rs.get_state()
+        assert (got[1] == ref[1]).all() and got[2] == ref[2]
+
+
+def check_train_matches_oracle(be, loss, opt, D, U=37, I=29, N=150, B=64, nn=3, epochs=2, tol=2e-5,
+                               seed=5):
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    params = [rs.normal(0, 0.3, (U, D)), rs.normal(0, 0.3, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    ora = BilinearOracle(*params, opt=opt, sparse_grads=True, **hp)
+    dev = be.model(params, opt=opt, **hp)
+    state = np.random.RandomState(9).get_state()
+    orng = Rng(state=state)
+    eng.rng_set_state(state)
+    n_mb = (N + B - 1) // B
+    d_users, d_items = be.alloc(users), be.alloc(items)
+    for epoch in range(epochs):
+        want_loss, want_neg = ora.train(orng, users, items, B, loss=loss, n_neg=nn, want_negs=True)
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.full(want_neg.size, -1, dtype=np.int64))
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
+                           be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+        assert (be.get(neg_out) == want_neg).all()
+        assert np.abs(be.get(mb_loss) - want_loss).max() / np.abs(want_loss).max() < 1e-5
+    assert dev.optim.step == ora.step_count == epochs * n_mb
+    for t in range(4):
+        assert rel_inf(be.get(dev.p[t]), ora.p[t]) < tol, t
+        assert rel_inf(be.get(dev.s1[t]), ora.s1[t]) < tol, t
+        if opt in ('sparse_adam', 'adam_dense'):
+            assert rel_inf(be.get(dev.s2[t]), ora.s2[t]) < tol, t
+    got, ref = eng.rng_get_state(), orng.get_state()
+    assert (got[1] == ref[1]).all() and got[2] == ref[2]
+    # predict on the engine's own tables: scalar user vs all items, and explicit pairs
+    # (factorization/implicit.py:277-311)
+    P = [be.get(x).astype(np.float64) for x in dev.p]
+    score = lambda u, i: (P[0][u] * P[1][i]).sum(-1) + P[2][u] + P[3][i]
+    uq = min(3, U - 1)
+    out = be.alloc(np.empty(I, dtype=np.float32))
+    d_u = be.alloc(np.array([uq], dtype=np.int64))
+    eng.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, I, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), score(np.full(I, uq), np.arange(I))) < 1e-5
+    m = min(50, N)
+    pu, pi = users[:m].copy(), items[:m].copy()
+    out = be.alloc(np.empty(m, dtype=np.float32))
+    d_pu, d_pi = be.alloc(pu), be.alloc(pi)
+    eng.bilinear_predict(dev.tables, be.ptr(d_pu), m, be.ptr(d_pi), m, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), score(pu, pi)) < 1e-5
+
+
+def check_single_step_gradients(be, loss, D, U=50, I=40, B=128, nn=3, seed=11):
+    """Identical minibatch, identical parameters: loss within 1e-5 rel, summed gradients
+    within 1e-5 of each table's inf-norm (bias tables: of their joint norm, the user-bias
+    gradient being a sum of cancelling +g/-g terms).  The engine's gradient is read back
+    through the ADAM_DENSE accumulate-only mode with lr = 0 (parameters stay put)."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, B).astype(np.int64)
+    items = rs.randint(0, I, B).astype(np.int64)
+    n_draw = B * (nn if loss == 'adaptive_hinge' else 1)
+    negs = rs.randint(0, I, n_draw).astype(np.int64)
+    params = [rs.normal(0, 0.5, (U, D)), rs.normal(0, 0.5, (I, D)), rs.normal(0, 0.2, U), rs.normal(0, 0.2, I)]
+    ora = BilinearOracle(*params, opt='adagrad', sparse_grads=True)
+    want_loss, want_g = ora.step(users, items, negs, loss=loss, n_neg=nn, want_grads=True)
+    # beta1 = 0 => exp_avg after one step == the gradient itself
+    dev = be.model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999))
+    mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+    d_users, d_items, d_negs = be.alloc(users), be.alloc(items), be.alloc(negs)
+    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), B, B, loss, nn,
+                       be.ptr(mb_loss), d_neg_in=be.ptr(d_negs), stream=be.stream)
+    assert abs(float(be.get(mb_loss)[0]) - want_loss) / abs(want_loss) < 1e-5
+    got = [be.get(dev.s1[t]) for t in range(4)]
+    bscale = max(np.abs(want_g[2]).max(), np.abs(want_g[3]).max())
+    for t in range(4):
+        scale = np.abs(want_g[t]).max() if t < 2 else bscale
+        assert np.abs(got[t].ravel() - want_g[t].ravel()).max() <= 1e-5 * scale, t
+    for t in range(4):  # lr = 0: parameters untouched
+        assert np.array_equal(be.get(dev.p[t]).ravel(), np.asarray(params[t], np.float32).ravel())
+
+
+def check_replays_reference_fixture(be, golden_dir, name):
+    """Golden vectors recorded from the live reference: same shuffled ids, same seed ->
+    bit-exact negatives, losses within 1e-5 (first minibatch) / 1e-3 (trajectory)."""
+    from oracle.replay import case_from_rec
+    eng = be.engine
+    rec = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = case_from_rec(rec)
+    hp = oracle_hparams(case)
+    hp.pop('sparse_grads')
+    dev = be.model([rec['init_%d' % t] for t in range(4)], opt=ORACLE_OPT[case['opt']], **hp)
+    eng.rng_set_state(('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    host = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, B = int(case['N']), int(case['B'])
+    n_mb = (N + B - 1) // B
+    losses, negs = [], []
+    for e in range(int(case['n_iter'])):
+        # the shuffle stays on the host (torch_utils.py:35-52) and shares the stream
+        host.set_state(eng.rng_get_state())
+        perm = host.shuffle_perm(N)
+        eng.rng_set_state(host.get_state())
+        su = rec['users'].astype(np.int64)[perm]
+        si = rec['items'].astype(np.int64)[perm]
+        assert (su == rec['shuffled_users'][e]).all()
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.empty(N * nn, dtype=np.int64))
+        d_su, d_si = be.alloc(su), be.alloc(si)
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_su), be.ptr(d_si), N, B,
+                           str(case['loss']), nn, be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+        losses.append(be.get(mb_loss))
+        negs.append(be.get(neg_out))
+    assert (np.concatenate(negs) == rec['negatives']).all()
+    losses = np.concatenate(losses)
+    assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
+    # later minibatches: trajectories are only conditionally stable (see oracle/make_golden.py:
+    # Adagrad's first step is lr*g/(|g|+1e-10), and at init bpr gradients of an item that is
+    # positive in one interaction and negative in another cancel to ~1e-11, so the update
+    # depends on summation order -- torch's own dense and sparse paths differ by this much)
+    assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
+    st = eng.rng_get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    for t in range(4):
+        ref = rec['final_%d' % t]
+        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
+        assert bad.mean() <= 0.05, (t, bad.mean())
+
+
+ALL_LOSSES = ('pointwise', 'bpr', 'hinge', 'adaptive_hinge')
+ALL_OPTS = ('adagrad', 'sparse_adam', 'adam_dense', 'adagrad_dense')
+FIXTURES = ['bpr_adagrad_sparse', 'hinge_sparse_adam', 'pointwise_adam_default', 'adaptive_hinge_adagrad',
+            'd64_bpr_adagrad', 'd64_adaptive_sparse_adam', 'c1_bpr_adam', 'c1_bpr_adagrad',
+            'd12_pointwise_adagrad_wd']
