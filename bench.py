@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- training interactions/sec of the fused BPR embedding step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one minibatch of the hot path (SURVEY.md 8(d), config C2 of BASELINE.json):
+synthetic uniform ids over 10M users x 1M items, dim 64, bpr loss, Adagrad(lr=1e-2), batch
+1,048,576 -- on-GPU numpy-exact negative draw, radix-sort grouping, user pass, item pass
+(gather + dot + loss + backward + optimizer), all inside the timed region, ids resident in
+HBM beforehand.  value = interactions processed by all ranks / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel: algorithmic bytes per launch / mean launch
+               duration from hipEvents recorded on the launch stream (slk_profile_*)
+  cpu_baseline oracle/slk_oracle.c (scalar C port of the reference path, 1 thread) timed on
+               the host on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from spotlight_amd import _native  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def algorithmic_bytes(dim, opt_state_words):
+    """per interaction, fp32, int64 ids, no credit for cache hits/duplicates.
+    user pass: user row param R+W + state R+W, two item rows read, user/pos/neg ids, user bias
+    R+W(+state), two item-bias reads; item pass: two item rows written + state R+W, two item
+    biases written + state R+W."""
+    s = opt_state_words
+    user_pass = (8 * dim + 8 * dim * s) + 2 * 4 * dim + 16 + (8 + 8 * s) + 8
+    item_pass = 2 * (4 * dim + 8 * dim * s) + 2 * (4 + 8 * s)
+    return user_pass, item_pass
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--users', type=int, default=10_000_000)
+    ap.add_argument('--items', type=int, default=1_000_000)
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--batch', type=int, default=1 << 20)
+    ap.add_argument('--loss', default='bpr')
+    ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (CPU port of spotlight/factorization/implicit.py:223-243 with a row-sparse
+    Adagrad, i.e. the reference's sparse=True + Adagrad path) on the same table shapes."""
+    from oracle.oracle import BilinearOracle, Rng
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 16 << 30
+    U, I, D = args.users, args.items, args.dim
+    need = (U + I) * D * 4 * 5
+    note = ''
+    while need > 0.6 * avail and U > 100_000:
+        U //= 2
+        need = (U + I) * D * 4 * 5
+        note = ' (user table scaled to %d rows to fit host RAM)' % U
+    rs = np.random.default_rng(0)
+    block = (rs.standard_normal(1 << 20, dtype=np.float32) / D)
+    p = [np.resize(block, (U, D)), np.resize(block, (I, D)), np.zeros(U, np.float32), np.zeros(I, np.float32)]
+    ora = BilinearOracle(*p, opt=args.opt, lr=1e-2, sparse_grads=True)
+    del p
+    rng = Rng(seed=1)
+    B = min(args.batch, 1 << 18)
+    done, t_total = 0, 0.0
+    # warm the page tables of the gradient buffers with one untimed minibatch
+    users, items = rs.integers(0, U, B), rs.integers(0, I, B)
+    ora.train(rng, users, items, B, loss=args.loss)
+    while t_total < seconds and done < (1 << 24):
+        users, items = rs.integers(0, U, B), rs.integers(0, I, B)
+        t0 = time.perf_counter()
+        ora.train(rng, users, items, B, loss=args.loss)
+        t_total += time.perf_counter() - t0
+        done += B
+    return {'value': done / t_total, 'unit': 'interactions/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d minibatches of %d interactions, same table shapes%s, oracle/slk_oracle.c '
+                      'single thread (%d host cores present)' % (done // B, B, note, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    U, I, D, B = args.users, args.items, args.dim, args.batch
+    K, W = args.steps, args.warmup
+
+    eng = _native.Engine(local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen),
+              torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen),
+              torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
+    s1 = [torch.zeros_like(t) for t in tables]
+    s2 = [torch.zeros_like(t) for t in tables] if args.opt == 'sparse_adam' else None
+    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
+    op = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None,
+                            lr=1e-2)
+    n_total = (W + K) * B
+    users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    items = torch.randint(0, I, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    mb_loss = torch.zeros(W + K, device=dev)
+    eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(first_mb, n_mb):
+        off = first_mb * B
+        eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, 1,
+                           mb_loss[first_mb:].data_ptr(), stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    if W:
+        run(0, W)
+    barrier()
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    run(W, K)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    prof = eng.profile_read()
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    losses = mb_loss.cpu().numpy()
+    assert np.isfinite(losses).all() and (losses[W:] > 0).all(), losses
+
+    if rank == 0:
+        value = world * K * B / elapsed
+        s_words = 1 if args.opt == 'adagrad' else 2
+        ub, ib = algorithmic_bytes(D, s_words)
+        kern = {}
+        for name, per_int in (('user_pass', ub), ('item_pass', ib)):
+            n, ms = prof[name]
+            avg_s = ms / max(n, 1) * 1e-3
+            kern[name] = {'launches': n, 'avg_ms': ms / max(n, 1), 'alg_bytes_per_launch': per_int * B,
+                          'achieved_GBs': per_int * B / avg_s / 1e9 if avg_s > 0 else 0.0}
+        dom = max(kern, key=lambda k: kern[k]['avg_ms'])
+        roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': kern[dom]['achieved_GBs'],
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kern[dom]['achieved_GBs'] / HBM_PEAK_GBS,
+                'traffic': None,
+                'kernels': kern,
+                'step_alg_bytes_per_interaction': ub + ib,
+                'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
+                'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep')}}
+        out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
+               'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+               'data': 'synthetic',
+               'config': {'workload': 'C2: synthetic uniform ids, %d users x %d items, dim %d, %s loss, '
+                                      '%s lr=1e-2, minibatch %d, on-GPU numpy-exact negatives'
+                                      % (U, I, D, args.loss, args.opt, B),
+                          'global_batch': B * world,
+                          'parallelism': 'single GPU' if world == 1 else
+                          'replicas only: %d independent models, one per GPU (row-sharded exchange path '
+                          'not built yet)' % world},
+               'roofline': roof,
+               'final_minibatch_loss': float(losses[-1])}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
