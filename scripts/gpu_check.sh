@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs on the MI355X box via gpurun: parity tests, smoke, bench, rocprofv3 kernel stats.
+# usage: scripts/gpu_check.sh <tag> [stages...]   stages: tests smoke bench prof pmc
+set -u
+TAG=${1:-r1}; shift || true
+STAGES=${@:-tests smoke bench prof}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+export TMPDIR=/tmp
+for st in $STAGES; do
+  case $st in
+    tests)
+      timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+      echo "pytest exit $?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
+    prof)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err)
+      echo "prof exit $?"; find $OUT/prof -name "*kernel_stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+    pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 900 rocprofv3 --pmc $c -d $OUT/pmc_$c -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err)
+        echo "pmc $c exit $?"
+      done ;;
+  esac
+done
+rocm-smi --showmeminfo vram 2>/dev/null | head -8 > $OUT/smi.txt

@@ -33,7 +33,7 @@ def _model_for(case):
 
 @pytest.mark.parametrize('name', ['bpr_adam_default', 'hinge_adagrad_sparse', 'pointwise_sparse_adam',
                                   'adaptive_hinge_adagrad', 'adaptive_hinge_sparse_adam', 'c1_bpr_adam',
-                                  'd64_bpr_adagrad'])
+                                  'd64_adaptive_sparse_adam'])
 def test_fit_predict_match_reference_run(name):
     from spotlight_amd.interactions import Interactions
     rec = np.load(os.path.join(GOLDEN, name + '.npz'))
