@@ -12,10 +12,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['slk_api.hip', 'slk_sort.hip', 'slk_rng.hip', 'slk_bilinear.hip']
+SOURCES = ['slk_api.hip', 'slk_sort.hip', 'slk_rng.hip', 'slk_mtjump.hip', 'slk_bilinear.hip']
 HEADERS = ['slk_common.h', os.path.join('..', '..', 'include', 'spotlight_hip.h')]
 LIB = os.path.join(CSRC, 'libspotlight_hip.so')
 ARCH = 'gfx950'
+# -ffp-contract=off: torch's eager ops round every product before adding; with FMA contraction
+# gp*v_pos + gn*v_neg does not cancel to an exact 0.0 when an interaction's sampled negative
+# equals its positive (gn == -gp), and Adagrad turns that 1e-11 residue into an O(lr) update.
+# The path is HBM-bound, so the extra VALU op is free.
 
 
 def _stale(target, deps):
@@ -41,7 +45,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
+            cmd = [hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
                    '-Wall', '-Wno-unused-function', '-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))

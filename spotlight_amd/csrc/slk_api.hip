@@ -112,11 +112,12 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     slk_buf *bufs[] = {&ctx->raw, &ctx->cnt, &ctx->neg32, &ctx->ukey[0], &ctx->ukey[1], &ctx->uval[0],
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
-                       &ctx->ipay[1], &ctx->gbuf, &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
+                       &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3]};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
+    if (ctx->d_jump) (void)hipFree(ctx->d_jump);
     delete ctx;
 }
 

@@ -45,8 +45,9 @@ struct slk_pass_args {
     const uint32_t *uk;      // sorted position -> chunk-local interaction index (PRE mode)
     const float *gk;         // PRE mode: dL/dscore per (interaction, pair)
     float *sk;               // PRE mode: scores per (interaction, pair)
-    float *gbuf;             // [pos*NP + s] dL/dscore, written by the user pass
-    float *snap;             // [(pos - begin)*D] pre-step user rows
+    float *snap;             // [(pos - begin)*RS]: record = pre-step user row (D floats) followed by the
+                             // NP dL/dscore values of that position (padded to a multiple of 4)
+    int RS;                  // record stride in floats
     const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
     uint32_t imask;
     const uint32_t *ipay;    // occurrence -> pos*NP + s
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         float gbu = 0.0f;
         uint32_t q = p;
         do {
-            if (on) slk_vstore<VEC>(a.snap + (size_t)(q - a.begin) * D + d0, u);
+            float *rec = a.snap + (size_t)(q - a.begin) * a.RS;
+            if (on) slk_vstore<VEC>(rec + d0, u);
             if (!PRE) {
                 const uint32_t ip = a.uit[2 * (size_t)q], in = a.uit[2 * (size_t)q + 1];
                 const slk_vec<VEC> vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
@@ -163,15 +165,15 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
                 gbu += gp + gn;
                 if (lane == 0) {
-                    a.gbuf[2 * (size_t)q] = gp;
-                    a.gbuf[2 * (size_t)q + 1] = gn;
+                    rec[D] = gp;
+                    rec[D + 1] = gn;
                     loss_acc += l;
                 }
             } else {
                 const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
                 for (int s = 0; s < a.NP; ++s) {
                     const float g = a.gk[kb + s];
-                    if (lane == 0) a.gbuf[qb + s] = g;
+                    if (lane == 0) rec[D + s] = g;
                     if (g != 0.0f) {
                         const uint32_t it = a.uit[qb + s];
                         const slk_vec<VEC> v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
@@ -195,17 +197,30 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
 // ---------------------------------------------------------------------------------------
 // ITEM PASS
 // ---------------------------------------------------------------------------------------
+// A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
+// list.  Per tile: (1) keys + payloads -> LDS; (2) all row groups gather the records of the
+// tile's positions round-robin (every load independent: memory-level parallelism instead of a
+// per-segment dependent chain) and park g * u_old in LDS; (3) each run of equal keys that
+// STARTS in the tile is summed from LDS by one group (runs that spill past the tile end are
+// finished from global memory; rows of a run that started in an earlier tile are skipped --
+// its owner already took them) and the optimizer is applied to that item's row and bias.
 template <int VEC, int G, int UPD>
 __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
-    __shared__ double red[256];
     constexpr int GPB = 256 / G;
+    constexpr int T = 4 * GPB;
+    constexpr int DL = G * VEC;  // LDS row length (>= D)
+    __shared__ double red[256];
+    __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
+    __shared__ uint32_t s_pay[T];
+    __shared__ float s_g[T];
+    __shared__ __attribute__((aligned(16))) float s_row[T * DL];
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int D = a.D;
     const int d0 = lane * VEC;
     const bool on = d0 < D;
-    const uint32_t stride = gridDim.x * GPB;
-    const uint32_t ibegin = a.begin * a.NP, iend = a.end * a.NP;
+    const uint32_t NP = (uint32_t)a.NP;
+    const uint32_t ibegin = a.begin * NP, iend = a.end * NP;
 
     if (blockIdx.x == 0) {
         // loss.item() of this minibatch: mean over the minibatch of the per-interaction loss
@@ -215,38 +230,94 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
         if (threadIdx.x == 0) *a.mb_loss_out = (float)(tot * (double)a.inv_b);
     }
 
-    for (uint32_t p = ibegin + blockIdx.x * GPB + grp; p < iend; p += stride) {
-        const uint32_t key = a.ikey[p];
-        if (p > ibegin && a.ikey[p - 1] == key) continue;
-        const uint32_t item = key & a.imask;
-        slk_vec<VEC> gv = slk_vzero<VEC>();
-        float gb = 0.0f;
-        bool any = false;
-        uint32_t q = p;
-        do {
-            const uint32_t r = a.ipay[q];
-            const float g = a.gbuf[r];
-            if (g != 0.0f) {
-                const uint32_t pos = (a.NP == 2) ? (r >> 1) : (r / (uint32_t)a.NP);
-                const slk_vec<VEC> u =
-                    on ? slk_vload<VEC>(a.snap + (size_t)(pos - a.begin) * D + d0) : slk_vzero<VEC>();
-                slk_vaxpy<VEC>(gv, g, u);
-                gb += g;
-                any = true;
-            }
-            ++q;
-        } while (q < iend && a.ikey[q] == key);
+    const uint32_t ntiles = (iend - ibegin + T - 1) / T;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t tb = ibegin + tile * T;
+        const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
+        const bool first_tile = tb == ibegin;
+        __syncthreads();  // LDS of the previous tile no longer in use
+        for (int i = threadIdx.x; i <= tn; i += 256)
+            s_key[i] = (i == 0 && first_tile) ? 0u : a.ikey[tb - 1 + i];
+        for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = a.ipay[tb + i];
+        __syncthreads();
 
-        // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
-        // moments of every looked-up row (torch coalesces zero-valued rows too).
-        if (UPD == SLK_UPD_ADAGRAD && !any) continue;
-        if (UPD == SLK_UPD_GRAD_ONLY && !any) continue;
-        const size_t voff = (size_t)item * D + d0;
-        if (on) {
-            slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
-            slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
+        // (2) gather: position j = grp + it * GPB
+        slk_vec<VEC> u[4];
+        float g[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = grp + it * GPB;
+            g[it] = 0.0f;
+            u[it] = slk_vzero<VEC>();
+            // rows of the run inherited from the previous tile belong to that tile's owner
+            const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
+            if (mine) {
+                const uint32_t r = s_pay[j];
+                const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
+                const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
+                g[it] = rec[D + (r - pos * NP)];
+                if (on) u[it] = slk_vload<VEC>(rec + d0);
+            }
         }
-        if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = grp + it * GPB;
+            if (j < tn) {
+                slk_vec<VEC> c;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c.v[i] = g[it] * u[it].v[i];
+                slk_vstore<VEC>(s_row + j * DL + d0, c);
+                if (lane == 0) s_g[j] = g[it];
+            }
+        }
+        __syncthreads();
+
+        // (3) one group per run that starts in this tile
+        for (int j = grp; j < tn; j += GPB) {
+            const uint32_t key = s_key[j + 1];
+            const bool head = (j == 0 && first_tile) || key != s_key[j];
+            if (!head) continue;
+            slk_vec<VEC> gv = slk_vzero<VEC>();
+            float gb = 0.0f;
+            bool any = false;
+            int k = j;
+            do {
+                const float gk = s_g[k];
+                if (gk != 0.0f) {
+                    const slk_vec<VEC> c = slk_vload<VEC>(s_row + k * DL + d0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv.v[i] += c.v[i];
+                    gb += gk;
+                    any = true;
+                }
+                ++k;
+            } while (k < tn && s_key[k + 1] == key);
+            if (k == tn) {  // the run may continue in the following tiles
+                for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
+                    const uint32_t r = a.ipay[q];
+                    const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
+                    const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
+                    const float gk = rec[D + (r - pos * NP)];
+                    if (gk != 0.0f) {
+                        const slk_vec<VEC> uu = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gv.v[i] += gk * uu.v[i];
+                        gb += gk;
+                        any = true;
+                    }
+                }
+            }
+            // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
+            // moments of every looked-up row (torch coalesces zero-valued rows too).
+            if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
+            const uint32_t item = key & a.imask;
+            const size_t voff = (size_t)item * D + d0;
+            if (on) {
+                slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
+                slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
+            }
+            if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
+        }
     }
 }
 
@@ -586,8 +657,8 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
         if ((rc = slk_ensure(ctx, ctx->ikey[b], nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->ipay[b], nc_max * NP * 4))) return rc;
     }
-    if ((rc = slk_ensure(ctx, ctx->gbuf, nc_max * NP * 4))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * D * 4))) return rc;
+    const int RS = D + ((NP + 3) / 4) * 4;  // record = user row + NP dL/dscore, 16-B granular
+    if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
     const unsigned max_grid = (unsigned)ctx->num_cus * 8;
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     if (adaptive) {
@@ -700,8 +771,8 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
             a.uk = uk;
             a.gk = (const float *)ctx->gk.p;
             a.sk = (float *)ctx->sk.p;
-            a.gbuf = (float *)ctx->gbuf.p;
             a.snap = (float *)ctx->snap.p;
+            a.RS = RS;
             a.ikey = (const uint32_t *)ctx->ikey[1].p;
             a.imask = (uint32_t)((1ull << ibits) - 1);
             a.ipay = (const uint32_t *)ctx->ipay[1].p;
@@ -719,7 +790,7 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
                 a.c_omb2 = (float)(1.0 - optim->beta2);
             }
             const unsigned ugrid = grid_for(ctx, bm, gpb);
-            const unsigned igrid = grid_for(ctx, (size_t)bm * NP, gpb);
+            const unsigned igrid = grid_for(ctx, (size_t)bm * NP, 4 * gpb);  // one tile per block-iteration
 
             if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);

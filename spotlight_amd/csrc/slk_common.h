@@ -39,9 +39,10 @@ struct slk_ctx {
     char err[512] = {0};
     hipStream_t last_stream = nullptr;
     slk_rng_dev *d_rng = nullptr;
+    uint32_t *d_jump = nullptr;  // device copy of the jump polynomial table
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
-    slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gbuf, gk, sk, snap, losspart,
+    slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
         sort_tmp, dgrad[4];
     size_t dgrad_elems[4] = {0, 0, 0, 0};
 
@@ -73,6 +74,13 @@ int slk_prof_drain(slk_ctx *ctx);
         if (e_ != hipSuccess)                                                                \
             return slk_fail((ctx), SLK_EIO, "launch of %s failed: %s", (what), hipGetErrorString(e_)); \
     } while (0)
+
+// MT19937 jump-ahead geometry: workgroup w of k_mt_generate_jump produces state blocks
+// [w*SLK_MT_JUMP_BLOCKS, (w+1)*SLK_MT_JUMP_BLOCKS); one launch covers up to
+// SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS blocks of 624 words (10.2 M words).
+#define SLK_MT_JUMP_BLOCKS 128
+#define SLK_MT_JUMP_WG 128
+const uint32_t *slk_mt_jump_table(slk_ctx *ctx);  // slk_mtjump.hip (host)
 
 // sampler (slk_rng.hip): `count` negatives into ctx->neg32 (uint32) [+ int64 copy to d_out64]
 int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,

@@ -32,36 +32,79 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// raw[0..624) = current key block; raw[b*624 ..] = state after b regenerations.
-__global__ __launch_bounds__(256) void k_mt_generate(const slk_rng_dev *st, uint32_t *raw, int nblocks) {
-    __shared__ uint32_t s[2][SLK_MT_N];
-    const int t = threadIdx.x;
-    for (int i = t; i < SLK_MT_N; i += 256) {
-        const uint32_t k = st->key[i];
-        s[0][i] = k;
-        raw[i] = k;
+// One regeneration: n[0..624) = next state block of o[0..624) (both in LDS).  The twist
+// x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old
+// words, [227,454) need the first round, [454,624) the second.  Ends with a barrier.
+__device__ __forceinline__ void mt_regen_block(const uint32_t *o, uint32_t *n, int t) {
+    if (t < 227) n[t] = mt_twist(o[t], o[t + 1], o[t + 397]);
+    __syncthreads();
+    if (t < 227) {
+        const int i = t + 227;
+        n[i] = mt_twist(o[i], o[i + 1], n[i - 227]);
     }
     __syncthreads();
-    int cur = 0;
-    for (int b = 1; b < nblocks; ++b) {
-        const uint32_t *o = s[cur];
-        uint32_t *n = s[cur ^ 1];
-        if (t < 227) n[t] = mt_twist(o[t], o[t + 1], o[t + 397]);
+    if (t < 170) {
+        const int i = t + 454;
+        const uint32_t nx = (i == SLK_MT_N - 1) ? n[0] : o[i + 1];
+        n[i] = mt_twist(o[i], nx, n[i - 227]);
+    }
+    __syncthreads();
+}
+
+#define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
+#define SLK_MT_LDS_WORDS (SLK_MT_PREFIX_BLOCKS * SLK_MT_N + 2 * SLK_MT_N)
+
+// raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.
+// Workgroup w owns blocks [w*L, (w+1)*L).  w > 0 first jumps to block w*L:
+//   x[624 m + j] = XOR_{i in g_m} x[1 + i + j]   (slk_mtjump.hip), evaluated from a 33-block
+// prefix of the stream that every workgroup regenerates for itself in LDS.
+__global__ __launch_bounds__(256) void k_mt_generate_jump(const uint32_t *key_src, const uint32_t *polys,
+                                                          uint32_t *raw, int nblocks) {
+    HIP_DYNAMIC_SHARED(uint32_t, lds)
+    uint32_t *X = lds;
+    uint32_t *pp0 = lds + SLK_MT_PREFIX_BLOCKS * SLK_MT_N;
+    uint32_t *pp1 = pp0 + SLK_MT_N;
+    const int t = threadIdx.x;
+    const int first = (int)blockIdx.x * SLK_MT_JUMP_BLOCKS;
+    if (first >= nblocks) return;
+    const int last = (first + SLK_MT_JUMP_BLOCKS < nblocks) ? first + SLK_MT_JUMP_BLOCKS : nblocks;
+
+    for (int i = t; i < SLK_MT_N; i += 256) X[i] = key_src[i];
+    const uint32_t *cur = X;
+    if (blockIdx.x > 0) {
+        const uint32_t *g = polys + (size_t)(blockIdx.x - 1) * SLK_MT_N;
+        for (int i = t; i < SLK_MT_N; i += 256) pp1[i] = g[i];  // jump polynomial -> LDS
         __syncthreads();
-        if (t < 227) {
-            const int i = t + 227;
-            n[i] = mt_twist(o[i], o[i + 1], n[i - 227]);
+        for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b)
+            mt_regen_block(X + (b - 1) * SLK_MT_N, X + b * SLK_MT_N, t);
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+        const bool third = t < SLK_MT_N - 512;
+        for (int wi = 0; wi < SLK_MT_N; ++wi) {
+            uint32_t gw = pp1[wi];
+            while (gw) {
+                const int bit = __ffs((int)gw) - 1;
+                gw &= gw - 1;
+                const uint32_t *p = X + 1 + wi * 32 + bit + t;
+                a0 ^= p[0];
+                a1 ^= p[256];
+                if (third) a2 ^= p[512];
+            }
         }
         __syncthreads();
-        if (t < 170) {
-            const int i = t + 454;
-            const uint32_t nx = (i == SLK_MT_N - 1) ? n[0] : o[i + 1];
-            n[i] = mt_twist(o[i], nx, n[i - 227]);
-        }
-        __syncthreads();
-        uint32_t *dst = raw + (size_t)b * SLK_MT_N;
-        for (int i = t; i < SLK_MT_N; i += 256) dst[i] = n[i];
-        cur ^= 1;
+        pp0[t] = a0;
+        pp0[t + 256] = a1;
+        if (third) pp0[t + 512] = a2;
+        cur = pp0;
+    }
+    __syncthreads();
+    uint32_t *dst = raw + (size_t)first * SLK_MT_N;
+    for (int i = t; i < SLK_MT_N; i += 256) dst[i] = cur[i];
+    for (int b = first + 1; b < last; ++b) {
+        uint32_t *nxt = (cur == pp0) ? pp1 : pp0;
+        mt_regen_block(cur, nxt, t);
+        dst = raw + (size_t)b * SLK_MT_N;
+        for (int i = t; i < SLK_MT_N; i += 256) dst[i] = nxt[i];
+        cur = nxt;
     }
 }
 
@@ -212,8 +255,37 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
     unsigned long long *off = (unsigned long long *)ctx->cnt.p;
     uint32_t *cnt = (uint32_t *)(off + nb);
 
-    hipLaunchKernelGGL(k_mt_generate, dim3(1), dim3(256), 0, s, (const slk_rng_dev *)ctx->d_rng, raw, (int)nblocks);
-    SLK_LAUNCH_CHECK(ctx, "k_mt_generate");
+    {
+        // block 0 of every launch is its input key block; further launches (> 10.2 M words)
+        // restart from the last block of the previous one
+        const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS;
+        const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_generate_jump,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        unsigned long long start = 0;  // index of the launch's block 0
+        const uint32_t *key_src = ctx->d_rng->key;
+        while (true) {
+            const unsigned long long nb_l = (nblocks - start < cap) ? nblocks - start : cap;
+            const unsigned wgs = (unsigned)((nb_l + SLK_MT_JUMP_BLOCKS - 1) / SLK_MT_JUMP_BLOCKS);
+            if (wgs > 1 && !ctx->d_jump) {
+                const uint32_t *tab = slk_mt_jump_table(ctx);
+                if (!tab) return SLK_EIO;
+                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_N * 4;
+                SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
+                SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
+            }
+            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(256), lds_bytes, s, key_src,
+                               (const uint32_t *)ctx->d_jump, raw + start * SLK_MT_N, (int)nb_l);
+            SLK_LAUNCH_CHECK(ctx, "k_mt_generate_jump");
+            if (start + nb_l >= nblocks) break;
+            start += nb_l - 1;
+            key_src = raw + start * SLK_MT_N;
+        }
+    }
     slk_accept_args a;
     a.raw = raw;
     a.st = ctx->d_rng;

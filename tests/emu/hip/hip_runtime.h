@@ -142,6 +142,9 @@ static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 static inline void __threadfence() {}
 
 #define __expf expf
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }

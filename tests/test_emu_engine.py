@@ -27,6 +27,12 @@ def test_sampler_fresh_seed_and_block_boundaries(be):
     ec.check_sampler_block_boundaries(be)
 
 
+def test_sampler_parallel_jump_ahead(be):
+    # > 128 state blocks: several workgroups, each jumping ahead with its GF(2) polynomial
+    ec.check_sampler_bit_exact(be, 10 ** 6, counts=(300000, 7, 90000))
+    ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 128 * 2 + 5,))
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
 @pytest.mark.parametrize('D', [8, 6])

@@ -27,6 +27,13 @@ def test_sampler_fresh_seed_and_block_boundaries(be):
     ec.check_sampler_block_boundaries(be)
 
 
+def test_sampler_parallel_jump_ahead(be):
+    # many workgroups jumping ahead; 12M draws also crosses the 10.2M-word launch limit
+    ec.check_sampler_bit_exact(be, 10 ** 6, counts=(300000, 7, 90000, 12000000))
+    ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 128 * 2 + 5, 624 * 128 * 128 + 1))
+    ec.check_sampler_bit_exact(be, 1682, counts=(5000000,))
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
 def test_train_matches_oracle(be, loss, opt):
