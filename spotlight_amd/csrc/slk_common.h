@@ -78,8 +78,10 @@ int slk_prof_drain(slk_ctx *ctx);
 // MT19937 jump-ahead geometry: workgroup w of k_mt_generate_jump produces state blocks
 // [w*SLK_MT_JUMP_BLOCKS, (w+1)*SLK_MT_JUMP_BLOCKS); one launch covers up to
 // SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS blocks of 624 words (10.2 M words).
-#define SLK_MT_JUMP_BLOCKS 128
-#define SLK_MT_JUMP_WG 128
+#define SLK_MT_JUMP_BLOCKS 64
+#define SLK_MT_JUMP_WG 256
+#define SLK_MT_JUMP_TERMS 10752                 // exponent-list capacity per polynomial (multiple of 8)
+#define SLK_MT_JUMP_PAD (33 * 624 - 1)          // exponent whose window X[1 + e + j] is the zero block
 const uint32_t *slk_mt_jump_table(slk_ctx *ctx);  // slk_mtjump.hip (host)
 
 // sampler (slk_rng.hip): `count` negatives into ctx->neg32 (uint32) [+ int64 copy to d_out64]

@@ -170,13 +170,16 @@ void xpow(const Field &F, clmul_fn cm, uint64_t e, uint64_t *r) {
 }
 
 std::mutex g_mu;
-std::vector<uint32_t> g_table;  // [SLK_MT_JUMP_WG - 1][624] u32 words, bit i of g at word i/32 bit i%32
+std::vector<uint32_t> g_table;  // [SLK_MT_JUMP_WG - 1][SLK_MT_JUMP_TERMS]: exponents of the set
+                                // coefficients of g_w, padded with SLK_MT_JUMP_PAD
 bool g_ok = false;
 
 }  // namespace
 
 // Host table of jump polynomials g_w = x^(624 * SLK_MT_JUMP_BLOCKS * w - 1) mod phi,
-// w = 1 .. SLK_MT_JUMP_WG-1, each 624 uint32 words; computed once per process (~0.1-1 s).
+// w = 1 .. SLK_MT_JUMP_WG-1, stored as exponent lists (~10k set coefficients each, padded to
+// SLK_MT_JUMP_TERMS with SLK_MT_JUMP_PAD, which the kernel maps onto a zeroed LDS block);
+// computed once per process (~0.1-1 s).
 const uint32_t *slk_mt_jump_table(slk_ctx *ctx) {
     std::lock_guard<std::mutex> lock(g_mu);
     if (g_ok) return g_table.data();
@@ -217,13 +220,20 @@ const uint32_t *slk_mt_jump_table(slk_ctx *ctx) {
             }
         }
     }
-    g_table.assign((size_t)(SLK_MT_JUMP_WG - 1) * 624, 0);
+    g_table.assign((size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS, (uint32_t)SLK_MT_JUMP_PAD);
     for (int w = 1; w < SLK_MT_JUMP_WG; ++w) {
-        uint32_t *dst = g_table.data() + (size_t)(w - 1) * 624;
-        for (int k = 0; k < NW; ++k) {
-            dst[2 * k] = (uint32_t)g[k];
-            dst[2 * k + 1] = (uint32_t)(g[k] >> 32);
-        }
+        uint32_t *dst = g_table.data() + (size_t)(w - 1) * SLK_MT_JUMP_TERMS;
+        int n = 0;
+        for (int i = 0; i < DEG; ++i)
+            if (getbit(g.data(), i)) {
+                if (n >= SLK_MT_JUMP_TERMS - 48) {
+                    slk_fail(ctx, SLK_EIO, "MT19937 jump polynomial has more than %d terms", SLK_MT_JUMP_TERMS);
+                    return nullptr;
+                }
+                dst[n++] = (uint32_t)i;
+            }
+        dst[SLK_MT_JUMP_TERMS - 1] = (uint32_t)((n + 15) / 16 * 16);  // rounded length; the kernel
+                                                                      // prefetches 16 entries past it
         if (w + 1 < SLK_MT_JUMP_WG) {
             mulmod(F, cm, g.data(), h.data(), nxt.data());
             g = nxt;

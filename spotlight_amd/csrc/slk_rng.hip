@@ -32,6 +32,8 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
+#define SLK_MT_THREADS 640  // 10 waves: one lane per state word in the jump convolution
+
 // One regeneration: n[0..624) = next state block of o[0..624) (both in LDS).  The twist
 // x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old
 // words, [227,454) need the first round, [454,624) the second.  Ends with a barrier.
@@ -52,58 +54,69 @@ __device__ __forceinline__ void mt_regen_block(const uint32_t *o, uint32_t *n, i
 }
 
 #define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
-#define SLK_MT_LDS_WORDS (SLK_MT_PREFIX_BLOCKS * SLK_MT_N + 2 * SLK_MT_N)
+// LDS: prefix X[33*624] | zero block [624] (target of the padding exponent) | ping | pong
+#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 3) * SLK_MT_N)
 
 // raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.
 // Workgroup w owns blocks [w*L, (w+1)*L).  w > 0 first jumps to block w*L:
 //   x[624 m + j] = XOR_{i in g_m} x[1 + i + j]   (slk_mtjump.hip), evaluated from a 33-block
-// prefix of the stream that every workgroup regenerates for itself in LDS.
-__global__ __launch_bounds__(256) void k_mt_generate_jump(const uint32_t *key_src, const uint32_t *polys,
-                                                          uint32_t *raw, int nblocks) {
+// prefix of the stream that every workgroup regenerates for itself in LDS; the exponent list
+// of g_m is wave-uniform (scalar loads), lane j XORs one LDS word per term.
+__global__ __launch_bounds__(SLK_MT_THREADS) void k_mt_generate_jump(const uint32_t *key_src,
+                                                                     const uint32_t *polys, uint32_t *raw,
+                                                                     int nblocks) {
     HIP_DYNAMIC_SHARED(uint32_t, lds)
     uint32_t *X = lds;
-    uint32_t *pp0 = lds + SLK_MT_PREFIX_BLOCKS * SLK_MT_N;
+    uint32_t *zero = lds + SLK_MT_PREFIX_BLOCKS * SLK_MT_N;
+    uint32_t *pp0 = zero + SLK_MT_N;
     uint32_t *pp1 = pp0 + SLK_MT_N;
     const int t = threadIdx.x;
     const int first = (int)blockIdx.x * SLK_MT_JUMP_BLOCKS;
     if (first >= nblocks) return;
     const int last = (first + SLK_MT_JUMP_BLOCKS < nblocks) ? first + SLK_MT_JUMP_BLOCKS : nblocks;
 
-    for (int i = t; i < SLK_MT_N; i += 256) X[i] = key_src[i];
+    if (t < SLK_MT_N) {
+        X[t] = key_src[t];
+        zero[t] = 0u;
+    }
     const uint32_t *cur = X;
     if (blockIdx.x > 0) {
-        const uint32_t *g = polys + (size_t)(blockIdx.x - 1) * SLK_MT_N;
-        for (int i = t; i < SLK_MT_N; i += 256) pp1[i] = g[i];  // jump polynomial -> LDS
         __syncthreads();
         for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b)
             mt_regen_block(X + (b - 1) * SLK_MT_N, X + b * SLK_MT_N, t);
-        uint32_t a0 = 0, a1 = 0, a2 = 0;
-        const bool third = t < SLK_MT_N - 512;
-        for (int wi = 0; wi < SLK_MT_N; ++wi) {
-            uint32_t gw = pp1[wi];
-            while (gw) {
-                const int bit = __ffs((int)gw) - 1;
-                gw &= gw - 1;
-                const uint32_t *p = X + 1 + wi * 32 + bit + t;
-                a0 ^= p[0];
-                a1 ^= p[256];
-                if (third) a2 ^= p[512];
+        const uint32_t *e = polys + (size_t)(blockIdx.x - 1) * SLK_MT_JUMP_TERMS;
+        const uint32_t *xj = X + 1 + (t < SLK_MT_N ? t : 0);
+        // the exponent list is wave-uniform: scalar loads, fetched one group of 16 ahead of the
+        // LDS reads that consume it; padding exponents hit the zero block
+        const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];  // list length rounded up to 16
+        uint32_t c[16], n[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = e[i];
+        uint32_t acc = 0;
+        for (int k = 0; k < nterms; k += 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) n[i] = e[k + 16 + i];  // (list has 16 spare entries)
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                a0 ^= xj[c[i]];
+                a1 ^= xj[c[i + 1]];
             }
+            acc ^= a0 ^ a1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c[i] = n[i];
         }
-        __syncthreads();
-        pp0[t] = a0;
-        pp0[t + 256] = a1;
-        if (third) pp0[t + 512] = a2;
+        if (t < SLK_MT_N) pp0[t] = acc;
         cur = pp0;
     }
     __syncthreads();
     uint32_t *dst = raw + (size_t)first * SLK_MT_N;
-    for (int i = t; i < SLK_MT_N; i += 256) dst[i] = cur[i];
+    if (t < SLK_MT_N) dst[t] = cur[t];
     for (int b = first + 1; b < last; ++b) {
         uint32_t *nxt = (cur == pp0) ? pp1 : pp0;
         mt_regen_block(cur, nxt, t);
         dst = raw + (size_t)b * SLK_MT_N;
-        for (int i = t; i < SLK_MT_N; i += 256) dst[i] = nxt[i];
+        if (t < SLK_MT_N) dst[t] = nxt[t];
         cur = nxt;
     }
 }
@@ -274,11 +287,11 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
             if (wgs > 1 && !ctx->d_jump) {
                 const uint32_t *tab = slk_mt_jump_table(ctx);
                 if (!tab) return SLK_EIO;
-                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_N * 4;
+                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
                 SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
                 SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
             }
-            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(256), lds_bytes, s, key_src,
+            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(SLK_MT_THREADS), lds_bytes, s, key_src,
                                (const uint32_t *)ctx->d_jump, raw + start * SLK_MT_N, (int)nb_l);
             SLK_LAUNCH_CHECK(ctx, "k_mt_generate_jump");
             if (start + nb_l >= nblocks) break;
