@@ -27,88 +27,7 @@
 // once per pass by the lanes that own it.
 #include <math.h>
 
-#include "slk_common.h"
-
-// ---------------------------------------------------------------------------------------
-// kernel arguments
-// ---------------------------------------------------------------------------------------
-struct slk_pass_args {
-    float *P[4];   // tables (user_emb, item_emb, user_bias, item_bias)
-    float *S1[4];  // optimizer state 1 / dense gradient buffer in *_DENSE modes
-    float *S2[4];
-    int D;
-    int NP;                  // score pairs per interaction: 1 positive + nn negatives
-    uint32_t begin, end;     // this minibatch's window in the user-sorted arrays
-    const uint32_t *ukey;    // (minibatch << ubits) | user, sorted
-    uint32_t umask;
-    const uint32_t *uit;     // [pos*NP + s] item of pair s at sorted position pos
-    const uint32_t *uk;      // sorted position -> chunk-local interaction index (PRE mode)
-    const float *gk;         // PRE mode: dL/dscore per (interaction, pair)
-    float *sk;               // PRE mode: scores per (interaction, pair)
-    float *snap;             // [(pos - begin)*RS]: record = pre-step user row (D floats) followed by the
-                             // NP dL/dscore values of that position (padded to a multiple of 4)
-    int RS;                  // record stride in floats
-    const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
-    uint32_t imask;
-    const uint32_t *ipay;    // occurrence -> pos*NP + s
-    double *loss_partial;    // per-block partial loss sums
-    int n_loss_partial;
-    float *mb_loss_out;      // this minibatch's loss.item()
-    int loss_kind;
-    float inv_b;             // 1 / (minibatch size)
-    // optimizer coefficients, rounded from double on the host exactly as torch does
-    float c_lr;    // Adagrad: clr.  SparseAdam: step_size.
-    float c_eps;
-    float c_omb1, c_omb2;  // 1-beta1, 1-beta2
-};
-
-enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
-
-// Row update for the elements one lane owns.  GRAD_ONLY stores the summed gradient into the
-// dense gradient buffer (aliased on S1) for the full-table sweep.
-template <int VEC, int UPD>
-__device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
-                                              const slk_vec<VEC> &g) {
-    if (UPD == SLK_UPD_ADAGRAD) {
-        // torch/optim/adagrad.py:360-385: sum += g^2; p += -clr * (g / (sqrt(sum) + eps))
-        slk_vec<VEC> s = slk_vload<VEC>(a.S1[t] + off);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            s.v[i] += g.v[i] * g.v[i];
-            p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
-        }
-        slk_vstore<VEC>(a.S1[t] + off, s);
-        slk_vstore<VEC>(a.P[t] + off, p);
-    } else if (UPD == SLK_UPD_SPARSE_ADAM) {
-        // torch/optim/_functional.py:61-84
-        slk_vec<VEC> m = slk_vload<VEC>(a.S1[t] + off);
-        slk_vec<VEC> v = slk_vload<VEC>(a.S2[t] + off);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const float mu = (g.v[i] - m.v[i]) * a.c_omb1;
-            const float vu = (g.v[i] * g.v[i] - v.v[i]) * a.c_omb2;
-            m.v[i] = mu + m.v[i];
-            v.v[i] = vu + v.v[i];
-            p.v[i] += -a.c_lr * (m.v[i] / (sqrtf(v.v[i]) + a.c_eps));
-        }
-        slk_vstore<VEC>(a.S1[t] + off, m);
-        slk_vstore<VEC>(a.S2[t] + off, v);
-        slk_vstore<VEC>(a.P[t] + off, p);
-    } else {
-        slk_vstore<VEC>(a.S1[t] + off, g);
-    }
-}
-
-template <int UPD>
-__device__ __forceinline__ void slk_apply_bias(const slk_pass_args &a, int t, size_t row, float g) {
-    slk_vec<1> gv;
-    gv.v[0] = g;
-    if (UPD == SLK_UPD_ADAGRAD && g == 0.0f) return;  // exact no-op: sum += 0, p -= 0
-    slk_vec<1> p = slk_vload<1>(a.P[t] + row);
-    slk_apply_vec<1, UPD>(a, t, row, p, gv);
-}
-
-__device__ __forceinline__ float slk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#include "slk_kernels.h"
 
 // ---------------------------------------------------------------------------------------
 // USER PASS
@@ -145,22 +64,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.P[3][ip];
                 const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.P[3][in];
                 float l, gp, gn;
-                if (a.loss_kind == SLK_LOSS_BPR) {  // losses.py:82-90
-                    const float s = slk_sigmoid(sp - sn);
-                    l = 1.0f - s;
-                    gp = -(s * (1.0f - s)) * a.inv_b;
-                    gn = -gp;
-                } else if (a.loss_kind == SLK_LOSS_HINGE) {  // losses.py:115-124
-                    const float x = sn - sp + 1.0f;
-                    l = x > 0.0f ? x : 0.0f;
-                    gn = x >= 0.0f ? a.inv_b : 0.0f;  // clamp backward is inclusive at 0
-                    gp = -gn;
-                } else {  // pointwise, losses.py:40-50
-                    const float sa = slk_sigmoid(sp), sb = slk_sigmoid(sn);
-                    l = (1.0f - sa) + sb;
-                    gp = -(sa * (1.0f - sa)) * a.inv_b;
-                    gn = (sb * (1.0f - sb)) * a.inv_b;
-                }
+                slk_pair_loss(a.loss_kind, sp, sn, a.inv_b, l, gp, gn);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
                 gbu += gp + gn;
@@ -191,133 +95,6 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     if (!PRE) {
         const double tot = slk_block_sum_256((double)loss_acc, red);
         if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// ITEM PASS
-// ---------------------------------------------------------------------------------------
-// A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
-// list.  Per tile: (1) keys + payloads -> LDS; (2) all row groups gather the records of the
-// tile's positions round-robin (every load independent: memory-level parallelism instead of a
-// per-segment dependent chain) and park g * u_old in LDS; (3) each run of equal keys that
-// STARTS in the tile is summed from LDS by one group (runs that spill past the tile end are
-// finished from global memory; rows of a run that started in an earlier tile are skipped --
-// its owner already took them) and the optimizer is applied to that item's row and bias.
-template <int VEC, int G, int UPD>
-__global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
-    constexpr int GPB = 256 / G;
-    constexpr int T = 4 * GPB;
-    constexpr int DL = G * VEC;  // LDS row length (>= D)
-    __shared__ double red[256];
-    __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
-    __shared__ uint32_t s_pay[T];
-    __shared__ float s_g[T];
-    __shared__ __attribute__((aligned(16))) float s_row[T * DL];
-    const int lane = threadIdx.x % G;
-    const int grp = threadIdx.x / G;
-    const int D = a.D;
-    const int d0 = lane * VEC;
-    const bool on = d0 < D;
-    const uint32_t NP = (uint32_t)a.NP;
-    const uint32_t ibegin = a.begin * NP, iend = a.end * NP;
-
-    if (blockIdx.x == 0) {
-        // loss.item() of this minibatch: mean over the minibatch of the per-interaction loss
-        double x = 0.0;
-        for (int i = threadIdx.x; i < a.n_loss_partial; i += 256) x += a.loss_partial[i];
-        const double tot = slk_block_sum_256(x, red);
-        if (threadIdx.x == 0) *a.mb_loss_out = (float)(tot * (double)a.inv_b);
-    }
-
-    const uint32_t ntiles = (iend - ibegin + T - 1) / T;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t tb = ibegin + tile * T;
-        const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
-        const bool first_tile = tb == ibegin;
-        __syncthreads();  // LDS of the previous tile no longer in use
-        for (int i = threadIdx.x; i <= tn; i += 256)
-            s_key[i] = (i == 0 && first_tile) ? 0u : a.ikey[tb - 1 + i];
-        for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = a.ipay[tb + i];
-        __syncthreads();
-
-        // (2) gather: position j = grp + it * GPB
-        slk_vec<VEC> u[4];
-        float g[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int j = grp + it * GPB;
-            g[it] = 0.0f;
-            u[it] = slk_vzero<VEC>();
-            // rows of the run inherited from the previous tile belong to that tile's owner
-            const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
-            if (mine) {
-                const uint32_t r = s_pay[j];
-                const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
-                const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
-                g[it] = rec[D + (r - pos * NP)];
-                if (on) u[it] = slk_vload<VEC>(rec + d0);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int j = grp + it * GPB;
-            if (j < tn) {
-                slk_vec<VEC> c;
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) c.v[i] = g[it] * u[it].v[i];
-                slk_vstore<VEC>(s_row + j * DL + d0, c);
-                if (lane == 0) s_g[j] = g[it];
-            }
-        }
-        __syncthreads();
-
-        // (3) one group per run that starts in this tile
-        for (int j = grp; j < tn; j += GPB) {
-            const uint32_t key = s_key[j + 1];
-            const bool head = (j == 0 && first_tile) || key != s_key[j];
-            if (!head) continue;
-            slk_vec<VEC> gv = slk_vzero<VEC>();
-            float gb = 0.0f;
-            bool any = false;
-            int k = j;
-            do {
-                const float gk = s_g[k];
-                if (gk != 0.0f) {
-                    const slk_vec<VEC> c = slk_vload<VEC>(s_row + k * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) gv.v[i] += c.v[i];
-                    gb += gk;
-                    any = true;
-                }
-                ++k;
-            } while (k < tn && s_key[k + 1] == key);
-            if (k == tn) {  // the run may continue in the following tiles
-                for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
-                    const uint32_t r = a.ipay[q];
-                    const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
-                    const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
-                    const float gk = rec[D + (r - pos * NP)];
-                    if (gk != 0.0f) {
-                        const slk_vec<VEC> uu = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) gv.v[i] += gk * uu.v[i];
-                        gb += gk;
-                        any = true;
-                    }
-                }
-            }
-            // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
-            // moments of every looked-up row (torch coalesces zero-valued rows too).
-            if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
-            const uint32_t item = key & a.imask;
-            const size_t voff = (size_t)item * D + d0;
-            if (on) {
-                slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
-                slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
-            }
-            if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
-        }
     }
 }
 
@@ -485,60 +262,7 @@ __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V,
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static unsigned grid_for(const slk_ctx *ctx, size_t work_items, unsigned per_block) {
-    size_t blocks = (work_items + per_block - 1) / per_block;
-    const size_t cap = (size_t)ctx->num_cus * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    return (unsigned)blocks;
-}
-
-// (VEC, G) layout for an embedding dim: 16 B per lane when dim % 4 == 0.
-static bool pick_layout(int D, int *vec, int *g) {
-    if (D <= 0) return false;
-    if (D % 4 == 0 && D <= 256) {
-        *vec = 4;
-        int need = D / 4, G = 1;
-        while (G < need) G <<= 1;
-        *g = G;
-        return true;
-    }
-    if (D <= 64) {
-        *vec = 1;
-        int G = 1;
-        while (G < D) G <<= 1;
-        *g = G;
-        return true;
-    }
-    return false;
-}
-
-#define SLK_FOR_LAYOUT(vec, g, MACRO)                                                 \
-    do {                                                                              \
-        if ((vec) == 4) {                                                             \
-            switch (g) {                                                              \
-                case 1: MACRO(4, 1); break;                                           \
-                case 2: MACRO(4, 2); break;                                           \
-                case 4: MACRO(4, 4); break;                                           \
-                case 8: MACRO(4, 8); break;                                           \
-                case 16: MACRO(4, 16); break;                                         \
-                case 32: MACRO(4, 32); break;                                         \
-                default: MACRO(4, 64); break;                                         \
-            }                                                                         \
-        } else {                                                                      \
-            switch (g) {                                                              \
-                case 1: MACRO(1, 1); break;                                           \
-                case 2: MACRO(1, 2); break;                                           \
-                case 4: MACRO(1, 4); break;                                           \
-                case 8: MACRO(1, 8); break;                                           \
-                case 16: MACRO(1, 16); break;                                         \
-                case 32: MACRO(1, 32); break;                                         \
-                default: MACRO(1, 64); break;                                         \
-            }                                                                         \
-        }                                                                             \
-    } while (0)
-
-typedef void (*pass_fn)(slk_pass_args);
+typedef slk_pass_fn pass_fn;
 
 template <int VEC, int G>
 static pass_fn user_pass_fn(int upd, bool pre) {
@@ -552,24 +276,91 @@ static pass_fn user_pass_fn(int upd, bool pre) {
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, false>;
 }
 
-template <int VEC, int G>
-static pass_fn item_pass_fn(int upd) {
-    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM>;
-    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY>;
-}
 
-static int check_tables(slk_ctx *ctx, const slk_tables *t, int *vec, int *g) {
+int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g) {
     if (!t) return slk_fail(ctx, SLK_EINVAL, "tables is NULL");
     for (int i = 0; i < 4; ++i)
-        if (!t->d_param[i]) return slk_fail(ctx, SLK_EINVAL, "tables->d_param[%d] is NULL", i);
-    if (t->num_users < 1 || t->num_items < 1 || t->num_users >= ((int64_t)1 << 31) ||
+        if (((table_mask >> i) & 1u) && !t->d_param[i])
+            return slk_fail(ctx, SLK_EINVAL, "tables->d_param[%d] is NULL", i);
+    if (((table_mask & 5u) && (t->num_users < 1 || t->num_users >= ((int64_t)1 << 31))) || t->num_items < 1 ||
         t->num_items >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "table rows must be in [1, 2^31): users %lld items %lld",
                         (long long)t->num_users, (long long)t->num_items);
-    if (!pick_layout(t->dim, vec, g))
+    if (!slk_pick_layout(t->dim, vec, g))
         return slk_fail(ctx, SLK_EINVAL,
                         "embedding dim %d unsupported (need dim %% 4 == 0 and <= 256, or dim <= 64)", t->dim);
+    return SLK_OK;
+}
+
+int slk_check_optim(slk_ctx *ctx, const slk_optim *optim, unsigned table_mask) {
+    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    if (optim->kind < SLK_OPT_ADAGRAD || optim->kind > SLK_OPT_ADAGRAD_DENSE)
+        return slk_fail(ctx, SLK_EINVAL, "unknown optimizer kind %d", optim->kind);
+    const bool need_s2 = optim->kind == SLK_OPT_SPARSE_ADAM || optim->kind == SLK_OPT_ADAM_DENSE;
+    for (int i = 0; i < 4; ++i) {
+        if (!((table_mask >> i) & 1u)) continue;
+        if (!optim->d_state1[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state1[%d] is NULL", i);
+        if (need_s2 && !optim->d_state2[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state2[%d] is NULL", i);
+    }
+    if (optim->kind == SLK_OPT_ADAGRAD && optim->weight_decay != 0.0)
+        return slk_fail(ctx, SLK_EINVAL, "row-sparse Adagrad requires weight_decay == 0 (use ADAGRAD_DENSE)");
+    return SLK_OK;
+}
+
+int slk_ensure_dgrad(slk_ctx *ctx, const size_t elems[4], unsigned table_mask, hipStream_t s) {
+    for (int t = 0; t < 4; ++t) {
+        if (!((table_mask >> t) & 1u)) continue;
+        if (ctx->dgrad_elems[t] != elems[t] || !ctx->dgrad[t].p) {
+            int rc = slk_ensure(ctx, ctx->dgrad[t], elems[t] * 4);
+            if (rc) return rc;
+            SLK_HIP(ctx, hipMemsetAsync(ctx->dgrad[t].p, 0, elems[t] * 4, s));
+            ctx->dgrad_elems[t] = elems[t];
+        }
+    }
+    return SLK_OK;
+}
+
+// Reference default optimizer (Adam + l2) / dense Adagrad with weight decay: sweep every row of
+// the tables in `table_mask`, consuming (and re-zeroing) the dense gradient buffers.
+int slk_dense_sweeps(slk_ctx *ctx, float *const params[4], const slk_optim *optim, unsigned table_mask,
+                     hipStream_t s) {
+    const double step = (double)(optim->step + 1);
+    slk_prof_begin(ctx, SLK_K_DENSE_SWEEP, s);
+    slk_sweep_args w;
+    memset(&w, 0, sizeof(w));
+    w.wd = (float)optim->weight_decay;
+    w.eps = (float)optim->eps;
+    if (optim->kind == SLK_OPT_ADAM_DENSE) {
+        const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
+        w.w1 = (float)(1.0 - optim->beta1);
+        w.beta2 = (float)optim->beta2;
+        w.omb2 = (float)(1.0 - optim->beta2);
+        w.step_size = (float)(optim->lr / bc1);
+        w.bc2_sqrt = (float)sqrt(bc2);
+    } else {
+        w.clr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
+    }
+    for (int t = 0; t < 4; ++t) {
+        if (!((table_mask >> t) & 1u)) continue;
+        w.p = params[t];
+        w.s1 = optim->d_state1[t];
+        w.s2 = optim->d_state2[t];
+        w.g = (float *)ctx->dgrad[t].p;
+        w.numel = ctx->dgrad_elems[t];
+        const unsigned wgrid = slk_grid_for(ctx, w.numel, 256);
+        if (optim->kind == SLK_OPT_ADAM_DENSE)
+            hipLaunchKernelGGL(k_adam_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
+        else
+            hipLaunchKernelGGL(k_adagrad_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
+        SLK_LAUNCH_CHECK(ctx, "dense sweep");
+    }
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}
+
+int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_i64_to_u32, dim3(slk_grid_for(ctx, n, 256)), dim3(256), 0, s, in, out, n);
+    SLK_LAUNCH_CHECK(ctx, "k_i64_to_u32");
     return SLK_OK;
 }
 
@@ -578,7 +369,7 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
                                     void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = check_tables(ctx, tables, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
     if (n < 0 || !d_users || (n > 0 && !d_out)) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_predict: bad arguments");
     if (n_users != 1 && n_users != n)
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_predict: n_users must be 1 or n (%lld vs %lld)",
@@ -589,7 +380,7 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
     ctx->last_stream = s;
     slk_prof_begin(ctx, SLK_K_SCORE, s);
 #define SLK_PREDICT(V_, G_)                                                                          \
-    hipLaunchKernelGGL((k_predict<V_, G_>), dim3(grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
+    hipLaunchKernelGGL((k_predict<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
                        (const float *)tables->d_param[0], (const float *)tables->d_param[1],          \
                        (const float *)tables->d_param[2], (const float *)tables->d_param[3],          \
                        (int)tables->dim, d_users, n_users, d_items, n, d_out)
@@ -606,26 +397,17 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
                                   int64_t *d_neg_out, float *d_mb_loss, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = check_tables(ctx, tables, &vec, &g))) return rc;
-    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (n < 0 || batch_size < 1) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: n %lld batch_size %lld",
                                                  (long long)n, (long long)batch_size);
     if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_ADAPTIVE_HINGE)
         return slk_fail(ctx, SLK_EINVAL, "unknown loss kind %d", loss);
-    if (optim->kind < SLK_OPT_ADAGRAD || optim->kind > SLK_OPT_ADAGRAD_DENSE)
-        return slk_fail(ctx, SLK_EINVAL, "unknown optimizer kind %d", optim->kind);
     const bool adaptive = loss == SLK_LOSS_ADAPTIVE_HINGE;
     const int nn = adaptive ? n_neg : 1;
     if (nn < 1 || nn > 1024) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", nn);
     const int NP = nn + 1;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
-    const bool need_s2 = optim->kind == SLK_OPT_SPARSE_ADAM || optim->kind == SLK_OPT_ADAM_DENSE;
-    for (int i = 0; i < 4; ++i) {
-        if (!optim->d_state1[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state1[%d] is NULL", i);
-        if (need_s2 && !optim->d_state2[i]) return slk_fail(ctx, SLK_EINVAL, "optim->d_state2[%d] is NULL", i);
-    }
-    if (optim->kind == SLK_OPT_ADAGRAD && optim->weight_decay != 0.0)
-        return slk_fail(ctx, SLK_EINVAL, "row-sparse Adagrad requires weight_decay == 0 (use ADAGRAD_DENSE)");
     if (n == 0) return SLK_OK;
     if (!d_users || !d_items || !d_mb_loss) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: NULL id/loss pointer");
     if (batch_size * (int64_t)NP >= ((int64_t)1 << 31))
@@ -669,22 +451,15 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
     if (dense) {
         const size_t elems[4] = {(size_t)tables->num_users * D, (size_t)tables->num_items * D,
                                  (size_t)tables->num_users, (size_t)tables->num_items};
-        for (int t = 0; t < 4; ++t) {
-            if (ctx->dgrad_elems[t] != elems[t] || !ctx->dgrad[t].p) {
-                if ((rc = slk_ensure(ctx, ctx->dgrad[t], elems[t] * 4))) return rc;
-                SLK_HIP(ctx, hipMemsetAsync(ctx->dgrad[t].p, 0, elems[t] * 4, s));
-                ctx->dgrad_elems[t] = elems[t];
-            }
-        }
+        if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
     }
 
-    const int upd = dense ? SLK_UPD_GRAD_ONLY
-                          : (optim->kind == SLK_OPT_ADAGRAD ? SLK_UPD_ADAGRAD : SLK_UPD_SPARSE_ADAM);
+    const int upd = slk_upd_for(optim->kind);
     pass_fn upass = nullptr, ipass = nullptr, spass = nullptr;
 #define SLK_PICK(V_, G_)                                  \
     do {                                                  \
         upass = user_pass_fn<V_, G_>(upd, adaptive);      \
-        ipass = item_pass_fn<V_, G_>(upd);                \
+        ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                \
         spass = k_score_pass<V_, G_>;                     \
     } while (0)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
@@ -701,7 +476,7 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
         if (d_neg_in) {
             slk_prof_begin(ctx, SLK_K_SAMPLE, s);
-            hipLaunchKernelGGL(k_i64_to_u32, dim3(grid_for(ctx, (size_t)nc * nn, 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_i64_to_u32, dim3(slk_grid_for(ctx, (size_t)nc * nn, 256)), dim3(256), 0, s,
                                d_neg_in + c0 * nn, neg32, (size_t)nc * nn);
             SLK_LAUNCH_CHECK(ctx, "k_i64_to_u32");
             if (d_neg_out)
@@ -720,7 +495,7 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
         uint32_t *ukey_in = (uint32_t *)ctx->ukey[0].p, *ukey = (uint32_t *)ctx->ukey[1].p;
         const uint32_t *uit, *uk = nullptr;
         if (!adaptive) {
-            hipLaunchKernelGGL((k_build_user_keys<true>), dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
+            hipLaunchKernelGGL((k_build_user_keys<true>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
                                (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
             if ((rc = slk_sort_pairs_u32_u64(ctx, ukey_in, ukey, (const uint64_t *)ctx->uval[0].p,
@@ -728,19 +503,19 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
                 return rc;
             uit = (const uint32_t *)ctx->uval[1].p;  // little-endian (pos, neg) pairs
         } else {
-            hipLaunchKernelGGL((k_build_user_keys<false>), dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
+            hipLaunchKernelGGL((k_build_user_keys<false>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
                                (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
             if ((rc = slk_sort_pairs_u32_u32(ctx, ukey_in, ukey, (const uint32_t *)ctx->uval[0].p,
                                              (uint32_t *)ctx->uval[1].p, nc, ubits + mbbits, s)))
                 return rc;
             uk = (const uint32_t *)ctx->uval[1].p;
-            hipLaunchKernelGGL(k_pack_items, dim3(grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, ci,
+            hipLaunchKernelGGL(k_pack_items, dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, ci,
                                (const uint32_t *)neg32, nc, nn, (uint32_t *)ctx->uit.p);
             SLK_LAUNCH_CHECK(ctx, "k_pack_items");
             uit = (const uint32_t *)ctx->uit.p;
         }
-        hipLaunchKernelGGL(k_build_item_keys, dim3(grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
+        hipLaunchKernelGGL(k_build_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
                            (uint32_t)bsz, ibits, (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
@@ -753,7 +528,6 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
         for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
             const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
             const uint32_t bm = b1 - b0;
-            const double step = (double)(optim->step + 1);
             slk_pass_args a;
             memset(&a, 0, sizeof(a));
             for (int t = 0; t < 4; ++t) {
@@ -780,24 +554,19 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
             a.mb_loss_out = d_mb_loss + mb_global;
             a.loss_kind = loss;
             a.inv_b = 1.0f / (float)bm;
-            a.c_eps = (float)optim->eps;
-            if (optim->kind == SLK_OPT_ADAGRAD) {
-                a.c_lr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
-            } else if (optim->kind == SLK_OPT_SPARSE_ADAM) {
-                const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
-                a.c_lr = (float)(optim->lr * sqrt(bc2) / bc1);
-                a.c_omb1 = (float)(1.0 - optim->beta1);
-                a.c_omb2 = (float)(1.0 - optim->beta2);
-            }
-            const unsigned ugrid = grid_for(ctx, bm, gpb);
-            const unsigned igrid = grid_for(ctx, (size_t)bm * NP, 4 * gpb);  // one tile per block-iteration
+            a.ibegin = b0 * (uint32_t)NP;
+            a.iend = b1 * (uint32_t)NP;
+            a.pad_item = 0xffffffffu;
+            slk_set_opt_coeffs(a, optim);
+            const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
+            const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb);  // one tile per block-iteration
 
             if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
                 SLK_HIP(ctx, hipMemsetAsync((float *)ctx->gk.p + (size_t)b0 * NP, 0, (size_t)bm * NP * 4, s));
                 hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_score_pass");
-                const unsigned sgrid = grid_for(ctx, bm, 256);
+                const unsigned sgrid = slk_grid_for(ctx, bm, 256);
                 hipLaunchKernelGGL(k_adaptive_select, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
                                    (float *)ctx->gk.p, b0, bm, nn, a.inv_b, (double *)ctx->losspart.p);
                 SLK_LAUNCH_CHECK(ctx, "k_adaptive_select");
@@ -817,37 +586,7 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
             SLK_LAUNCH_CHECK(ctx, "k_item_pass");
             slk_prof_end(ctx, s);
 
-            if (dense) {
-                slk_prof_begin(ctx, SLK_K_DENSE_SWEEP, s);
-                slk_sweep_args w;
-                memset(&w, 0, sizeof(w));
-                w.wd = (float)optim->weight_decay;
-                w.eps = (float)optim->eps;
-                if (optim->kind == SLK_OPT_ADAM_DENSE) {
-                    const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
-                    w.w1 = (float)(1.0 - optim->beta1);
-                    w.beta2 = (float)optim->beta2;
-                    w.omb2 = (float)(1.0 - optim->beta2);
-                    w.step_size = (float)(optim->lr / bc1);
-                    w.bc2_sqrt = (float)sqrt(bc2);
-                } else {
-                    w.clr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
-                }
-                for (int t = 0; t < 4; ++t) {
-                    w.p = tables->d_param[t];
-                    w.s1 = optim->d_state1[t];
-                    w.s2 = optim->d_state2[t];
-                    w.g = (float *)ctx->dgrad[t].p;
-                    w.numel = ctx->dgrad_elems[t];
-                    const unsigned wgrid = grid_for(ctx, w.numel, 256);
-                    if (optim->kind == SLK_OPT_ADAM_DENSE)
-                        hipLaunchKernelGGL(k_adam_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
-                    else
-                        hipLaunchKernelGGL(k_adagrad_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
-                    SLK_LAUNCH_CHECK(ctx, "dense sweep");
-                }
-                slk_prof_end(ctx, s);
-            }
+            if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, 15u, s))) return rc;
             optim->step += 1;
         }
     }

@@ -94,6 +94,10 @@ int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, co
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s);
 
+// shared host helpers (slk_bilinear.hip)
+int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g);
+int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
+
 static inline unsigned slk_bits_for(uint64_t max_value) {
     unsigned b = 1;
     while (b < 64 && (max_value >> b)) ++b;

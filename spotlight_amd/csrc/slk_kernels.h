@@ -1,0 +1,373 @@
+// slk_kernels.h -- device templates shared by the engine's training paths
+// (slk_bilinear.hip: one-GPU BilinearNet; slk_shard.hip: row-sharded BilinearNet;
+// slk_seq.hip: PoolNet): kernel argument block, row optimizer updates, pair losses and the
+// ITEM PASS (one owner group per unique item row: sum the row's gradient contributions, apply
+// the optimizer once).
+#pragma once
+#include <math.h>
+
+#include "slk_common.h"
+
+// ---------------------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------------------
+struct slk_pass_args {
+    float *P[4];   // tables (user_emb, item_emb, user_bias, item_bias)
+    float *S1[4];  // optimizer state 1 / dense gradient buffer in *_DENSE modes
+    float *S2[4];
+    int D;
+    int NP;                  // score pairs per interaction: 1 positive + nn negatives
+    uint32_t begin, end;     // this minibatch's window in the user-sorted arrays
+    const uint32_t *ukey;    // (minibatch << ubits) | user, sorted
+    uint32_t umask;
+    const uint32_t *uit;     // [pos*NP + s] item of pair s at sorted position pos
+    const uint32_t *uk;      // sorted position -> chunk-local interaction index (PRE mode)
+    const float *gk;         // PRE mode: dL/dscore per (interaction, pair)
+    float *sk;               // PRE mode: scores per (interaction, pair)
+    float *snap;             // records, see slk_item_mode
+    int RS;                  // record stride in floats
+    uint32_t ibegin, iend;   // this minibatch's window in the item-sorted occurrence arrays
+    const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
+    uint32_t imask;
+    const uint32_t *ipay;    // occurrence -> record reference (see slk_item_mode)
+    uint32_t pad_item;       // occurrences of this item row are never updated (padding_idx); ~0u = none
+    double *loss_partial;    // per-block partial loss sums
+    int n_loss_partial;
+    float *mb_loss_out;      // this minibatch's loss.item()
+    int loss_kind;
+    float inv_b;             // 1 / (minibatch size)   [sequences: 1 / mask.sum()]
+    // row-sharded path: item rows arrive in / gradient rows leave through exchange buffers
+    const float *vrows;      // [slot * RSV]: item row (D floats) + bias at [D]
+    float *grows;            // [slot * RSV]: g * u_old (D floats) + g at [D]
+    const uint32_t *vslot;   // [pos*NP + s] -> slot
+    int RSV;
+    // optimizer coefficients, rounded from double on the host exactly as torch does
+    float c_lr;    // Adagrad: clr.  SparseAdam: step_size.
+    float c_eps;
+    float c_omb1, c_omb2;  // 1-beta1, 1-beta2
+};
+
+enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
+
+// How the item pass turns an occurrence payload r into a gradient contribution:
+//   SNAP  r = pos*NP + s; record(pos) = [u_old (D) | g_0..g_{NP-1}];  vec = g_s * u_old, bias g_s
+//   SEQ   r = pos*NP + s; record(pos) = [repr (D) | hist (D) | g_0..g_{NP-1}];
+//         vec = g_s * repr (+ hist when s == 0), bias g_s                       (PoolNet)
+//   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (row-sharded)
+enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2 };
+
+// Row update for the elements one lane owns.  GRAD_ONLY stores the summed gradient into the
+// dense gradient buffer (aliased on S1) for the full-table sweep.
+template <int VEC, int UPD>
+__device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
+                                              const slk_vec<VEC> &g) {
+    if (UPD == SLK_UPD_ADAGRAD) {
+        // torch/optim/adagrad.py:360-385: sum += g^2; p += -clr * (g / (sqrt(sum) + eps))
+        slk_vec<VEC> s = slk_vload<VEC>(a.S1[t] + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s.v[i] += g.v[i] * g.v[i];
+            p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
+        }
+        slk_vstore<VEC>(a.S1[t] + off, s);
+        slk_vstore<VEC>(a.P[t] + off, p);
+    } else if (UPD == SLK_UPD_SPARSE_ADAM) {
+        // torch/optim/_functional.py:61-84
+        slk_vec<VEC> m = slk_vload<VEC>(a.S1[t] + off);
+        slk_vec<VEC> v = slk_vload<VEC>(a.S2[t] + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float mu = (g.v[i] - m.v[i]) * a.c_omb1;
+            const float vu = (g.v[i] * g.v[i] - v.v[i]) * a.c_omb2;
+            m.v[i] = mu + m.v[i];
+            v.v[i] = vu + v.v[i];
+            p.v[i] += -a.c_lr * (m.v[i] / (sqrtf(v.v[i]) + a.c_eps));
+        }
+        slk_vstore<VEC>(a.S1[t] + off, m);
+        slk_vstore<VEC>(a.S2[t] + off, v);
+        slk_vstore<VEC>(a.P[t] + off, p);
+    } else {
+        slk_vstore<VEC>(a.S1[t] + off, g);
+    }
+}
+
+template <int UPD>
+__device__ __forceinline__ void slk_apply_bias(const slk_pass_args &a, int t, size_t row, float g) {
+    slk_vec<1> gv;
+    gv.v[0] = g;
+    if (UPD == SLK_UPD_ADAGRAD && g == 0.0f) return;  // exact no-op: sum += 0, p -= 0
+    slk_vec<1> p = slk_vload<1>(a.P[t] + row);
+    slk_apply_vec<1, UPD>(a, t, row, p, gv);
+}
+
+__device__ __forceinline__ float slk_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Loss of one (positive score, negative score) pair and its derivatives, already scaled by
+// inv_b (spotlight/losses.py: pointwise :40-50, bpr :82-90, hinge :115-124).
+__device__ __forceinline__ void slk_pair_loss(int loss_kind, float sp, float sn, float inv_b, float &l,
+                                              float &gp, float &gn) {
+    if (loss_kind == SLK_LOSS_BPR) {
+        const float s = slk_sigmoid(sp - sn);
+        l = 1.0f - s;
+        gp = -(s * (1.0f - s)) * inv_b;
+        gn = -gp;
+    } else if (loss_kind == SLK_LOSS_HINGE || loss_kind == SLK_LOSS_ADAPTIVE_HINGE) {
+        const float x = sn - sp + 1.0f;
+        l = x > 0.0f ? x : 0.0f;
+        gn = x >= 0.0f ? inv_b : 0.0f;  // clamp backward is inclusive at 0
+        gp = -gn;
+    } else {
+        const float sa = slk_sigmoid(sp), sb = slk_sigmoid(sn);
+        l = (1.0f - sa) + sb;
+        gp = -(sa * (1.0f - sa)) * inv_b;
+        gn = (sb * (1.0f - sb)) * inv_b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ITEM PASS
+// ---------------------------------------------------------------------------------------
+// One occurrence's contribution, read from its record.
+template <int VEC, int MODE>
+__device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_t r, int D, int d0, bool on,
+                                                 slk_vec<VEC> &c, float &gb) {
+    if (MODE == SLK_ITEM_ROW) {
+        const float *rec = a.snap + (size_t)r * a.RS;
+        gb = rec[D];
+        c = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+    } else {
+        const uint32_t NP = (uint32_t)a.NP;
+        const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
+        const uint32_t s = r - pos * NP;
+        const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
+        if (MODE == SLK_ITEM_SNAP) {
+            gb = rec[D + s];
+            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
+        } else {
+            gb = rec[2 * D + s];
+            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
+            if (s == 0 && on) {
+                const slk_vec<VEC> h = slk_vload<VEC>(rec + D + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c.v[i] += h.v[i];
+            }
+        }
+    }
+}
+
+// A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
+// list.  Per tile: (1) keys + payloads -> LDS; (2) all row groups gather the records of the
+// tile's positions round-robin (every load independent: memory-level parallelism instead of a
+// per-segment dependent chain) and park the contributions in LDS; (3) each run of equal keys
+// that STARTS in the tile is summed from LDS by one group (runs that spill past the tile end
+// are finished from global memory; rows of a run that started in an earlier tile are skipped --
+// its owner already took them) and the optimizer is applied to that item's row and bias.
+// Block 0 also reduces the loss partials of the preceding pass into loss.item().
+template <int VEC, int G, int UPD, int MODE>
+__global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    constexpr int T = 4 * GPB;
+    constexpr int DL = G * VEC;  // LDS row length (>= D)
+    __shared__ double red[256];
+    __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
+    __shared__ uint32_t s_pay[T];
+    __shared__ float s_g[T];
+    __shared__ uint8_t s_live[T];
+    __shared__ __attribute__((aligned(16))) float s_row[T * DL];
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t ibegin = a.ibegin, iend = a.iend;
+
+    if (blockIdx.x == 0 && a.mb_loss_out) {
+        // loss.item() of this minibatch: mean over the minibatch of the per-interaction loss
+        double x = 0.0;
+        for (int i = threadIdx.x; i < a.n_loss_partial; i += 256) x += a.loss_partial[i];
+        const double tot = slk_block_sum_256(x, red);
+        if (threadIdx.x == 0) *a.mb_loss_out = (float)(tot * (double)a.inv_b);
+    }
+
+    const uint32_t ntiles = (iend - ibegin + T - 1) / T;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t tb = ibegin + tile * T;
+        const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
+        const bool first_tile = tb == ibegin;
+        __syncthreads();  // LDS of the previous tile no longer in use
+        for (int i = threadIdx.x; i <= tn; i += 256)
+            s_key[i] = (i == 0 && first_tile) ? 0u : a.ikey[tb - 1 + i];
+        for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = a.ipay[tb + i];
+        __syncthreads();
+
+        // (2) gather: position j = grp + it * GPB
+        slk_vec<VEC> c[4];
+        float g[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = grp + it * GPB;
+            g[it] = 0.0f;
+            c[it] = slk_vzero<VEC>();
+            // rows of the run inherited from the previous tile belong to that tile's owner
+            const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
+            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, on, c[it], g[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = grp + it * GPB;
+            if (j < tn) {
+                slk_vstore<VEC>(s_row + j * DL + d0, c[it]);
+                if (lane == 0) {
+                    s_g[j] = g[it];
+                    // SNAP: a zero dL/dscore contributes an exact zero row; SEQ/ROW records
+                    // carry a vector that is not a multiple of the bias gradient
+                    s_live[j] = (MODE == SLK_ITEM_SNAP) ? (g[it] != 0.0f) : 1;
+                }
+            }
+        }
+        __syncthreads();
+
+        // (3) one group per run that starts in this tile
+        for (int j = grp; j < tn; j += GPB) {
+            const uint32_t key = s_key[j + 1];
+            const bool head = (j == 0 && first_tile) || key != s_key[j];
+            if (!head) continue;
+            const uint32_t item = key & a.imask;
+            if (item == a.pad_item) continue;  // padding_idx rows receive no gradient
+            slk_vec<VEC> gv = slk_vzero<VEC>();
+            float gb = 0.0f;
+            bool any = false;
+            int k = j;
+            do {
+                if (s_live[k]) {
+                    const slk_vec<VEC> cc = slk_vload<VEC>(s_row + k * DL + d0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
+                    gb += s_g[k];
+                    any = true;
+                }
+                ++k;
+            } while (k < tn && s_key[k + 1] == key);
+            if (k == tn) {  // the run may continue in the following tiles
+                for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
+                    slk_vec<VEC> cc;
+                    float gq;
+                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, on, cc, gq);
+                    if (MODE != SLK_ITEM_SNAP || gq != 0.0f) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
+                        gb += gq;
+                        any = true;
+                    }
+                }
+            }
+            // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
+            // moments of every looked-up row (torch coalesces zero-valued rows too).
+            if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
+            const size_t voff = (size_t)item * D + d0;
+            if (on) {
+                slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
+                slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
+            }
+            if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------
+static inline unsigned slk_grid_for(const slk_ctx *ctx, size_t work_items, unsigned per_block) {
+    size_t blocks = (work_items + per_block - 1) / per_block;
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// (VEC, G) layout for an embedding dim: 16 B per lane when dim % 4 == 0.
+static inline bool slk_pick_layout(int D, int *vec, int *g) {
+    if (D <= 0) return false;
+    if (D % 4 == 0 && D <= 256) {
+        *vec = 4;
+        int need = D / 4, G = 1;
+        while (G < need) G <<= 1;
+        *g = G;
+        return true;
+    }
+    if (D <= 64) {
+        *vec = 1;
+        int G = 1;
+        while (G < D) G <<= 1;
+        *g = G;
+        return true;
+    }
+    return false;
+}
+
+#define SLK_FOR_LAYOUT(vec, g, MACRO)                                                 \
+    do {                                                                              \
+        if ((vec) == 4) {                                                             \
+            switch (g) {                                                              \
+                case 1: MACRO(4, 1); break;                                           \
+                case 2: MACRO(4, 2); break;                                           \
+                case 4: MACRO(4, 4); break;                                           \
+                case 8: MACRO(4, 8); break;                                           \
+                case 16: MACRO(4, 16); break;                                         \
+                case 32: MACRO(4, 32); break;                                         \
+                default: MACRO(4, 64); break;                                         \
+            }                                                                         \
+        } else {                                                                      \
+            switch (g) {                                                              \
+                case 1: MACRO(1, 1); break;                                           \
+                case 2: MACRO(1, 2); break;                                           \
+                case 4: MACRO(1, 4); break;                                           \
+                case 8: MACRO(1, 8); break;                                           \
+                case 16: MACRO(1, 16); break;                                         \
+                case 32: MACRO(1, 32); break;                                         \
+                default: MACRO(1, 64); break;                                         \
+            }                                                                         \
+        }                                                                             \
+    } while (0)
+
+typedef void (*slk_pass_fn)(slk_pass_args);
+
+template <int VEC, int G, int MODE>
+static slk_pass_fn slk_item_pass_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE>;
+    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE>;
+}
+
+// Row-update mode of the fused passes for an optimizer kind.
+static inline int slk_upd_for(int opt_kind) {
+    if (opt_kind == SLK_OPT_ADAGRAD) return SLK_UPD_ADAGRAD;
+    if (opt_kind == SLK_OPT_SPARSE_ADAM) return SLK_UPD_SPARSE_ADAM;
+    return SLK_UPD_GRAD_ONLY;
+}
+
+// Per-step optimizer coefficients, formed in double and rounded to fp32 as torch does.
+static inline void slk_set_opt_coeffs(slk_pass_args &a, const slk_optim *optim) {
+    const double step = (double)(optim->step + 1);
+    a.c_eps = (float)optim->eps;
+    if (optim->kind == SLK_OPT_ADAGRAD) {
+        a.c_lr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
+    } else if (optim->kind == SLK_OPT_SPARSE_ADAM) {
+        const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
+        a.c_lr = (float)(optim->lr * sqrt(bc2) / bc1);
+        a.c_omb1 = (float)(1.0 - optim->beta1);
+        a.c_omb2 = (float)(1.0 - optim->beta2);
+    }
+}
+
+// slk_bilinear.hip: validates the optimizer block (kinds, state pointers for tables in `mask`)
+int slk_check_optim(slk_ctx *ctx, const slk_optim *optim, unsigned table_mask);
+// slk_bilinear.hip: (re)allocates + zeroes the dense gradient buffers of the tables in `mask`
+int slk_ensure_dgrad(slk_ctx *ctx, const size_t elems[4], unsigned table_mask, hipStream_t s);
+// slk_bilinear.hip: full-table sweeps of the *_DENSE optimizers over the tables in `mask`
+int slk_dense_sweeps(slk_ctx *ctx, float *const params[4], const slk_optim *optim, unsigned table_mask,
+                     hipStream_t s);

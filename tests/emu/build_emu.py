@@ -14,7 +14,7 @@ LIB = os.path.join(OUT, 'libspotlight_emu.so')
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
-    deps = srcs + [os.path.join(CSRC, 'slk_common.h'), os.path.join(ROOT, 'include', 'spotlight_hip.h'),
+    deps = srcs + [os.path.join(CSRC, 'slk_common.h'), os.path.join(CSRC, 'slk_kernels.h'), os.path.join(ROOT, 'include', 'spotlight_hip.h'),
                    os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'),
                    os.path.join(HERE, 'rocprim', 'rocprim.hpp')]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
