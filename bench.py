@@ -55,6 +55,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=1 << 20)
     ap.add_argument('--loss', default='bpr')
     ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam'])
+    ap.add_argument('--sharded', action='store_true',
+                    help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -104,9 +106,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29400')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     U, I, D, B = args.users, args.items, args.dim, args.batch
@@ -115,6 +119,8 @@ def main():
     eng = _native.Engine(local_rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
+    # per-GPU shard: U x D users, I x D items (N > 1: the global tables are world times larger,
+    # row-sharded cyclically; per-GPU work is fixed = weak scaling)
     tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen),
               torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen),
               torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
@@ -124,16 +130,29 @@ def main():
     op = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None,
                             lr=1e-2)
     n_total = (W + K) * B
+    I_global = I * world
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
-    items = torch.randint(0, I, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    items = torch.randint(0, I_global, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     mb_loss = torch.zeros(W + K, device=dev)
     eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
     stream = torch.cuda.current_stream(dev).cuda_stream
+    trainer = None
+    if dist is not None:
+        from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
+        trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream)
+    xgmi_rows = [0]
 
     def run(first_mb, n_mb):
-        off = first_mb * B
-        eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, 1,
-                           mb_loss[first_mb:].data_ptr(), stream=stream)
+        if trainer is None:
+            off = first_mb * B
+            eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, 1,
+                               mb_loss[first_mb:].data_ptr(), stream=stream)
+            return
+        for k in range(first_mb, first_mb + n_mb):
+            # this rank's B interactions of global minibatch k (users it owns; items anywhere)
+            part = trainer.step(users[k * B:(k + 1) * B], items[k * B:(k + 1) * B], B * world, loss=args.loss)
+            mb_loss[k:k + 1].copy_(part)
+            xgmi_rows[0] += trainer.last_exchange_rows
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -144,6 +163,7 @@ def main():
     if W:
         run(0, W)
     barrier()
+    xgmi_rows[0] = 0
     eng.profile_reset()
     eng.profile_enable(True)
     t0 = time.perf_counter()
@@ -157,6 +177,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        dist.all_reduce(mb_loss)  # per-rank shares of each global minibatch loss
 
     losses = mb_loss.cpu().numpy()
     assert np.isfinite(losses).all() and (losses[W:] > 0).all(), losses
@@ -178,18 +199,26 @@ def main():
                 'kernels': kern,
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
-                'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep')}}
+                'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange')}}
+        if trainer is not None:
+            rsv = eng.shard_row_floats(D)
+            kern_ms = sum(prof[k][1] for k in ('sample', 'prep', 'user_pass', 'item_pass', 'exchange')) / K
+            roof['xgmi'] = {'rows_per_step_per_gpu': xgmi_rows[0] / K,
+                            'bytes_per_step_per_gpu_each_way': xgmi_rows[0] / K * (2 * rsv * 4 + 8),
+                            'kernel_ms_per_step': kern_ms,
+                            'exchange_and_host_ms_per_step': elapsed / K * 1e3 - kern_ms}
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
                'data': 'synthetic',
                'config': {'workload': 'C2: synthetic uniform ids, %d users x %d items, dim %d, %s loss, '
-                                      '%s lr=1e-2, minibatch %d, on-GPU numpy-exact negatives'
-                                      % (U, I, D, args.loss, args.opt, B),
+                                      '%s lr=1e-2, minibatch %d%s, on-GPU numpy-exact negatives'
+                                      % (U * world, I * world, D, args.loss, args.opt, B * world,
+                                         '' if world == 1 else ' (= %d per GPU; tables and batch grow with N)' % B),
                           'global_batch': B * world,
-                          'parallelism': 'single GPU' if world == 1 else
-                          'replicas only: %d independent models, one per GPU (row-sharded exchange path '
-                          'not built yet)' % world},
+                          'parallelism': 'single GPU' if trainer is None else
+                          'row-sharded x%d: users and items sharded cyclically, 3 RCCL all-to-all phases per '
+                          'minibatch (ids, rows, gradient rows); no replicas' % world},
                'roofline': roof,
                'final_minibatch_loss': float(losses[-1])}
         if world == 1 and not args.no_cpu_baseline:

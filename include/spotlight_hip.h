@@ -127,6 +127,52 @@ int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *
                          int64_t n_users, const int64_t *d_items, int64_t n, float *d_out,
                          void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Row-sharded BilinearNet training (the reference has no multi-GPU code, the
+ * boundary is fixed by BASELINE.json's north star).  One process per GPU; user and item
+ * tables (+ biases, optimizer state) are row-sharded cyclically: owner(row) = row % world,
+ * local row = row / world; `tables` passed below are the LOCAL shards.  A rank processes the
+ * interactions of the global minibatch whose user it owns.  The four calls are the compute
+ * phases of ONE global minibatch; between them the host runs three all-to-all exchanges
+ * (torch.distributed all_to_all_single = RCCL over xGMI):
+ *
+ *   slk_shard_begin      -> d_send_ids[2n] (owner-local item rows, grouped by owner rank in
+ *                           ascending rank order), d_send_counts[world] (device, int64)
+ *        a2a #1: counts and ids to the owners
+ *   slk_shard_gather     owner: d_rows_out[j] = row record of d_ids[j]
+ *        a2a #2: row records back to the requesters (same slot order as d_send_ids)
+ *   slk_shard_user_pass  forward/loss/backward/user update (factorization/implicit.py:229-243
+ *                        restricted to this rank's users); d_grad_out[slot] = gradient record
+ *        a2a #3: gradient records to the owners (same split sizes as a2a #1)
+ *   slk_shard_item_pass  owner: per unique item row, sum of the received records, then ONE
+ *                        optimizer update (duplicates summed before the update, as autograd
+ *                        does); advances optim->step.
+ *
+ * A record is slk_shard_row_floats(dim) floats: [row or gradient (dim) | bias or bias gradient
+ * | pad to 16 B].  pointwise/bpr/hinge only (one negative per interaction). */
+typedef struct slk_shard {
+    int32_t world, rank;
+    int64_t num_items_global; /* negatives are drawn in [0, num_items_global) (sampling.py:34) */
+    int64_t global_batch;     /* size of the GLOBAL minibatch: losses are means over it */
+} slk_shard;
+
+int slk_shard_row_floats(int32_t dim);
+/* d_users_local: LOCAL user rows (user / world) of this rank's n interactions; d_items: GLOBAL
+ * item ids; negatives: sampled from the ctx RNG over the global item range, or d_neg_in[n]. */
+int slk_shard_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                    const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                    const int64_t *d_neg_in, int64_t *d_neg_out, int64_t *d_send_ids,
+                    int64_t *d_send_counts, void *stream);
+int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, const int64_t *d_ids, int64_t n_ids,
+                     float *d_rows_out, void *stream);
+/* d_loss_out[0] = (sum of this rank's per-interaction losses) / global_batch; the minibatch's
+ * loss.item() is the sum of d_loss_out over ranks. */
+int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim,
+                        const slk_shard *sh, int64_t n, int32_t loss, const float *d_rows_in,
+                        float *d_grad_out, float *d_loss_out, void *stream);
+int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, const int64_t *d_ids,
+                        const float *d_grad_in, int64_t n_ids, void *stream);
+
 /* Measurement support (the reference has none; examples/bloom_embeddings/performance.py
  * times fit() with time.time()): when enabled, every launch of the engine's kernels is
  * bracketed by hipEvents on the launch stream.  slk_profile_read synchronises and returns,
@@ -138,7 +184,9 @@ enum slk_kernel_class {
     SLK_K_ITEM_PASS = 3,
     SLK_K_DENSE_SWEEP = 4,
     SLK_K_SCORE = 5,    /* adaptive-hinge score/select; predict    */
-    SLK_K_COUNT = 6
+    SLK_K_EXCHANGE = 6, /* row-sharded path: owner-side row gather  */
+    SLK_K_SEQ_PASS = 7, /* PoolNet sequence pass                    */
+    SLK_K_COUNT = 8
 };
 int slk_profile_enable(slk_ctx *ctx, int32_t on);
 int slk_profile_read(slk_ctx *ctx, int32_t kernel_class, int64_t *launches, double *total_ms);

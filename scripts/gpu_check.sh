@@ -21,6 +21,8 @@ for st in $STAGES; do
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err)
       echo "prof exit $?"; find $OUT/prof -name "*kernel_stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+    shard)
+      timeout 600 python bench.py --sharded --no-cpu-baseline > $OUT/bench_sharded1.json 2> $OUT/bench_sharded1.err; echo "bench --sharded exit $?"; cat $OUT/bench_sharded1.json; tail -5 $OUT/bench_sharded1.err ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && timeout 900 rocprofv3 --pmc $c -d $OUT/pmc_$c -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err)

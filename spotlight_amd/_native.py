@@ -18,7 +18,8 @@ SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
 OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
-KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5}
+KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5,
+                  'exchange': 6, 'seq_pass': 7}
 
 
 class SlkTables(C.Structure):
@@ -31,6 +32,11 @@ class SlkOptim(C.Structure):
                 ('lr', C.c_double), ('eps', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
                 ('weight_decay', C.c_double), ('lr_decay', C.c_double),
                 ('d_state1', C.c_void_p * 4), ('d_state2', C.c_void_p * 4)]
+
+
+class SlkShard(C.Structure):
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('num_items_global', C.c_int64),
+                ('global_batch', C.c_int64)]
 
 
 _PROTOTYPES = {
@@ -46,6 +52,15 @@ _PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_shard_row_floats': (C.c_int, [C.c_int32]),
+    'slk_shard_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_shard_gather': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p]),
+    'slk_shard_user_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.POINTER(SlkShard),
+                                      C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_shard_item_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
     'slk_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'slk_profile_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'slk_profile_reset': (C.c_int, [C.c_void_p]),
@@ -143,6 +158,27 @@ class Engine(object):
         self._check(self._lib.slk_bilinear_predict(self._ctx, C.byref(tables), d_users, int(n_users),
                                                    d_items, int(n), d_out, stream))
 
+    # -- row-sharded training phases (include/spotlight_hip.h: slk_shard_*) --------------
+    def shard_row_floats(self, dim):
+        return int(self._lib.slk_shard_row_floats(int(dim)))
+
+    def shard_begin(self, tables, shard, d_users_local, d_items, n, d_send_ids, d_send_counts,
+                    d_neg_in=None, d_neg_out=None, stream=0):
+        self._check(self._lib.slk_shard_begin(self._ctx, C.byref(tables), C.byref(shard), d_users_local, d_items,
+                                              int(n), d_neg_in, d_neg_out, d_send_ids, d_send_counts, stream))
+
+    def shard_gather(self, tables, d_ids, n_ids, d_rows_out, stream=0):
+        self._check(self._lib.slk_shard_gather(self._ctx, C.byref(tables), d_ids, int(n_ids), d_rows_out, stream))
+
+    def shard_user_pass(self, tables, optim, shard, n, loss, d_rows_in, d_grad_out, d_loss_out, stream=0):
+        self._check(self._lib.slk_shard_user_pass(
+            self._ctx, C.byref(tables), C.byref(optim), C.byref(shard), int(n),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_rows_in, d_grad_out, d_loss_out, stream))
+
+    def shard_item_pass(self, tables, optim, d_ids, d_grad_in, n_ids, stream=0):
+        self._check(self._lib.slk_shard_item_pass(self._ctx, C.byref(tables), C.byref(optim), d_ids, d_grad_in,
+                                                  int(n_ids), stream))
+
     # -- measurement -------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._check(self._lib.slk_profile_enable(self._ctx, 1 if on else 0))
@@ -165,6 +201,13 @@ def make_tables(ptrs, num_users, num_items, dim):
         t.d_param[i] = ptrs[i]
     t.num_users, t.num_items, t.dim = int(num_users), int(num_items), int(dim)
     return t
+
+
+def make_shard(world, rank, num_items_global, global_batch):
+    sh = SlkShard()
+    sh.world, sh.rank = int(world), int(rank)
+    sh.num_items_global, sh.global_batch = int(num_items_global), int(global_batch)
+    return sh
 
 
 def make_optim(kind, state1, state2=None, lr=1e-2, eps=None, betas=(0.9, 0.999), weight_decay=0.0,

@@ -116,6 +116,8 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3]};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (slk_buf &b : ctx->extra)
+        if (b.p) (void)hipFree(b.p);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
     if (ctx->d_jump) (void)hipFree(ctx->d_jump);
     delete ctx;

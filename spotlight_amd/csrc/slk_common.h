@@ -28,6 +28,8 @@ struct slk_rng_dev {
     unsigned long long accepted;
 };
 
+#define SLK_EXTRA_BUFS 16
+
 struct slk_prof_span {
     int cls;
     hipEvent_t a, b;
@@ -45,6 +47,8 @@ struct slk_ctx {
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
         sort_tmp, dgrad[4];
     size_t dgrad_elems[4] = {0, 0, 0, 0};
+    slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)
+    int64_t shard_n = 0;            // local interactions staged by the last slk_shard_begin
 
     // profiling
     bool prof_on = false;

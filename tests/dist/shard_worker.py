@@ -1,0 +1,136 @@
+"""TEST HARNESS: one rank of the row-sharded training parity check (tests/test_sharded.py).
+
+Backend 'emu': the fiber-emulator build of the engine sources + gloo on CPU tensors (runs
+anywhere).  Backend 'hip': the real gfx950 library + nccl (needs one GPU per rank).  Every
+rank trains its shards through spotlight_amd.factorization.sharded.ShardedBilinearTrainer;
+rank 0 then reassembles the tables and compares them with (a) the CPU oracle and (b) the
+single-device engine run on the same minibatches and negatives."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from spotlight_amd import _native  # noqa: E402
+from spotlight_amd.factorization.sharded import ShardedBilinearTrainer, local_rows  # noqa: E402
+
+
+def main():
+    backend, loss, opt, D = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    sample_on_device = len(sys.argv) > 5 and sys.argv[5] == 'sample'
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if backend == 'emu':
+        from emu_backend import emu_lib
+        dist.init_process_group('gloo')
+        dev = torch.device('cpu')
+        eng = _native.Engine(0, lib=emu_lib())
+        stream = 0
+    else:
+        torch.cuda.set_device(rank)
+        dev = torch.device('cuda', rank)
+        dist.init_process_group('nccl', device_id=dev)
+        eng = _native.Engine(rank)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+
+    U, I, B, n_mb = 41, 53, 96, 3
+    N = B * n_mb - 17  # short last minibatch
+    rs = np.random.RandomState(123)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    negs = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)).astype(np.float32), rs.normal(0, sc, (I, D)).astype(np.float32),
+              rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+
+    loc = [torch.from_numpy(np.array(p[rank::world], order="C", copy=True)).to(dev) for p in params]
+    assert loc[0].shape[0] == local_rows(U, world, rank) and loc[1].shape[0] == local_rows(I, world, rank)
+    s1 = [torch.zeros_like(t) for t in loc]
+    s2 = [torch.zeros_like(t) for t in loc]
+    optim = _native.make_optim(opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2], **hp)
+    trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream)
+    if sample_on_device:
+        eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
+
+    losses, used_negs = [], np.full(N, -1, dtype=np.int64)
+    for k in range(n_mb):
+        lo, hi = k * B, min((k + 1) * B, N)
+        idx = np.nonzero(users[lo:hi] % world == rank)[0] + lo
+        ul = torch.from_numpy(users[idx] // world).to(dev)
+        il = torch.from_numpy(items[idx]).to(dev)
+        if sample_on_device:
+            neg_out = torch.full((len(idx),), -1, dtype=torch.int64, device=dev)
+            part = trainer.step(ul, il, hi - lo, loss=loss, neg_out=neg_out)
+            used_negs[idx] = neg_out.cpu().numpy()
+        else:
+            ng = torch.from_numpy(negs[idx]).to(dev)
+            part = trainer.step(ul, il, hi - lo, loss=loss, neg_in=ng)
+            used_negs[idx] = negs[idx]
+        dist.all_reduce(part)
+        losses.append(float(part.item()))
+    assert optim.step == n_mb
+
+    # reassemble on rank 0
+    un = torch.from_numpy(np.where(used_negs >= 0, used_negs, 0)).to(dev)
+    dist.all_reduce(un)  # every interaction belongs to exactly one rank
+    used_negs = un.cpu().numpy()
+    full = []
+    for t, (src, st1) in enumerate(zip(loc, s1)):
+        outs = []
+        for tens in (src, st1):
+            rows = [local_rows(params[t].shape[0], world, r) for r in range(world)]
+            pad = max(rows)
+            buf = torch.zeros((pad,) + tuple(tens.shape[1:]), dtype=tens.dtype, device=dev)
+            buf[:tens.shape[0]] = tens
+            gathered = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(gathered, buf)
+            whole = np.zeros_like(params[t])
+            for r in range(world):
+                whole[r::world] = gathered[r][:rows[r]].cpu().numpy()
+            outs.append(whole)
+        full.append(outs)
+
+    if rank == 0:
+        from engine_checks import assert_close_table
+        from oracle.oracle import BilinearOracle
+        assert (used_negs >= 0).all() and (used_negs < I).all()
+        # CPU oracle.  First minibatch: loss within 1e-5.  Whole run: hinge gradients are sums of
+        # +-1/B terms that cancel to an order-dependent ~1e-9 residue which Adam's m/sqrt(v)
+        # normalises to O(lr) (see engine_checks.assert_close_table), so the trajectory is judged
+        # by the fraction of elements outside 1e-4 of the table norm (<= 5 %); the tight check
+        # is the one against the single-device engine below.
+        ora = BilinearOracle(*params, opt=opt, sparse_grads=True, **hp)
+        want = ora.train(None, users, items, B, loss=loss, neg_in=used_negs)
+        assert abs(losses[0] - want[0]) / abs(want[0]) < 1e-5, (losses, want)
+        assert np.abs(np.array(losses) - want).max() / np.abs(want).max() < 1e-3, (losses, want)
+        for t in range(4):
+            ref = ora.p[t].reshape(full[t][0].shape)
+            bad = np.abs(full[t][0] - ref) > 1e-4 * np.abs(ref).max()
+            assert bad.mean() <= 0.05, (t, bad.mean())
+        # single-device engine on the same minibatches
+        f = lambda a: torch.from_numpy(np.array(a, order='C', copy=True)).to(dev)
+        P = [f(p) for p in params]
+        S1, S2 = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
+        tb = _native.make_tables([p.data_ptr() for p in P], U, I, D)
+        op = _native.make_optim(opt, [p.data_ptr() for p in S1], [p.data_ptr() for p in S2], **hp)
+        mb = torch.zeros(n_mb, dtype=torch.float32, device=dev)
+        du, di, dn = f(users), f(items), f(used_negs)
+        eng.bilinear_train(tb, op, du.data_ptr(), di.data_ptr(), N, B, loss, 1, mb.data_ptr(),
+                           d_neg_in=dn.data_ptr(), stream=stream)
+        assert np.abs(np.array(losses) - mb.cpu().numpy()).max() / np.abs(want).max() < 1e-5
+        for t in range(4):
+            assert_close_table(full[t][0], P[t].cpu().numpy(), 2e-5, ('param vs single', t))
+            assert_close_table(full[t][1], S1[t].cpu().numpy(), 2e-5, ('state1 vs single', t))
+        print('SHARD_PARITY_OK world=%d loss=%s opt=%s D=%d' % (world, loss, opt, D))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,73 @@
+"""Row-sharded training: world_size-2 (and 3) gloo runs of the real host
+code (spotlight_amd/factorization/sharded.py) over the emulator build of the engine,
+compared on rank 0 with the CPU oracle and with the single-device engine."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, 'dist', 'shard_worker.py')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_world(world, args, backend='emu', timeout=600):
+    from emu_backend import emu_lib
+    if backend == 'emu':
+        emu_lib()  # build once, before the ranks race for it
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable, WORKER, backend] + [str(a) for a in args], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-4000:])
+    assert 'SHARD_PARITY_OK' in outs[0], outs[0][-2000:]
+
+
+@pytest.mark.parametrize('loss,opt,D', [('bpr', 'adagrad', 8), ('hinge', 'sparse_adam', 8),
+                                        ('pointwise', 'adam_dense', 6), ('bpr', 'adagrad', 64)])
+def test_sharded_world2_matches_oracle_and_single_device(loss, opt, D):
+    run_world(2, [loss, opt, D])
+
+
+def test_sharded_world3_device_sampled_negatives():
+    run_world(3, ['bpr', 'adagrad', 16, 'sample'])
+
+
+def test_sharded_world1_degenerates_to_local_exchange():
+    run_world(1, ['pointwise', 'adagrad_dense', 8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss,opt,D', [('bpr', 'adagrad', 64), ('hinge', 'sparse_adam', 32),
+                                        ('pointwise', 'adam_dense', 8)])
+def test_gpu_sharded_phases_world1_nccl(loss, opt, D):
+    """The real gfx950 kernels of the four shard phases + RCCL all_to_all_single (a single rank:
+    the exchange degenerates to a device copy), against the oracle and the fused one-GPU path."""
+    run_world(1, [loss, opt, D], backend='hip')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_world1_device_sampled_negatives():
+    run_world(1, ['bpr', 'adagrad', 16, 'sample'], backend='hip')
