@@ -102,6 +102,11 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    # libraries (RCCL's version banner, rocm-smi) write to fd 1; keep stdout clean for the ONE
+    # JSON line the driver parses: everything else goes to stderr until the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -223,10 +228,15 @@ def main():
                'final_minibatch_loss': float(losses[-1])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
-        print(json.dumps(out))
+    else:
+        out = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -183,3 +183,85 @@ class BilinearOracle(object):
                                        _ptr(neg_in), _ptr(neg_out), _ptr(mb_loss))
         assert rc == 0
         return (mb_loss, neg_out) if want_negs else mb_loss
+
+
+class _SeqModel(C.Structure):
+    _fields_ = [('p', C.c_void_p * 2), ('s1', C.c_void_p * 2), ('s2', C.c_void_p * 2),
+                ('num_items', C.c_int64), ('dim', C.c_int32), ('opt_kind', C.c_int32),
+                ('padding_idx', C.c_int64), ('step', C.c_int64),
+                ('lr', C.c_double), ('eps', C.c_double), ('beta1', C.c_double),
+                ('beta2', C.c_double), ('weight_decay', C.c_double), ('lr_decay', C.c_double)]
+
+
+class PoolNetOracle(object):
+    """fp32 numpy copies of PoolNet's two tables (item_embeddings, item_biases) + optimizer
+    state; restates spotlight/sequence/implicit.py:193-340 with sequence/representations.py:76-144."""
+
+    def __init__(self, item_emb, item_bias, opt='adagrad', lr=1e-2, eps=None, betas=(0.9, 0.999),
+                 weight_decay=0.0, lr_decay=0.0, step=0, state1=None, state2=None, padding_idx=0):
+        assert lib().slko_sizeof_seq_model() == C.sizeof(_SeqModel)
+        f = lambda a: np.array(a, dtype=np.float32, order='C', copy=True)
+        self.p = [f(item_emb), f(item_bias).reshape(-1)]
+        if eps is None:
+            eps = 1e-10 if opt.startswith('adagrad') else 1e-8
+        self.s1 = [f(s) for s in state1] if state1 is not None else [np.zeros_like(p) for p in self.p]
+        self.s2 = [f(s) for s in state2] if state2 is not None else [np.zeros_like(p) for p in self.p]
+        self.m = _SeqModel()
+        for t in range(2):
+            self.m.p[t] = self.p[t].ctypes.data
+            self.m.s1[t] = self.s1[t].ctypes.data
+            self.m.s2[t] = self.s2[t].ctypes.data
+        self.m.num_items, self.m.dim = self.p[0].shape
+        self.m.opt_kind = OPTS[opt]
+        self.m.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        self.m.lr, self.m.eps = lr, eps
+        self.m.beta1, self.m.beta2 = betas
+        self.m.weight_decay, self.m.lr_decay = weight_decay, lr_decay
+        self.m.step = step
+
+    @property
+    def step_count(self):
+        return int(self.m.step)
+
+    def step(self, seqs, neg, loss='bpr', n_neg=1, want_grads=False):
+        seqs = np.ascontiguousarray(seqs, dtype=np.int64)
+        B, L = seqs.shape
+        neg = np.ascontiguousarray(neg, dtype=np.int64).ravel()
+        assert neg.size == B * L * (n_neg if loss == 'adaptive_hinge' else 1)
+        loss_out = C.c_float()
+        dg, dgp = None, None
+        if want_grads:
+            dg = [np.zeros_like(p) for p in self.p]
+            dgp = (C.c_void_p * 2)(*[g.ctypes.data for g in dg])
+        rc = lib().slko_poolnet_step(C.byref(self.m), _ptr(seqs), _ptr(neg), C.c_int64(B), C.c_int64(L),
+                                     C.c_int(n_neg), C.c_int(LOSSES[loss]), C.byref(loss_out), dgp)
+        assert rc == 0
+        return (float(loss_out.value), dg) if want_grads else float(loss_out.value)
+
+    def train(self, rng, seqs, batch_size, loss='bpr', n_neg=1, neg_in=None, want_negs=False):
+        seqs = np.ascontiguousarray(seqs, dtype=np.int64)
+        n, L = seqs.shape
+        nn = n_neg if loss == 'adaptive_hinge' else 1
+        n_mb = (n + batch_size - 1) // batch_size
+        mb_loss = np.empty(n_mb, dtype=np.float32)
+        neg_out = np.empty(n * nn * L, dtype=np.int64) if want_negs else None
+        if neg_in is not None:
+            neg_in = np.ascontiguousarray(neg_in, dtype=np.int64).ravel()
+        rc = lib().slko_poolnet_train(C.byref(self.m), C.byref(rng._r) if rng is not None else None,
+                                      _ptr(seqs), C.c_int64(n), C.c_int64(L), C.c_int64(batch_size),
+                                      C.c_int(LOSSES[loss]), C.c_int(n_neg), _ptr(neg_in), _ptr(neg_out),
+                                      _ptr(mb_loss))
+        assert rc == 0
+        return (mb_loss, neg_out) if want_negs else mb_loss
+
+    def predict(self, seq, items=None):
+        seq = np.ascontiguousarray(np.asarray(seq).reshape(-1), dtype=np.int64)
+        if items is None:
+            n = int(self.m.num_items)
+        else:
+            items = np.ascontiguousarray(np.asarray(items).reshape(-1), dtype=np.int64)
+            n = items.size
+        out = np.empty(n, dtype=np.float32)
+        lib().slko_poolnet_predict(C.byref(self.m), _ptr(seq), C.c_int64(seq.size), _ptr(items), C.c_int64(n),
+                                   _ptr(out))
+        return out
