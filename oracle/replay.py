@@ -99,3 +99,49 @@ def case_from_rec(rec):
             v = rec[k]
             case[k[5:]] = v.item() if v.shape == () else v
     return case
+
+
+def replay_seq_with_oracle(case, rec):
+    """Replays a recorded ImplicitSequenceModel(PoolNet) run through the C oracle."""
+    from oracle.oracle import PoolNetOracle
+    hp = _oracle_hparams(case)
+    mk = lambda: PoolNetOracle(rec['init_0'], rec['init_1'], opt=ORACLE_OPT[case['opt']], **hp)
+    o = mk()
+    rng = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, L, B = int(case['N']), int(case['L']), int(case['B'])
+    seqs64 = rec['sequences'].astype(np.int64)
+    losses, negs, errs = [], [], {}
+    for e in range(int(case['n_iter'])):
+        # sequence/implicit.py:215-216 rebinds `sequences` to its shuffled copy, so the
+        # permutations of successive epochs COMPOSE (unlike the factorization model's)
+        perm = rng.shuffle_perm(N)
+        seqs64 = seqs64[perm]
+        ss = seqs64
+        assert (ss == rec['shuffled'][e]).all()
+        if e == 0:
+            B0 = min(B, N)
+            l0, dg = mk().step(ss[:B0], rec['negatives'][:B0 * nn * L], loss=str(case['loss']), n_neg=nn,
+                               want_grads=True)
+            errs['loss0'] = abs(l0 - rec['losses'][0]) / abs(rec['losses'][0])
+            for t in range(2):
+                ref = rec['grad0_%d' % t]
+                errs['grad0_%d' % t] = rel_inf(dg[t].reshape(ref.shape), ref)
+        l, ng = o.train(rng, ss, B, loss=str(case['loss']), n_neg=nn, want_negs=True)
+        losses.append(l)
+        negs.append(ng)
+    assert (np.concatenate(negs) == rec['negatives']).all(), 'negative ids differ'
+    errs['loss'] = np.max(np.abs(np.concatenate(losses) - rec['losses']) / np.abs(rec['losses']))
+    fr = {}
+    for t in range(2):
+        ref = rec['final_%d' % t]
+        errs['final_%d' % t] = rel_inf(o.p[t].reshape(ref.shape), ref)
+        fr['final_%d' % t] = frac_outside(o.p[t].reshape(ref.shape), ref)
+        errs['state1_%d' % t] = rel_inf(o.s1[t].reshape(ref.shape), rec['state1_%d' % t])
+    st = rng.get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    # predictions from the reference's own final tables (the trajectory may legitimately drift)
+    po = PoolNetOracle(rec['final_0'], rec['final_1'])
+    errs['predict_all'] = rel_inf(po.predict(rec['predict_seq']), rec['predict_all'])
+    errs['predict_some'] = rel_inf(po.predict(rec['predict_seq2'], rec['predict_items']), rec['predict_some'])
+    return errs, fr

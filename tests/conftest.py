@@ -15,8 +15,11 @@ def pytest_configure(config):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
-def golden_names():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz'))
+def golden_names(sequence=False):
+    """Fixtures recorded from the live reference: BilinearNet runs (oracle/make_golden.py) or,
+    with sequence=True, ImplicitSequenceModel/PoolNet runs (oracle/make_golden_seq.py)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN)
+                  if f.endswith('.npz') and f.startswith('seq_') == bool(sequence))
 
 
 @pytest.fixture(scope='session')

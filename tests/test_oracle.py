@@ -7,7 +7,7 @@ import pytest
 
 from conftest import GOLDEN, golden_names
 from oracle.oracle import Rng, bloom_indices, murmur3_32
-from oracle.replay import case_from_rec, replay_with_oracle
+from oracle.replay import case_from_rec, replay_seq_with_oracle, replay_with_oracle
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -19,6 +19,18 @@ def test_oracle_replays_reference_run(name):
     assert step < 1e-5, errs          # north-star tolerance on identical minibatches
     assert errs['loss'] < 1e-4
     assert max(frac.values()) <= 0.02, frac
+
+
+@pytest.mark.parametrize('name', golden_names(sequence=True))
+def test_oracle_replays_reference_sequence_run(name):
+    """PoolNet / ImplicitSequenceModel (sequence/implicit.py:193-340) fixtures."""
+    rec = np.load(os.path.join(GOLDEN, name + '.npz'))
+    case = case_from_rec(rec)
+    errs, frac = replay_seq_with_oracle(case, rec)  # asserts bit-exact shuffles/negatives/rng state
+    step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
+    assert step < 1e-5, errs
+    assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_some'] < 1e-5
+    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
 
 
 @pytest.mark.parametrize('seed', [0, 42, 2 ** 31 + 5])
