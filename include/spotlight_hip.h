@@ -128,6 +128,31 @@ int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *
                          void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * PoolNet / ImplicitSequenceModel (spotlight/sequence/implicit.py, representation='pooling').
+ * `tables` uses d_param[1] = item_embeddings.weight [num_items, dim] and d_param[3] =
+ * item_biases.weight [num_items]; d_param[0], d_param[2] and num_users are ignored, as are
+ * optim->d_state*[0] and [2].  padding_idx: the item row that never receives a gradient
+ * (nn.Embedding padding_idx; PoolNet uses 0, sequence/representations.py:13,66-74), -1 = none.
+ *
+ * slk_poolnet_train: the minibatch loop of one epoch of ImplicitSequenceModel.fit() after the
+ * shuffle (sequence/implicit.py:213-255) over d_sequences[n_seq][seq_len] (int64, left-padded
+ * with 0): contiguous minibatches of `batch_size` sequences; per minibatch the negatives
+ * randint(0, num_items, (B, L)) -- or ((n*B), L) for adaptive hinge, viewed (n, B, L), :266-286 --
+ * from the ctx RNG or d_neg_in (same layout, minibatch after minibatch), PoolNet
+ * user_representation + forward for the sequence itself and the negatives
+ * (sequence/representations.py:76-144), the masked loss (losses.py, mask = sequence != 0),
+ * backward and the optimizer update.  d_mb_loss[ceil(n_seq / batch_size)] = loss.item(). */
+int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, int64_t padding_idx,
+                      const int64_t *d_sequences, int64_t n_seq, int64_t seq_len, int64_t batch_size,
+                      int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
+                      float *d_mb_loss, void *stream);
+
+/* ImplicitSequenceModel.predict (sequence/implicit.py:288-340): d_out[k] = score of item
+ * d_items[k] (NULL: item k) as the next item after d_sequence[seq_len]. */
+int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_sequence,
+                        int64_t seq_len, const int64_t *d_items, int64_t n, float *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Row-sharded BilinearNet training (the reference has no multi-GPU code, the
  * boundary is fixed by BASELINE.json's north star).  One process per GPU; user and item
  * tables (+ biases, optimizer state) are row-sharded cyclically: owner(row) = row % world,

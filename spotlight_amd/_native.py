@@ -52,6 +52,11 @@ _PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_poolnet_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_poolnet_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shard_row_floats': (C.c_int, [C.c_int32]),
     'slk_shard_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -158,6 +163,19 @@ class Engine(object):
         self._check(self._lib.slk_bilinear_predict(self._ctx, C.byref(tables), d_users, int(n_users),
                                                    d_items, int(n), d_out, stream))
 
+    # -- PoolNet (sequence model) -------------------------------------------------------
+    def poolnet_train(self, tables, optim, padding_idx, d_sequences, n_seq, seq_len, batch_size, loss, n_neg,
+                      d_mb_loss, d_neg_in=None, d_neg_out=None, stream=0):
+        self._check(self._lib.slk_poolnet_train(
+            self._ctx, C.byref(tables), C.byref(optim), -1 if padding_idx is None else int(padding_idx),
+            d_sequences, int(n_seq), int(seq_len), int(batch_size),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), d_neg_in, d_neg_out,
+            d_mb_loss, stream))
+
+    def poolnet_predict(self, tables, d_sequence, seq_len, d_items, n, d_out, stream=0):
+        self._check(self._lib.slk_poolnet_predict(self._ctx, C.byref(tables), d_sequence, int(seq_len), d_items,
+                                                  int(n), d_out, stream))
+
     # -- row-sharded training phases (include/spotlight_hip.h: slk_shard_*) --------------
     def shard_row_floats(self, dim):
         return int(self._lib.slk_shard_row_floats(int(dim)))
@@ -200,6 +218,15 @@ def make_tables(ptrs, num_users, num_items, dim):
     for i in range(4):
         t.d_param[i] = ptrs[i]
     t.num_users, t.num_items, t.dim = int(num_users), int(num_items), int(dim)
+    return t
+
+
+def make_seq_tables(item_emb_ptr, item_bias_ptr, num_items, dim):
+    """slk_tables for the PoolNet entry points: only slots 1 (item embeddings) and 3 (item
+    biases) are populated."""
+    t = SlkTables()
+    t.d_param[1], t.d_param[3] = item_emb_ptr, item_bias_ptr
+    t.num_users, t.num_items, t.dim = 0, int(num_items), int(dim)
     return t
 
 

@@ -1,0 +1,520 @@
+// slk_seq.hip -- PoolNet / ImplicitSequenceModel training and prediction for gfx950.
+//
+// Replaces the minibatch body of ImplicitSequenceModel.fit() with representation='pooling'
+// (spotlight/sequence/implicit.py:225-255): PoolNet.user_representation (running, padding-aware
+// average of the item embeddings seen so far, sequence/representations.py:76-114),
+// PoolNet.forward for the positive targets (the sequence itself) and the sampled negatives
+// (:116-144), the masked loss (losses.py, mask = sequence != 0), autograd's backward (the
+// cumsum's reverse scan + embedding backward with duplicate rows summed, padding_idx rows
+// skipped) and the optimizer step.
+//
+//   SEQUENCE PASS  one workgroup per sequence; the L item rows are staged once in LDS; row
+//        groups (G = dim/4 lanes) each own a chunk of consecutive timesteps and the running
+//        sums are stitched with a block-level scan (forward: prefix sum + non-zero count ->
+//        representation -> scores -> loss -> dL/dscore; backward: suffix sum of
+//        dL/d(prefix sum)).  Per timestep it writes one record
+//             [ representation (D) | history gradient (D) | dL/dscore of the 1+n pairs ]
+//        -- everything the item rows' owners need.
+//   ITEM PASS (slk_kernels.h, SEQ mode)  occurrences (timestep, pair) sorted by item; one
+//        owner group per unique item sums  g * representation (+ history gradient for the
+//        sequence's own item)  and applies the optimizer once.
+#include <math.h>
+
+#include "slk_kernels.h"
+
+enum { SQ_MCOUNT = 8, SQ_REP };  // ctx->extra slots (0..5 belong to slk_shard.hip)
+
+struct slk_seq_args {
+    const float *E;         // item_embeddings
+    const float *bias;      // item_biases
+    int D, L, NP;           // NP = 1 + candidates per timestep
+    const int64_t *seqs;    // chunk base, [n_seq][L]
+    const uint32_t *neg32;  // this minibatch's draws (sampling order of sequence/implicit.py:266-286)
+    uint32_t s_begin, s_end;  // this minibatch's sequences (chunk-local)
+    float *rec;             // records of this minibatch: index (s - s_begin) * L + t
+    int RS;
+    const uint32_t *mcount;  // mask.sum() of this minibatch
+    double *loss_partial;
+    int loss_kind;
+    int C;                  // timesteps per row-group chunk
+};
+
+// non-zero sequence entries per minibatch (mask.sum(), losses.py:45-48)
+__global__ __launch_bounds__(256) void k_seq_count(const int64_t *seqs, uint32_t n_seq, uint32_t L, uint32_t bsz,
+                                                   uint32_t *mcount) {
+    __shared__ unsigned red[256];
+    const uint32_t mb = blockIdx.y;
+    const uint32_t s0 = mb * bsz, s1 = (n_seq - s0 < bsz) ? n_seq : s0 + bsz;
+    const size_t lo = (size_t)s0 * L, hi = (size_t)s1 * L;
+    unsigned c = 0;
+    for (size_t i = lo + (size_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (size_t)gridDim.x * 256)
+        c += seqs[i] != 0;
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0]) atomicAdd(&mcount[mb], red[0]);
+}
+
+template <int VEC, int G, bool ADAPT>
+__global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    __shared__ double red[256];
+    constexpr int NG = 256 / G;
+    constexpr int DL = G * VEC;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D, L = a.L;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    float *sE = lds;                   // [L][DL]  item rows, later dL/d(prefix sum)
+    float *sT = lds + (size_t)L * DL;  // [NG][DL] per-chunk sums
+    float *sC = sT + NG * DL;          // [NG][DL] per-chunk non-zero counts
+    const float M = (float)*a.mcount;
+    const uint32_t Bs = a.s_end - a.s_begin;
+    const int nn = a.NP - 1;
+    const int t0 = grp * a.C < L ? grp * a.C : L;
+    const int t1 = t0 + a.C < L ? t0 + a.C : L;
+    double loss_acc = 0.0;
+
+    for (uint32_t s = a.s_begin + blockIdx.x; s < a.s_end; s += gridDim.x) {
+        const int64_t *seq = a.seqs + (size_t)s * L;
+        const uint32_t bl = s - a.s_begin;
+        float *recs = a.rec + (size_t)bl * L * a.RS;
+        __syncthreads();  // LDS of the previous sequence no longer in use
+        // ---- (A) stage the sequence's item rows
+        for (int t = grp; t < L; t += NG) {
+            const slk_vec<VEC> e = on ? slk_vload<VEC>(a.E + (size_t)seq[t] * D + d0) : slk_vzero<VEC>();
+            slk_vstore<VEC>(sE + t * DL + d0, e);
+        }
+        __syncthreads();
+        // ---- (B1) per-chunk sum and non-zero count
+        {
+            slk_vec<VEC> sum = slk_vzero<VEC>(), cnt = slk_vzero<VEC>();
+            for (int t = t0; t < t1; ++t) {
+                const slk_vec<VEC> e = slk_vload<VEC>(sE + t * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    sum.v[i] += e.v[i];
+                    cnt.v[i] += (e.v[i] != 0.0f) ? 1.0f : 0.0f;
+                }
+            }
+            slk_vstore<VEC>(sT + grp * DL + d0, sum);
+            slk_vstore<VEC>(sC + grp * DL + d0, cnt);
+        }
+        __syncthreads();
+        // ---- (B2) exclusive prefix -> representation -> scores -> loss -> dL/d(prefix sum)
+        {
+            slk_vec<VEC> S = slk_vzero<VEC>(), Cn = slk_vzero<VEC>();
+            for (int gq = 0; gq < grp; ++gq) {
+                const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0), y = slk_vload<VEC>(sC + gq * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    S.v[i] += x.v[i];
+                    Cn.v[i] += y.v[i];
+                }
+            }
+            for (int tb = t0; tb < t1; tb += 4) {
+                // independent loads of up to 4 timesteps first (memory-level parallelism)
+                uint32_t it[4], nid[4];
+                slk_vec<VEC> nrow[4];
+                float pb[4], nb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = tb + k;
+                    it[k] = nid[k] = 0;
+                    pb[k] = nb[k] = 0.0f;
+                    nrow[k] = slk_vzero<VEC>();
+                    if (t < t1) {
+                        it[k] = (uint32_t)seq[t];
+                        pb[k] = a.bias[it[k]];
+                        if (!ADAPT) {
+                            nid[k] = a.neg32[(size_t)bl * L + t];
+                            if (on) nrow[k] = slk_vload<VEC>(a.E + (size_t)nid[k] * D + d0);
+                            nb[k] = a.bias[nid[k]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = tb + k;
+                    if (t >= t1) break;
+                    const slk_vec<VEC> e = slk_vload<VEC>(sE + t * DL + d0);
+                    slk_vec<VEC> rep, c1;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        c1.v[i] = Cn.v[i] + 1.0f;
+                        rep.v[i] = S.v[i] / c1.v[i];
+                    }
+                    const float sp = pb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, e));
+                    float sn;
+                    int chosen = 0;
+                    slk_vec<VEC> nr = nrow[k];
+                    if (!ADAPT) {
+                        sn = nb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, nr));
+                    } else {
+                        // losses.py:164-166: the highest-scoring of the n candidates drawn for this
+                        // (sequence, timestep); row (r*B + b) of the (n*B, L) draw; first maximum wins
+                        sn = 0.0f;
+                        for (int rb = 0; rb < nn; rb += 4) {
+                            slk_vec<VEC> cr[4];
+                            float cb[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                cr[j] = slk_vzero<VEC>();
+                                cb[j] = 0.0f;
+                                if (rb + j < nn) {
+                                    const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
+                                    if (on) cr[j] = slk_vload<VEC>(a.E + (size_t)cid * D + d0);
+                                    cb[j] = a.bias[cid];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (rb + j < nn) {
+                                    const float sc = cb[j] + slk_group_sum<G>(slk_vdot<VEC>(rep, cr[j]));
+                                    if (rb + j == 0 || sc > sn) {
+                                        sn = sc;
+                                        chosen = rb + j;
+                                        nr = cr[j];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    float l, gp, gn;
+                    slk_pair_loss(a.loss_kind, sp, sn, 1.0f, l, gp, gn);
+                    const float mask = it[k] != 0u ? 1.0f : 0.0f;
+                    const float w = mask / M;  // d(sum(loss*mask)/sum(mask)) / d loss
+                    gp = gp * w;
+                    gn = gn * w;
+                    float *rec = recs + (size_t)t * a.RS;
+                    if (on) slk_vstore<VEC>(rec + d0, rep);
+                    if (lane == 0) {
+                        loss_acc += (double)(l * mask);
+                        rec[2 * D] = gp;
+                        if (!ADAPT) {
+                            rec[2 * D + 1] = gn;
+                        } else {
+                            for (int j = 0; j < nn; ++j) rec[2 * D + 1 + j] = (j == chosen) ? gn : 0.0f;
+                        }
+                    }
+                    // advance the running sums, then overwrite the staged row by dL/d(prefix sum)
+                    slk_vec<VEC> gs;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        gs.v[i] = (gp * e.v[i] + gn * nr.v[i]) / c1.v[i];
+                        S.v[i] += e.v[i];
+                        Cn.v[i] += (e.v[i] != 0.0f) ? 1.0f : 0.0f;
+                    }
+                    slk_vstore<VEC>(sE + t * DL + d0, gs);
+                }
+            }
+        }
+        __syncthreads();  // every group has consumed the chunk sums
+        // ---- (C) cumsum backward: row j receives the sum of dL/d(prefix sum) over t > j
+        {
+            slk_vec<VEC> sum = slk_vzero<VEC>();
+            for (int t = t0; t < t1; ++t) {
+                const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) sum.v[i] += x.v[i];
+            }
+            slk_vstore<VEC>(sT + grp * DL + d0, sum);
+        }
+        __syncthreads();
+        {
+            slk_vec<VEC> suf = slk_vzero<VEC>();
+            for (int gq = NG - 1; gq > grp; --gq) {
+                const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
+            }
+            for (int t = t1 - 1; t >= t0; --t) {
+                if (on) slk_vstore<VEC>(recs + (size_t)t * a.RS + D + d0, suf);
+                const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
+            }
+        }
+    }
+    const double tot = slk_block_sum_256(loss_acc, red);
+    if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot / (double)M;
+}
+
+// occurrence r = pos * NP + s (pos = chunk-local timestep): key = (minibatch, item), value = r
+__global__ __launch_bounds__(256) void k_seq_item_keys(const int64_t *seqs, const uint32_t *neg32, uint32_t nocc,
+                                                       uint32_t n_seq, uint32_t L, uint32_t NP, uint32_t bsz,
+                                                       unsigned ibits, uint32_t *key, uint32_t *val) {
+    const uint32_t nn = NP - 1;
+    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nocc; r += gridDim.x * 256) {
+        const uint32_t pos = r / NP, s = r - pos * NP;
+        const uint32_t sc = pos / L, t = pos - sc * L;
+        const uint32_t mb = sc / bsz;
+        uint32_t item;
+        if (s == 0) {
+            item = (uint32_t)seqs[pos];
+        } else {
+            const uint32_t b0 = mb * bsz, bl = sc - b0;
+            const uint32_t Bs = (n_seq - b0 < bsz) ? n_seq - b0 : bsz;
+            item = neg32[(size_t)b0 * nn * L + ((size_t)(s - 1) * Bs + bl) * L + t];
+        }
+        key[r] = (mb << ibits) | item;
+        val[r] = r;
+    }
+}
+
+// PoolNet.user_representation's final state for ONE sequence (sequence/implicit.py:331-335)
+template <int VEC, int G>
+__global__ void k_seq_final_repr(const float *E, int D, const int64_t *seq, int L, float *rep) {
+    const int lane = threadIdx.x;
+    const int d0 = lane * VEC;
+    if (d0 >= D) return;
+    slk_vec<VEC> S = slk_vzero<VEC>(), Cn = slk_vzero<VEC>();
+    for (int t = 0; t < L; ++t) {
+        const slk_vec<VEC> e = slk_vload<VEC>(E + (size_t)seq[t] * D + d0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            S.v[i] += e.v[i];
+            Cn.v[i] += (e.v[i] != 0.0f) ? 1.0f : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) S.v[i] = S.v[i] / (Cn.v[i] + 1.0f);
+    slk_vstore<VEC>(rep + d0, S);
+}
+
+// PoolNet.forward of one representation against many items (sequence/representations.py:136-144)
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const float *V, const float *bi, int D,
+                                                     const int64_t *items, int64_t n, float *out) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const slk_vec<VEC> r = on ? slk_vload<VEC>(rep + d0) : slk_vzero<VEC>();
+    for (int64_t k = (int64_t)blockIdx.x * GPB + grp; k < n; k += (int64_t)gridDim.x * GPB) {
+        const int64_t i = items ? items[k] : k;
+        const slk_vec<VEC> b = on ? slk_vload<VEC>(V + (size_t)i * D + d0) : slk_vzero<VEC>();
+        const float s = bi[i] + slk_group_sum<G>(slk_vdot<VEC>(r, b));
+        if (lane == 0) out[k] = s;
+    }
+}
+
+typedef void (*seq_pass_fn)(slk_seq_args);
+
+SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, int64_t padding_idx,
+                                 const int64_t *d_sequences, int64_t n_seq, int64_t seq_len, int64_t batch_size,
+                                 int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
+                                 float *d_mb_loss, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    const unsigned TM = 10u;  // tables 1 (item_embeddings) and 3 (item_biases)
+    if ((rc = slk_check_tables(ctx, tables, TM, &vec, &g))) return rc;
+    if ((rc = slk_check_optim(ctx, optim, TM))) return rc;
+    if (n_seq < 0 || batch_size < 1 || seq_len < 1)
+        return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: n_seq %lld batch_size %lld seq_len %lld", (long long)n_seq,
+                        (long long)batch_size, (long long)seq_len);
+    if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_ADAPTIVE_HINGE)
+        return slk_fail(ctx, SLK_EINVAL, "unknown loss kind %d", loss);
+    const bool adaptive = loss == SLK_LOSS_ADAPTIVE_HINGE;
+    const int nn = adaptive ? n_neg : 1;
+    if (nn < 1 || nn > 1024) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", nn);
+    const int NP = nn + 1;
+    if (padding_idx < -1 || padding_idx >= tables->num_items)
+        return slk_fail(ctx, SLK_EINVAL, "padding_idx %lld outside [-1, num_items)", (long long)padding_idx);
+    if (n_seq == 0) return SLK_OK;
+    if (!d_sequences || !d_mb_loss) return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: NULL pointer");
+    const int D = tables->dim;
+    const int64_t L = seq_len;
+    const int NG = 256 / g, DL = g * vec;
+    const size_t lds_bytes = ((size_t)L * DL + 2 * (size_t)NG * DL) * 4;
+    if (lds_bytes > 160 * 1024 - 4096)
+        return slk_fail(ctx, SLK_EINVAL, "sequence length %lld x dim %d does not fit the 160 KB LDS of a CU",
+                        (long long)L, D);
+    const int64_t bsz = batch_size < n_seq ? batch_size : n_seq;
+    if (bsz * L * NP >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "batch_size * seq_len * (1 + negatives) must be < 2^31");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+
+    const unsigned ibits = slk_bits_for((uint64_t)tables->num_items - 1);
+    // minibatches per chunk: keys fit 32 bits, occurrences < 2^31, ~4M timesteps of scratch
+    int64_t mb_per_chunk = (int64_t)1 << (32 - ibits);
+    const int64_t cap_ts = (int64_t)1 << 22;
+    if (mb_per_chunk > 32768) mb_per_chunk = 32768;  // gridDim.y of the mask-count launch
+    if (mb_per_chunk * bsz * L > cap_ts) mb_per_chunk = cap_ts / (bsz * L);
+    while (mb_per_chunk > 1 && mb_per_chunk * bsz * L * NP >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
+    if (mb_per_chunk < 1) mb_per_chunk = 1;
+    const int64_t chunk_seqs = mb_per_chunk * bsz;
+    const size_t ns_max = (size_t)(chunk_seqs < n_seq ? chunk_seqs : n_seq);
+    const size_t nts_max = ns_max * L;
+
+    if ((rc = slk_ensure(ctx, ctx->neg32, nts_max * nn * 4))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = slk_ensure(ctx, ctx->ikey[b], nts_max * NP * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->ipay[b], nts_max * NP * 4))) return rc;
+    }
+    const int RS = 2 * D + ((NP + 3) / 4) * 4;
+    if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * L * RS * 4))) return rc;
+    const unsigned max_grid = (unsigned)ctx->num_cus * 8;
+    if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SQ_MCOUNT], (size_t)mb_per_chunk * 4))) return rc;
+    const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    if (dense) {
+        const size_t elems[4] = {0, (size_t)tables->num_items * D, 0, (size_t)tables->num_items};
+        if ((rc = slk_ensure_dgrad(ctx, elems, TM, s))) return rc;
+    }
+    const int upd = slk_upd_for(optim->kind);
+    seq_pass_fn spass = nullptr;
+    slk_pass_fn ipass = nullptr;
+#define SLK_PICK(V_, G_)                                                                 \
+    do {                                                                                 \
+        spass = adaptive ? k_seq_pass<V_, G_, true> : k_seq_pass<V_, G_, false>;         \
+        ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ>(upd);                             \
+    } while (0)
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK);
+#undef SLK_PICK
+    if (lds_bytes > 48 * 1024)
+        SLK_HIP(ctx, hipFuncSetAttribute((const void *)spass, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+    const unsigned gpb = 256u / (unsigned)g;
+
+    int64_t mb_global = 0;
+    for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs) {
+        const uint32_t ns = (uint32_t)((n_seq - c0 < chunk_seqs) ? (n_seq - c0) : chunk_seqs);
+        const uint32_t nts = ns * (uint32_t)L;
+        const uint32_t nocc = nts * (uint32_t)NP;
+        const int64_t *cs = d_sequences + c0 * L;
+        uint32_t *neg32 = (uint32_t *)ctx->neg32.p;
+        const uint32_t n_mb = (uint32_t)((ns + bsz - 1) / bsz);
+        // ---- negatives: one randint per minibatch == one contiguous draw over the chunk
+        if (d_neg_in) {
+            slk_prof_begin(ctx, SLK_K_SAMPLE, s);
+            if ((rc = slk_launch_i64_to_u32(ctx, d_neg_in + c0 * L * nn, neg32, (size_t)nts * nn, s))) return rc;
+            if (d_neg_out)
+                SLK_HIP(ctx, hipMemcpyAsync(d_neg_out + c0 * L * nn, d_neg_in + c0 * L * nn, (size_t)nts * nn * 8,
+                                            hipMemcpyDeviceToDevice, s));
+            slk_prof_end(ctx, s);
+        } else {
+            if ((rc = slk_sample_u32(ctx, tables->num_items, (int64_t)nts * nn, neg32,
+                                     d_neg_out ? d_neg_out + c0 * L * nn : nullptr, s)))
+                return rc;
+        }
+        // ---- prep: mask counts; occurrences sorted by (minibatch, item)
+        slk_prof_begin(ctx, SLK_K_PREP, s);
+        uint32_t *mcount = (uint32_t *)ctx->extra[SQ_MCOUNT].p;
+        SLK_HIP(ctx, hipMemsetAsync(mcount, 0, (size_t)n_mb * 4, s));
+        {
+            unsigned gx = (unsigned)(((size_t)bsz * L + 8191) / 8192);
+            if (gx > 256) gx = 256;
+            hipLaunchKernelGGL(k_seq_count, dim3(gx, n_mb), dim3(256), 0, s, cs, ns, (uint32_t)L, (uint32_t)bsz,
+                               mcount);
+            SLK_LAUNCH_CHECK(ctx, "k_seq_count");
+        }
+        const unsigned mbbits = slk_bits_for((uint64_t)(n_mb - 1));
+        hipLaunchKernelGGL(k_seq_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, cs,
+                           (const uint32_t *)neg32, nocc, ns, (uint32_t)L, (uint32_t)NP, (uint32_t)bsz, ibits,
+                           (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+        SLK_LAUNCH_CHECK(ctx, "k_seq_item_keys");
+        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
+                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
+                                         ibits + mbbits, s)))
+            return rc;
+        slk_prof_end(ctx, s);
+
+        for (uint32_t b0 = 0, mb = 0; b0 < ns; b0 += (uint32_t)bsz, ++mb, ++mb_global) {
+            const uint32_t b1 = (ns - b0 < (uint32_t)bsz) ? ns : b0 + (uint32_t)bsz;
+            slk_seq_args q;
+            memset(&q, 0, sizeof(q));
+            q.E = tables->d_param[1];
+            q.bias = tables->d_param[3];
+            q.D = D;
+            q.L = (int)L;
+            q.NP = NP;
+            q.seqs = cs;
+            q.neg32 = neg32 + (size_t)b0 * nn * L;
+            q.s_begin = b0;
+            q.s_end = b1;
+            q.rec = (float *)ctx->snap.p;
+            q.RS = RS;
+            q.mcount = mcount + mb;
+            q.loss_partial = (double *)ctx->losspart.p;
+            q.loss_kind = loss;
+            q.C = (int)((L + NG - 1) / NG);
+            unsigned sgrid = b1 - b0;
+            if (sgrid > max_grid) sgrid = max_grid;
+            slk_prof_begin(ctx, SLK_K_SEQ_PASS, s);
+            hipLaunchKernelGGL(spass, dim3(sgrid), dim3(256), lds_bytes, s, q);
+            SLK_LAUNCH_CHECK(ctx, "k_seq_pass");
+            slk_prof_end(ctx, s);
+
+            slk_pass_args a;
+            memset(&a, 0, sizeof(a));
+            for (int t = 0; t < 4; ++t) {
+                a.P[t] = tables->d_param[t];
+                a.S1[t] = dense ? (float *)ctx->dgrad[t].p : optim->d_state1[t];
+                a.S2[t] = optim->d_state2[t];
+            }
+            a.D = D;
+            a.NP = NP;
+            a.begin = b0 * (uint32_t)L;
+            a.end = b1 * (uint32_t)L;
+            a.snap = (float *)ctx->snap.p;
+            a.RS = RS;
+            a.ibegin = a.begin * (uint32_t)NP;
+            a.iend = a.end * (uint32_t)NP;
+            a.ikey = (const uint32_t *)ctx->ikey[1].p;
+            a.imask = (uint32_t)((1ull << ibits) - 1);
+            a.ipay = (const uint32_t *)ctx->ipay[1].p;
+            a.pad_item = padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx;
+            a.loss_partial = (double *)ctx->losspart.p;
+            a.n_loss_partial = (int)sgrid;
+            a.mb_loss_out = d_mb_loss + mb_global;
+            a.loss_kind = loss;
+            a.inv_b = 1.0f;  // the sequence pass already divided its partials by mask.sum()
+            slk_set_opt_coeffs(a, optim);
+            slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
+            hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb)), dim3(256), 0, s,
+                               a);
+            SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ>");
+            slk_prof_end(ctx, s);
+            if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, TM, s))) return rc;
+            optim->step += 1;
+        }
+    }
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_sequence,
+                                   int64_t seq_len, const int64_t *d_items, int64_t n, float *d_out, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, tables, 10u, &vec, &g))) return rc;
+    if (n < 0 || seq_len < 1 || !d_sequence || (n > 0 && !d_out))
+        return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_predict: bad arguments");
+    if (n == 0) return SLK_OK;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    if ((rc = slk_ensure(ctx, ctx->extra[SQ_REP], 256 * 4 * 4))) return rc;
+    float *rep = (float *)ctx->extra[SQ_REP].p;
+    slk_prof_begin(ctx, SLK_K_SCORE, s);
+#define SLK_SEQ_PREDICT(V_, G_)                                                                                  \
+    do {                                                                                                         \
+        hipLaunchKernelGGL((k_seq_final_repr<V_, G_>), dim3(1), dim3(64), 0, s, (const float *)tables->d_param[1], \
+                           (int)tables->dim, d_sequence, (int)seq_len, rep);                                     \
+        hipLaunchKernelGGL((k_seq_predict<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
+                           (const float *)rep, (const float *)tables->d_param[1],                                \
+                           (const float *)tables->d_param[3], (int)tables->dim, d_items, n, d_out);              \
+    } while (0)
+    SLK_FOR_LAYOUT(vec, g, SLK_SEQ_PREDICT);
+#undef SLK_SEQ_PREDICT
+    SLK_LAUNCH_CHECK(ctx, "k_seq_predict");
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}

@@ -1,0 +1,193 @@
+"""ImplicitSequenceModel -- drop-in for spotlight/sequence/implicit.py:23-340 with the
+'pooling' (PoolNet) representation.
+
+Same constructor, fit(), predict(), error behaviour and random-state consumption as the
+reference; everything inside the epoch loop (negative sampling, PoolNet forward for the
+sequence and the negatives, masked loss, backward, optimizer update) is one C-ABI call into
+csrc/libspotlight_hip.so per epoch (include/spotlight_hip.h: slk_poolnet_train).
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from spotlight_amd import _native
+from spotlight_amd.factorization import implicit as _host
+from spotlight_amd.factorization.implicit import _OptimizerBinding
+from spotlight_amd.helpers import _repr_model
+from spotlight_amd.sequence.representations import PADDING_IDX, PoolNet
+from spotlight_amd.torch_utils import set_seed, shuffle
+
+
+class _SeqOptimizerBinding(_OptimizerBinding):
+    """slk_optim over PoolNet's two tables: ABI slots 1 (item embeddings) and 3 (item biases)."""
+
+    def as_struct(self):
+        slot = lambda xs: [None, xs[0].data_ptr(), None, xs[1].data_ptr()]
+        return _native.make_optim(self.kind, slot(self.s1), slot(self.s2) if self.s2 else None,
+                                  step=self.steps_taken(), **self.hp)
+
+
+class ImplicitSequenceModel(object):
+    """Implicit-feedback sequence model (next-item prediction from the items seen so far).
+
+    Parameters follow spotlight/sequence/implicit.py:85-97.  `representation` must be
+    'pooling' or a :class:`PoolNet`; the reference's 'cnn' / 'lstm' / 'mixture' encoders are
+    outside this package's scope and raise NotImplementedError.  `use_cuda` is accepted for
+    signature compatibility; the model always lives on the HIP device.
+    """
+
+    def __init__(self, loss='pointwise', representation='pooling', embedding_dim=32, n_iter=10,
+                 batch_size=256, l2=0.0, learning_rate=1e-2, optimizer_func=None, use_cuda=False,
+                 sparse=False, random_state=None, num_negative_samples=5):
+
+        assert loss in ('pointwise', 'bpr', 'hinge', 'adaptive_hinge')
+
+        if isinstance(representation, str):
+            assert representation in ('pooling', 'cnn', 'lstm', 'mixture')
+
+        self._loss = loss
+        self._representation = representation
+        self._embedding_dim = embedding_dim
+        self._n_iter = n_iter
+        self._learning_rate = learning_rate
+        self._batch_size = batch_size
+        self._l2 = l2
+        self._use_cuda = use_cuda
+        self._sparse = sparse
+        self._optimizer_func = optimizer_func
+        self._random_state = random_state or np.random.RandomState()
+        self._num_negative_samples = num_negative_samples
+
+        self._num_items = None
+        self._net = None
+        self._optimizer = None
+        self._loss_func = None
+        self._binding = None
+
+        # consumes one draw of the stream, like the reference (sequence/implicit.py:131-132)
+        set_seed(self._random_state.randint(-10**8, 10**8), cuda=self._use_cuda)
+
+    def __repr__(self):
+        return _repr_model(self)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_binding'] = None  # raw pointers; rebuilt on the next fit()
+        return state
+
+    @property
+    def _initialized(self):
+        return self._net is not None
+
+    def _initialize(self, interactions):
+        self._num_items = interactions.num_items
+        if self._representation == 'pooling':
+            net = PoolNet(self._num_items, self._embedding_dim, sparse=self._sparse)
+        elif isinstance(self._representation, PoolNet):
+            net = self._representation
+        else:
+            raise NotImplementedError(
+                'representation {!r}: only the pooling (PoolNet) representation has a fused gfx950 '
+                'path; the cnn / lstm / mixture encoders are out of scope'.format(self._representation))
+        if type(net.item_embeddings).__name__ == 'BloomEmbedding':
+            raise NotImplementedError('BloomEmbedding item layers are not supported by the PoolNet kernels yet')
+        self._net = net.to(_host._model_device())
+
+        if self._optimizer_func is None:
+            self._optimizer = optim.Adam(self._net.parameters(), weight_decay=self._l2,
+                                         lr=self._learning_rate)
+        else:
+            self._optimizer = self._optimizer_func(self._net.parameters())
+        self._loss_func = self._loss  # fused into the kernel; kept for introspection
+        self._binding = None
+
+    def _bind(self):
+        if self._binding is None:
+            tables = self._net.tables()
+            for t in tables:
+                if not (t.device.type == _host._model_device().type and t.is_contiguous()
+                        and t.dtype == torch.float32):
+                    raise RuntimeError('model tables must be contiguous fp32 tensors on the HIP device')
+            self._binding = _SeqOptimizerBinding(self._optimizer, tables, self._sparse)
+        return self._binding
+
+    def _check_input(self, item_ids):
+        if isinstance(item_ids, int):
+            item_id_max = item_ids
+        else:
+            item_id_max = item_ids.max()
+        if item_id_max >= self._num_items:
+            raise ValueError('Maximum item id greater than number of items in model.')
+
+    def _slk_tables(self):
+        w = self._net.tables()
+        return _native.make_seq_tables(w[0].data_ptr(), w[1].data_ptr(), w[0].shape[0], w[0].shape[1])
+
+    def _padding_idx(self):
+        return self._net.item_embeddings.padding_idx
+
+    def fit(self, interactions, verbose=False):
+        """Fit the model on a SequenceInteractions dataset; repeated calls resume
+        (sequence/implicit.py:193-264)."""
+        sequences = interactions.sequences.astype(np.int64)
+
+        if not self._initialized:
+            self._initialize(interactions)
+
+        self._check_input(sequences)
+
+        binding = self._bind()
+        device = self._net.tables()[0].device
+        engine = _host._engine_for(device)
+        stream = _host._stream_for(device)
+        tables = self._slk_tables()
+        n_seq, seq_len = sequences.shape
+        n_minibatches = (n_seq + self._batch_size - 1) // self._batch_size
+        mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
+
+        for epoch_num in range(self._n_iter):
+            # host shuffle on the model's RandomState; `sequences` is rebound, so successive
+            # epochs' permutations compose exactly as in the reference (:215-216)
+            sequences = shuffle(sequences, random_state=self._random_state)
+            d_sequences = torch.from_numpy(np.ascontiguousarray(sequences)).to(device)
+
+            engine.rng_set_state(self._random_state.get_state())
+            ostruct = binding.as_struct()
+            engine.poolnet_train(tables, ostruct, self._padding_idx(), d_sequences.data_ptr(), n_seq, seq_len,
+                                 self._batch_size, self._loss, self._num_negative_samples,
+                                 mb_loss.data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
+
+            epoch_loss = float(mb_loss.double().mean().item())
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def predict(self, sequences, item_ids=None):
+        """Scores of the next item after `sequences` (one sequence) for all items or for
+        `item_ids`; flat np.float32 array (sequence/implicit.py:288-340)."""
+        self._net.train(False)
+
+        sequences = np.atleast_2d(sequences)
+
+        if item_ids is None:
+            item_ids = np.arange(self._num_items).reshape(-1, 1)
+
+        self._check_input(item_ids)
+        self._check_input(sequences)
+
+        seq = np.ascontiguousarray(sequences.astype(np.int64).reshape(-1))
+        items = np.ascontiguousarray(np.asarray(item_ids).astype(np.int64).reshape(-1))
+
+        device = self._net.tables()[0].device
+        engine = _host._engine_for(device)
+        d_seq = torch.from_numpy(seq).to(device)
+        d_items = torch.from_numpy(items).to(device)
+        out = torch.empty(items.size, dtype=torch.float32, device=device)
+        engine.poolnet_predict(self._slk_tables(), d_seq.data_ptr(), seq.size, d_items.data_ptr(), items.size,
+                               out.data_ptr(), _host._stream_for(device))
+        return out.cpu().numpy().flatten()

@@ -37,6 +37,20 @@ class _Model(object):
         self.optim = _native.make_optim(opt, [be.ptr(x) for x in self.s1], [be.ptr(x) for x in self.s2], **hp)
 
 
+class _SeqModel(object):
+    """PoolNet tables (item_embeddings, item_biases) + optimizer state in ABI slots 1 and 3."""
+
+    def __init__(self, be, params, opt='adagrad', **hp):
+        f = lambda x: be.alloc(np.array(x, dtype=np.float32, order='C'))
+        self.p = [f(params[0]), f(np.asarray(params[1]).reshape(-1))]
+        self.s1 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
+        self.s2 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
+        I, D = be.get(self.p[0]).shape
+        self.tables = _native.make_seq_tables(be.ptr(self.p[0]), be.ptr(self.p[1]), I, D)
+        slot = lambda xs: [None, be.ptr(xs[0]), None, be.ptr(xs[1])]
+        self.optim = _native.make_optim(opt, slot(self.s1), slot(self.s2), **hp)
+
+
 class EmuBackend(object):
     stream = 0
 
@@ -54,6 +68,9 @@ class EmuBackend(object):
 
     def model(self, params, opt='adagrad', **hp):
         return _Model(self, params, opt, **hp)
+
+    def seq_model(self, params, opt='adagrad', **hp):
+        return _SeqModel(self, params, opt, **hp)
 
     def close(self):
         self.engine.close()

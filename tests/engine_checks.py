@@ -195,3 +195,141 @@ ALL_OPTS = ('adagrad', 'sparse_adam', 'adam_dense', 'adagrad_dense')
 FIXTURES = ['bpr_adagrad_sparse', 'hinge_sparse_adam', 'pointwise_adam_default', 'adaptive_hinge_adagrad',
             'd64_bpr_adagrad', 'd64_adaptive_sparse_adam', 'c1_bpr_adam', 'c1_bpr_adagrad',
             'd12_pointwise_adagrad_wd']
+
+
+# ---------------------------------------------------------------------------------------
+# PoolNet / ImplicitSequenceModel (slk_poolnet_*)
+# ---------------------------------------------------------------------------------------
+def make_sequences(rs, n_seq, L, num_items, pad_frac=0.5):
+    seqs = rs.randint(1, num_items, (n_seq, L)).astype(np.int64)
+    for b in range(n_seq):
+        if L > 1 and rs.rand() < pad_frac:
+            seqs[b, :rs.randint(1, L)] = 0  # left padding, at least one real item
+    return seqs
+
+
+def _seq_params(rs, I, D):
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    E = rs.normal(0, sc, (I, D)).astype(np.float32)
+    bias = rs.normal(0, 0.1, I).astype(np.float32)
+    E[0] = 0.0   # padding row (ScaledEmbedding/ZeroEmbedding with padding_idx=0, layers.py:35-37,54-56)
+    bias[0] = 0.0
+    return [E, bias]
+
+
+def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3, epochs=2, tol=2e-5, seed=5,
+                                   pad_frac=0.5):
+    from oracle.oracle import PoolNetOracle
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    seqs = make_sequences(rs, N, L, I, pad_frac)
+    params = _seq_params(rs, I, D)
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    ora = PoolNetOracle(*params, opt=opt, **hp)
+    dev = be.seq_model(params, opt=opt, **hp)
+    state = np.random.RandomState(9).get_state()
+    orng = Rng(state=state)
+    eng.rng_set_state(state)
+    n_mb = (N + B - 1) // B
+    d_seqs = be.alloc(seqs)
+    for epoch in range(epochs):
+        want_loss, want_neg = ora.train(orng, seqs, B, loss=loss, n_neg=nn, want_negs=True)
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.full(want_neg.size, -1, dtype=np.int64))
+        eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), N, L, B, loss, nn, be.ptr(mb_loss),
+                          d_neg_out=be.ptr(neg_out), stream=be.stream)
+        assert (be.get(neg_out) == want_neg).all()
+        got_loss = be.get(mb_loss)
+        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-5, (got_loss, want_loss)
+    assert dev.optim.step == ora.step_count == epochs * n_mb
+    for t in range(2):
+        assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t))
+        assert_close_table(be.get(dev.s1[t]), ora.s1[t], tol, ('state1', t))
+        if opt in ('sparse_adam', 'adam_dense'):
+            assert_close_table(be.get(dev.s2[t]), ora.s2[t], tol, ('state2', t))
+    assert (be.get(dev.p[0])[0] == 0).all() and be.get(dev.p[1])[0] == 0  # padding row untouched
+    got, ref = eng.rng_get_state(), orng.get_state()
+    assert (got[1] == ref[1]).all() and got[2] == ref[2]
+    # predict on the engine's own tables (sequence/implicit.py:288-340)
+    po = PoolNetOracle(be.get(dev.p[0]), be.get(dev.p[1]))
+    out = be.alloc(np.empty(I, dtype=np.float32))
+    d_seq = be.alloc(seqs[1])
+    eng.poolnet_predict(dev.tables, be.ptr(d_seq), L, None, I, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), po.predict(seqs[1])) < 1e-5
+    some = np.arange(1, min(I, 12), dtype=np.int64)
+    out = be.alloc(np.empty(some.size, dtype=np.float32))
+    d_some = be.alloc(some)
+    eng.poolnet_predict(dev.tables, be.ptr(d_seq), L, be.ptr(d_some), some.size, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), po.predict(seqs[1], some)) < 1e-5
+
+
+def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11):
+    """Identical minibatch and parameters: loss within 1e-5 rel, summed gradients within 1e-5 of
+    each table's inf-norm; read back through ADAM_DENSE with lr = 0, beta1 = 0."""
+    from oracle.oracle import PoolNetOracle
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    seqs = make_sequences(rs, B, L, I)
+    n_draw = B * L * (nn if loss == 'adaptive_hinge' else 1)
+    negs = rs.randint(0, I, n_draw).astype(np.int64)
+    params = _seq_params(rs, I, D)
+    want_loss, want_g = PoolNetOracle(*params, opt='adagrad').step(seqs, negs, loss=loss, n_neg=nn, want_grads=True)
+    dev = be.seq_model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999))
+    mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+    d_seqs, d_negs = be.alloc(seqs), be.alloc(negs)
+    eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), B, L, B, loss, nn, be.ptr(mb_loss),
+                      d_neg_in=be.ptr(d_negs), stream=be.stream)
+    assert abs(float(be.get(mb_loss)[0]) - want_loss) / abs(want_loss) < 1e-5
+    for t in range(2):
+        got = be.get(dev.s1[t])
+        assert np.abs(got.ravel() - want_g[t].ravel()).max() <= 1e-5 * np.abs(want_g[t]).max(), t
+        assert np.array_equal(be.get(dev.p[t]).ravel(), np.asarray(params[t], np.float32).ravel())
+
+
+def check_seq_replays_reference_fixture(be, golden_dir, name):
+    """Sequence fixtures recorded from the live reference (oracle/make_golden_seq.py)."""
+    from oracle.replay import case_from_rec, _oracle_hparams
+    eng = be.engine
+    rec = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = case_from_rec(rec)
+    dev = be.seq_model([rec['init_0'], rec['init_1']], opt=ORACLE_OPT[str(case['opt'])], **_oracle_hparams(case))
+    state = ('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit']))
+    eng.rng_set_state(state)
+    host = Rng(state=state)
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, L, B = int(case['N']), int(case['L']), int(case['B'])
+    n_mb = (N + B - 1) // B
+    seqs = rec['sequences'].astype(np.int64)
+    losses, negs = [], []
+    for e in range(int(case['n_iter'])):
+        host.set_state(eng.rng_get_state())
+        seqs = seqs[host.shuffle_perm(N)]  # epochs compose (sequence/implicit.py:215-216)
+        eng.rng_set_state(host.get_state())
+        assert (seqs == rec['shuffled'][e]).all()
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.empty(N * L * nn, dtype=np.int64))
+        d_seqs = be.alloc(seqs)
+        eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), N, L, B, str(case['loss']), nn, be.ptr(mb_loss),
+                          d_neg_out=be.ptr(neg_out), stream=be.stream)
+        losses.append(be.get(mb_loss))
+        negs.append(be.get(neg_out))
+    assert (np.concatenate(negs) == rec['negatives']).all()
+    losses = np.concatenate(losses)
+    assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
+    assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
+    st = eng.rng_get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    for t in range(2):
+        ref = rec['final_%d' % t]
+        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
+        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+    # predictions on the reference's final tables
+    fin = be.seq_model([rec['final_0'], rec['final_1']])
+    out = be.alloc(np.empty(int(case['I']), dtype=np.float32))
+    d_seq = be.alloc(rec['predict_seq'].astype(np.int64))
+    eng.poolnet_predict(fin.tables, be.ptr(d_seq), L, None, int(case['I']), be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), rec['predict_all']) < 1e-5
+
+
+SEQ_FIXTURES = ['seq_bpr_adagrad_sparse', 'seq_hinge_sparse_adam', 'seq_pointwise_adam_default',
+                'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam']

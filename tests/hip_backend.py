@@ -3,7 +3,7 @@ tensors as device memory, torch's current stream."""
 import numpy as np
 import torch
 
-from emu_backend import _Model
+from emu_backend import _Model, _SeqModel
 from spotlight_amd import _native
 
 
@@ -27,6 +27,9 @@ class HipBackend(object):
 
     def model(self, params, opt='adagrad', **hp):
         return _Model(self, params, opt, **hp)
+
+    def seq_model(self, params, opt='adagrad', **hp):
+        return _SeqModel(self, params, opt, **hp)
 
     def close(self):
         torch.cuda.synchronize()

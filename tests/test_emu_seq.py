@@ -1,0 +1,58 @@
+"""PoolNet / ImplicitSequenceModel kernels (spotlight_amd/csrc/slk_seq.hip, unmodified) run by
+the fiber emulator against the CPU oracle and the sequence fixtures recorded from the live
+reference.  The same checks run on the real gfx950 library in tests/test_gpu_engine.py."""
+import numpy as np
+import pytest
+
+import engine_checks as ec
+from conftest import GOLDEN
+from emu_backend import EmuBackend
+from spotlight_amd import _native
+
+
+@pytest.fixture(scope='module')
+def be():
+    b = EmuBackend()
+    yield b
+    b.close()
+
+
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_seq_train_matches_oracle(be, loss, opt):
+    ec.check_seq_train_matches_oracle(be, loss, opt, 8)
+
+
+@pytest.mark.parametrize('D,L,B', [(32, 20, 10), (64, 33, 6), (128, 5, 8), (6, 300, 3), (3, 1, 16), (16, 130, 4)])
+def test_seq_other_layouts_and_lengths(be, D, L, B):
+    # L > number of row groups (several timesteps per chunk), L == 1, odd dims
+    ec.check_seq_train_matches_oracle(be, 'bpr', 'adagrad', D, I=47, N=B + 3, L=L, B=B, epochs=1)
+
+
+def test_seq_no_padding_and_heavy_duplicates(be):
+    ec.check_seq_train_matches_oracle(be, 'pointwise', 'adagrad', 8, I=5, N=20, L=12, B=8, pad_frac=0.0, tol=1e-4)
+    ec.check_seq_train_matches_oracle(be, 'adaptive_hinge', 'sparse_adam', 8, I=60, N=12, L=6, B=12, nn=5, epochs=1)
+
+
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+def test_seq_single_step_loss_and_gradients(be, loss):
+    ec.check_seq_single_step_gradients(be, loss, 16)
+
+
+@pytest.mark.parametrize('name', ec.SEQ_FIXTURES)
+def test_seq_replays_reference_fixture(be, name):
+    ec.check_seq_replays_reference_fixture(be, GOLDEN, name)
+
+
+def test_seq_argument_errors(be):
+    eng = be.engine
+    dev = be.seq_model([np.zeros((5, 8)), np.zeros(5)])
+    seqs = np.zeros((2, 4), dtype=np.int64)
+    loss = np.zeros(1, dtype=np.float32)
+    with pytest.raises(_native.SlkError) as e:
+        eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(seqs), 2, 0, 2, 'bpr', 1, be.ptr(loss))
+    assert e.value.code == _native.SLK_EINVAL
+    with pytest.raises(_native.SlkError):
+        eng.poolnet_train(dev.tables, dev.optim, 7, be.ptr(seqs), 2, 4, 2, 'bpr', 1, be.ptr(loss))  # padding_idx
+    with pytest.raises(_native.SlkError):
+        eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(seqs), 2, 100000, 2, 'bpr', 1, be.ptr(loss))  # LDS

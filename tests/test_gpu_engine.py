@@ -71,3 +71,36 @@ def test_single_step_loss_and_gradients(be, loss, D):
 @pytest.mark.parametrize('name', ec.FIXTURES)
 def test_train_replays_reference_fixture(be, name):
     ec.check_replays_reference_fixture(be, GOLDEN, name)
+
+
+# ---- PoolNet / ImplicitSequenceModel kernels (csrc/slk_seq.hip) ----
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_seq_train_matches_oracle(be, loss, opt):
+    ec.check_seq_train_matches_oracle(be, loss, opt, 8)
+
+
+@pytest.mark.parametrize('D,L,B', [(32, 20, 10), (64, 33, 6), (128, 5, 8), (6, 300, 3), (3, 1, 16), (16, 130, 4),
+                                   (64, 200, 5), (128, 200, 3), (256, 100, 2)])
+def test_seq_other_layouts_and_lengths(be, D, L, B):
+    ec.check_seq_train_matches_oracle(be, 'bpr', 'adagrad', D, I=47, N=B + 3, L=L, B=B, epochs=1)
+
+
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('pointwise', 'sparse_adam'), ('adaptive_hinge', 'adagrad')])
+def test_seq_train_matches_oracle_at_scale(be, loss, opt):
+    """Many workgroups, several minibatches per chunk, duplicates everywhere: 600 sequences of
+    length 50, D=64, minibatches of 128 (+ a short one)."""
+    ec.check_seq_train_matches_oracle(be, loss, opt, 64, I=2000, N=600, L=50, B=128, nn=5, epochs=1, tol=1e-4,
+                                      pad_frac=0.2)
+
+
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('D', [16, 64])
+def test_seq_single_step_loss_and_gradients(be, loss, D):
+    ec.check_seq_single_step_gradients(be, loss, D)
+    ec.check_seq_single_step_gradients(be, loss, D, I=3000, B=200, L=40, seed=3)
+
+
+@pytest.mark.parametrize('name', ec.SEQ_FIXTURES)
+def test_seq_replays_reference_fixture(be, name):
+    ec.check_seq_replays_reference_fixture(be, GOLDEN, name)

@@ -98,3 +98,35 @@ def test_training_learns_planted_structure():
         other = s[np.arange(I) % C != u % C].mean()
         wins += own > other
     assert wins >= 190, wins
+
+
+@pytest.mark.parametrize('name', ['seq_bpr_adam_default', 'seq_hinge_adagrad_sparse', 'seq_pointwise_sparse_adam',
+                                  'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam'])
+def test_sequence_model_fit_predict_match_reference_run(name):
+    """ImplicitSequenceModel (PoolNet) drop-in API on cuda:0 against the reference's recordings."""
+    from test_host_seq_model import check_fit_predict_against_fixture
+    model = check_fit_predict_against_fixture(name, to_numpy=lambda w: w.detach().cpu().numpy(), use_cuda=True)
+    assert all(w.is_cuda for w in model._net.tables())
+
+
+def test_sequence_model_learns_planted_structure():
+    """Size-independent property at a size the oracle would not finish: sequences walk a ring of
+    items (next = current + 1); after training, the model must rank the true next item of a
+    held-out prefix far above a random item (cf. the reference's MRR floors,
+    tests/sequence/test_sequence_implicit.py)."""
+    from spotlight_amd.interactions import SequenceInteractions
+    from spotlight_amd.sequence.implicit import ImplicitSequenceModel
+    rs = np.random.RandomState(11)
+    I, L, N = 500, 20, 20000
+    start = rs.randint(1, I, N)
+    seqs = ((start[:, None] + np.arange(L)[None, :] - 1) % (I - 1) + 1).astype(np.int32)
+    model = ImplicitSequenceModel(loss='bpr', embedding_dim=32, n_iter=6, batch_size=512,
+                                  optimizer_func=_adagrad, random_state=np.random.RandomState(3))
+    model.fit(SequenceInteractions(seqs, num_items=I))
+    wins = 0
+    for k in range(100):
+        prefix = seqs[k, :-1]
+        scores = model.predict(prefix)
+        nxt = seqs[k, -1]
+        wins += (scores[nxt] > scores[1:]).mean() > 0.9  # top decile
+    assert wins >= 80, wins
