@@ -23,6 +23,8 @@ for st in $STAGES; do
       echo "prof exit $?"; find $OUT/prof -name "*kernel_stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
     shard)
       timeout 600 python bench.py --sharded --no-cpu-baseline > $OUT/bench_sharded1.json 2> $OUT/bench_sharded1.err; echo "bench --sharded exit $?"; cat $OUT/bench_sharded1.json; tail -5 $OUT/bench_sharded1.err ;;
+    c4)
+      timeout 600 python bench.py --workload c4 --steps 8 --warmup 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "bench c4 exit $?"; cat $OUT/bench_c4.json; tail -5 $OUT/bench_c4.err ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && timeout 900 rocprofv3 --pmc $c -d $OUT/pmc_$c -o bench -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err)
