@@ -265,3 +265,110 @@ class PoolNetOracle(object):
         lib().slko_poolnet_predict(C.byref(self.m), _ptr(seq), C.c_int64(seq.size), _ptr(items), C.c_int64(n),
                                    _ptr(out))
         return out
+
+
+BLOOM_SEEDS = [179424941, 179425457, 179425907, 179426369,
+               179424977, 179425517, 179425943, 179426407]  # spotlight/layers.py:13-20, first eight
+
+
+class _Bloom(C.Structure):
+    _fields_ = [('rows', C.c_int64), ('n_hash', C.c_int32), ('pad_', C.c_int32), ('padding_idx', C.c_int64),
+                ('skip_row', C.c_int64), ('seeds', C.c_uint32 * 8)]
+
+
+class _BModel(C.Structure):
+    _fields_ = [('p', C.c_void_p * 4), ('s1', C.c_void_p * 4), ('s2', C.c_void_p * 4),
+                ('num_users', C.c_int64), ('num_items', C.c_int64), ('dim', C.c_int32), ('opt_kind', C.c_int32),
+                ('step', C.c_int64),
+                ('lr', C.c_double), ('eps', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('weight_decay', C.c_double), ('lr_decay', C.c_double), ('bloom', _Bloom * 2)]
+
+
+def bloom_desc(n_hash=4, padding_idx=0, bag=False, seeds=None):
+    """Descriptor of a BloomEmbedding (layers.py:134-176); the compressed row count comes from
+    the table itself."""
+    return dict(n_hash=n_hash, padding_idx=padding_idx, skip_row=-1 if bag else padding_idx,
+                seeds=list(seeds if seeds is not None else BLOOM_SEEDS[:n_hash]))
+
+
+class BloomBilinearOracle(object):
+    """BilinearNet whose user and/or item embedding layer is a BloomEmbedding
+    (spotlight/layers.py:74-244); `user_bloom` / `item_bloom` are bloom_desc() dicts or None."""
+
+    def __init__(self, user_emb, item_emb, user_bias, item_bias, user_bloom=None, item_bloom=None,
+                 opt='adagrad', lr=1e-2, eps=None, betas=(0.9, 0.999), weight_decay=0.0, lr_decay=0.0, step=0):
+        assert lib().slko_sizeof_bmodel() == C.sizeof(_BModel)
+        f = lambda a: np.array(a, dtype=np.float32, order='C', copy=True)
+        self.p = [f(user_emb), f(item_emb), f(user_bias).reshape(-1), f(item_bias).reshape(-1)]
+        if eps is None:
+            eps = 1e-10 if opt.startswith('adagrad') else 1e-8
+        self.s1 = [np.zeros_like(p) for p in self.p]
+        self.s2 = [np.zeros_like(p) for p in self.p]
+        self.m = _BModel()
+        for t in range(4):
+            self.m.p[t] = self.p[t].ctypes.data
+            self.m.s1[t] = self.s1[t].ctypes.data
+            self.m.s2[t] = self.s2[t].ctypes.data
+        self.m.num_users, self.m.num_items = self.p[2].size, self.p[3].size
+        self.m.dim = self.p[0].shape[1]
+        self.m.opt_kind = OPTS[opt]
+        self.m.lr, self.m.eps = lr, eps
+        self.m.beta1, self.m.beta2 = betas
+        self.m.weight_decay, self.m.lr_decay = weight_decay, lr_decay
+        self.m.step = step
+        for side, desc in enumerate((user_bloom, item_bloom)):
+            b = self.m.bloom[side]
+            if desc is None:
+                b.n_hash = 0
+                assert self.p[side].shape[0] == (self.m.num_users, self.m.num_items)[side]
+                continue
+            b.rows, b.n_hash = self.p[side].shape[0], desc['n_hash']
+            b.padding_idx, b.skip_row = desc['padding_idx'], desc['skip_row']
+            for h, s in enumerate(desc['seeds']):
+                b.seeds[h] = s
+
+    @property
+    def step_count(self):
+        return int(self.m.step)
+
+    def predict(self, users, items=None):
+        users = np.ascontiguousarray(np.atleast_1d(users), dtype=np.int64)
+        if items is None:
+            n = int(self.m.num_items)
+        else:
+            items = np.ascontiguousarray(items, dtype=np.int64)
+            n = items.size
+        out = np.empty(n, dtype=np.float32)
+        lib().slko_bloom_predict(C.byref(self.m), _ptr(users), C.c_int64(users.size), _ptr(items), C.c_int64(n),
+                                 _ptr(out))
+        return out
+
+    def step(self, users, pos, neg, loss='bpr', n_neg=1, want_grads=False):
+        users = np.ascontiguousarray(users, dtype=np.int64)
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        neg = np.ascontiguousarray(neg, dtype=np.int64).ravel()
+        loss_out = C.c_float()
+        dg, dgp = None, None
+        if want_grads:
+            dg = [np.zeros_like(p) for p in self.p]
+            dgp = (C.c_void_p * 4)(*[g.ctypes.data for g in dg])
+        rc = lib().slko_bloom_step(C.byref(self.m), _ptr(users), _ptr(pos), _ptr(neg), C.c_int64(users.size),
+                                   C.c_int(n_neg), C.c_int(LOSSES[loss]), C.byref(loss_out), dgp)
+        assert rc == 0
+        return (float(loss_out.value), dg) if want_grads else float(loss_out.value)
+
+    def train(self, rng, users, items, batch_size, loss='bpr', n_neg=1, neg_in=None, want_negs=False):
+        users = np.ascontiguousarray(users, dtype=np.int64)
+        items = np.ascontiguousarray(items, dtype=np.int64)
+        n = users.size
+        nn = n_neg if loss == 'adaptive_hinge' else 1
+        n_mb = (n + batch_size - 1) // batch_size
+        mb_loss = np.empty(n_mb, dtype=np.float32)
+        neg_out = np.empty(n * nn, dtype=np.int64) if want_negs else None
+        if neg_in is not None:
+            neg_in = np.ascontiguousarray(neg_in, dtype=np.int64).ravel()
+        rc = lib().slko_bloom_train(C.byref(self.m), C.byref(rng._r) if rng is not None else None, _ptr(users),
+                                    _ptr(items), C.c_int64(n), C.c_int64(batch_size), C.c_int(LOSSES[loss]),
+                                    C.c_int(n_neg), _ptr(neg_in), _ptr(neg_out), _ptr(mb_loss))
+        assert rc == 0
+        return (mb_loss, neg_out) if want_negs else mb_loss

@@ -145,3 +145,51 @@ def replay_seq_with_oracle(case, rec):
     errs['predict_all'] = rel_inf(po.predict(rec['predict_seq']), rec['predict_all'])
     errs['predict_some'] = rel_inf(po.predict(rec['predict_seq2'], rec['predict_items']), rec['predict_some'])
     return errs, fr
+
+
+def bloom_oracle_for(case, rec, which='init'):
+    from oracle.oracle import BloomBilinearOracle, bloom_desc
+    mk = lambda on: bloom_desc(n_hash=int(case['H']), bag=bool(case.get('bag', False))) if on else None
+    return BloomBilinearOracle(rec[which + '_0'], rec[which + '_1'], rec[which + '_2'], rec[which + '_3'],
+                               user_bloom=mk(int(case['user_bloom'])), item_bloom=mk(int(case['item_bloom'])),
+                               opt=ORACLE_OPT[str(case['opt'])], **_oracle_hparams(case))
+
+
+def replay_bloom_with_oracle(case, rec):
+    """Replays a recorded BloomEmbedding BilinearNet run through the C oracle."""
+    o = bloom_oracle_for(case, rec)
+    rng = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, B = int(case['N']), int(case['B'])
+    users64, items64 = rec['users'].astype(np.int64), rec['items'].astype(np.int64)
+    losses, negs, errs = [], [], {}
+    for e in range(int(case['n_iter'])):
+        perm = rng.shuffle_perm(N)
+        su, si = users64[perm], items64[perm]
+        assert (su == rec['shuffled_users'][e]).all() and (si == rec['shuffled_items'][e]).all()
+        if e == 0:
+            B0 = min(B, N)
+            l0, dg = bloom_oracle_for(case, rec).step(su[:B0], si[:B0], rec['negatives'][:B0 * nn],
+                                                      loss=str(case['loss']), n_neg=nn, want_grads=True)
+            errs['loss0'] = abs(l0 - rec['losses'][0]) / abs(rec['losses'][0])
+            bscale = max(np.abs(rec['grad0_2']).max(), np.abs(rec['grad0_3']).max())
+            for t in range(4):
+                ref = rec['grad0_%d' % t]
+                errs['grad0_%d' % t] = (rel_inf(dg[t].reshape(ref.shape), ref) if t < 2
+                                        else np.abs(dg[t].reshape(ref.shape) - ref).max() / bscale)
+        l, ng = o.train(rng, su, si, B, loss=str(case['loss']), n_neg=nn, want_negs=True)
+        losses.append(l)
+        negs.append(ng)
+    assert (np.concatenate(negs) == rec['negatives']).all(), 'negative ids differ'
+    errs['loss'] = np.max(np.abs(np.concatenate(losses) - rec['losses']) / np.abs(rec['losses']))
+    fr = {}
+    for t in range(4):
+        ref = rec['final_%d' % t]
+        errs['final_%d' % t] = rel_inf(o.p[t].reshape(ref.shape), ref)
+        fr['final_%d' % t] = frac_outside(o.p[t].reshape(ref.shape), ref)
+    st = rng.get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    po = bloom_oracle_for(case, rec, which='final')
+    errs['predict_all'] = rel_inf(po.predict(3), rec['predict_user3_all'])
+    errs['predict_pairs'] = rel_inf(po.predict(rec['predict_pairs_u'], rec['predict_pairs_i']), rec['predict_pairs'])
+    return errs, fr

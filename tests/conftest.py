@@ -15,11 +15,13 @@ def pytest_configure(config):
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
-def golden_names(sequence=False):
-    """Fixtures recorded from the live reference: BilinearNet runs (oracle/make_golden.py) or,
-    with sequence=True, ImplicitSequenceModel/PoolNet runs (oracle/make_golden_seq.py)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN)
-                  if f.endswith('.npz') and f.startswith('seq_') == bool(sequence))
+def golden_names(kind='bilinear'):
+    """Fixtures recorded from the live reference: 'bilinear' = plain BilinearNet runs
+    (oracle/make_golden.py), 'seq' = ImplicitSequenceModel/PoolNet (oracle/make_golden_seq.py),
+    'bloom' = BilinearNet with BloomEmbedding layers (oracle/make_golden_bloom.py)."""
+    def kind_of(f):
+        return 'seq' if f.startswith('seq_') else 'bloom' if f.startswith('bloom_') else 'bilinear'
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and kind_of(f) == kind)
 
 
 @pytest.fixture(scope='session')

@@ -7,7 +7,7 @@ import pytest
 
 from conftest import GOLDEN, golden_names
 from oracle.oracle import Rng, bloom_indices, murmur3_32
-from oracle.replay import case_from_rec, replay_seq_with_oracle, replay_with_oracle
+from oracle.replay import case_from_rec, replay_bloom_with_oracle, replay_seq_with_oracle, replay_with_oracle
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -21,7 +21,7 @@ def test_oracle_replays_reference_run(name):
     assert max(frac.values()) <= 0.02, frac
 
 
-@pytest.mark.parametrize('name', golden_names(sequence=True))
+@pytest.mark.parametrize('name', golden_names('seq'))
 def test_oracle_replays_reference_sequence_run(name):
     """PoolNet / ImplicitSequenceModel (sequence/implicit.py:193-340) fixtures."""
     rec = np.load(os.path.join(GOLDEN, name + '.npz'))
@@ -30,6 +30,18 @@ def test_oracle_replays_reference_sequence_run(name):
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
     assert step < 1e-5, errs
     assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_some'] < 1e-5
+    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
+
+
+@pytest.mark.parametrize('name', golden_names('bloom'))
+def test_oracle_replays_reference_bloom_run(name):
+    """BilinearNet with BloomEmbedding user/item layers (layers.py:74-244) fixtures."""
+    rec = np.load(os.path.join(GOLDEN, name + '.npz'))
+    case = case_from_rec(rec)
+    errs, frac = replay_bloom_with_oracle(case, rec)
+    step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
+    assert step < 1e-5, errs
+    assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_pairs'] < 1e-5
     assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
 
 
