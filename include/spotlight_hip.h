@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 1
+#define SLK_ABI_VERSION 2
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -59,6 +59,22 @@ enum slk_opt {
     SLK_OPT_ADAGRAD_DENSE = 3
 };
 
+/* spotlight/layers.py:74-244 BloomEmbedding(num_embeddings, embedding_dim, compression_ratio,
+ * num_hash_functions, padding_idx): the embedding of id x is the SUM of the rows
+ *   row_h(x) = murmurhash3_32(int32 x, seed = seeds[h]) mod rows     (signed hash, floor-mod)
+ * h = 0..n_hash-1, of a compressed table with rows = int(compression_ratio * num_embeddings);
+ * x == padding_idx maps to row 0 for every h (:180-186); the inner table's padding row
+ * `skip_row` (:167-169) is zero and never receives a gradient (-1: none).  Hashes are computed
+ * in-kernel; the reference's [num_embeddings, n_hash] int64 hash cache (:188-198) is not used. */
+typedef struct slk_bloom {
+    int64_t rows;
+    int32_t n_hash; /* 1..8 (layers.py:13-20 SEEDS, in order) */
+    int32_t reserved;
+    int64_t padding_idx;
+    int64_t skip_row;
+    uint32_t seeds[8];
+} slk_bloom;
+
 /* Table order everywhere = BilinearNet parameter creation order
  * (factorization/representations.py:46-59):
  *   0 user_embeddings.weight [num_users, dim]   1 item_embeddings.weight [num_items, dim]
@@ -69,6 +85,12 @@ typedef struct slk_tables {
     int64_t num_items;
     int32_t dim;
     int32_t reserved;
+    /* NULL: plain table ([num_users|num_items, dim]).  Otherwise d_param[0] / d_param[1] is the
+     * BloomEmbedding's compressed table [bloom->rows, dim] (BilinearNet's user_embedding_layer /
+     * item_embedding_layer arguments, factorization/representations.py:46-56); the bias tables
+     * stay [num_users] / [num_items]. */
+    const slk_bloom *user_bloom;
+    const slk_bloom *item_bloom;
 } slk_tables;
 
 /* Optimizer hyper-parameters are doubles because torch keeps them as Python floats and

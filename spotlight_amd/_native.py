@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 1
+SLK_ABI_VERSION = 2
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
@@ -22,9 +22,15 @@ KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense
                   'exchange': 6, 'seq_pass': 7}
 
 
+class SlkBloom(C.Structure):
+    _fields_ = [('rows', C.c_int64), ('n_hash', C.c_int32), ('reserved', C.c_int32),
+                ('padding_idx', C.c_int64), ('skip_row', C.c_int64), ('seeds', C.c_uint32 * 8)]
+
+
 class SlkTables(C.Structure):
     _fields_ = [('d_param', C.c_void_p * 4), ('num_users', C.c_int64), ('num_items', C.c_int64),
-                ('dim', C.c_int32), ('reserved', C.c_int32)]
+                ('dim', C.c_int32), ('reserved', C.c_int32),
+                ('user_bloom', C.POINTER(SlkBloom)), ('item_bloom', C.POINTER(SlkBloom))]
 
 
 class SlkOptim(C.Structure):
@@ -213,11 +219,31 @@ class Engine(object):
         return out
 
 
-def make_tables(ptrs, num_users, num_items, dim):
+BLOOM_SEEDS = (179424941, 179425457, 179425907, 179426369,
+               179424977, 179425517, 179425943, 179426407)  # spotlight/layers.py:13-20, in order
+
+
+def make_bloom(rows, n_hash, padding_idx=0, skip_row=0, seeds=None):
+    b = SlkBloom()
+    b.rows, b.n_hash = int(rows), int(n_hash)
+    b.padding_idx = -1 if padding_idx is None else int(padding_idx)
+    b.skip_row = -1 if skip_row is None else int(skip_row)
+    for h, s in enumerate(seeds if seeds is not None else BLOOM_SEEDS[:n_hash]):
+        b.seeds[h] = int(s)
+    return b
+
+
+def make_tables(ptrs, num_users, num_items, dim, user_bloom=None, item_bloom=None):
+    """`user_bloom` / `item_bloom`: SlkBloom descriptors (kept alive by the returned struct)."""
     t = SlkTables()
     for i in range(4):
         t.d_param[i] = ptrs[i]
     t.num_users, t.num_items, t.dim = int(num_users), int(num_items), int(dim)
+    t._keep = (user_bloom, item_bloom)
+    if user_bloom is not None:
+        t.user_bloom = C.pointer(user_bloom)
+    if item_bloom is not None:
+        t.item_bloom = C.pointer(item_bloom)
     return t
 
 

@@ -32,7 +32,10 @@
 // ---------------------------------------------------------------------------------------
 // USER PASS
 // ---------------------------------------------------------------------------------------
-template <int VEC, int G, int UPD, bool PRE>
+// BLOOM: the user and/or item embedding layer is a BloomEmbedding (slk_kernels.h).  Item vectors
+// are then sums of hashed rows; a bloom USER vector is shared between users, so its gradient is
+// not applied here but parked in a.urec for a ROW-mode owner pass over the hashed user rows.
+template <int VEC, int G, int UPD, bool PRE, bool BLOOM>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     __shared__ double red[256];
     constexpr int GPB = 256 / G;
@@ -49,7 +52,11 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
-        slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
+        slk_vec<VEC> u;
+        if (BLOOM)
+            u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
+        else
+            u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
@@ -59,8 +66,14 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             if (on) slk_vstore<VEC>(rec + d0, u);
             if (!PRE) {
                 const uint32_t ip = a.uit[2 * (size_t)q], in = a.uit[2 * (size_t)q + 1];
-                const slk_vec<VEC> vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
-                const slk_vec<VEC> vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
+                slk_vec<VEC> vi, vj;
+                if (BLOOM) {
+                    vi = slk_emb_vec<VEC>(a.P[1], a.ib, ip, D, d0, on);
+                    vj = slk_emb_vec<VEC>(a.P[1], a.ib, in, D, d0, on);
+                } else {
+                    vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
+                    vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
+                }
                 const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.P[3][ip];
                 const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.P[3][in];
                 float l, gp, gn;
@@ -80,7 +93,11 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     if (lane == 0) rec[D + s] = g;
                     if (g != 0.0f) {
                         const uint32_t it = a.uit[qb + s];
-                        const slk_vec<VEC> v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
+                        slk_vec<VEC> v;
+                        if (BLOOM)
+                            v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
+                        else
+                            v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
                         slk_vaxpy<VEC>(gu, g, v);
                         gbu += g;
                     }
@@ -89,7 +106,11 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             ++q;
         } while (q < a.end && a.ukey[q] == key);
 
-        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu);
+        if (BLOOM && a.ub.n_hash) {
+            if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
+        } else if (on) {
+            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu);
+        }
         if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
     }
     if (!PRE) {
@@ -113,12 +134,12 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
     const uint32_t stride = gridDim.x * GPB;
     for (uint32_t q = a.begin + blockIdx.x * GPB + grp; q < a.end; q += stride) {
         const uint32_t user = a.ukey[q] & a.umask;
-        const slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + (size_t)user * D + d0) : slk_vzero<VEC>();
+        const slk_vec<VEC> u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         const float bu = a.P[2][user];
         const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
         for (int s = 0; s < a.NP; ++s) {
             const uint32_t it = a.uit[qb + s];
-            const slk_vec<VEC> v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
+            const slk_vec<VEC> v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
             const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v)) + bu + a.P[3][it];
             if (lane == 0) a.sk[kb + s] = sc;
         }
@@ -237,13 +258,44 @@ __global__ __launch_bounds__(256) void k_build_item_keys(const uint32_t *uit, ui
     }
 }
 
+// BloomEmbedding item layer: occurrence r contributes to the n_hash hashed rows of its item:
+// key[r*H + h] = (minibatch, row_h(item)), value = r (same record as the plain occurrence)
+__global__ __launch_bounds__(256) void k_build_item_bloom_keys(const uint32_t *uit, uint32_t nocc, int NP,
+                                                               uint32_t bsz, unsigned cbits, slk_bloom_dev ib,
+                                                               uint32_t *key, uint32_t *val) {
+    const uint32_t H = (uint32_t)ib.n_hash;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nocc * H; e += gridDim.x * 256) {
+        const uint32_t r = e / H, h = e - r * H;
+        const uint32_t q = r / (uint32_t)NP;
+        key[e] = ((q / bsz) << cbits) | slk_bloom_row(ib, uit[r], (int)h);
+        val[e] = r;
+    }
+}
+
+// BloomEmbedding user layer: the head position p of every user segment contributes its summed
+// gradient record to the n_hash hashed rows of the user; non-head positions get the sentinel
+// row `ub.rows` (never updated).  value = p.
+__global__ __launch_bounds__(256) void k_build_user_bloom_keys(const uint32_t *ukey, uint32_t umask, uint32_t nc,
+                                                               uint32_t bsz, unsigned cbits, slk_bloom_dev ub,
+                                                               uint32_t *key, uint32_t *val) {
+    const uint32_t H = (uint32_t)ub.n_hash;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nc * H; e += gridDim.x * 256) {
+        const uint32_t p = e / H, h = e - p * H;
+        const uint32_t mb = p / bsz;
+        const bool head = (p % bsz == 0) || ukey[p - 1] != ukey[p];
+        key[e] = (mb << cbits) | (head ? slk_bloom_row(ub, ukey[p] & umask, (int)h) : ub.rows);
+        val[e] = p;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // predict
 // ---------------------------------------------------------------------------------------
 template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V, const float *bu,
-                                                 const float *bi, int D, const int64_t *users,
-                                                 int64_t n_users, const int64_t *items, int64_t n, float *out) {
+                                                 const float *bi, int D, slk_bloom_dev ub, slk_bloom_dev ib,
+                                                 const int64_t *users, int64_t n_users, const int64_t *items,
+                                                 int64_t n, float *out) {
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
@@ -252,8 +304,8 @@ __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V,
     for (int64_t k = (int64_t)blockIdx.x * GPB + grp; k < n; k += (int64_t)gridDim.x * GPB) {
         const int64_t u = users[n_users == 1 ? 0 : k];
         const int64_t i = items ? items[k] : k;
-        const slk_vec<VEC> a = on ? slk_vload<VEC>(U + (size_t)u * D + d0) : slk_vzero<VEC>();
-        const slk_vec<VEC> b = on ? slk_vload<VEC>(V + (size_t)i * D + d0) : slk_vzero<VEC>();
+        const slk_vec<VEC> a = slk_emb_vec<VEC>(U, ub, (uint32_t)u, D, d0, on);
+        const slk_vec<VEC> b = slk_emb_vec<VEC>(V, ib, (uint32_t)i, D, d0, on);
         const float s = slk_group_sum<G>(slk_vdot<VEC>(a, b)) + bu[u] + bi[i];
         if (lane == 0) out[k] = s;
     }
@@ -264,16 +316,21 @@ __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V,
 // ---------------------------------------------------------------------------------------
 typedef slk_pass_fn pass_fn;
 
-template <int VEC, int G>
-static pass_fn user_pass_fn(int upd, bool pre) {
+template <int VEC, int G, bool BLOOM>
+static pass_fn user_pass_fn2(int upd, bool pre) {
     if (pre) {
-        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, true>;
-        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, true>;
-        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, true>;
+        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, true, BLOOM>;
+        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, true, BLOOM>;
+        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, true, BLOOM>;
     }
-    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, false>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, false>;
-    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, false>;
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, false, BLOOM>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, false, BLOOM>;
+    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, false, BLOOM>;
+}
+
+template <int VEC, int G>
+static pass_fn user_pass_fn(int upd, bool pre, bool bloom) {
+    return bloom ? user_pass_fn2<VEC, G, true>(upd, pre) : user_pass_fn2<VEC, G, false>(upd, pre);
 }
 
 
@@ -289,6 +346,15 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
     if (!slk_pick_layout(t->dim, vec, g))
         return slk_fail(ctx, SLK_EINVAL,
                         "embedding dim %d unsupported (need dim %% 4 == 0 and <= 256, or dim <= 64)", t->dim);
+    const slk_bloom *bl[2] = {(table_mask & 1u) ? t->user_bloom : nullptr, (table_mask & 2u) ? t->item_bloom : nullptr};
+    for (int side = 0; side < 2; ++side) {
+        const slk_bloom *b = bl[side];
+        if (!b) continue;
+        if (b->n_hash < 1 || b->n_hash > 8 || b->rows < 1 || b->rows >= ((int64_t)1 << 30) || b->skip_row >= b->rows ||
+            b->skip_row < -1 || b->padding_idx < -1)
+            return slk_fail(ctx, SLK_EINVAL, "bad BloomEmbedding descriptor: rows %lld n_hash %d skip_row %lld",
+                            (long long)b->rows, b->n_hash, (long long)b->skip_row);
+    }
     return SLK_OK;
 }
 
@@ -383,7 +449,10 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
     hipLaunchKernelGGL((k_predict<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
                        (const float *)tables->d_param[0], (const float *)tables->d_param[1],          \
                        (const float *)tables->d_param[2], (const float *)tables->d_param[3],          \
-                       (int)tables->dim, d_users, n_users, d_items, n, d_out)
+                       (int)tables->dim, ubd, ibd, d_users, n_users, d_items, n, d_out)
+    slk_bloom_dev ubd, ibd;
+    slk_bloom_to_dev(tables->user_bloom, &ubd);
+    slk_bloom_to_dev(tables->item_bloom, &ibd);
     SLK_FOR_LAYOUT(vec, g, SLK_PREDICT);
 #undef SLK_PREDICT
     SLK_LAUNCH_CHECK(ctx, "k_predict");
@@ -419,15 +488,29 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
     const int D = tables->dim;
     const unsigned ubits = slk_bits_for((uint64_t)tables->num_users - 1);
     const unsigned ibits = slk_bits_for((uint64_t)tables->num_items - 1);
-    const unsigned idbits = ubits > ibits ? ubits : ibits;
+    unsigned idbits = ubits > ibits ? ubits : ibits;
+    // BloomEmbedding layers (layers.py:74-244): keys of the row-owner passes are hashed rows
+    slk_bloom_dev ubd, ibd;
+    slk_bloom_to_dev(tables->user_bloom, &ubd);
+    slk_bloom_to_dev(tables->item_bloom, &ibd);
+    const bool bloom = ubd.n_hash || ibd.n_hash;
+    const int Hu = ubd.n_hash, Hi = ibd.n_hash;
+    const unsigned ucbits = Hu ? slk_bits_for((uint64_t)ubd.rows) : 0;  // + the non-head sentinel row
+    const unsigned icbits = Hi ? slk_bits_for((uint64_t)ibd.rows - 1) : 0;
+    if (ucbits > idbits) idbits = ucbits;
+    if (icbits > idbits) idbits = icbits;
+    const int64_t occ_mult = (int64_t)NP * (Hi ? Hi : 1) > (int64_t)(Hu ? Hu : 1) ? (int64_t)NP * (Hi ? Hi : 1)
+                                                                                 : (int64_t)(Hu ? Hu : 1);
     // minibatches per chunk: keys must fit 32 bits, occurrences must fit 2^31, and scratch
     // stays bounded (~8M interactions).
     const int64_t bsz = batch_size < n ? batch_size : n;
     int64_t mb_per_chunk = (int64_t)1 << (32 - idbits);
     const int64_t cap_inter = (int64_t)1 << 23;
     if (mb_per_chunk * bsz > cap_inter) mb_per_chunk = cap_inter / bsz;
-    while (mb_per_chunk > 1 && mb_per_chunk * bsz * NP >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
+    while (mb_per_chunk > 1 && mb_per_chunk * bsz * occ_mult >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
     if (mb_per_chunk < 1) mb_per_chunk = 1;
+    if (bsz * occ_mult >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "batch_size * lookups per interaction must be < 2^31");
     const int64_t chunk_cap = mb_per_chunk * bsz;
 
     // scratch
@@ -448,19 +531,35 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
         if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
+    enum { BL_IKEY0 = 16, BL_IKEY1, BL_IPAY0, BL_IPAY1, BL_UKEY0, BL_UKEY1, BL_UPAY0, BL_UPAY1, BL_UREC };
+    const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
+    for (int b = 0; b < 2; ++b) {
+        if (Hi && (rc = slk_ensure(ctx, ctx->extra[BL_IKEY0 + b], nc_max * NP * Hi * 4))) return rc;
+        if (Hi && (rc = slk_ensure(ctx, ctx->extra[BL_IPAY0 + b], nc_max * NP * Hi * 4))) return rc;
+        if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UKEY0 + b], nc_max * Hu * 4))) return rc;
+        if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UPAY0 + b], nc_max * Hu * 4))) return rc;
+    }
+    if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     if (dense) {
-        const size_t elems[4] = {(size_t)tables->num_users * D, (size_t)tables->num_items * D,
-                                 (size_t)tables->num_users, (size_t)tables->num_items};
+        const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
+                                 (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
+                                 (size_t)tables->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
     }
 
     const int upd = slk_upd_for(optim->kind);
-    pass_fn upass = nullptr, ipass = nullptr, spass = nullptr;
-#define SLK_PICK(V_, G_)                                  \
-    do {                                                  \
-        upass = user_pass_fn<V_, G_>(upd, adaptive);      \
-        ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                \
-        spass = k_score_pass<V_, G_>;                     \
+    pass_fn upass = nullptr, ipass = nullptr, spass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr,
+            rpass_rows = nullptr;
+#define SLK_PICK(V_, G_)                                                                  \
+    do {                                                                                  \
+        upass = user_pass_fn<V_, G_>(upd, adaptive, bloom);                               \
+        ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
+        spass = k_score_pass<V_, G_>;                                                     \
+        if (bloom) {                                                                      \
+            ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_ROWS>(upd);     \
+            ipass_bias = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_BIAS>(upd);     \
+            rpass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_ROW, SLK_PART_ROWS>(upd);      \
+        }                                                                                 \
     } while (0)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
@@ -522,6 +621,28 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
                                          (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
                                          ibits + mbbits, s)))
             return rc;
+        if (Hi) {
+            hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,
+                               uit, nocc, NP, (uint32_t)bsz, icbits, ibd, (uint32_t *)ctx->extra[BL_IKEY0].p,
+                               (uint32_t *)ctx->extra[BL_IPAY0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_build_item_bloom_keys");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_IKEY0].p,
+                                             (uint32_t *)ctx->extra[BL_IKEY1].p,
+                                             (const uint32_t *)ctx->extra[BL_IPAY0].p,
+                                             (uint32_t *)ctx->extra[BL_IPAY1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+                return rc;
+        }
+        if (Hu) {
+            hipLaunchKernelGGL(k_build_user_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nc * Hu, 256)), dim3(256), 0, s,
+                               (const uint32_t *)ukey, (uint32_t)((1ull << ubits) - 1), nc, (uint32_t)bsz, ucbits, ubd,
+                               (uint32_t *)ctx->extra[BL_UKEY0].p, (uint32_t *)ctx->extra[BL_UPAY0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_build_user_bloom_keys");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_UKEY0].p,
+                                             (uint32_t *)ctx->extra[BL_UKEY1].p,
+                                             (const uint32_t *)ctx->extra[BL_UPAY0].p,
+                                             (uint32_t *)ctx->extra[BL_UPAY1].p, (size_t)nc * Hu, ucbits + mbbits, s)))
+                return rc;
+        }
         slk_prof_end(ctx, s);
 
         // ---- minibatches, in order
@@ -556,7 +677,11 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
             a.inv_b = 1.0f / (float)bm;
             a.ibegin = b0 * (uint32_t)NP;
             a.iend = b1 * (uint32_t)NP;
-            a.pad_item = 0xffffffffu;
+            a.pad_item = a.pad_item2 = 0xffffffffu;
+            a.ub = ubd;
+            a.ib = ibd;
+            a.urec = (float *)ctx->extra[BL_UREC].p;
+            a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
             const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb);  // one tile per block-iteration
@@ -582,8 +707,47 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
             slk_prof_end(ctx, s);
 
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-            hipLaunchKernelGGL(ipass, dim3(igrid), dim3(256), 0, s, a);
-            SLK_LAUNCH_CHECK(ctx, "k_item_pass");
+            if (!Hi) {
+                hipLaunchKernelGGL(ipass, dim3(igrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass");
+            } else {
+                // item biases are indexed by the item id: plain occurrence list, bias only ...
+                hipLaunchKernelGGL(ipass_bias, dim3(igrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<BIAS>");
+                // ... while every occurrence feeds the n_hash hashed rows of the compressed table
+                slk_pass_args r = a;
+                r.mb_loss_out = nullptr;
+                r.ikey = (const uint32_t *)ctx->extra[BL_IKEY1].p;
+                r.ipay = (const uint32_t *)ctx->extra[BL_IPAY1].p;
+                r.ibegin = a.ibegin * (uint32_t)Hi;
+                r.iend = a.iend * (uint32_t)Hi;
+                r.imask = (uint32_t)((1ull << icbits) - 1);
+                r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
+                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb)), dim3(256),
+                                   0, s, r);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROWS>");
+            }
+            if (Hu) {
+                // owner pass over the hashed USER rows: table slot 1 of the pass is remapped onto
+                // the user embedding table, records are the segment gradients parked by the user pass
+                slk_pass_args r = a;
+                r.mb_loss_out = nullptr;
+                r.P[1] = a.P[0];
+                r.S1[1] = a.S1[0];
+                r.S2[1] = a.S2[0];
+                r.snap = a.urec;
+                r.RS = RSU;
+                r.ikey = (const uint32_t *)ctx->extra[BL_UKEY1].p;
+                r.ipay = (const uint32_t *)ctx->extra[BL_UPAY1].p;
+                r.ibegin = b0 * (uint32_t)Hu;
+                r.iend = b1 * (uint32_t)Hu;
+                r.imask = (uint32_t)((1ull << ucbits) - 1);
+                r.pad_item = tables->user_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->user_bloom->skip_row;
+                r.pad_item2 = ubd.rows;  // sentinel of non-head positions
+                hipLaunchKernelGGL(rpass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb)), dim3(256),
+                                   0, s, r);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW,ROWS>");
+            }
             slk_prof_end(ctx, s);
 
             if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, 15u, s))) return rc;

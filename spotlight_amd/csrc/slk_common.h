@@ -28,7 +28,7 @@ struct slk_rng_dev {
     unsigned long long accepted;
 };
 
-#define SLK_EXTRA_BUFS 16
+#define SLK_EXTRA_BUFS 32
 
 struct slk_prof_span {
     int cls;

@@ -9,6 +9,70 @@
 #include "slk_common.h"
 
 // ---------------------------------------------------------------------------------------
+// BloomEmbedding (spotlight/layers.py:74-244): the vector of id x is the sum of n_hash rows
+//   row_h(x) = murmurhash3_32(int32 x, seed_h) mod rows   (signed hash, floor-mod; x == pad_id -> 0)
+// of a compressed table.  The hash is ~15 integer ops: computed in-kernel instead of reading
+// the reference's [num_embeddings, n_hash] int64 cache (8*H bytes per lookup).
+// ---------------------------------------------------------------------------------------
+struct slk_bloom_dev {
+    uint32_t rows;    // compressed rows; n_hash == 0: plain table (row = id)
+    int32_t n_hash;
+    uint32_t pad_id;  // ~0u: none
+    uint32_t seeds[8];
+};
+
+__device__ __forceinline__ uint32_t slk_murmur3_32(uint32_t k, uint32_t seed) {
+    // MurmurHash3_x86_32 of the 4 little-endian bytes of one int32 key (sklearn.utils.murmurhash3_32)
+    uint32_t h = seed;
+    k *= 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    h ^= k;
+    h = (h << 13) | (h >> 19);
+    h = h * 5u + 0xe6546b64u;
+    h ^= 4u;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t slk_bloom_row(const slk_bloom_dev &b, uint32_t id, int h) {
+    if (id == b.pad_id) return 0u;
+    const int32_t hv = (int32_t)slk_murmur3_32(id, b.seeds[h]);
+    int32_t v = hv % (int32_t)b.rows;  // rows < 2^31
+    if (v < 0) v += (int32_t)b.rows;
+    return (uint32_t)v;
+}
+
+// embedding vector of `id`: one row of a plain table, or embeddings(hashed).sum(1) (layers.py:236-242)
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_emb_vec(const float *T, const slk_bloom_dev &b, uint32_t id, int D,
+                                                    int d0, bool on) {
+    if (!on) return slk_vzero<VEC>();
+    if (b.n_hash == 0) return slk_vload<VEC>(T + (size_t)id * D + d0);
+    slk_vec<VEC> v = slk_vload<VEC>(T + (size_t)slk_bloom_row(b, id, 0) * D + d0);
+    for (int h = 1; h < b.n_hash; ++h) {
+        const slk_vec<VEC> x = slk_vload<VEC>(T + (size_t)slk_bloom_row(b, id, h) * D + d0);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v.v[i] += x.v[i];
+    }
+    return v;
+}
+
+static inline void slk_bloom_to_dev(const slk_bloom *b, slk_bloom_dev *out) {
+    memset(out, 0, sizeof(*out));
+    out->pad_id = 0xffffffffu;
+    if (!b) return;
+    out->rows = (uint32_t)b->rows;
+    out->n_hash = b->n_hash;
+    out->pad_id = b->padding_idx < 0 ? 0xffffffffu : (uint32_t)b->padding_idx;
+    for (int h = 0; h < 8; ++h) out->seeds[h] = b->seeds[h];
+}
+
+// ---------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------
 struct slk_pass_args {
@@ -31,6 +95,10 @@ struct slk_pass_args {
     uint32_t imask;
     const uint32_t *ipay;    // occurrence -> record reference (see slk_item_mode)
     uint32_t pad_item;       // occurrences of this item row are never updated (padding_idx); ~0u = none
+    uint32_t pad_item2;      // a second never-updated key (sentinel of non-head positions); ~0u = none
+    slk_bloom_dev ub, ib;    // BloomEmbedding user / item layers (n_hash == 0: plain)
+    float *urec;             // user-bloom: [(p - begin) * RSU] summed user-vector gradient of the
+    int RSU;                 //   segment headed at sorted position p (applied by a ROW item pass)
     double *loss_partial;    // per-block partial loss sums
     int n_loss_partial;
     float *mb_loss_out;      // this minibatch's loss.item()
@@ -132,7 +200,7 @@ template <int VEC, int MODE>
 __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_t r, int D, int d0, bool on,
                                                  slk_vec<VEC> &c, float &gb) {
     if (MODE == SLK_ITEM_ROW) {
-        const float *rec = a.snap + (size_t)r * a.RS;
+        const float *rec = a.snap + (size_t)(r - a.begin) * a.RS;
         gb = rec[D];
         c = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
     } else {
@@ -167,7 +235,12 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 // are finished from global memory; rows of a run that started in an earlier tile are skipped --
 // its owner already took them) and the optimizer is applied to that item's row and bias.
 // Block 0 also reduces the loss partials of the preceding pass into loss.item().
-template <int VEC, int G, int UPD, int MODE>
+// PART: which of the run owner's two updates are applied -- the embedding row (table slot 1), the
+// bias (slot 3), or both.  They separate when the embedding rows are BloomEmbedding rows (keys =
+// hashed rows) while the bias table is indexed by the item id itself.
+enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
+
+template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH>
 __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
@@ -214,7 +287,7 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
             c[it] = slk_vzero<VEC>();
             // rows of the run inherited from the previous tile belong to that tile's owner
             const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
-            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, on, c[it], g[it]);
+            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, on && PART != SLK_PART_BIAS, c[it], g[it]);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -237,7 +310,7 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
             const bool head = (j == 0 && first_tile) || key != s_key[j];
             if (!head) continue;
             const uint32_t item = key & a.imask;
-            if (item == a.pad_item) continue;  // padding_idx rows receive no gradient
+            if (item == a.pad_item || item == a.pad_item2) continue;  // padding_idx rows receive no gradient
             slk_vec<VEC> gv = slk_vzero<VEC>();
             float gb = 0.0f;
             bool any = false;
@@ -256,7 +329,7 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
                 for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
                     slk_vec<VEC> cc;
                     float gq;
-                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, on, cc, gq);
+                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, on && PART != SLK_PART_BIAS, cc, gq);
                     if (MODE != SLK_ITEM_SNAP || gq != 0.0f) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
@@ -269,11 +342,11 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
             // moments of every looked-up row (torch coalesces zero-valued rows too).
             if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
             const size_t voff = (size_t)item * D + d0;
-            if (on) {
+            if (on && PART != SLK_PART_BIAS) {
                 slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
                 slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
             }
-            if (lane == 0) slk_apply_bias<UPD>(a, 3, item, gb);
+            if (lane == 0 && PART != SLK_PART_ROWS) slk_apply_bias<UPD>(a, 3, item, gb);
         }
     }
 }
@@ -336,11 +409,11 @@ static inline bool slk_pick_layout(int D, int *vec, int *g) {
 
 typedef void (*slk_pass_fn)(slk_pass_args);
 
-template <int VEC, int G, int MODE>
+template <int VEC, int G, int MODE, int PART = SLK_PART_BOTH>
 static slk_pass_fn slk_item_pass_fn(int upd) {
-    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE>;
-    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE>;
+    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART>;
+    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART>;
 }
 
 // Row-update mode of the fused passes for an optimizer kind.

@@ -314,6 +314,8 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     int vec, g, rc;
     const unsigned TM = 10u;  // tables 1 (item_embeddings) and 3 (item_biases)
     if ((rc = slk_check_tables(ctx, tables, TM, &vec, &g))) return rc;
+    if (tables->item_bloom)
+        return slk_fail(ctx, SLK_EINVAL, "BloomEmbedding item tables are not supported by the PoolNet path yet");
     if ((rc = slk_check_optim(ctx, optim, TM))) return rc;
     if (n_seq < 0 || batch_size < 1 || seq_len < 1)
         return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: n_seq %lld batch_size %lld seq_len %lld", (long long)n_seq,
@@ -472,6 +474,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             a.imask = (uint32_t)((1ull << ibits) - 1);
             a.ipay = (const uint32_t *)ctx->ipay[1].p;
             a.pad_item = padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx;
+            a.pad_item2 = 0xffffffffu;
             a.loss_partial = (double *)ctx->losspart.p;
             a.n_loss_partial = (int)sgrid;
             a.mb_loss_out = d_mb_loss + mb_global;
@@ -495,6 +498,8 @@ SLK_EXPORT int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, tables, 10u, &vec, &g))) return rc;
+    if (tables->item_bloom)
+        return slk_fail(ctx, SLK_EINVAL, "BloomEmbedding item tables are not supported by the PoolNet path yet");
     if (n < 0 || seq_len < 1 || !d_sequence || (n > 0 && !d_out))
         return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_predict: bad arguments");
     if (n == 0) return SLK_OK;

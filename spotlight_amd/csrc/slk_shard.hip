@@ -165,6 +165,12 @@ __global__ __launch_bounds__(256) void k_shard_item_keys(const int64_t *ids, uin
     }
 }
 
+static int check_plain(slk_ctx *ctx, const slk_tables *t) {
+    if (t->user_bloom || t->item_bloom)
+        return slk_fail(ctx, SLK_EINVAL, "BloomEmbedding tables are not supported by the row-sharded path");
+    return SLK_OK;
+}
+
 static int check_shard(slk_ctx *ctx, const slk_shard *sh) {
     if (!sh) return slk_fail(ctx, SLK_EINVAL, "shard descriptor is NULL");
     if (sh->world < 1 || sh->world > SLK_MAX_WORLD || sh->rank < 0 || sh->rank >= sh->world)
@@ -183,6 +189,7 @@ SLK_EXPORT int slk_shard_begin(slk_ctx *ctx, const slk_tables *local, const slk_
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
     if (n < 0 || n >= ((int64_t)1 << 30)) return slk_fail(ctx, SLK_EINVAL, "slk_shard_begin: n %lld outside [0, 2^30)", (long long)n);
     if (!d_send_counts || (n > 0 && (!d_users_local || !d_items || !d_send_ids)))
@@ -254,6 +261,7 @@ SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, const int
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
     if (n_ids < 0 || (n_ids > 0 && (!d_ids || !d_rows_out))) return slk_fail(ctx, SLK_EINVAL, "slk_shard_gather: bad arguments");
     if (n_ids == 0) return SLK_OK;
     SLK_HIP(ctx, hipSetDevice(ctx->device));
@@ -287,7 +295,7 @@ static void fill_tables(slk_pass_args &a, slk_ctx *ctx, const slk_tables *local,
     }
     a.D = local->dim;
     a.NP = 2;
-    a.pad_item = 0xffffffffu;
+    a.pad_item = a.pad_item2 = 0xffffffffu;
     slk_set_opt_coeffs(a, optim);
 }
 
@@ -297,6 +305,7 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
     if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_HINGE)
@@ -352,6 +361,7 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (n_ids < 0 || n_ids >= ((int64_t)1 << 31) || (n_ids > 0 && (!d_ids || !d_grad_in)))
         return slk_fail(ctx, SLK_EINVAL, "slk_shard_item_pass: bad arguments");

@@ -8,7 +8,7 @@ storage; `forward` is provided for API parity and runs the same predict kernel.
 import torch
 import torch.nn as nn
 
-from spotlight_amd.layers import ScaledEmbedding, ZeroEmbedding
+from spotlight_amd.layers import BloomEmbedding, ScaledEmbedding, ZeroEmbedding
 
 
 class BilinearNet(nn.Module):
@@ -29,9 +29,19 @@ class BilinearNet(nn.Module):
         self.item_biases = ZeroEmbedding(num_items, 1, sparse=sparse)
 
     def tables(self):
-        """The four fp32 tables in the C ABI's order (include/spotlight_hip.h: slk_tables)."""
+        """The four fp32 tables in the C ABI's order (include/spotlight_hip.h: slk_tables); a
+        BloomEmbedding layer contributes its compressed table."""
         return [self.user_embeddings.weight, self.item_embeddings.weight,
                 self.user_biases.weight, self.item_biases.weight]
+
+    def slk_tables(self):
+        """slk_tables over this net's storage (with slk_bloom descriptors for bloom layers)."""
+        from spotlight_amd import _native
+        w = self.tables()
+        bloom = [layer.descriptor() if isinstance(layer, BloomEmbedding) else None
+                 for layer in (self.user_embeddings, self.item_embeddings)]
+        return _native.make_tables([t.data_ptr() for t in w], w[2].shape[0], w[3].shape[0], w[0].shape[1],
+                                   user_bloom=bloom[0], item_bloom=bloom[1])
 
     def forward(self, user_ids, item_ids):
         """score[k] = <U[user_k], V[item_k]> + bu[user_k] + bi[item_k]  (no autograd: the
@@ -44,9 +54,7 @@ class BilinearNet(nn.Module):
         items = item_ids.reshape(-1).to(device=w[0].device, dtype=torch.int64).contiguous()
         out = torch.empty(items.numel(), dtype=torch.float32, device=w[0].device)
         eng = host._engine_for(w[0].device)
-        from spotlight_amd import _native
-        tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0],
-                                     w[0].shape[1])
+        tables = self.slk_tables()
         eng.bilinear_predict(tables, users.data_ptr(), users.numel(), items.data_ptr(), items.numel(),
                              out.data_ptr(), host._stream_for(w[0].device))
         return out

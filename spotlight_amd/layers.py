@@ -24,3 +24,65 @@ class ZeroEmbedding(nn.Embedding):
         self.weight.data.zero_()
         if self.padding_idx is not None:
             self.weight.data[self.padding_idx].fill_(0)
+
+
+SEEDS = [
+    179424941, 179425457, 179425907, 179426369,
+    179424977, 179425517, 179425943, 179426407,
+    179424989, 179425529, 179425993, 179426447,
+    179425003, 179425537, 179426003, 179426453,
+    179425019, 179425559, 179426029, 179426491,
+    179425027, 179425579, 179426081, 179426549
+]
+
+
+class BloomEmbedding(nn.Module):
+    """Hashed (bloom) embedding layer -- mirrors spotlight/layers.py:74-244.
+
+    The embedding of index x is the sum of `num_hash_functions` rows of a compressed table
+    with int(compression_ratio * num_embeddings) rows, selected by MurmurHash3 with the
+    reference's seeds; index `padding_idx` maps to row 0, which is zero and never trained.
+    The hashing, the gather-and-sum, the backward into the hashed rows and the optimizer
+    update run inside the fused gfx950 kernels (csrc/slk_kernels.h: slk_emb_vec, hashed-row
+    owner passes); hashes are recomputed in-kernel instead of being cached per index.
+
+    `bag=True` is not supported: the reference builds its EmbeddingBag offsets with stride 1
+    instead of num_hash_functions (layers.py:219-222), so that mode does not compute the
+    documented sum -- there is nothing well-defined to reproduce.
+    """
+
+    def __init__(self, num_embeddings, embedding_dim, compression_ratio=0.2, num_hash_functions=4,
+                 bag=False, padding_idx=0):
+        super(BloomEmbedding, self).__init__()
+        self.num_embeddings = num_embeddings
+        self.embedding_dim = embedding_dim
+        self.compression_ratio = compression_ratio
+        self.compressed_num_embeddings = int(compression_ratio * num_embeddings)
+        self.num_hash_functions = num_hash_functions
+        self.padding_idx = padding_idx
+        self._bag = bag
+        if num_hash_functions > len(SEEDS):
+            raise ValueError('Can use at most {} hash functions ({} requested)'
+                             .format(len(SEEDS), num_hash_functions))
+        if num_hash_functions > 8:
+            raise NotImplementedError('the gfx950 kernels support at most 8 hash functions')
+        if bag:
+            raise NotImplementedError('BloomEmbedding(bag=True) is not supported (see class docstring)')
+        self._masks = SEEDS[:self.num_hash_functions]
+        self.embeddings = ScaledEmbedding(self.compressed_num_embeddings, self.embedding_dim,
+                                          padding_idx=self.padding_idx)
+
+    def __repr__(self):
+        return ('<BloomEmbedding (compression_ratio: {}): {}>'
+                .format(self.compression_ratio, repr(self.embeddings)))
+
+    @property
+    def weight(self):
+        """The compressed table (what the kernels read and update in place)."""
+        return self.embeddings.weight
+
+    def descriptor(self):
+        """include/spotlight_hip.h: slk_bloom for this layer."""
+        from spotlight_amd import _native
+        return _native.make_bloom(self.compressed_num_embeddings, self.num_hash_functions,
+                                  padding_idx=self.padding_idx, skip_row=self.padding_idx, seeds=self._masks)

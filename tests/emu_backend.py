@@ -25,15 +25,25 @@ def emu_lib():
     return _EMU
 
 
+def _bloom_struct(desc, rows):
+    """oracle.bloom_desc() dict -> SlkBloom for a compressed table with `rows` rows."""
+    if desc is None:
+        return None
+    return _native.make_bloom(rows, desc['n_hash'], padding_idx=desc['padding_idx'],
+                              skip_row=None if desc['skip_row'] < 0 else desc['skip_row'], seeds=desc['seeds'])
+
+
 class _Model(object):
-    def __init__(self, be, params, opt='adagrad', **hp):
+    def __init__(self, be, params, opt='adagrad', user_bloom=None, item_bloom=None, **hp):
         f = lambda x: be.alloc(np.array(x, dtype=np.float32, order='C'))
         self.p = [f(params[0]), f(params[1]), f(np.asarray(params[2]).reshape(-1)), f(np.asarray(params[3]).reshape(-1))]
         self.s1 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
         self.s2 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
-        U, D = be.get(self.p[0]).shape
-        I = be.get(self.p[1]).shape[0]
-        self.tables = _native.make_tables([be.ptr(x) for x in self.p], U, I, D)
+        D = be.get(self.p[0]).shape[1]
+        U, I = be.get(self.p[2]).shape[0], be.get(self.p[3]).shape[0]  # id ranges = bias rows
+        self.tables = _native.make_tables([be.ptr(x) for x in self.p], U, I, D,
+                                          user_bloom=_bloom_struct(user_bloom, be.get(self.p[0]).shape[0]),
+                                          item_bloom=_bloom_struct(item_bloom, be.get(self.p[1]).shape[0]))
         self.optim = _native.make_optim(opt, [be.ptr(x) for x in self.s1], [be.ptr(x) for x in self.s2], **hp)
 
 
@@ -67,7 +77,7 @@ class EmuBackend(object):
         return a
 
     def model(self, params, opt='adagrad', **hp):
-        return _Model(self, params, opt, **hp)
+        return _Model(self, params, opt, **hp)  # hp may carry user_bloom / item_bloom descriptors
 
     def seq_model(self, params, opt='adagrad', **hp):
         return _SeqModel(self, params, opt, **hp)

@@ -333,3 +333,133 @@ def check_seq_replays_reference_fixture(be, golden_dir, name):
 
 SEQ_FIXTURES = ['seq_bpr_adagrad_sparse', 'seq_hinge_sparse_adam', 'seq_pointwise_adam_default',
                 'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam']
+
+
+# ---------------------------------------------------------------------------------------
+# BilinearNet with BloomEmbedding layers
+# ---------------------------------------------------------------------------------------
+def _bloom_setup(rs, U, I, D, user_bloom, item_bloom, ratio):
+    from oracle.oracle import bloom_desc
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    ud = bloom_desc(n_hash=user_bloom) if user_bloom else None
+    idesc = bloom_desc(n_hash=item_bloom) if item_bloom else None
+    ru = int(ratio * U) if ud else U
+    ri = int(ratio * I) if idesc else I
+    params = [rs.normal(0, sc, (ru, D)).astype(np.float32), rs.normal(0, sc, (ri, D)).astype(np.float32),
+              rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
+    if ud:
+        params[0][0] = 0.0  # the compressed table's padding row (layers.py:167-169)
+    if idesc:
+        params[1][0] = 0.0
+    return params, ud, idesc
+
+
+def check_bloom_train_matches_oracle(be, loss, opt, D, user_bloom=0, item_bloom=4, U=45, I=60, N=170, B=64, nn=3,
+                                     epochs=2, ratio=0.4, tol=2e-5, seed=5):
+    from oracle.oracle import BloomBilinearOracle
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    params, ud, idesc = _bloom_setup(rs, U, I, D, user_bloom, item_bloom, ratio)
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    ora = BloomBilinearOracle(*params, user_bloom=ud, item_bloom=idesc, opt=opt, **hp)
+    dev = be.model(params, opt=opt, user_bloom=ud, item_bloom=idesc, **hp)
+    state = np.random.RandomState(9).get_state()
+    orng = Rng(state=state)
+    eng.rng_set_state(state)
+    n_mb = (N + B - 1) // B
+    d_users, d_items = be.alloc(users), be.alloc(items)
+    for epoch in range(epochs):
+        want_loss, want_neg = ora.train(orng, users, items, B, loss=loss, n_neg=nn, want_negs=True)
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.full(want_neg.size, -1, dtype=np.int64))
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
+                           be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+        assert (be.get(neg_out) == want_neg).all()
+        got_loss = be.get(mb_loss)
+        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-5, (got_loss, want_loss)
+    for t in range(4):
+        assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t))
+        assert_close_table(be.get(dev.s1[t]), ora.s1[t], tol, ('state1', t))
+    if ud:
+        assert (be.get(dev.p[0])[0] == 0).all()  # padding rows of the compressed tables stay zero
+    if idesc:
+        assert (be.get(dev.p[1])[0] == 0).all()
+    # predict (scalar user vs all items; pairs) on the engine's own tables
+    po = BloomBilinearOracle(*[be.get(x) for x in dev.p], user_bloom=ud, item_bloom=idesc)
+    out = be.alloc(np.empty(I, dtype=np.float32))
+    d_u = be.alloc(np.array([3], dtype=np.int64))
+    eng.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, I, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), po.predict(3)) < 1e-5
+    m = min(50, N)
+    out = be.alloc(np.empty(m, dtype=np.float32))
+    d_pu, d_pi = be.alloc(users[:m].copy()), be.alloc(items[:m].copy())
+    eng.bilinear_predict(dev.tables, be.ptr(d_pu), m, be.ptr(d_pi), m, be.ptr(out), be.stream)
+    assert rel_inf(be.get(out), po.predict(users[:m], items[:m])) < 1e-5
+
+
+def check_bloom_single_step_gradients(be, loss, D, user_bloom=0, item_bloom=4, U=50, I=70, B=128, nn=3, seed=11):
+    from oracle.oracle import BloomBilinearOracle
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, B).astype(np.int64)
+    items = rs.randint(0, I, B).astype(np.int64)
+    negs = rs.randint(0, I, B * (nn if loss == 'adaptive_hinge' else 1)).astype(np.int64)
+    params, ud, idesc = _bloom_setup(rs, U, I, D, user_bloom, item_bloom, 0.4)
+    want_loss, want_g = BloomBilinearOracle(*params, user_bloom=ud, item_bloom=idesc).step(
+        users, items, negs, loss=loss, n_neg=nn, want_grads=True)
+    dev = be.model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999), user_bloom=ud, item_bloom=idesc)
+    mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+    d_users, d_items, d_negs = be.alloc(users), be.alloc(items), be.alloc(negs)
+    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), B, B, loss, nn, be.ptr(mb_loss),
+                       d_neg_in=be.ptr(d_negs), stream=be.stream)
+    assert abs(float(be.get(mb_loss)[0]) - want_loss) / abs(want_loss) < 1e-5
+    bscale = max(np.abs(want_g[2]).max(), np.abs(want_g[3]).max())
+    for t in range(4):
+        scale = np.abs(want_g[t]).max() if t < 2 else bscale
+        assert np.abs(be.get(dev.s1[t]).ravel() - want_g[t].ravel()).max() <= 1e-5 * scale, t
+
+
+def check_bloom_replays_reference_fixture(be, golden_dir, name):
+    """Fixtures recorded from the live reference with BloomEmbedding layers (oracle/make_golden_bloom.py)."""
+    from oracle.oracle import bloom_desc
+    from oracle.replay import case_from_rec, _oracle_hparams
+    eng = be.engine
+    rec = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = case_from_rec(rec)
+    mk = lambda on: bloom_desc(n_hash=int(case['H'])) if int(on) else None
+    dev = be.model([rec['init_%d' % t] for t in range(4)], opt=ORACLE_OPT[str(case['opt'])],
+                   user_bloom=mk(case['user_bloom']), item_bloom=mk(case['item_bloom']), **_oracle_hparams(case))
+    state = ('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit']))
+    eng.rng_set_state(state)
+    host = Rng(state=state)
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, B = int(case['N']), int(case['B'])
+    n_mb = (N + B - 1) // B
+    losses, negs = [], []
+    for e in range(int(case['n_iter'])):
+        host.set_state(eng.rng_get_state())
+        perm = host.shuffle_perm(N)
+        eng.rng_set_state(host.get_state())
+        su, si = rec['users'].astype(np.int64)[perm], rec['items'].astype(np.int64)[perm]
+        assert (su == rec['shuffled_users'][e]).all()
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.empty(N * nn, dtype=np.int64))
+        d_su, d_si = be.alloc(su), be.alloc(si)
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_su), be.ptr(d_si), N, B, str(case['loss']), nn,
+                           be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+        losses.append(be.get(mb_loss))
+        negs.append(be.get(neg_out))
+    assert (np.concatenate(negs) == rec['negatives']).all()
+    losses = np.concatenate(losses)
+    assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
+    assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
+    for t in range(4):
+        ref = rec['final_%d' % t]
+        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
+        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+
+
+BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_default', 'bloom_both_bpr_adagrad',
+                  'bloom_both_adaptive_adam', 'bloom_user_pointwise_adagrad', 'bloom_c3_adaptive_adagrad']

@@ -104,3 +104,37 @@ def test_seq_single_step_loss_and_gradients(be, loss, D):
 @pytest.mark.parametrize('name', ec.SEQ_FIXTURES)
 def test_seq_replays_reference_fixture(be, name):
     ec.check_seq_replays_reference_fixture(be, GOLDEN, name)
+
+
+# ---- BloomEmbedding layers in the BilinearNet path ----
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('opt', ['adagrad', 'adam_dense'])
+def test_item_bloom_train_matches_oracle(be, loss, opt):
+    ec.check_bloom_train_matches_oracle(be, loss, opt, 8, user_bloom=0, item_bloom=4)
+
+
+@pytest.mark.parametrize('ub,ib', [(4, 0), (4, 4), (2, 3), (1, 8)])
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('adaptive_hinge', 'adam_dense')])
+def test_user_and_both_bloom_train_matches_oracle(be, ub, ib, loss, opt):
+    ec.check_bloom_train_matches_oracle(be, loss, opt, 8, user_bloom=ub, item_bloom=ib)
+
+
+def test_bloom_c3_shape_at_scale(be):
+    """C3-shaped (adaptive hinge n=5, bloom item table ratio 0.2 x 4 hashes, D=128) at a size with
+    many workgroups and several minibatches per chunk."""
+    ec.check_bloom_train_matches_oracle(be, 'adaptive_hinge', 'adagrad', 128, user_bloom=0, item_bloom=4, U=3000,
+                                        I=5000, N=20000, B=4096, nn=5, epochs=1, ratio=0.2, tol=1e-4)
+    ec.check_bloom_train_matches_oracle(be, 'bpr', 'adagrad', 64, user_bloom=4, item_bloom=4, U=3000,
+                                        I=5000, N=20000, B=4096, epochs=1, ratio=0.2, tol=1e-4)
+
+
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('ub,ib', [(0, 4), (4, 4)])
+def test_bloom_single_step_loss_and_gradients(be, loss, ub, ib):
+    ec.check_bloom_single_step_gradients(be, loss, 16, user_bloom=ub, item_bloom=ib)
+    ec.check_bloom_single_step_gradients(be, loss, 64, user_bloom=ub, item_bloom=ib, U=4000, I=6000, B=20000, seed=3)
+
+
+@pytest.mark.parametrize('name', ec.BLOOM_FIXTURES)
+def test_bloom_replays_reference_fixture(be, name):
+    ec.check_bloom_replays_reference_fixture(be, GOLDEN, name)

@@ -130,3 +130,12 @@ def test_sequence_model_learns_planted_structure():
         nxt = seqs[k, -1]
         wins += (scores[nxt] > scores[1:]).mean() > 0.9  # top decile
     assert wins >= 80, wins
+
+
+@pytest.mark.parametrize('name', ['bloom_item_bpr_adagrad', 'bloom_both_adaptive_adam',
+                                  'bloom_user_pointwise_adagrad', 'bloom_c3_adaptive_adagrad'])
+def test_bloom_model_fit_predict_match_reference_run(name):
+    """BilinearNet with BloomEmbedding layers through the drop-in model API on cuda:0."""
+    from test_host_model import check_bloom_fit_predict_against_fixture
+    model = check_bloom_fit_predict_against_fixture(name, to_numpy=lambda w: w.detach().cpu().numpy(), use_cuda=True)
+    assert all(w.is_cuda for w in model._net.tables())
