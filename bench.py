@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--seq-len', type=int, default=200)
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
+    ap.add_argument('--side-stream', type=int, default=1, help='1: run the engine on a dedicated HIP stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -191,12 +192,17 @@ def main():
     tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
     op = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None,
                             lr=1e-2)
-    n_total = (W + K) * B
+    n_total = (W + 2 * K) * B  # W warmup + K timed + K profiled
     I_global = I * world
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     items = torch.randint(0, I_global, (n_total,), device=dev, dtype=torch.int64, generator=gen)
-    mb_loss = torch.zeros(W + K, device=dev)
+    mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
+    # the engine runs on its own HIP stream (ordered against torch's current stream by events)
+    side = torch.cuda.Stream(dev) if args.side_stream else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
     stream = torch.cuda.current_stream(dev).cuda_stream
     trainer = None
     if dist is not None:
@@ -222,18 +228,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if trainer is None:
+        eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # scratch for the timed call's shape
     if W:
         run(0, W)
     barrier()
     xgmi_rows[0] = 0
-    eng.profile_reset()
-    eng.profile_enable(True)
+    # timed region: EXACTLY K steps, no instrumentation inside
     t0 = time.perf_counter()
     run(W, K)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    barrier()
+    # per-kernel durations: K more steps with hipEvents around every launch (slk_profile_*);
+    # outside the timed region because the event records themselves cost ~10 us per launch
+    xg = xgmi_rows[0]
+    eng.profile_reset()
+    eng.profile_enable(True)
+    t1 = time.perf_counter()
+    run(W + K, K)
+    torch.cuda.synchronize(dev)
+    elapsed_profiled = time.perf_counter() - t1
     eng.profile_enable(False)
     prof = eng.profile_read()
+    xgmi_rows[0] = xg
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -243,6 +261,7 @@ def main():
 
     losses = mb_loss.cpu().numpy()
     assert np.isfinite(losses).all() and (losses[W:] > 0).all(), losses
+    losses = losses[:W + K]
 
     if rank == 0:
         value = world * K * B / elapsed
@@ -282,6 +301,7 @@ def main():
                           'row-sharded x%d: users and items sharded cyclically, 3 RCCL all-to-all phases per '
                           'minibatch (ids, rows, gradient rows); no replicas' % world},
                'roofline': roof,
+               'ms_per_step_with_kernel_timers': elapsed_profiled / K * 1e3,
                'final_minibatch_loss': float(losses[-1])}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)

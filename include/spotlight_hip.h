@@ -142,6 +142,13 @@ int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                        int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
                        int64_t *d_neg_out, float *d_mb_loss, void *stream);
 
+/* Allocates every scratch buffer a later slk_bilinear_train call of this shape (same tables,
+ * optimizer kind, n, batch_size, loss, n_neg) will need, so that the training call itself
+ * performs no allocation (torch's caching allocator plays this role for the reference).  Optional:
+ * slk_bilinear_train grows its scratch on demand. */
+int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n,
+                         int64_t batch_size, int32_t loss, int32_t n_neg, void *stream);
+
 /* ImplicitFactorizationModel.predict (factorization/implicit.py:277-311 with
  * _components.py:8-25): d_out[k] = score(user_k, item_k); n_users == 1 broadcasts the user;
  * d_items == NULL means items 0..n-1. */

@@ -56,6 +56,8 @@ _PROTOTYPES = {
     'slk_bilinear_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
                                      C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_reserve': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_void_p]),
     'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_poolnet_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_void_p,
@@ -164,6 +166,11 @@ class Engine(object):
             self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, int(n), int(batch_size),
             LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), d_neg_in, d_neg_out,
             d_mb_loss, stream))
+
+    def bilinear_reserve(self, tables, optim, n, batch_size, loss, n_neg, stream=0):
+        self._check(self._lib.slk_bilinear_reserve(
+            self._ctx, C.byref(tables), C.byref(optim), int(n), int(batch_size),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), stream))
 
     def bilinear_predict(self, tables, d_users, n_users, d_items, n, d_out, stream=0):
         self._check(self._lib.slk_bilinear_predict(self._ctx, C.byref(tables), d_users, int(n_users),

@@ -460,10 +460,32 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
     return SLK_OK;
 }
 
+static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                               const int64_t *d_users, const int64_t *d_items, int64_t n,
+                               int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
+                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only);
+
 SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                                   const int64_t *d_users, const int64_t *d_items, int64_t n,
                                   int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
                                   int64_t *d_neg_out, float *d_mb_loss, void *stream) {
+    return bilinear_train_impl(ctx, tables, optim, d_users, d_items, n, batch_size, loss, n_neg, d_neg_in,
+                               d_neg_out, d_mb_loss, stream, false);
+}
+
+SLK_EXPORT int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n,
+                                    int64_t batch_size, int32_t loss, int32_t n_neg, void *stream) {
+    slk_optim o;
+    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    o = *optim;
+    return bilinear_train_impl(ctx, tables, &o, nullptr, nullptr, n, batch_size, loss, n_neg, nullptr, nullptr,
+                               nullptr, stream, true);
+}
+
+static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                               const int64_t *d_users, const int64_t *d_items, int64_t n,
+                               int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
+                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
@@ -478,7 +500,8 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
     const int NP = nn + 1;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (n == 0) return SLK_OK;
-    if (!d_users || !d_items || !d_mb_loss) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: NULL id/loss pointer");
+    if (!reserve_only && (!d_users || !d_items || !d_mb_loss))
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: NULL id/loss pointer");
     if (batch_size * (int64_t)NP >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "batch_size * (1 + negatives) must be < 2^31");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
@@ -545,6 +568,12 @@ SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_op
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
                                  (size_t)tables->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
+    }
+
+    if (reserve_only) {
+        // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
+        if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;
+        return slk_sort_reserve(ctx, nc_max * (size_t)occ_mult);
     }
 
     const int upd = slk_upd_for(optim->kind);

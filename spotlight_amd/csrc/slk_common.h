@@ -102,6 +102,9 @@ int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, co
 int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g);
 int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
 
+int slk_sort_reserve(slk_ctx *ctx, size_t n);
+int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
+
 static inline unsigned slk_bits_for(uint64_t max_value) {
     unsigned b = 1;
     while (b < 64 && (max_value >> b)) ++b;

@@ -319,6 +319,31 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
     return SLK_OK;
 }
 
+// scratch of a later slk_sample_u32(num_items, count): same sizing rule as above
+int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count) {
+    if (num_items < 2 || count <= 0) return SLK_OK;
+    const uint32_t rng = (uint32_t)(num_items - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const double p = ((double)rng + 1.0) / ((double)mask + 1.0);
+    double need = (double)count / p + 12.0 * sqrt((double)count * (1.0 - p)) / p + 64.0;
+    if (p == 1.0) need = (double)count;
+    const unsigned long long nblocks = 1ull + (unsigned long long)((need + SLK_MT_N - 1) / SLK_MT_N);
+    const unsigned long long total_words = nblocks * SLK_MT_N;
+    const unsigned long long nb = (total_words + SLK_TILE - 1) / SLK_TILE;
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->cnt, nb * 4 + nb * 8 + 64))) return rc;
+    if (nblocks > SLK_MT_JUMP_BLOCKS && !ctx->d_jump) {
+        const uint32_t *tab = slk_mt_jump_table(ctx);
+        if (!tab) return SLK_EIO;
+        const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
+        SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
+        SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
+    }
+    return SLK_OK;
+}
+
 SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos) {
     if (!ctx || !h_key) return SLK_EINVAL;
     if (pos < 0 || pos > SLK_MT_N) return slk_fail(ctx, SLK_EINVAL, "slk_rng_set_state: pos %d outside [0, 624]", pos);

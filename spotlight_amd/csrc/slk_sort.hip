@@ -28,3 +28,14 @@ int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, co
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
     return sort_impl<uint64_t>(ctx, kin, kout, vin, vout, n, end_bit, s);
 }
+
+// Sizes the temporary storage for pair sorts of up to n elements (both value widths).
+int slk_sort_reserve(slk_ctx *ctx, size_t n) {
+    if (n == 0) return SLK_OK;
+    size_t t32 = 0, t64 = 0;
+    SLK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t32, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (const uint32_t *)nullptr, (uint32_t *)nullptr, n, 0u, 32u, (hipStream_t)0));
+    SLK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, t64, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (const uint64_t *)nullptr, (uint64_t *)nullptr, n, 0u, 32u, (hipStream_t)0));
+    return slk_ensure(ctx, ctx->sort_tmp, t32 > t64 ? t32 : t64);
+}

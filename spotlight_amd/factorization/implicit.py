@@ -239,6 +239,8 @@ class ImplicitFactorizationModel(object):
         n_minibatches = (n + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 
+        engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
+                                self._num_negative_samples, stream=stream)
         for epoch_num in range(self._n_iter):
             # host shuffle: numpy Fisher-Yates on the model's RandomState (torch_utils.py:35-52)
             users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
