@@ -61,6 +61,8 @@ def parse():
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
     ap.add_argument('--side-stream', type=int, default=1, help='1: run the engine on a dedicated HIP stream')
+    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
+                    help='engine tuning option (slk_ctx_set_option), e.g. item_grid_mult=28')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -180,6 +182,9 @@ def main():
     K, W = args.steps, args.warmup
 
     eng = _native.Engine(local_rank)
+    for kv in args.set:
+        name, value = kv.split('=')
+        eng.set_option(name, int(value))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     # per-GPU shard: U x D users, I x D items (N > 1: the global tables are world times larger,

@@ -113,6 +113,13 @@ int slk_ctx_create(slk_ctx **out, int device_id);
 void slk_ctx_destroy(slk_ctx *ctx);
 const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create error */
 
+/* Tuning knobs (none changes results):
+ *   "chunk_interactions"  interactions per prep chunk (default 2^21): the negatives + sorts of chunk
+ *                         c+1 run on a second HIP stream while chunk c trains
+ *   "item_grid_mult"      item pass: workgroups per CU (default 64)
+ *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond) */
+int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
+
 /* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference
  * draws shuffles and negatives from (torch_utils.py:46-47, sampling.py:34).  h_key is
  * uint32[624].  get_state synchronises the stream last used by this ctx. */

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the MI355X box via gpurun: rocprofv3 PMC passes over bench.py (one counter group per pass, no
+# tracing flags -- MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots").   usage: scripts/pmc_run.sh <tag> [bench args]
+set -u
+TAG=${1:-pmc}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+run() {  # name, counters...
+  local name=$1; shift
+  timeout 600 rocprofv3 --pmc "$@" -d $OUT/$name -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "${BARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
+  echo "pmc $name exit $?"
+}
+BARGS=("$@")
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run sq SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+ls $OUT

@@ -69,6 +69,14 @@ int slk_prof_drain(slk_ctx *ctx) {
     return SLK_OK;
 }
 
+int slk_prep_stream_init(slk_ctx *ctx) {
+    if (ctx->prep_stream) return SLK_OK;
+    SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1]})
+        SLK_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return SLK_OK;
+}
+
 SLK_EXPORT int slk_abi_version(void) { return SLK_ABI_VERSION; }
 
 SLK_EXPORT int slk_ctx_create(slk_ctx **out, int device_id) {
@@ -118,12 +126,37 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
         if (b.p) (void)hipFree(b.p);
+    for (slk_prep_bufs &pb : ctx->pb) {
+        slk_buf *pbs[] = {&pb.neg32, &pb.ukey[0], &pb.ukey[1], &pb.uval[0], &pb.uval[1], &pb.uit, &pb.ikey[0],
+                          &pb.ikey[1], &pb.ipay[0], &pb.ipay[1], &pb.bik[0], &pb.bik[1], &pb.bip[0], &pb.bip[1],
+                          &pb.buk[0], &pb.buk[1], &pb.bup[0], &pb.bup[1]};
+        for (slk_buf *b : pbs)
+            if (b->p) (void)hipFree(b->p);
+    }
+    for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
     if (ctx->d_jump) (void)hipFree(ctx->d_jump);
     delete ctx;
 }
 
 SLK_EXPORT const char *slk_last_error(const slk_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return SLK_EINVAL;
+    if (!strcmp(name, "chunk_interactions") && value >= 1) {
+        ctx->opt_chunk_interactions = value;
+    } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
+        ctx->opt_item_grid_mult = (int)value;
+    } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {
+        ctx->opt_user_grid_mult = (int)value;
+    } else {
+        return slk_fail(ctx, SLK_EINVAL, "slk_ctx_set_option: unknown option or bad value: %s = %lld", name,
+                        (long long)value);
+    }
+    return SLK_OK;
+}
 
 SLK_EXPORT int slk_profile_enable(slk_ctx *ctx, int32_t on) {
     if (!ctx) return SLK_EINVAL;

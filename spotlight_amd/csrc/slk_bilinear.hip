@@ -528,7 +528,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // stays bounded (~8M interactions).
     const int64_t bsz = batch_size < n ? batch_size : n;
     int64_t mb_per_chunk = (int64_t)1 << (32 - idbits);
-    const int64_t cap_inter = (int64_t)1 << 23;
+    // ~2M interactions (at least two minibatches... of a large batch: one) per chunk: small enough
+    // for the next chunk's prep to hide behind this chunk's passes, large enough for the sorts
+    // and the MT19937 jump-ahead sampler to fill the GPU
+    const int64_t cap_inter = ctx->opt_chunk_interactions;
     if (mb_per_chunk * bsz > cap_inter) mb_per_chunk = cap_inter / bsz;
     while (mb_per_chunk > 1 && mb_per_chunk * bsz * occ_mult >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
     if (mb_per_chunk < 1) mb_per_chunk = 1;
@@ -536,32 +539,36 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return slk_fail(ctx, SLK_EINVAL, "batch_size * lookups per interaction must be < 2^31");
     const int64_t chunk_cap = mb_per_chunk * bsz;
 
-    // scratch
+    // scratch.  The value-independent part of a chunk (negatives, sort by user, sort by item) is
+    // prepared on a second HIP stream while the previous chunk's passes run, so those buffers
+    // exist twice (ctx->pb[0|1]) as soon as a call spans more than one chunk.
     const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
-    if ((rc = slk_ensure(ctx, ctx->neg32, nc_max * nn * 4))) return rc;
-    for (int b = 0; b < 2; ++b) {
-        if ((rc = slk_ensure(ctx, ctx->ukey[b], nc_max * 4))) return rc;
-        if ((rc = slk_ensure(ctx, ctx->uval[b], nc_max * 8))) return rc;
-        if ((rc = slk_ensure(ctx, ctx->ikey[b], nc_max * NP * 4))) return rc;
-        if ((rc = slk_ensure(ctx, ctx->ipay[b], nc_max * NP * 4))) return rc;
+    const int nsets = (n > chunk_cap) ? 2 : 1;
+    for (int st = 0; st < nsets; ++st) {
+        slk_prep_bufs &pb = ctx->pb[st];
+        if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;
+        for (int b = 0; b < 2; ++b) {
+            if ((rc = slk_ensure(ctx, pb.ukey[b], nc_max * 4))) return rc;
+            if ((rc = slk_ensure(ctx, pb.uval[b], nc_max * 8))) return rc;
+            if ((rc = slk_ensure(ctx, pb.ikey[b], nc_max * NP * 4))) return rc;
+            if ((rc = slk_ensure(ctx, pb.ipay[b], nc_max * NP * 4))) return rc;
+            if (Hi && (rc = slk_ensure(ctx, pb.bik[b], nc_max * NP * Hi * 4))) return rc;
+            if (Hi && (rc = slk_ensure(ctx, pb.bip[b], nc_max * NP * Hi * 4))) return rc;
+            if (Hu && (rc = slk_ensure(ctx, pb.buk[b], nc_max * Hu * 4))) return rc;
+            if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
+        }
+        if (adaptive && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
     }
     const int RS = D + ((NP + 3) / 4) * 4;  // record = user row + NP dL/dscore, 16-B granular
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
-    const unsigned max_grid = (unsigned)ctx->num_cus * 8;
+    const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     if (adaptive) {
-        if ((rc = slk_ensure(ctx, ctx->uit, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
-    enum { BL_IKEY0 = 16, BL_IKEY1, BL_IPAY0, BL_IPAY1, BL_UKEY0, BL_UKEY1, BL_UPAY0, BL_UPAY1, BL_UREC };
+    enum { BL_UREC = 16 };
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
-    for (int b = 0; b < 2; ++b) {
-        if (Hi && (rc = slk_ensure(ctx, ctx->extra[BL_IKEY0 + b], nc_max * NP * Hi * 4))) return rc;
-        if (Hi && (rc = slk_ensure(ctx, ctx->extra[BL_IPAY0 + b], nc_max * NP * Hi * 4))) return rc;
-        if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UKEY0 + b], nc_max * Hu * 4))) return rc;
-        if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UPAY0 + b], nc_max * Hu * 4))) return rc;
-    }
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     if (dense) {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
@@ -594,12 +601,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 #undef SLK_PICK
     const unsigned gpb = 256u / (unsigned)g;
 
-    int64_t mb_global = 0;
-    for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
+    // ---- prep of one chunk on stream `s` into buffer set `pb` (value-independent: ids only)
+    auto do_prep = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
+        int rc;
         const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
         const uint32_t nocc = nc * (uint32_t)NP;
         const int64_t *cu = d_users + c0, *ci = d_items + c0;
-        uint32_t *neg32 = (uint32_t *)ctx->neg32.p;
+        uint32_t *neg32 = (uint32_t *)pb.neg32.p;
 
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
         if (d_neg_in) {
@@ -620,60 +628,72 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         // ---- prep: sort interactions by (minibatch, user), occurrences by (minibatch, item)
         slk_prof_begin(ctx, SLK_K_PREP, s);
         const unsigned mbbits = slk_bits_for((uint64_t)((nc - 1) / (uint32_t)bsz));
-        uint32_t *ukey_in = (uint32_t *)ctx->ukey[0].p, *ukey = (uint32_t *)ctx->ukey[1].p;
+        uint32_t *ukey_in = (uint32_t *)pb.ukey[0].p, *ukey = (uint32_t *)pb.ukey[1].p;
         const uint32_t *uit, *uk = nullptr;
+        (void)uk;
         if (!adaptive) {
             hipLaunchKernelGGL((k_build_user_keys<true>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
-                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
+                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
-            if ((rc = slk_sort_pairs_u32_u64(ctx, ukey_in, ukey, (const uint64_t *)ctx->uval[0].p,
-                                             (uint64_t *)ctx->uval[1].p, nc, ubits + mbbits, s)))
+            if ((rc = slk_sort_pairs_u32_u64(ctx, ukey_in, ukey, (const uint64_t *)pb.uval[0].p,
+                                             (uint64_t *)pb.uval[1].p, nc, ubits + mbbits, s)))
                 return rc;
-            uit = (const uint32_t *)ctx->uval[1].p;  // little-endian (pos, neg) pairs
+            uit = (const uint32_t *)pb.uval[1].p;  // little-endian (pos, neg) pairs
         } else {
             hipLaunchKernelGGL((k_build_user_keys<false>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
-                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, ctx->uval[0].p);
+                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, ukey_in, ukey, (const uint32_t *)ctx->uval[0].p,
-                                             (uint32_t *)ctx->uval[1].p, nc, ubits + mbbits, s)))
+            if ((rc = slk_sort_pairs_u32_u32(ctx, ukey_in, ukey, (const uint32_t *)pb.uval[0].p,
+                                             (uint32_t *)pb.uval[1].p, nc, ubits + mbbits, s)))
                 return rc;
-            uk = (const uint32_t *)ctx->uval[1].p;
+            uk = (const uint32_t *)pb.uval[1].p;
             hipLaunchKernelGGL(k_pack_items, dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, ci,
-                               (const uint32_t *)neg32, nc, nn, (uint32_t *)ctx->uit.p);
+                               (const uint32_t *)neg32, nc, nn, (uint32_t *)pb.uit.p);
             SLK_LAUNCH_CHECK(ctx, "k_pack_items");
-            uit = (const uint32_t *)ctx->uit.p;
+            uit = (const uint32_t *)pb.uit.p;
         }
         hipLaunchKernelGGL(k_build_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
-                           (uint32_t)bsz, ibits, (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+                           (uint32_t)bsz, ibits, (uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ipay[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
-        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
-                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
+        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p,
+                                         (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
                                          ibits + mbbits, s)))
             return rc;
         if (Hi) {
             hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,
-                               uit, nocc, NP, (uint32_t)bsz, icbits, ibd, (uint32_t *)ctx->extra[BL_IKEY0].p,
-                               (uint32_t *)ctx->extra[BL_IPAY0].p);
+                               uit, nocc, NP, (uint32_t)bsz, icbits, ibd, (uint32_t *)pb.bik[0].p,
+                               (uint32_t *)pb.bip[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_item_bloom_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_IKEY0].p,
-                                             (uint32_t *)ctx->extra[BL_IKEY1].p,
-                                             (const uint32_t *)ctx->extra[BL_IPAY0].p,
-                                             (uint32_t *)ctx->extra[BL_IPAY1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.bik[0].p,
+                                             (uint32_t *)pb.bik[1].p,
+                                             (const uint32_t *)pb.bip[0].p,
+                                             (uint32_t *)pb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
                 return rc;
         }
         if (Hu) {
             hipLaunchKernelGGL(k_build_user_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nc * Hu, 256)), dim3(256), 0, s,
                                (const uint32_t *)ukey, (uint32_t)((1ull << ubits) - 1), nc, (uint32_t)bsz, ucbits, ubd,
-                               (uint32_t *)ctx->extra[BL_UKEY0].p, (uint32_t *)ctx->extra[BL_UPAY0].p);
+                               (uint32_t *)pb.buk[0].p, (uint32_t *)pb.bup[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_bloom_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_UKEY0].p,
-                                             (uint32_t *)ctx->extra[BL_UKEY1].p,
-                                             (const uint32_t *)ctx->extra[BL_UPAY0].p,
-                                             (uint32_t *)ctx->extra[BL_UPAY1].p, (size_t)nc * Hu, ucbits + mbbits, s)))
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.buk[0].p,
+                                             (uint32_t *)pb.buk[1].p,
+                                             (const uint32_t *)pb.bup[0].p,
+                                             (uint32_t *)pb.bup[1].p, (size_t)nc * Hu, ucbits + mbbits, s)))
                 return rc;
         }
         slk_prof_end(ctx, s);
 
+        return SLK_OK;
+    };
+
+    int64_t mb_global = 0;
+    // ---- the minibatches of one prepared chunk, in order, on the caller's stream
+    auto do_passes = [&](int64_t c0, slk_prep_bufs &pb) -> int {
+        int rc;
+        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const uint32_t *ukey = (const uint32_t *)pb.ukey[1].p;
+        const uint32_t *uit = adaptive ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
+        const uint32_t *uk = adaptive ? (const uint32_t *)pb.uval[1].p : nullptr;
         // ---- minibatches, in order
         for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
             const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
@@ -697,9 +717,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.sk = (float *)ctx->sk.p;
             a.snap = (float *)ctx->snap.p;
             a.RS = RS;
-            a.ikey = (const uint32_t *)ctx->ikey[1].p;
+            a.ikey = (const uint32_t *)pb.ikey[1].p;
             a.imask = (uint32_t)((1ull << ibits) - 1);
-            a.ipay = (const uint32_t *)ctx->ipay[1].p;
+            a.ipay = (const uint32_t *)pb.ipay[1].p;
             a.loss_partial = (double *)ctx->losspart.p;
             a.mb_loss_out = d_mb_loss + mb_global;
             a.loss_kind = loss;
@@ -713,7 +733,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
-            const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb);  // one tile per block-iteration
+            const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
             if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
@@ -746,13 +766,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
-                r.ikey = (const uint32_t *)ctx->extra[BL_IKEY1].p;
-                r.ipay = (const uint32_t *)ctx->extra[BL_IPAY1].p;
+                r.ikey = (const uint32_t *)pb.bik[1].p;
+                r.ipay = (const uint32_t *)pb.bip[1].p;
                 r.ibegin = a.ibegin * (uint32_t)Hi;
                 r.iend = a.iend * (uint32_t)Hi;
                 r.imask = (uint32_t)((1ull << icbits) - 1);
                 r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
-                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb)), dim3(256),
+                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
                                    0, s, r);
                 SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROWS>");
             }
@@ -766,14 +786,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 r.S2[1] = a.S2[0];
                 r.snap = a.urec;
                 r.RS = RSU;
-                r.ikey = (const uint32_t *)ctx->extra[BL_UKEY1].p;
-                r.ipay = (const uint32_t *)ctx->extra[BL_UPAY1].p;
+                r.ikey = (const uint32_t *)pb.buk[1].p;
+                r.ipay = (const uint32_t *)pb.bup[1].p;
                 r.ibegin = b0 * (uint32_t)Hu;
                 r.iend = b1 * (uint32_t)Hu;
                 r.imask = (uint32_t)((1ull << ucbits) - 1);
                 r.pad_item = tables->user_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->user_bloom->skip_row;
                 r.pad_item2 = ubd.rows;  // sentinel of non-head positions
-                hipLaunchKernelGGL(rpass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb)), dim3(256),
+                hipLaunchKernelGGL(rpass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
                                    0, s, r);
                 SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW,ROWS>");
             }
@@ -782,6 +802,34 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, 15u, s))) return rc;
             optim->step += 1;
         }
+        return SLK_OK;
+    };
+
+    if (nsets == 1) {
+        if ((rc = do_prep(0, ctx->pb[0], s))) return rc;
+        rc = do_passes(0, ctx->pb[0]);
+        ctx->last_stream = s;
+        return rc;
     }
+    // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream
+    if ((rc = slk_prep_stream_init(ctx))) return rc;
+    hipStream_t ps = ctx->prep_stream;
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
+    SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+    if ((rc = do_prep(0, ctx->pb[0], ps))) return rc;
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
+    int set = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += chunk_cap, set ^= 1) {
+        if (c0 + chunk_cap < n) {
+            // the other buffer set was last read by the passes of the previous chunk
+            if (c0 > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
+            if ((rc = do_prep(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
+        }
+        SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
+        if ((rc = do_passes(c0, ctx->pb[set]))) return rc;
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
+    }
+    ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
     return SLK_OK;
 }

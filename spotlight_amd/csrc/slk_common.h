@@ -30,6 +30,12 @@ struct slk_rng_dev {
 
 #define SLK_EXTRA_BUFS 32
 
+// buffers filled by the value-independent prep of one chunk of minibatches (slk_bilinear.hip)
+struct slk_prep_bufs {
+    slk_buf neg32, ukey[2], uval[2], uit, ikey[2], ipay[2];
+    slk_buf bik[2], bip[2], buk[2], bup[2];  // BloomEmbedding hashed-row occurrence lists
+};
+
 struct slk_prof_span {
     int cls;
     hipEvent_t a, b;
@@ -47,6 +53,13 @@ struct slk_ctx {
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
         sort_tmp, dgrad[4];
     size_t dgrad_elems[4] = {0, 0, 0, 0};
+    // tuning (slk_ctx_set_option)
+    int64_t opt_chunk_interactions = (int64_t)1 << 21;  // interactions per prep chunk
+    int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
+    int opt_user_grid_mult = 8;    // user pass / other row passes
+    slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)
     int64_t shard_n = 0;            // local interactions staged by the last slk_shard_begin
 
@@ -63,6 +76,7 @@ int slk_ensure(slk_ctx *ctx, slk_buf &b, size_t bytes);
 void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s);
 void slk_prof_end(slk_ctx *ctx, hipStream_t s);
 int slk_prof_drain(slk_ctx *ctx);
+int slk_prep_stream_init(slk_ctx *ctx);
 
 #define SLK_HIP(ctx, call)                                                                   \
     do {                                                                                     \

@@ -354,9 +354,12 @@ __global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
 // ---------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------
-static inline unsigned slk_grid_for(const slk_ctx *ctx, size_t work_items, unsigned per_block) {
+// Row passes keep 8 workgroups (32 waves) per CU busy with grid-stride loops.  The item pass uses
+// many more, smaller workgroups instead (mult = ctx->opt_item_grid_mult): at 69 VGPRs only 7 of 8
+// fit a CU at once, and with equal work per workgroup the 8th ran alone in a second round.
+static inline unsigned slk_grid_for(const slk_ctx *ctx, size_t work_items, unsigned per_block, int mult = 0) {
     size_t blocks = (work_items + per_block - 1) / per_block;
-    const size_t cap = (size_t)ctx->num_cus * 8;
+    const size_t cap = (size_t)ctx->num_cus * (size_t)(mult > 0 ? mult : ctx->opt_user_grid_mult);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;

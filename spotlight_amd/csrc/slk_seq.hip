@@ -482,7 +482,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             a.inv_b = 1.0f;  // the sequence pass already divided its partials by mask.sum()
             slk_set_opt_coeffs(a, optim);
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-            hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb)), dim3(256), 0, s,
+            hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s,
                                a);
             SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ>");
             slk_prof_end(ctx, s);

@@ -321,7 +321,7 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
                                  (size_t)local->num_users, (size_t)local->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
     }
-    const unsigned max_grid = (unsigned)ctx->num_cus * 8;
+    const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     slk_pass_args a;
     memset(&a, 0, sizeof(a));
@@ -407,7 +407,7 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
 #undef SLK_PICK
         const unsigned gpb = 256u / (unsigned)g;
         slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-        hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, nr, 4 * gpb)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, nr, 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
         SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW>");
         slk_prof_end(ctx, s);
     }

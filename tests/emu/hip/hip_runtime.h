@@ -169,6 +169,11 @@ hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipEventCreate(hipEvent_t *e);
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(0x10); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st);
 hipError_t hipEventSynchronize(hipEvent_t e);

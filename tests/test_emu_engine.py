@@ -78,3 +78,24 @@ def test_argument_errors(be):
         eng.sample_items(0, 4, be.ptr(ids))
     with pytest.raises(_native.SlkError):
         _native.Engine(7, lib=eng._lib)  # no such device
+
+
+def test_pipelined_chunks_match_single_chunk(be):
+    """chunk_interactions small => several prep chunks per call: the double-buffered prep pipeline
+    (negatives + sorts of chunk c+1 on the prep stream while chunk c trains) must give the same
+    results, negatives and RNG state as one big chunk."""
+    eng = be.engine
+    try:
+        eng.set_option('chunk_interactions', 100)
+        ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 8, N=450, B=32, epochs=2)
+        ec.check_train_matches_oracle(be, 'adaptive_hinge', 'sparse_adam', 8, N=450, B=32, nn=4, epochs=1)
+        ec.check_bloom_train_matches_oracle(be, 'bpr', 'adagrad', 8, user_bloom=2, item_bloom=3, N=450, B=32)
+        eng.set_option('item_grid_mult', 1)
+        eng.set_option('user_grid_mult', 1)
+        ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, N=450, B=32, epochs=1)
+    finally:
+        eng.set_option('chunk_interactions', 1 << 21)
+        eng.set_option('item_grid_mult', 64)
+        eng.set_option('user_grid_mult', 8)
+    with pytest.raises(_native.SlkError):
+        eng.set_option('no_such_option', 1)
