@@ -114,8 +114,10 @@ void slk_ctx_destroy(slk_ctx *ctx);
 const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create error */
 
 /* Tuning knobs (none changes results):
- *   "chunk_interactions"  interactions per prep chunk (default 2^21): the negatives + sorts of chunk
- *                         c+1 run on a second HIP stream while chunk c trains
+ *   "chunk_interactions"  interactions per prep chunk (default 2^23)
+ *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while
+ *                         chunk c trains (default 0: the passes are HBM-bound and lose more than
+ *                         the prep they hide, see profiles/README.md)
  *   "item_grid_mult"      item pass: workgroups per CU (default 64)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond) */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);

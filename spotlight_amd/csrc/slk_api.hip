@@ -147,6 +147,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
     if (!ctx || !name) return SLK_EINVAL;
     if (!strcmp(name, "chunk_interactions") && value >= 1) {
         ctx->opt_chunk_interactions = value;
+    } else if (!strcmp(name, "overlap_prep") && (value == 0 || value == 1)) {
+        ctx->opt_overlap_prep = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {

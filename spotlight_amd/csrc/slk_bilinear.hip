@@ -528,9 +528,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // stays bounded (~8M interactions).
     const int64_t bsz = batch_size < n ? batch_size : n;
     int64_t mb_per_chunk = (int64_t)1 << (32 - idbits);
-    // ~2M interactions (at least two minibatches... of a large batch: one) per chunk: small enough
-    // for the next chunk's prep to hide behind this chunk's passes, large enough for the sorts
-    // and the MT19937 jump-ahead sampler to fill the GPU
+    // ~8M interactions per chunk (option "chunk_interactions"): large enough for the sorts and the
+    // MT19937 jump-ahead sampler to fill the GPU, small enough to bound the scratch
     const int64_t cap_inter = ctx->opt_chunk_interactions;
     if (mb_per_chunk * bsz > cap_inter) mb_per_chunk = cap_inter / bsz;
     while (mb_per_chunk > 1 && mb_per_chunk * bsz * occ_mult >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
@@ -539,11 +538,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return slk_fail(ctx, SLK_EINVAL, "batch_size * lookups per interaction must be < 2^31");
     const int64_t chunk_cap = mb_per_chunk * bsz;
 
-    // scratch.  The value-independent part of a chunk (negatives, sort by user, sort by item) is
-    // prepared on a second HIP stream while the previous chunk's passes run, so those buffers
-    // exist twice (ctx->pb[0|1]) as soon as a call spans more than one chunk.
+    // scratch.  With the "overlap_prep" option the value-independent part of a chunk (negatives,
+    // sort by user, sort by item) is prepared on a second HIP stream while the previous chunk's
+    // passes run, and those buffers exist twice (ctx->pb[0|1]).  Off by default: measured on
+    // MI355X (profiles/README.md) the passes are HBM-bound and slow down by more than the prep
+    // they hide.
     const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
-    const int nsets = (n > chunk_cap) ? 2 : 1;
+    const int nsets = (ctx->opt_overlap_prep && n > chunk_cap) ? 2 : 1;
     for (int st = 0; st < nsets; ++st) {
         slk_prep_bufs &pb = ctx->pb[st];
         if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;
@@ -578,6 +579,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
 
     if (reserve_only) {
+        if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
         // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;
         return slk_sort_reserve(ctx, nc_max * (size_t)occ_mult);
@@ -806,10 +808,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     };
 
     if (nsets == 1) {
-        if ((rc = do_prep(0, ctx->pb[0], s))) return rc;
-        rc = do_passes(0, ctx->pb[0]);
+        // everything in order on the caller's stream
+        for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
+            if ((rc = do_prep(c0, ctx->pb[0], s))) return rc;
+            if ((rc = do_passes(c0, ctx->pb[0]))) return rc;
+        }
         ctx->last_stream = s;
-        return rc;
+        return SLK_OK;
     }
     // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream
     if ((rc = slk_prep_stream_init(ctx))) return rc;

@@ -11,6 +11,14 @@
 
 #define SLK_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Occupancy target of a kernel in waves per SIMD (caps its VGPR budget at 512 / n).  hipcc only;
+// the test harness's host build of these sources ignores it.
+#if defined(__HIPCC__)
+#define SLK_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#else
+#define SLK_WAVES_PER_EU(n)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // ctx
 // ---------------------------------------------------------------------------------------
@@ -54,7 +62,8 @@ struct slk_ctx {
         sort_tmp, dgrad[4];
     size_t dgrad_elems[4] = {0, 0, 0, 0};
     // tuning (slk_ctx_set_option)
-    int64_t opt_chunk_interactions = (int64_t)1 << 21;  // interactions per prep chunk
+    int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
+    int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)

@@ -241,7 +241,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 
 template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH>
-__global__ __launch_bounds__(256) void k_item_pass(slk_pass_args a) {
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
     constexpr int DL = G * VEC;  // LDS row length (>= D)

@@ -86,15 +86,19 @@ def test_pipelined_chunks_match_single_chunk(be):
     results, negatives and RNG state as one big chunk."""
     eng = be.engine
     try:
+        eng.set_option('overlap_prep', 1)
         eng.set_option('chunk_interactions', 100)
         ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 8, N=450, B=32, epochs=2)
         ec.check_train_matches_oracle(be, 'adaptive_hinge', 'sparse_adam', 8, N=450, B=32, nn=4, epochs=1)
         ec.check_bloom_train_matches_oracle(be, 'bpr', 'adagrad', 8, user_bloom=2, item_bloom=3, N=450, B=32)
+        eng.set_option('overlap_prep', 0)  # several chunks, in order on one stream
+        ec.check_train_matches_oracle(be, 'pointwise', 'adagrad', 8, N=450, B=32, epochs=1)
         eng.set_option('item_grid_mult', 1)
         eng.set_option('user_grid_mult', 1)
         ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, N=450, B=32, epochs=1)
     finally:
-        eng.set_option('chunk_interactions', 1 << 21)
+        eng.set_option('chunk_interactions', 1 << 23)
+        eng.set_option('overlap_prep', 0)
         eng.set_option('item_grid_mult', 64)
         eng.set_option('user_grid_mult', 8)
     with pytest.raises(_native.SlkError):
