@@ -463,3 +463,41 @@ def check_bloom_replays_reference_fixture(be, golden_dir, name):
 
 BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_default', 'bloom_both_bpr_adagrad',
                   'bloom_both_adaptive_adam', 'bloom_user_pointwise_adagrad', 'bloom_c3_adaptive_adagrad']
+
+
+def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1000, nn=5, user_bloom=0, item_bloom=0,
+                                  chunk=4096, overlap=1, seed=21):
+    """The engine is deterministic (sorted ownership, no atomics), and chunking / the prep pipeline
+    only change WHEN value-independent work happens: one big chunk on one stream and many small
+    chunks with prep on the second stream must agree bit for bit -- losses, negatives, every table,
+    every optimizer-state tensor and the final RNG state."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    params, ud, idesc = _bloom_setup(rs, U, I, D, user_bloom, item_bloom, 0.2)
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    n_draw = N * (nn if loss == 'adaptive_hinge' else 1)
+    results = []
+    for chunk_i, overlap_i in ((1 << 23, 0), (chunk, overlap)):
+        eng.set_option('chunk_interactions', chunk_i)
+        eng.set_option('overlap_prep', overlap_i)
+        try:
+            dev = be.model(params, opt=opt, lr=0.05, user_bloom=ud, item_bloom=idesc)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+            neg_out = be.alloc(np.full(n_draw, -1, dtype=np.int64))
+            for _ in range(2):
+                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
+                                   be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+            st = eng.rng_get_state()
+            results.append([be.get(mb_loss), be.get(neg_out), st[1], np.array(st[2])] +
+                           [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+        finally:
+            eng.set_option('chunk_interactions', 1 << 23)
+            eng.set_option('overlap_prep', 0)
+    for k, (a, b) in enumerate(zip(*results)):
+        assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined run' % k,
+                                      float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))

@@ -142,22 +142,21 @@ def test_bloom_replays_reference_fixture(be, name):
 
 def test_pipelined_chunks_match_oracle(be):
     """Real streams: prep of chunk c+1 on the engine's second HIP stream while chunk c trains on the
-    caller's.  13+ chunks per call; negatives, losses, tables and the final RNG state must match
-    the oracle exactly as in the single-chunk runs (a missing event dependency shows up here)."""
+    caller's.  Many chunks per call; results must match the oracle as in the single-chunk runs and,
+    stronger, the single-chunk engine run BIT FOR BIT (a missing event dependency shows up here)."""
     eng = be.engine
     try:
         eng.set_option('overlap_prep', 1)
         eng.set_option('chunk_interactions', 4096)
         for _ in range(3):
             ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 64, U=3000, I=1000, N=50000, B=1024, epochs=1, tol=1e-4)
-        ec.check_train_matches_oracle(be, 'adaptive_hinge', 'adagrad', 32, U=3000, I=1000, N=30000, B=1000, nn=5,
-                                      epochs=1, tol=1e-4)
-        ec.check_train_matches_oracle(be, 'bpr', 'sparse_adam', 32, U=3000, I=1000, N=30000, B=1000, epochs=1, tol=1e-4)
-        ec.check_bloom_train_matches_oracle(be, 'bpr', 'adagrad', 64, user_bloom=2, item_bloom=4, U=3000, I=5000,
-                                            N=20000, B=512, epochs=1, ratio=0.2, tol=1e-4)
-        eng.set_option('item_grid_mult', 1)
-        ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, N=4500, B=320, epochs=1)
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 0)
-        eng.set_option('item_grid_mult', 64)
+    for overlap in (0, 1):
+        ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, overlap=overlap)
+        ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=overlap)
+        ec.check_chunking_is_bit_neutral(be, 'hinge', 'adam_dense', 16, N=12000, chunk=2048, overlap=overlap)
+        ec.check_chunking_is_bit_neutral(be, 'pointwise', 'adagrad', 64, user_bloom=2, item_bloom=4, I=5000,
+                                         N=20000, B=512, overlap=overlap)
+    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, U=200000, I=50000, N=600000, B=65536, chunk=131072)
