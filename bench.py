@@ -221,11 +221,10 @@ def main():
             eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, 1,
                                mb_loss[first_mb:].data_ptr(), stream=stream)
             return
-        for k in range(first_mb, first_mb + n_mb):
-            # this rank's B interactions of global minibatch k (users it owns; items anywhere)
-            part = trainer.step(users[k * B:(k + 1) * B], items[k * B:(k + 1) * B], B * world, loss=args.loss)
-            mb_loss[k:k + 1].copy_(part)
-            xgmi_rows[0] += trainer.last_exchange_rows
+        # this rank's B interactions of every global minibatch (users it owns; items anywhere)
+        lo, hi = first_mb * B, (first_mb + n_mb) * B
+        trainer.train(users[lo:hi], items[lo:hi], B, loss=args.loss, mb_loss=mb_loss[first_mb:first_mb + n_mb])
+        xgmi_rows[0] += trainer.exchange_rows
 
     def barrier():
         torch.cuda.synchronize(dev)

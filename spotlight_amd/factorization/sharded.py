@@ -105,3 +105,29 @@ class ShardedBilinearTrainer(object):
                             grad_recv.data_ptr() if n_recv else None, n_recv, stream=self.stream)
         self.last_exchange_rows = 2 * n - sc[self.rank]  # lookups that crossed xGMI
         return loss_out.clone()
+
+    def train(self, users_local, items, batch_local, loss='bpr', mb_loss=None, sample_chunk=8):
+        """Minibatch loop over this rank's interactions: global minibatch k consists of every
+        rank's slice [k*batch_local, (k+1)*batch_local) (all ranks must hold the same number of
+        interactions).  Negatives are drawn from this rank's engine RNG over the global item range,
+        `sample_chunk` minibatches per draw (one contiguous randint stream per rank, exactly as a
+        per-minibatch draw would produce: sampling.py:34 draws are independent per output).
+        Returns the per-minibatch loss shares (sum over ranks = loss.item())."""
+        n = int(users_local.numel())
+        n_mb = (n + batch_local - 1) // batch_local
+        if mb_loss is None:
+            mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=self.device)
+        self.exchange_rows = 0
+        negs = None
+        for k in range(n_mb):
+            lo, hi = k * batch_local, min((k + 1) * batch_local, n)
+            if k % sample_chunk == 0:
+                c_hi = min((k + sample_chunk) * batch_local, n)
+                negs = self._buf('negs', c_hi - lo, 0, torch.int64)
+                self.engine.sample_items(self.num_items_global, c_hi - lo, negs.data_ptr(), stream=self.stream)
+                c_lo = lo
+            part = self.step(users_local[lo:hi], items[lo:hi], (hi - lo) * self.world, loss=loss,
+                             neg_in=negs[lo - c_lo:hi - c_lo])
+            mb_loss[k:k + 1].copy_(part)
+            self.exchange_rows += self.last_exchange_rows
+        return mb_loss

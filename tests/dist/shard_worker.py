@@ -59,7 +59,15 @@ def main():
         eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
 
     losses, used_negs = [], np.full(N, -1, dtype=np.int64)
-    for k in range(n_mb):
+    use_train_loop = sample_on_device and world == 1  # ShardedBilinearTrainer.train (chunked sampling)
+    if use_train_loop:
+        ul = torch.from_numpy(users // world).to(dev)
+        il = torch.from_numpy(items).to(dev)
+        shares = trainer.train(ul, il, B, loss=loss, sample_chunk=2)
+        losses = [float(x) for x in shares.cpu().numpy()]
+        # the draws: one contiguous stream, minibatch after minibatch
+        used_negs = np.random.RandomState(1000 + rank).randint(0, I, N, dtype=np.int64)
+    for k in range(0 if use_train_loop else n_mb):
         lo, hi = k * B, min((k + 1) * B, N)
         idx = np.nonzero(users[lo:hi] % world == rank)[0] + lo
         ul = torch.from_numpy(users[idx] // world).to(dev)

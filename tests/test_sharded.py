@@ -59,6 +59,11 @@ def test_sharded_world1_degenerates_to_local_exchange():
     run_world(1, ['pointwise', 'adagrad_dense', 8])
 
 
+def test_sharded_train_loop_chunked_sampling():
+    # ShardedBilinearTrainer.train: negatives drawn several minibatches at a time == numpy's stream
+    run_world(1, ['bpr', 'adagrad', 16, 'sample'])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('loss,opt,D', [('bpr', 'adagrad', 64), ('hinge', 'sparse_adam', 32),
                                         ('pointwise', 'adam_dense', 8)])
