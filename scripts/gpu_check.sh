@@ -20,7 +20,10 @@ for st in $STAGES; do
       timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; cat $OUT/bench.json; tail -5 $OUT/bench.err ;;
     prof)
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err)
-      echo "prof exit $?"; find $OUT/prof -name "*kernel_stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" ;;
+      echo "prof exit $?"
+      # keep only the summary: the rocpd database is tens of MB and gpurun copies back <= 64 MiB
+      db=$(find $OUT/prof -name "*.db" | head -1)
+      [ -n "$db" ] && python $ROOT/scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -30 $OUT/kernel_stats.md ;;
     shard)
       timeout 600 python bench.py --sharded --no-cpu-baseline > $OUT/bench_sharded1.json 2> $OUT/bench_sharded1.err; echo "bench --sharded exit $?"; cat $OUT/bench_sharded1.json; tail -5 $OUT/bench_sharded1.err ;;
     c4)

@@ -18,4 +18,6 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-ls $OUT
+python $ROOT/scripts/summarize_pmc.py $OUT $OUT/pmc_summary "rocprofv3 --pmc passes over python bench.py --steps 4 --warmup 1 ${BARGS[*]} ($TAG)" > /dev/null
+for g in fetch write sq tcc; do rm -rf $OUT/$g; done
+ls $OUT; cat $OUT/pmc_summary.md | head -60
