@@ -44,6 +44,22 @@ def algorithmic_bytes(dim, opt_state_words):
     return user_pass, item_pass
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this very
+    workload (profiles/pmc_traffic.json, produced by scripts/pmc_run.sh + scripts/summarize_pmc.py:
+    2 x FETCH_SIZE + WRITE_SIZE, separate passes; MI355X_MICROARCH.md "HBM").  PMC counters cannot
+    be collected from inside the benchmark process, so this is null unless the committed
+    measurement matches the workload being run."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    cfg = rec.get('config', {})
+    same = all(cfg.get(k) == getattr(args, k) for k in ('users', 'items', 'dim', 'batch', 'loss', 'opt'))
+    return rec.get('kernels', {}).get(kernel, {}).get('hbm_bytes_per_launch') if same else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -280,7 +296,9 @@ def main():
         dom = max(kern, key=lambda k: kern[k]['avg_ms'])
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': kern[dom]['achieved_GBs'],
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kern[dom]['achieved_GBs'] / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': pmc_traffic(args, 'k_' + dom) if trainer is None else None,
+                'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic.json '
+                                '(rocprofv3 --pmc passes over this workload); null if no committed measurement matches',
                 'kernels': kern,
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
@@ -314,10 +332,16 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL printf()s its banner into libc's stdout buffer: flush it while fd 1 still points at stderr
     sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     os.dup2(real_stdout, 1)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(1, (json.dumps(out) + '\n').encode())
 
 
 if __name__ == '__main__':
