@@ -131,3 +131,160 @@ class ShardedBilinearTrainer(object):
             mb_loss[k:k + 1].copy_(part)
             self.exchange_rows += self.last_exchange_rows
         return mb_loss
+
+
+# ---------------------------------------------------------------------------------------------
+# The drop-in model on top of the trainer
+# ---------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+from spotlight_amd.factorization import implicit as _host  # noqa: E402
+from spotlight_amd.factorization._components import _predict_process_ids  # noqa: E402
+from spotlight_amd.factorization.implicit import ImplicitFactorizationModel  # noqa: E402
+from spotlight_amd.factorization.representations import BilinearNet  # noqa: E402
+from spotlight_amd.torch_utils import shuffle  # noqa: E402
+
+_FULL_INIT_LIMIT_BYTES = 8 << 30
+
+
+class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
+    """ImplicitFactorizationModel whose four tables are row-sharded over the ranks of a
+    torch.distributed process group (one process per GPU; `torchrun`).
+
+    Same constructor, `fit(interactions)` and `predict(user_ids, item_ids=None)` as the
+    single-device model (spotlight/factorization/implicit.py:76-311); every rank makes the same
+    calls with the same arguments (SPMD) and gets the same return values.  Given the same
+    `random_state` seed on every rank, a run consumes the RandomState exactly like the
+    single-device model: same model seed draw, same shuffles, and the SAME negatives (every rank
+    draws the epoch's whole negative stream on its GPU and keeps the entries of its own
+    interactions), so the trained tables match a single-device run to summation-order noise.
+    Initial values also match when the full tables fit the host (< 8 GB): they are drawn from
+    torch's CPU generator in the reference's order and this rank keeps rows `rank::world`.
+
+    Restrictions of the exchange path: pointwise / bpr / hinge losses, plain (non-bloom) tables.
+    """
+
+    def __init__(self, *args, **kwargs):
+        self._group = kwargs.pop('group', None)
+        super(ShardedImplicitFactorizationModel, self).__init__(*args, **kwargs)
+        if self._loss == 'adaptive_hinge':
+            raise NotImplementedError('adaptive_hinge is not supported by the row-sharded path yet')
+        if self._representation is not None:
+            raise NotImplementedError('custom representations are not supported by the row-sharded path')
+        self._trainer = None
+
+    def __getstate__(self):
+        state = super(ShardedImplicitFactorizationModel, self).__getstate__()
+        state['_trainer'] = None
+        state['_group'] = None
+        return state
+
+    @property
+    def _world(self):
+        return dist.get_world_size(self._group)
+
+    @property
+    def _rank(self):
+        return dist.get_rank(self._group)
+
+    def _initialize(self, interactions):
+        self._num_users, self._num_items = interactions.num_users, interactions.num_items
+        world, rank, D = self._world, self._rank, self._embedding_dim
+        U, I = self._num_users, self._num_items
+        full = None
+        if (U + I) * D * 4 <= _FULL_INIT_LIMIT_BYTES:
+            full = BilinearNet(U, I, D, sparse=self._sparse)  # the reference's draws, in its order
+        net = BilinearNet(local_rows(U, world, rank), local_rows(I, world, rank), D, sparse=self._sparse)
+        if full is not None:
+            with torch.no_grad():
+                for loc, whole in zip(net.tables(), full.tables()):
+                    loc.copy_(whole[rank::world])
+        self._net = net.to(_host._model_device())
+        if self._optimizer_func is None:
+            self._optimizer = torch.optim.Adam(self._net.parameters(), weight_decay=self._l2,
+                                               lr=self._learning_rate)
+        else:
+            self._optimizer = self._optimizer_func(self._net.parameters())
+        self._loss_func = self._loss
+        self._binding = None
+        self._trainer = None
+
+    def fit(self, interactions, verbose=False):
+        user_ids = interactions.user_ids.astype(np.int64)
+        item_ids = interactions.item_ids.astype(np.int64)
+        if not self._initialized:
+            self._initialize(interactions)
+        self._check_input(user_ids, item_ids)
+
+        binding = self._bind()
+        tables = self._net.tables()
+        device = tables[0].device
+        engine = _host._engine_for(device)
+        stream = _host._stream_for(device)
+        world, rank, B = self._world, self._rank, self._batch_size
+        n = len(user_ids)
+        n_mb = (n + B - 1) // B
+
+        for epoch_num in range(self._n_iter):
+            users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
+            d_users = torch.from_numpy(users).to(device)
+            d_items = torch.from_numpy(items).to(device)
+            # the epoch's negatives: one randint per minibatch == one contiguous draw over the epoch
+            negs = torch.empty(n, dtype=torch.int64, device=device)
+            engine.rng_set_state(self._random_state.get_state())
+            engine.sample_items(self._num_items, n, negs.data_ptr(), stream=stream)
+            self._random_state.set_state(engine.rng_get_state())
+            # this rank's interactions, minibatch membership unchanged
+            idx = torch.nonzero(d_users % world == rank).squeeze(1)
+            bounds = torch.searchsorted(idx, torch.arange(0, n_mb + 1, device=device) * B).tolist()
+            ul = (d_users[idx] // world).contiguous()
+            il = d_items[idx].contiguous()
+            ng = negs[idx].contiguous()
+            ostruct = binding.as_struct()
+            trainer = ShardedBilinearTrainer(engine, tables, ostruct, self._num_items, group=self._group,
+                                             stream=stream) if self._trainer is None else self._trainer
+            trainer.optim = ostruct
+            self._trainer = trainer
+            mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=device)
+            for k in range(n_mb):
+                a, b = bounds[k], bounds[k + 1]
+                share = trainer.step(ul[a:b], il[a:b], min(B, n - k * B), loss=self._loss, neg_in=ng[a:b])
+                mb_loss[k:k + 1].copy_(share)
+            dist.all_reduce(mb_loss, group=self._group)
+            binding.store_steps(ostruct.step)
+            epoch_loss = float(mb_loss.double().mean().item())
+            if verbose and rank == 0:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def _fetch_rows(self, t_emb, t_bias, ids, device):
+        """[len(ids), D + 1]: embedding row and bias of every id, assembled from the owners."""
+        world, rank = self._world, self._rank
+        w = self._net.tables()
+        d_ids = torch.from_numpy(np.ascontiguousarray(ids)).to(device)
+        out = torch.zeros(d_ids.numel(), w[t_emb].shape[1] + 1, dtype=torch.float32, device=device)
+        mine = torch.nonzero(d_ids % world == rank).squeeze(1)
+        loc = d_ids[mine] // world
+        out[mine, :-1] = w[t_emb].detach()[loc]
+        out[mine, -1] = w[t_bias].detach()[loc, 0]
+        dist.all_reduce(out, group=self._group)  # every row has exactly one owner
+        return out
+
+    def predict(self, user_ids, item_ids=None):
+        self._check_input(user_ids, item_ids, allow_items_none=True)
+        self._net.train(False)
+        users, items, n = _predict_process_ids(user_ids, item_ids, self._num_items)
+        if items is None:
+            items = np.arange(n, dtype=np.int64)
+        device = self._net.tables()[0].device
+        engine = _host._engine_for(device)
+        ru = self._fetch_rows(0, 2, users.reshape(-1), device)
+        ri = self._fetch_rows(1, 3, items.reshape(-1), device)
+        D = ru.shape[1] - 1
+        gathered = [ru[:, :D].contiguous(), ri[:, :D].contiguous(), ru[:, D].contiguous(), ri[:, D].contiguous()]
+        tb = _native.make_tables([t.data_ptr() for t in gathered], ru.shape[0], ri.shape[0], D)
+        d_u = torch.arange(ru.shape[0], dtype=torch.int64, device=device)
+        out = torch.empty(n, dtype=torch.float32, device=device)
+        engine.bilinear_predict(tb, d_u.data_ptr(), ru.shape[0], None, n, out.data_ptr(), _host._stream_for(device))
+        return out.cpu().numpy().flatten()

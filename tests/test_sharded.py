@@ -10,6 +10,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, 'dist', 'shard_worker.py')
+MODEL_WORKER = os.path.join(HERE, 'dist', 'shard_model_worker.py')
 
 
 def _free_port():
@@ -20,7 +21,8 @@ def _free_port():
     return port
 
 
-def run_world(world, args, backend='emu', timeout=600):
+def run_world(world, args, backend='emu', timeout=600, worker=None, token='SHARD_PARITY_OK'):
+    worker = worker or WORKER
     from emu_backend import emu_lib
     if backend == 'emu':
         emu_lib()  # build once, before the ranks race for it
@@ -29,7 +31,7 @@ def run_world(world, args, backend='emu', timeout=600):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
-        procs.append(subprocess.Popen([sys.executable, WORKER, backend] + [str(a) for a in args], env=env,
+        procs.append(subprocess.Popen([sys.executable, worker, backend] + [str(a) for a in args], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -42,7 +44,7 @@ def run_world(world, args, backend='emu', timeout=600):
         outs.append(out.decode())
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, 'rank %d failed:\n%s' % (r, out[-4000:])
-    assert 'SHARD_PARITY_OK' in outs[0], outs[0][-2000:]
+    assert token in outs[0], outs[0][-2000:]
 
 
 @pytest.mark.parametrize('loss,opt,D', [('bpr', 'adagrad', 8), ('hinge', 'sparse_adam', 8),
@@ -62,6 +64,18 @@ def test_sharded_world1_degenerates_to_local_exchange():
 def test_sharded_train_loop_chunked_sampling():
     # ShardedBilinearTrainer.train: negatives drawn several minibatches at a time == numpy's stream
     run_world(1, ['bpr', 'adagrad', 16, 'sample'])
+
+
+@pytest.mark.parametrize('world,loss,opt', [(2, 'bpr', 'adagrad'), (3, 'pointwise', 'adam'), (2, 'hinge', 'sparse_adam')])
+def test_sharded_model_fit_predict_match_single_device_model(world, loss, opt):
+    """The drop-in ShardedImplicitFactorizationModel: same seed => same RandomState consumption
+    (shuffles, negatives), same tables and predictions as ImplicitFactorizationModel."""
+    run_world(world, [loss, opt], worker=MODEL_WORKER, token='SHARD_MODEL_OK')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_model_world1_nccl():
+    run_world(1, ['bpr', 'adagrad'], backend='hip', worker=MODEL_WORKER, token='SHARD_MODEL_OK')
 
 
 @pytest.mark.gpu
