@@ -76,11 +76,20 @@ def main():
         assert (a[1] == b[1]).all() and a[2] == b[2], 'RandomState consumption differs'
         for t, w in enumerate(ref._net.tables()):
             want = w.detach().cpu().numpy()
-            err = np.abs(full[t] - want).max() / max(np.abs(want).max(), 1e-3)
-            assert err < 2e-4, (t, err)  # 20 optimizer steps; only the summation order of item rows differs
+            scale = max(np.abs(want).max(), 1e-3)
+            if opt == 'adagrad':
+                err = np.abs(full[t] - want).max() / scale
+                assert err < 2e-4, (t, err)  # 20 optimizer steps; only the summation order of item rows differs
+            else:
+                # Adam normalises by sqrt(v): an element whose gradient is +-1/B cancellation noise moves
+                # by O(lr) in a direction set by summation order -- judge the
+                # trajectory by the fraction of elements outside tolerance, as engine_checks does
+                bad = np.abs(full[t] - want) > 1e-3 * scale
+                assert bad.mean() <= 0.05, (t, bad.mean())
         want_all, want_pairs = ref.predict(5), ref.predict(pu, pi)
-        assert np.abs(pred_all - want_all).max() <= 1e-4 * np.abs(want_all).max()
-        assert np.abs(pred_pairs - want_pairs).max() <= 1e-4 * np.abs(want_pairs).max()
+        ptol = 1e-4 if opt == 'adagrad' else 5e-3
+        assert np.abs(pred_all - want_all).max() <= ptol * np.abs(want_all).max()
+        assert np.abs(pred_pairs - want_pairs).max() <= ptol * np.abs(want_pairs).max()
         assert pred_all.dtype == np.float32 and pred_all.shape == (I,)
         print('SHARD_MODEL_OK world=%d loss=%s opt=%s' % (world, loss, opt))
     dist.barrier()
