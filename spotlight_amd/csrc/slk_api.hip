@@ -1,6 +1,8 @@
 // slk_api.hip -- ctx lifetime, error text, scratch, event-based kernel timing.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "slk_common.h"
 
 static char g_create_err[512] = {0};
@@ -147,12 +149,14 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
     if (!ctx || !name) return SLK_EINVAL;
     if (!strcmp(name, "chunk_interactions") && value >= 1) {
         ctx->opt_chunk_interactions = value;
-    } else if (!strcmp(name, "overlap_prep") && (value == 0 || value == 1)) {
+    } else if (!strcmp(name, "overlap_prep") && value >= 0 && value <= 2) {
         ctx->opt_overlap_prep = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_user_grid_mult = (int)value;
+    } else if (!strcmp(name, "nt") && value >= 0 && value <= 15) {
+        ctx->opt_nt = (int)value;
     } else {
         return slk_fail(ctx, SLK_EINVAL, "slk_ctx_set_option: unknown option or bad value: %s = %lld", name,
                         (long long)value);

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     float loss_acc = 0.0f;
 
     for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
-        const uint32_t key = a.ukey[p];
+        const bool nt_keys = (a.nt & 8) != 0;
+        const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
         if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         if (BLOOM)
             u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         else
-            u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
+            u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (a.nt & 1) != 0) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             float *rec = a.snap + (size_t)(q - a.begin) * a.RS;
             if (on) slk_vstore<VEC>(rec + d0, u);
             if (!PRE) {
-                const uint32_t ip = a.uit[2 * (size_t)q], in = a.uit[2 * (size_t)q + 1];
+                const uint32_t ip = slk_ld_u32(a.uit + 2 * (size_t)q, nt_keys), in = slk_ld_u32(a.uit + 2 * (size_t)q + 1, nt_keys);
                 slk_vec<VEC> vi, vj;
                 if (BLOOM) {
                     vi = slk_emb_vec<VEC>(a.P[1], a.ib, ip, D, d0, on);
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         if (BLOOM && a.ub.n_hash) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
-            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu);
+            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
         }
         if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
     }
@@ -603,12 +604,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 #undef SLK_PICK
     const unsigned gpb = 256u / (unsigned)g;
 
-    // ---- prep of one chunk on stream `s` into buffer set `pb` (value-independent: ids only)
-    auto do_prep = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
+    // ---- prep of one chunk into buffer set `pb` (value-independent: ids only), in two halves:
+    // the negatives (ALU/latency-bound MT19937 generator), then the sorts (HBM-bound)
+    auto do_sample = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
         int rc;
         const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
-        const uint32_t nocc = nc * (uint32_t)NP;
-        const int64_t *cu = d_users + c0, *ci = d_items + c0;
         uint32_t *neg32 = (uint32_t *)pb.neg32.p;
 
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
@@ -626,6 +626,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                      d_neg_out ? d_neg_out + c0 * nn : nullptr, s)))
                 return rc;
         }
+        return SLK_OK;
+    };
+    auto do_sort = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
+        int rc;
+        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const uint32_t nocc = nc * (uint32_t)NP;
+        const int64_t *cu = d_users + c0, *ci = d_items + c0;
+        uint32_t *neg32 = (uint32_t *)pb.neg32.p;
 
         // ---- prep: sort interactions by (minibatch, user), occurrences by (minibatch, item)
         slk_prof_begin(ctx, SLK_K_PREP, s);
@@ -734,6 +742,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.urec = (float *)ctx->extra[BL_UREC].p;
             a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
+            a.nt = ctx->opt_nt;
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
             const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
@@ -810,28 +819,35 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (nsets == 1) {
         // everything in order on the caller's stream
         for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
-            if ((rc = do_prep(c0, ctx->pb[0], s))) return rc;
+            if ((rc = do_sample(c0, ctx->pb[0], s))) return rc;
+            if ((rc = do_sort(c0, ctx->pb[0], s))) return rc;
             if ((rc = do_passes(c0, ctx->pb[0]))) return rc;
         }
         ctx->last_stream = s;
         return SLK_OK;
     }
-    // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream
+    // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream.
+    // overlap_prep = 1: negatives and sorts; = 2: only the negatives (the generator is ALU-bound and
+    // shares the chip with the HBM-bound passes; the sorts stay in line on the caller's stream)
+    const bool sort_ahead = ctx->opt_overlap_prep == 1;
     if ((rc = slk_prep_stream_init(ctx))) return rc;
     hipStream_t ps = ctx->prep_stream;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
     SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
-    if ((rc = do_prep(0, ctx->pb[0], ps))) return rc;
+    if ((rc = do_sample(0, ctx->pb[0], ps))) return rc;
+    if (sort_ahead && (rc = do_sort(0, ctx->pb[0], ps))) return rc;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
     int set = 0;
     for (int64_t c0 = 0; c0 < n; c0 += chunk_cap, set ^= 1) {
+        SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
+        if (!sort_ahead && (rc = do_sort(c0, ctx->pb[set], s))) return rc;
         if (c0 + chunk_cap < n) {
             // the other buffer set was last read by the passes of the previous chunk
             if (c0 > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
-            if ((rc = do_prep(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
+            if ((rc = do_sample(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
+            if (sort_ahead && (rc = do_sort(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
         }
-        SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
         if ((rc = do_passes(c0, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }

@@ -66,6 +66,8 @@ struct slk_ctx {
     int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
+    int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
+                                   // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -187,6 +189,59 @@ __device__ __forceinline__ void slk_vstore<4>(float *p, const slk_vec<4> &x) {
 template <>
 __device__ __forceinline__ void slk_vstore<1>(float *p, const slk_vec<1> &x) {
     *p = x.v[0];
+}
+
+// Non-temporal (streaming) variants for rows that a pass touches exactly once: they should not
+// displace the re-read data (item rows, records) from L2 / Infinity Cache.  hipcc only; the test
+// harness's host build uses the plain accesses.
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_vload_nt(const float *p) {
+#if defined(__HIPCC__)
+    slk_vec<VEC> r;
+    if (VEC == 4) {
+        typedef float slk_f4 __attribute__((ext_vector_type(4)));
+        const slk_f4 t = __builtin_nontemporal_load(reinterpret_cast<const slk_f4 *>(p));
+        r.v[0] = t.x; r.v[1 % VEC] = t.y; r.v[2 % VEC] = t.z; r.v[3 % VEC] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r.v[i] = __builtin_nontemporal_load(p + i);
+    }
+    return r;
+#else
+    return slk_vload<VEC>(p);
+#endif
+}
+template <int VEC>
+__device__ __forceinline__ void slk_vstore_nt(float *p, const slk_vec<VEC> &x) {
+#if defined(__HIPCC__)
+    if (VEC == 4) {
+        typedef float slk_f4 __attribute__((ext_vector_type(4)));
+        slk_f4 t;
+        t.x = x.v[0]; t.y = x.v[1 % VEC]; t.z = x.v[2 % VEC]; t.w = x.v[3 % VEC];
+        __builtin_nontemporal_store(t, reinterpret_cast<slk_f4 *>(p));
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) __builtin_nontemporal_store(x.v[i], p + i);
+    }
+#else
+    slk_vstore<VEC>(p, x);
+#endif
+}
+__device__ __forceinline__ uint32_t slk_ld_u32(const uint32_t *p, bool nt) {
+#if defined(__HIPCC__)
+    return nt ? __builtin_nontemporal_load(p) : *p;
+#else
+    return *p;
+#endif
+}
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_vload_if_nt(const float *p, bool nt) {
+    return nt ? slk_vload_nt<VEC>(p) : slk_vload<VEC>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void slk_vstore_if_nt(float *p, const slk_vec<VEC> &x, bool nt) {
+    if (nt) slk_vstore_nt<VEC>(p, x);
+    else slk_vstore<VEC>(p, x);
 }
 
 template <int VEC>

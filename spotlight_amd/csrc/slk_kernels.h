@@ -113,6 +113,7 @@ struct slk_pass_args {
     float c_lr;    // Adagrad: clr.  SparseAdam: step_size.
     float c_eps;
     float c_omb1, c_omb2;  // 1-beta1, 1-beta2
+    int nt;                // cache-policy bits (ctx option "nt")
 };
 
 enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
@@ -128,21 +129,21 @@ enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2 };
 // dense gradient buffer (aliased on S1) for the full-table sweep.
 template <int VEC, int UPD>
 __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
-                                              const slk_vec<VEC> &g) {
+                                              const slk_vec<VEC> &g, bool nt = false) {
     if (UPD == SLK_UPD_ADAGRAD) {
         // torch/optim/adagrad.py:360-385: sum += g^2; p += -clr * (g / (sqrt(sum) + eps))
-        slk_vec<VEC> s = slk_vload<VEC>(a.S1[t] + off);
+        slk_vec<VEC> s = slk_vload_if_nt<VEC>(a.S1[t] + off, nt);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             s.v[i] += g.v[i] * g.v[i];
             p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
         }
-        slk_vstore<VEC>(a.S1[t] + off, s);
-        slk_vstore<VEC>(a.P[t] + off, p);
+        slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
     } else if (UPD == SLK_UPD_SPARSE_ADAM) {
         // torch/optim/_functional.py:61-84
-        slk_vec<VEC> m = slk_vload<VEC>(a.S1[t] + off);
-        slk_vec<VEC> v = slk_vload<VEC>(a.S2[t] + off);
+        slk_vec<VEC> m = slk_vload_if_nt<VEC>(a.S1[t] + off, nt);
+        slk_vec<VEC> v = slk_vload_if_nt<VEC>(a.S2[t] + off, nt);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float mu = (g.v[i] - m.v[i]) * a.c_omb1;
@@ -151,9 +152,9 @@ __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, siz
             v.v[i] = vu + v.v[i];
             p.v[i] += -a.c_lr * (m.v[i] / (sqrtf(v.v[i]) + a.c_eps));
         }
-        slk_vstore<VEC>(a.S1[t] + off, m);
-        slk_vstore<VEC>(a.S2[t] + off, v);
-        slk_vstore<VEC>(a.P[t] + off, p);
+        slk_vstore_if_nt<VEC>(a.S1[t] + off, m, nt);
+        slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
     } else {
         slk_vstore<VEC>(a.S1[t] + off, g);
     }
@@ -228,38 +229,77 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 }
 
 // A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
-// list.  Per tile: (1) keys + payloads -> LDS; (2) all row groups gather the records of the
-// tile's positions round-robin (every load independent: memory-level parallelism instead of a
-// per-segment dependent chain) and park the contributions in LDS; (3) each run of equal keys
-// that STARTS in the tile is summed from LDS by one group (runs that spill past the tile end
-// are finished from global memory; rows of a run that started in an earlier tile are skipped --
-// its owner already took them) and the optimizer is applied to that item's row and bias.
-// Block 0 also reduces the loss partials of the preceding pass into loss.item().
+// list.  Per tile: (1) keys + payloads -> LDS; wave 0 compacts the heads of the runs of equal keys
+// that START in the tile into a list, head r belongs to row group r mod GPB (an even 1-2 heads per
+// group); (2) a group issues the loads of its first two heads' item rows + optimizer state TOGETHER
+// with its four record gathers (every load independent: one HBM round trip covers both) and parks
+// the contributions in LDS; (3) each run is summed from LDS by its owner group (runs that spill
+// past the tile end are finished from global memory; rows of a run that started in an earlier
+// tile are skipped -- its owner already took them) and the optimizer is applied to that item's
+// row and bias.  Block 0 also reduces the loss partials of the preceding pass into loss.item().
+// Measured on MI355X (profiles/README.md, r01_e): 0.415 -> 0.351 ms against the first version,
+// which waited for the records, then made one dependent row round trip per head, back to back.
 // PART: which of the run owner's two updates are applied -- the embedding row (table slot 1), the
 // bias (slot 3), or both.  They separate when the embedding rows are BloomEmbedding rows (keys =
 // hashed rows) while the bias table is indexed by the item id itself.
 enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 
+// Row update with the parameter / first-state elements already in registers (loaded early, see
+// k_item_pass).  Same arithmetic, in the same order, as slk_apply_vec.
+template <int VEC, int UPD, bool S2PRE = false>
+__device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
+                                                  slk_vec<VEC> &s, const slk_vec<VEC> &g,
+                                                  const slk_vec<VEC> *s2 = nullptr, bool nt = false) {
+    if (UPD == SLK_UPD_ADAGRAD) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s.v[i] += g.v[i] * g.v[i];
+            p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
+        }
+        slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+    } else if (UPD == SLK_UPD_SPARSE_ADAM) {
+        slk_vec<VEC> v = S2PRE ? *s2 : slk_vload<VEC>(a.S2[t] + off);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float mu = (g.v[i] - s.v[i]) * a.c_omb1;
+            const float vu = (g.v[i] * g.v[i] - v.v[i]) * a.c_omb2;
+            s.v[i] = mu + s.v[i];
+            v.v[i] = vu + v.v[i];
+            p.v[i] += -a.c_lr * (s.v[i] / (sqrtf(v.v[i]) + a.c_eps));
+        }
+        slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
+        slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+    } else {
+        slk_vstore<VEC>(a.S1[t] + off, g);
+    }
+}
+
 template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH>
-__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_args a) {
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(6) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
     constexpr int DL = G * VEC;  // LDS row length (>= D)
+    constexpr int NPRE = 2;      // heads per group whose rows are loaded early
     __shared__ double red[256];
     __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
     __shared__ uint32_t s_pay[T];
     __shared__ float s_g[T];
     __shared__ uint8_t s_live[T];
+    __shared__ uint16_t s_head[T];
+    __shared__ int s_nheads;
     __shared__ __attribute__((aligned(16))) float s_row[T * DL];
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int D = a.D;
     const int d0 = lane * VEC;
     const bool on = d0 < D;
+    const bool rows_on = on && PART != SLK_PART_BIAS;
+    const bool nt_rows = (a.nt & 2) != 0, nt_keys = (a.nt & 8) != 0;
     const uint32_t ibegin = a.ibegin, iend = a.iend;
 
     if (blockIdx.x == 0 && a.mb_loss_out) {
-        // loss.item() of this minibatch: mean over the minibatch of the per-interaction loss
         double x = 0.0;
         for (int i = threadIdx.x; i < a.n_loss_partial; i += 256) x += a.loss_partial[i];
         const double tot = slk_block_sum_256(x, red);
@@ -273,11 +313,60 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_
         const bool first_tile = tb == ibegin;
         __syncthreads();  // LDS of the previous tile no longer in use
         for (int i = threadIdx.x; i <= tn; i += 256)
-            s_key[i] = (i == 0 && first_tile) ? 0u : a.ikey[tb - 1 + i];
-        for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = a.ipay[tb + i];
+            s_key[i] = (i == 0 && first_tile) ? 0u : slk_ld_u32(a.ikey + (tb - 1 + i), nt_keys);
+        for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = slk_ld_u32(a.ipay + (tb + i), nt_keys);
         __syncthreads();
 
-        // (2) gather: position j = grp + it * GPB
+        // (1b) wave 0 compacts the heads of the runs that start in this tile
+        if (threadIdx.x < 64) {
+            int base = 0;
+            for (int c = 0; c < T; c += 64) {
+                const int j = c + (int)threadIdx.x;
+                int f = 0;
+                if (j < tn) {
+                    const uint32_t key = s_key[j + 1];
+                    const uint32_t item = key & a.imask;
+                    // padding_idx rows receive no gradient: they never become heads
+                    f = (((j == 0 && first_tile) || key != s_key[j]) && item != a.pad_item && item != a.pad_item2) ? 1 : 0;
+                }
+                int incl = f;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d, 64);
+                    if ((int)threadIdx.x >= d) incl += up;
+                }
+                if (f) s_head[base + incl - 1] = (uint16_t)j;
+                base += __shfl(incl, 63, 64);
+            }
+            if (threadIdx.x == 0) s_nheads = base;
+        }
+        __syncthreads();
+        const int nheads = s_nheads;
+
+        // (2a) early loads: row + state (+ bias) of this group's first NPRE heads
+        slk_vec<VEC> pv[NPRE], sv[NPRE];
+        float pb[NPRE], sb[NPRE];
+#pragma unroll
+        for (int h = 0; h < NPRE; ++h) {
+            pv[h] = slk_vzero<VEC>();
+            sv[h] = slk_vzero<VEC>();
+            pb[h] = sb[h] = 0.0f;
+            const int r = grp + h * GPB;
+            if (r < nheads) {
+                const uint32_t item = s_key[(int)s_head[r] + 1] & a.imask;
+                if (rows_on && UPD != SLK_UPD_GRAD_ONLY) {
+                    const size_t voff = (size_t)item * D + d0;
+                    pv[h] = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
+                    sv[h] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+                }
+                if (PART != SLK_PART_ROWS && UPD != SLK_UPD_GRAD_ONLY) {
+                    pb[h] = a.P[3][item];
+                    sb[h] = a.S1[3][item];
+                }
+            }
+        }
+
+        // (2b) gather: position j = grp + it * GPB
         slk_vec<VEC> c[4];
         float g[4];
 #pragma unroll
@@ -287,7 +376,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_
             c[it] = slk_vzero<VEC>();
             // rows of the run inherited from the previous tile belong to that tile's owner
             const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
-            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, on && PART != SLK_PART_BIAS, c[it], g[it]);
+            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, rows_on, c[it], g[it]);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -296,21 +385,16 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_
                 slk_vstore<VEC>(s_row + j * DL + d0, c[it]);
                 if (lane == 0) {
                     s_g[j] = g[it];
-                    // SNAP: a zero dL/dscore contributes an exact zero row; SEQ/ROW records
-                    // carry a vector that is not a multiple of the bias gradient
                     s_live[j] = (MODE == SLK_ITEM_SNAP) ? (g[it] != 0.0f) : 1;
                 }
             }
         }
         __syncthreads();
 
-        // (3) one group per run that starts in this tile
-        for (int j = grp; j < tn; j += GPB) {
+        // (3) head r -> group r mod GPB
+        auto finish = [&](int j, bool pre, slk_vec<VEC> &p, slk_vec<VEC> &s, float bp, float bs) {
             const uint32_t key = s_key[j + 1];
-            const bool head = (j == 0 && first_tile) || key != s_key[j];
-            if (!head) continue;
             const uint32_t item = key & a.imask;
-            if (item == a.pad_item || item == a.pad_item2) continue;  // padding_idx rows receive no gradient
             slk_vec<VEC> gv = slk_vzero<VEC>();
             float gb = 0.0f;
             bool any = false;
@@ -329,7 +413,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_
                 for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
                     slk_vec<VEC> cc;
                     float gq;
-                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, on && PART != SLK_PART_BIAS, cc, gq);
+                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, rows_on, cc, gq);
                     if (MODE != SLK_ITEM_SNAP || gq != 0.0f) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
@@ -338,15 +422,37 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(8) void k_item_pass(slk_pass_
                     }
                 }
             }
-            // Adagrad with an all-zero gradient is an exact no-op; SparseAdam still decays the
-            // moments of every looked-up row (torch coalesces zero-valued rows too).
-            if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
+            if (UPD != SLK_UPD_SPARSE_ADAM && !any) return;
             const size_t voff = (size_t)item * D + d0;
-            if (on && PART != SLK_PART_BIAS) {
-                slk_vec<VEC> v = slk_vload<VEC>(a.P[1] + voff);
-                slk_apply_vec<VEC, UPD>(a, 1, voff, v, gv);
+            if (rows_on) {
+                if (!pre && UPD != SLK_UPD_GRAD_ONLY) {
+                    p = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
+                    s = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+                }
+                slk_apply_vec_pre<VEC, UPD>(a, 1, voff, p, s, gv, nullptr, nt_rows);
             }
-            if (lane == 0 && PART != SLK_PART_ROWS) slk_apply_bias<UPD>(a, 3, item, gb);
+            if (lane == 0 && PART != SLK_PART_ROWS) {
+                if (UPD == SLK_UPD_ADAGRAD && gb == 0.0f) return;  // exact no-op
+                slk_vec<1> bpv, bsv, gbv;
+                if (pre || UPD == SLK_UPD_GRAD_ONLY) {
+                    bpv.v[0] = bp;
+                    bsv.v[0] = bs;
+                } else {
+                    bpv.v[0] = a.P[3][item];
+                    bsv.v[0] = a.S1[3][item];
+                }
+                gbv.v[0] = gb;
+                slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
+            }
+        };
+#pragma unroll
+        for (int h = 0; h < NPRE; ++h) {
+            const int r = grp + h * GPB;
+            if (r < nheads) finish((int)s_head[r], true, pv[h], sv[h], pb[h], sb[h]);
+        }
+        for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
+            slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
+            finish((int)s_head[r], false, p, s, 0.0f, 0.0f);
         }
     }
 }

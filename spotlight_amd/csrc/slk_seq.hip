@@ -481,6 +481,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             a.loss_kind = loss;
             a.inv_b = 1.0f;  // the sequence pass already divided its partials by mask.sum()
             slk_set_opt_coeffs(a, optim);
+            a.nt = ctx->opt_nt;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s,
                                a);

@@ -297,6 +297,7 @@ static void fill_tables(slk_pass_args &a, slk_ctx *ctx, const slk_tables *local,
     a.NP = 2;
     a.pad_item = a.pad_item2 = 0xffffffffu;
     slk_set_opt_coeffs(a, optim);
+    a.nt = ctx->opt_nt;
 }
 
 SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim,

@@ -466,7 +466,7 @@ BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_defa
 
 
 def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1000, nn=5, user_bloom=0, item_bloom=0,
-                                  chunk=4096, overlap=1, seed=21):
+                                  chunk=4096, overlap=1, seed=21, nt=None):
     """The engine is deterministic (sorted ownership, no atomics), and chunking / the prep pipeline
     only change WHEN value-independent work happens: one big chunk on one stream and many small
     chunks with prep on the second stream must agree bit for bit -- losses, negatives, every table,
@@ -483,6 +483,8 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
     for chunk_i, overlap_i in ((1 << 23, 0), (chunk, overlap)):
         eng.set_option('chunk_interactions', chunk_i)
         eng.set_option('overlap_prep', overlap_i)
+        if nt is not None and chunk_i == chunk:  # the second run also uses another cache policy
+            eng.set_option('nt', nt)
         try:
             dev = be.model(params, opt=opt, lr=0.05, user_bloom=ud, item_bloom=idesc)
             eng.rng_set_state(state)
@@ -498,6 +500,8 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
         finally:
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('overlap_prep', 0)
+            if nt is not None:
+                eng.set_option('nt', 3)
     for k, (a, b) in enumerate(zip(*results)):
         assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined run' % k,
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))

@@ -102,9 +102,12 @@ def test_pipelined_chunks_match_single_chunk(be):
         eng.set_option('item_grid_mult', 64)
         eng.set_option('user_grid_mult', 8)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100)
+    ec.check_chunking_is_bit_neutral(be, 'hinge', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100, overlap=2)
     ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 8, U=40, I=30, N=300, B=32, nn=3, chunk=64,
                                      overlap=0)
     ec.check_chunking_is_bit_neutral(be, 'pointwise', 'adam_dense', 8, U=40, I=50, N=300, B=32, chunk=64,
                                      user_bloom=2, item_bloom=3)
+    # the cache-policy option only changes load/store hints
+    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100, overlap=0, nt=0)
     with pytest.raises(_native.SlkError):
         eng.set_option('no_such_option', 1)

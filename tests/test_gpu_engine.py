@@ -153,10 +153,14 @@ def test_pipelined_chunks_match_oracle(be):
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 0)
-    for overlap in (0, 1):
+    for overlap in (0, 1, 2):
         ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'hinge', 'adam_dense', 16, N=12000, chunk=2048, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'pointwise', 'adagrad', 64, user_bloom=2, item_bloom=4, I=5000,
                                          N=20000, B=512, overlap=overlap)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, U=200000, I=50000, N=600000, B=65536, chunk=131072)
+    # the cache-policy option (non-temporal hints on once-per-pass rows) is bit-neutral
+    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, U=200000, I=50000, N=600000, B=65536, chunk=131072,
+                                     overlap=0, nt=0)
+    ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=0, nt=15)
