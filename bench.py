@@ -76,6 +76,7 @@ def parse():
     ap.add_argument('--seq-len', type=int, default=200)
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
+    ap.add_argument('--slices', type=int, default=0, help='row-sharded path: user-slices per minibatch (0: default)')
     ap.add_argument('--side-stream', type=int, default=1, help='1: run the engine on a dedicated HIP stream')
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
                     help='engine tuning option (slk_ctx_set_option), e.g. item_grid_mult=28')
@@ -228,7 +229,7 @@ def main():
     trainer = None
     if dist is not None:
         from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
-        trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream)
+        trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
     xgmi_rows = [0]
 
     def run(first_mb, n_mb):
@@ -307,7 +308,8 @@ def main():
             rsv = eng.shard_row_floats(D)
             kern_ms = sum(prof[k][1] for k in ('sample', 'prep', 'user_pass', 'item_pass', 'exchange')) / K
             roof['xgmi'] = {'rows_per_step_per_gpu': xgmi_rows[0] / K,
-                            'bytes_per_step_per_gpu_each_way': xgmi_rows[0] / K * (2 * rsv * 4 + 8),
+                            'bytes_per_step_per_gpu_each_way': xgmi_rows[0] / K * (2 * rsv * 4 + 4),
+                            'slices_per_minibatch': trainer.slices,
                             'kernel_ms_per_step': kern_ms,
                             'exchange_and_host_ms_per_step': elapsed / K * 1e3 - kern_ms}
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
@@ -320,8 +322,9 @@ def main():
                                          '' if world == 1 else ' (= %d per GPU; tables and batch grow with N)' % B),
                           'global_batch': B * world,
                           'parallelism': 'single GPU' if trainer is None else
-                          'row-sharded x%d: users and items sharded cyclically, 3 RCCL all-to-all phases per '
-                          'minibatch (ids, rows, gradient rows); no replicas' % world},
+                          'row-sharded x%d: users and items sharded cyclically; RCCL all-to-all of ids per chunk of '
+                          'minibatches, of rows and gradient rows per user-slice of a minibatch (async, overlapping '
+                          'the other slices\' compute); no replicas' % world},
                'roofline': roof,
                'ms_per_step_with_kernel_timers': elapsed_profiled / K * 1e3,
                'final_minibatch_loss': float(losses[-1])}

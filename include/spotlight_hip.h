@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 2
+#define SLK_ABI_VERSION 3
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -195,46 +195,61 @@ int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d
  * boundary is fixed by BASELINE.json's north star).  One process per GPU; user and item
  * tables (+ biases, optimizer state) are row-sharded cyclically: owner(row) = row % world,
  * local row = row / world; `tables` passed below are the LOCAL shards.  A rank processes the
- * interactions of the global minibatch whose user it owns.  The four calls are the compute
- * phases of ONE global minibatch; between them the host runs three all-to-all exchanges
- * (torch.distributed all_to_all_single = RCCL over xGMI):
+ * interactions of every global minibatch whose user it owns.  The host (torch.distributed
+ * all_to_all_single = RCCL over xGMI) runs the exchanges between these calls.
  *
- *   slk_shard_begin      -> d_send_ids[2n] (owner-local item rows, grouped by owner rank in
- *                           ascending rank order), d_send_counts[world] (device, int64)
- *        a2a #1: counts and ids to the owners
- *   slk_shard_gather     owner: d_rows_out[j] = row record of d_ids[j]
- *        a2a #2: row records back to the requesters (same slot order as d_send_ids)
- *   slk_shard_user_pass  forward/loss/backward/user update (factorization/implicit.py:229-243
- *                        restricted to this rank's users); d_grad_out[slot] = gradient record
- *        a2a #3: gradient records to the owners (same split sizes as a2a #1)
- *   slk_shard_item_pass  owner: per unique item row, sum of the received records, then ONE
- *                        optimizer update (duplicates summed before the update, as autograd
- *                        does); advances optim->step.
+ * Per CHUNK of M minibatches, each cut into S slices by user (unit t = minibatch * S + slice):
+ *   slk_shard_chunk_begin  -> d_send_ids[2n] (owner-local item rows, int32, grouped
+ *                             [owner][unit]), d_send_counts[world * M * S] (device, int64,
+ *                             [owner][unit])
+ *        a2a: counts (M*S per peer); the ONE host synchronisation of the chunk; a2a: ids
+ *   slk_shard_chunk_commit    both count matrices (host) + the received ids ([source][unit])
+ * Per unit t (no host synchronisation: every split size is known from the matrices):
+ *   slk_shard_gather       owner: d_rows_out[j] = row record of unit t's j-th request
+ *                          ([source] order)
+ *        a2a: row records back to the requesters
+ *   slk_shard_user_pass    forward/loss/backward/user update (factorization/implicit.py:229-243
+ *                          restricted to this rank's users of unit t); d_grad_out[slot] =
+ *                          gradient record, same slot order as the rows received
+ *        a2a: gradient records to the owners
+ * Per minibatch:
+ *   slk_shard_item_pass    owner: per unique item row, sum of the records received for the S
+ *                          units of the minibatch ([slice][source] order), then ONE optimizer
+ *                          update (duplicates summed before the update, as autograd does);
+ *                          advances optim->step.
  *
  * A record is slk_shard_row_floats(dim) floats: [row or gradient (dim) | bias or bias gradient
  * | pad to 16 B].  pointwise/bpr/hinge only (one negative per interaction). */
 typedef struct slk_shard {
     int32_t world, rank;
     int64_t num_items_global; /* negatives are drawn in [0, num_items_global) (sampling.py:34) */
-    int64_t global_batch;     /* size of the GLOBAL minibatch: losses are means over it */
+    int64_t global_batch;     /* unused since ABI 3 (passed per minibatch to slk_shard_user_pass) */
 } slk_shard;
 
 int slk_shard_row_floats(int32_t dim);
-/* d_users_local: LOCAL user rows (user / world) of this rank's n interactions; d_items: GLOBAL
- * item ids; negatives: sampled from the ctx RNG over the global item range, or d_neg_in[n]. */
-int slk_shard_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
-                    const int64_t *d_users_local, const int64_t *d_items, int64_t n,
-                    const int64_t *d_neg_in, int64_t *d_neg_out, int64_t *d_send_ids,
-                    int64_t *d_send_counts, void *stream);
-int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, const int64_t *d_ids, int64_t n_ids,
-                     float *d_rows_out, void *stream);
-/* d_loss_out[0] = (sum of this rank's per-interaction losses) / global_batch; the minibatch's
- * loss.item() is the sum of d_loss_out over ranks. */
+/* d_users_local: LOCAL user rows (user / world) of this rank's n interactions of the chunk;
+ * d_items: GLOBAL item ids; h_mb_off[M + 1] (host): minibatch boundaries inside [0, n];
+ * negatives: sampled from the ctx RNG over the global item range (one contiguous draw for the
+ * chunk), or d_neg_in[n]. */
+int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                          const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                          const int64_t *h_mb_off, int32_t n_minibatches, int32_t n_slices,
+                          const int64_t *d_neg_in, int64_t *d_neg_out, int32_t *d_send_ids,
+                          int64_t *d_send_counts, void *stream);
+/* h_send_counts / h_recv_counts: [world][M * S] (host): lookups this rank sends to / receives
+ * from each peer per unit; d_recv_ids: the ids received, grouped [source][unit]. */
+int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                           const int64_t *h_send_counts, const int64_t *h_recv_counts,
+                           const int32_t *d_recv_ids, void *stream);
+int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, int32_t unit, float *d_rows_out, void *stream);
+/* d_loss_out[0] (+)= (sum of this rank's per-interaction losses of the unit) / global_batch;
+ * a minibatch's loss.item() is the sum over its slices and over the ranks. */
 int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim,
-                        const slk_shard *sh, int64_t n, int32_t loss, const float *d_rows_in,
-                        float *d_grad_out, float *d_loss_out, void *stream);
-int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, const int64_t *d_ids,
-                        const float *d_grad_in, int64_t n_ids, void *stream);
+                        const slk_shard *sh, int32_t unit, int64_t global_batch, int32_t loss,
+                        const float *d_rows_in, float *d_grad_out, float *d_loss_out, int32_t accumulate,
+                        void *stream);
+int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, int32_t minibatch,
+                        const float *d_grad_in, void *stream);
 
 /* Measurement support (the reference has none; examples/bloom_embeddings/performance.py
  * times fit() with time.time()): when enabled, every launch of the engine's kernels is

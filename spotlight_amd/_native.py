@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 2
+SLK_ABI_VERSION = 3
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
@@ -67,14 +67,17 @@ _PROTOTYPES = {
     'slk_poolnet_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shard_row_floats': (C.c_int, [C.c_int32]),
-    'slk_shard_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
-                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'slk_shard_gather': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
-                                   C.c_void_p]),
+    'slk_shard_chunk_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_shard_chunk_commit': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    'slk_shard_gather': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_int32, C.c_void_p, C.c_void_p]),
     'slk_shard_user_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.POINTER(SlkShard),
-                                      C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'slk_shard_item_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
-                                      C.c_void_p, C.c_int64, C.c_void_p]),
+                                      C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_void_p]),
+    'slk_shard_item_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int32, C.c_void_p,
+                                      C.c_void_p]),
     'slk_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'slk_profile_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'slk_profile_reset': (C.c_int, [C.c_void_p]),
@@ -198,22 +201,34 @@ class Engine(object):
     def shard_row_floats(self, dim):
         return int(self._lib.slk_shard_row_floats(int(dim)))
 
-    def shard_begin(self, tables, shard, d_users_local, d_items, n, d_send_ids, d_send_counts,
-                    d_neg_in=None, d_neg_out=None, stream=0):
-        self._check(self._lib.slk_shard_begin(self._ctx, C.byref(tables), C.byref(shard), d_users_local, d_items,
-                                              int(n), d_neg_in, d_neg_out, d_send_ids, d_send_counts, stream))
+    def shard_chunk_begin(self, tables, shard, d_users_local, d_items, n, mb_off, n_slices, d_send_ids,
+                          d_send_counts, d_neg_in=None, d_neg_out=None, stream=0):
+        m = len(mb_off) - 1
+        off = (C.c_int64 * (m + 1))(*[int(x) for x in mb_off])
+        self._check(self._lib.slk_shard_chunk_begin(self._ctx, C.byref(tables), C.byref(shard), d_users_local, d_items,
+                                                    int(n), off, m, int(n_slices), d_neg_in, d_neg_out, d_send_ids,
+                                                    d_send_counts, stream))
 
-    def shard_gather(self, tables, d_ids, n_ids, d_rows_out, stream=0):
-        self._check(self._lib.slk_shard_gather(self._ctx, C.byref(tables), d_ids, int(n_ids), d_rows_out, stream))
+    def shard_chunk_commit(self, tables, shard, send_counts, recv_counts, d_recv_ids, stream=0):
+        """send_counts / recv_counts: flat host sequences [world][units]."""
+        sc = (C.c_int64 * len(send_counts))(*send_counts)
+        rc = (C.c_int64 * len(recv_counts))(*recv_counts)
+        self._check(self._lib.slk_shard_chunk_commit(self._ctx, C.byref(tables), C.byref(shard), sc, rc, d_recv_ids,
+                                                     stream))
 
-    def shard_user_pass(self, tables, optim, shard, n, loss, d_rows_in, d_grad_out, d_loss_out, stream=0):
+    def shard_gather(self, tables, unit, d_rows_out, stream=0):
+        self._check(self._lib.slk_shard_gather(self._ctx, C.byref(tables), int(unit), d_rows_out, stream))
+
+    def shard_user_pass(self, tables, optim, shard, unit, global_batch, loss, d_rows_in, d_grad_out, d_loss_out,
+                        accumulate=False, stream=0):
         self._check(self._lib.slk_shard_user_pass(
-            self._ctx, C.byref(tables), C.byref(optim), C.byref(shard), int(n),
-            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_rows_in, d_grad_out, d_loss_out, stream))
+            self._ctx, C.byref(tables), C.byref(optim), C.byref(shard), int(unit), int(global_batch),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_rows_in, d_grad_out, d_loss_out,
+            1 if accumulate else 0, stream))
 
-    def shard_item_pass(self, tables, optim, d_ids, d_grad_in, n_ids, stream=0):
-        self._check(self._lib.slk_shard_item_pass(self._ctx, C.byref(tables), C.byref(optim), d_ids, d_grad_in,
-                                                  int(n_ids), stream))
+    def shard_item_pass(self, tables, optim, minibatch, d_grad_in, stream=0):
+        self._check(self._lib.slk_shard_item_pass(self._ctx, C.byref(tables), C.byref(optim), int(minibatch),
+                                                  d_grad_in, stream))
 
     # -- measurement -------------------------------------------------------------------
     def profile_enable(self, on=True):
@@ -268,7 +283,7 @@ def make_seq_tables(item_emb_ptr, item_bias_ptr, num_items, dim):
     return t
 
 
-def make_shard(world, rank, num_items_global, global_batch):
+def make_shard(world, rank, num_items_global, global_batch=0):
     sh = SlkShard()
     sh.world, sh.rank = int(world), int(rank)
     sh.num_items_global, sh.global_batch = int(num_items_global), int(global_batch)

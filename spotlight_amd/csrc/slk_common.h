@@ -72,7 +72,13 @@ struct slk_ctx {
     hipStream_t prep_stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)
-    int64_t shard_n = 0;            // local interactions staged by the last slk_shard_begin
+    // row-sharded path (slk_shard.hip): geometry of the chunk staged by slk_shard_chunk_begin/commit
+    int64_t shard_n = -1;           // interactions of the committed chunk (-1: none)
+    int64_t sh_n = 0;
+    int sh_M = 0, sh_S = 0, sh_world = 0;
+    unsigned sh_ubits = 0;
+    std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
+    std::vector<uint64_t> sh_host, sh_host2;     // host staging for small H2D tables (begin / commit)
 
     // profiling
     bool prof_on = false;

@@ -1,90 +1,149 @@
-// slk_shard.hip -- row-sharded BilinearNet training step for G = world GPUs.
+// slk_shard.hip -- row-sharded BilinearNet training for G = world GPUs.
 //
 // The reference has no multi-GPU code; the north star fixes the design: user and item tables
 // (with their biases and optimizer state) are row-sharded cyclically (owner(row) = row mod G,
 // local row = row div G), every rank processes the interactions of the global minibatch whose
-// USER it owns (so user rows are always local), and item rows move over xGMI in three RCCL
-// all-to-all phases per minibatch, issued by the host between the calls below:
+// USER it owns (so user rows are always local), and item rows move over xGMI in RCCL
+// all-to-all exchanges issued by the host (torch.distributed) between the calls below.
 //
-//   slk_shard_begin      negatives; sort the local interactions by user; bucket the 2n item
-//                        lookups by owner -> send_ids (owner-local rows, grouped by owner),
-//                        send_counts                                  [a2a #1: ids -> owners]
-//   slk_shard_gather     owner side: requested rows (+ bias) -> row records
-//                                                               [a2a #2: rows -> requesters]
-//   slk_shard_user_pass  USER PASS of slk_bilinear.hip reading item rows from the received
-//                        records; writes one gradient record g * u_old (+ g) per lookup,
-//                        updates the local user rows in place      [a2a #3: grads -> owners]
-//   slk_shard_item_pass  owner side: sort the received lookups by item, ITEM PASS (ROW mode):
-//                        one owner group per unique row sums the records and applies the
-//                        optimizer -- duplicate semantics stay exact (sum, then one update).
+// Everything that depends only on IDS is done once per CHUNK of M minibatches, so that the
+// minibatch loop needs no host synchronisation (the split sizes of every exchange of the chunk
+// are known after one count exchange):
 //
+//   slk_shard_chunk_begin   negatives; sort the chunk's local interactions by (unit, user), a
+//                           unit being one of the S user-slices of one minibatch; bucket the 2n
+//                           item lookups by (owner, unit) -> send_ids (owner-local rows),
+//                           send_counts[owner][unit]
+//        [a2a: counts; ONE host sync; a2a: ids to the owners]
+//   slk_shard_chunk_commit  both count matrices come back from the host; owner side: received
+//                           ids regrouped by (unit, source) and sorted by (minibatch, row)
+//   per unit t:
+//     slk_shard_gather      owner: row records of unit t's requests   [a2a: rows -> requesters]
+//     slk_shard_user_pass   USER PASS of slk_bilinear.hip over unit t reading item rows from the
+//                           received records; one gradient record g * u_old (+ g) per lookup;
+//                           local user rows updated in place            [a2a: grads -> owners]
+//   per minibatch:
+//     slk_shard_item_pass   owner: ITEM PASS (ROW mode) over the records of the minibatch's S
+//                           units: one owner group per unique row sums them and applies the
+//                           optimizer -- duplicate semantics stay exact (sum, then one update).
+//
+// Slices exist so that the exchanges of one unit overlap the compute of another (xGMI and HBM
+// work in parallel); users of different slices are disjoint, so their in-place updates commute.
 // Every forward still reads pre-step parameters and every row still gets the sum of its
 // contributions before one optimizer update, exactly as on one GPU; only the summation order
-// of an item row's contributions differs (by source rank).
+// of an item row's contributions differs (by slice and source rank).
 #include <math.h>
 
 #include "slk_kernels.h"
 
 #define SLK_MAX_WORLD 64
+#define SLK_SHARD_MAX_BINS 2048  // world * units per chunk
 
 // scratch slots in ctx->extra
-enum { SH_OKEY0 = 0, SH_OKEY1, SH_OVAL0, SH_OVAL1, SH_VSLOT, SH_HIST };
+enum { SH_OKEY0 = 0, SH_OKEY1, SH_OVAL0, SH_OVAL1, SH_VSLOT, SH_HIST, SH_SEGSTART, SH_UNITBASE, SH_MBOFF, SH_RID,
+       SH_SEGTAB };
 
 static inline int shard_rsv(int D) { return ((D + 1 + 3) / 4) * 4; }
 
 SLK_EXPORT int slk_shard_row_floats(int32_t dim) { return shard_rsv(dim); }
 
-// key = user (one minibatch); value = (neg << 32) | pos so the sorted values are the item pairs
+// key = (unit << ubits) | user with unit = minibatch * S + user % S; value = (neg << 32) | pos so
+// the sorted values are the item pairs.  mb_off[0..M]: minibatch boundaries in the chunk.
 __global__ __launch_bounds__(256) void k_shard_user_keys(const int64_t *users, const int64_t *items,
-                                                         const uint32_t *neg32, uint32_t n, uint32_t *key,
-                                                         uint64_t *val) {
+                                                         const uint32_t *neg32, uint32_t n,
+                                                         const uint32_t *mb_off, uint32_t M, uint32_t S,
+                                                         unsigned ubits, uint32_t *key, uint64_t *val) {
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-        key[k] = (uint32_t)users[k];
+        uint32_t lo = 0, hi = M;  // largest mb with mb_off[mb] <= k
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (mb_off[mid] <= k) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t u = (uint32_t)users[k];
+        key[k] = ((lo * S + u % S) << ubits) | u;
         val[k] = ((uint64_t)neg32[k] << 32) | (uint64_t)(uint32_t)items[k];
     }
 }
 
-// lookup l = 2*q + s (sorted position q, pair s): key = owner of the item, value = l
-__global__ __launch_bounds__(256) void k_shard_owner_keys(const uint32_t *uit, uint32_t nl, uint32_t world,
-                                                          uint32_t *okey, uint32_t *oval,
-                                                          unsigned long long *hist) {
-    __shared__ unsigned h[SLK_MAX_WORLD];
-    if (threadIdx.x < SLK_MAX_WORLD) h[threadIdx.x] = 0;
+// lookup l = 2*q + s (sorted position q, pair s): key = owner * T + unit, value = l
+__global__ __launch_bounds__(256) void k_shard_owner_keys(const uint32_t *uit, const uint32_t *ukey, unsigned ubits,
+                                                          uint32_t nl, uint32_t world, uint32_t T, uint32_t *okey,
+                                                          uint32_t *oval, unsigned long long *hist) {
+    __shared__ unsigned h[SLK_SHARD_MAX_BINS];
+    const uint32_t bins = world * T;
+    for (uint32_t i = threadIdx.x; i < bins; i += 256) h[i] = 0;
     __syncthreads();
     for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < nl; l += gridDim.x * 256) {
-        const uint32_t o = uit[l] % world;
-        okey[l] = o;
+        const uint32_t b = (uit[l] % world) * T + (ukey[l >> 1] >> ubits);
+        okey[l] = b;
         oval[l] = l;
-        atomicAdd(&h[o], 1u);
+        atomicAdd(&h[b], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < world && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+    for (uint32_t i = threadIdx.x; i < bins; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ __launch_bounds__(256) void k_shard_slots(const uint32_t *uit, const uint32_t *oval_sorted, uint32_t nl,
-                                                     uint32_t world, int64_t *send_ids, uint32_t *vslot) {
+// one block: seg_start = exclusive scan of the (owner, unit) counts in sorted order;
+// unit_base[o][t] = lookups of unit t owned by ranks < o (slot offset inside unit t's buffers)
+__global__ __launch_bounds__(256) void k_shard_scan(const unsigned long long *hist, uint32_t world, uint32_t T,
+                                                    uint32_t *seg_start, uint32_t *unit_base, int64_t *counts_out) {
+    const uint32_t bins = world * T;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < bins; ++b) {
+            seg_start[b] = run;
+            run += (uint32_t)hist[b];
+        }
+    }
+    for (uint32_t t = threadIdx.x; t < T; t += 256) {
+        uint32_t run = 0;
+        for (uint32_t o = 0; o < world; ++o) {
+            unit_base[o * T + t] = run;
+            run += (uint32_t)hist[o * T + t];
+        }
+    }
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) counts_out[b] = (int64_t)hist[b];
+}
+
+__global__ __launch_bounds__(256) void k_shard_slots(const uint32_t *uit, const uint32_t *okey_sorted,
+                                                     const uint32_t *oval_sorted, uint32_t nl, uint32_t world,
+                                                     const uint32_t *seg_start, const uint32_t *unit_base,
+                                                     int32_t *send_ids, uint32_t *vslot) {
     for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nl; j += gridDim.x * 256) {
-        const uint32_t l = oval_sorted[j];
-        send_ids[j] = (int64_t)(uit[l] / world);
-        vslot[l] = j;
+        const uint32_t l = oval_sorted[j], b = okey_sorted[j];
+        send_ids[j] = (int32_t)(uit[l] / world);
+        vslot[l] = unit_base[b] + (j - seg_start[b]);
     }
 }
 
-__global__ void k_shard_counts(const unsigned long long *hist, uint32_t world, int64_t *out) {
-    if (threadIdx.x < world) out[threadIdx.x] = (int64_t)hist[threadIdx.x];
+// owner side: one block per received segment (source, unit): ids move from [source][unit] order
+// to [unit][source] order, with the item-pass key (minibatch, row) and payload (slot inside the
+// minibatch's record buffer).  segtab[seg] = {from, to, len, minibatch, first slot of the minibatch}
+__global__ __launch_bounds__(256) void k_shard_regroup(const int32_t *recv_ids, const uint32_t *segtab, unsigned ibits,
+                                                       int32_t *rid, uint32_t *ikey, uint32_t *ipay) {
+    const uint32_t *sg = segtab + 5 * (size_t)blockIdx.x;
+    const uint32_t from = sg[0], to = sg[1], len = sg[2], mb = sg[3], mb_first = sg[4];
+    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+        const int32_t id = recv_ids[from + i];
+        rid[to + i] = id;
+        ikey[to + i] = (mb << ibits) | (uint32_t)id;
+        ipay[to + i] = to + i - mb_first;
+    }
 }
 
 // owner side: record(j) = [V[id_j] (D) | bias[id_j] | pad]
 template <int VEC, int G>
 __global__ __launch_bounds__(256) void k_shard_gather(const float *V, const float *bi, int D, int RSV,
-                                                      const int64_t *ids, int64_t n, float *out) {
+                                                      const int32_t *ids, int64_t n, float *out) {
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const int d0 = lane * VEC;
     const bool on = d0 < D;
     for (int64_t j = (int64_t)blockIdx.x * GPB + grp; j < n; j += (int64_t)gridDim.x * GPB) {
-        const int64_t i = ids[j];
+        const int64_t i = (int64_t)ids[j];
         float *rec = out + (size_t)j * RSV;
         if (on) slk_vstore<VEC>(rec + d0, slk_vload<VEC>(V + (size_t)i * D + d0));
         if (lane == 0) rec[D] = bi[i];
@@ -109,7 +168,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
-        slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
+        slk_vec<VEC> u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (a.nt & 1) != 0) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
@@ -141,7 +200,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
             }
             ++q;
         } while (q < a.end && a.ukey[q] == key);
-        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu);
+        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
         if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
     }
     const double tot = slk_block_sum_256((double)loss_acc, red);
@@ -149,20 +208,13 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
 }
 
 // this rank's share of the minibatch loss: (sum of its per-interaction losses) / global batch
-__global__ __launch_bounds__(256) void k_shard_loss(const double *partial, int n, float inv_b, float *out) {
+__global__ __launch_bounds__(256) void k_shard_loss(const double *partial, int n, float inv_b, float *out,
+                                                     int accumulate) {
     __shared__ double red[256];
     double x = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) x += partial[i];
     const double tot = slk_block_sum_256(x, red);
-    if (threadIdx.x == 0) *out = (float)(tot * (double)inv_b);
-}
-
-__global__ __launch_bounds__(256) void k_shard_item_keys(const int64_t *ids, uint32_t n, uint32_t *key,
-                                                         uint32_t *val) {
-    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-        key[j] = (uint32_t)ids[j];
-        val[j] = j;
-    }
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0f) + (float)(tot * (double)inv_b);
 }
 
 static int check_plain(slk_ctx *ctx, const slk_tables *t) {
@@ -178,30 +230,53 @@ static int check_shard(slk_ctx *ctx, const slk_shard *sh) {
                         sh->rank, SLK_MAX_WORLD);
     if (sh->num_items_global < 1 || sh->num_items_global > ((int64_t)1 << 32))
         return slk_fail(ctx, SLK_EINVAL, "num_items_global %lld outside [1, 2^32]", (long long)sh->num_items_global);
-    if (sh->global_batch < 1) return slk_fail(ctx, SLK_EINVAL, "global_batch must be >= 1");
     return SLK_OK;
 }
 
-SLK_EXPORT int slk_shard_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
-                               const int64_t *d_users_local, const int64_t *d_items, int64_t n,
-                               const int64_t *d_neg_in, int64_t *d_neg_out, int64_t *d_send_ids,
-                               int64_t *d_send_counts, void *stream) {
+
+static int check_chunk(slk_ctx *ctx, const slk_shard *sh, int32_t M, int32_t S) {
+    if (M < 1 || S < 1 || (int64_t)M * S * sh->world > SLK_SHARD_MAX_BINS)
+        return slk_fail(ctx, SLK_EINVAL, "shard chunk: minibatches %d x slices %d x world %d must be in [1, %d]", M, S,
+                        sh->world, SLK_SHARD_MAX_BINS);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                     const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                                     const int64_t *h_mb_off, int32_t M, int32_t S, const int64_t *d_neg_in,
+                                     int64_t *d_neg_out, int32_t *d_send_ids, int64_t *d_send_counts,
+                                     void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
-    if (n < 0 || n >= ((int64_t)1 << 30)) return slk_fail(ctx, SLK_EINVAL, "slk_shard_begin: n %lld outside [0, 2^30)", (long long)n);
-    if (!d_send_counts || (n > 0 && (!d_users_local || !d_items || !d_send_ids)))
-        return slk_fail(ctx, SLK_EINVAL, "slk_shard_begin: NULL pointer");
+    if ((rc = check_chunk(ctx, sh, M, S))) return rc;
+    if (n < 0 || n >= ((int64_t)1 << 30)) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin: n %lld outside [0, 2^30)", (long long)n);
+    if (!d_send_counts || !h_mb_off || (n > 0 && (!d_users_local || !d_items || !d_send_ids)))
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin: NULL pointer");
+    if (h_mb_off[0] != 0 || h_mb_off[M] != n) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin: minibatch offsets must span [0, n]");
+    for (int m = 0; m < M; ++m)
+        if (h_mb_off[m + 1] < h_mb_off[m]) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin: minibatch offsets must ascend");
+    const unsigned ubits = slk_bits_for((uint64_t)local->num_users - 1);
+    const uint32_t T = (uint32_t)M * (uint32_t)S, world = (uint32_t)sh->world, bins = world * T;
+    if (ubits + slk_bits_for((uint64_t)T - 1) > 32)
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin: %u units do not fit beside %u user-id bits in a 32-bit key (use fewer minibatches per chunk)", T, ubits);
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
-    const uint32_t world = (uint32_t)sh->world;
-    if ((rc = slk_ensure(ctx, ctx->extra[SH_HIST], SLK_MAX_WORLD * 8))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_HIST], (size_t)SLK_SHARD_MAX_BINS * 8))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGSTART], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_UNITBASE], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_MBOFF], (size_t)(SLK_SHARD_MAX_BINS + 1) * 4))) return rc;
     unsigned long long *hist = (unsigned long long *)ctx->extra[SH_HIST].p;
-    SLK_HIP(ctx, hipMemsetAsync(hist, 0, SLK_MAX_WORLD * 8, s));
-    ctx->shard_n = 0;
+    SLK_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)bins * 8, s));
+    ctx->shard_n = -1;  // no committed chunk
+    ctx->sh_M = M;
+    ctx->sh_S = S;
+    ctx->sh_world = (int)world;
+    ctx->sh_ubits = ubits;
+    ctx->sh_n = n;
     if (n > 0) {
         const uint32_t nn = (uint32_t)n, nl = 2 * nn;
         if ((rc = slk_ensure(ctx, ctx->neg32, (size_t)nn * 4))) return rc;
@@ -223,50 +298,146 @@ SLK_EXPORT int slk_shard_begin(slk_ctx *ctx, const slk_tables *local, const slk_
         } else {
             if ((rc = slk_sample_u32(ctx, sh->num_items_global, n, neg32, d_neg_out, s))) return rc;
         }
-        // ---- sort by user; bucket the lookups by owner
+        // ---- sort by (unit, user); bucket the lookups by (owner, unit)
         slk_prof_begin(ctx, SLK_K_PREP, s);
-        const unsigned ubits = slk_bits_for((uint64_t)local->num_users - 1);
+        ctx->sh_host.resize((size_t)(M + 1) / 2 + 1);
+        uint32_t *h32 = (uint32_t *)ctx->sh_host.data();
+        for (int m = 0; m <= M; ++m) h32[m] = (uint32_t)h_mb_off[m];
+        SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_MBOFF].p, h32, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_shard_user_keys, dim3(slk_grid_for(ctx, nn, 256)), dim3(256), 0, s, d_users_local,
-                           d_items, (const uint32_t *)neg32, nn, (uint32_t *)ctx->ukey[0].p,
-                           (uint64_t *)ctx->uval[0].p);
+                           d_items, (const uint32_t *)neg32, nn, (const uint32_t *)ctx->extra[SH_MBOFF].p,
+                           (uint32_t)M, (uint32_t)S, ubits, (uint32_t *)ctx->ukey[0].p, (uint64_t *)ctx->uval[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_shard_user_keys");
         if ((rc = slk_sort_pairs_u32_u64(ctx, (const uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->ukey[1].p,
-                                         (const uint64_t *)ctx->uval[0].p, (uint64_t *)ctx->uval[1].p, nn, ubits,
-                                         s)))
+                                         (const uint64_t *)ctx->uval[0].p, (uint64_t *)ctx->uval[1].p, nn,
+                                         ubits + slk_bits_for((uint64_t)T - 1), s)))
             return rc;
         const uint32_t *uit = (const uint32_t *)ctx->uval[1].p;
-        hipLaunchKernelGGL(k_shard_owner_keys, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s, uit, nl, world,
-                           (uint32_t *)ctx->extra[SH_OKEY0].p, (uint32_t *)ctx->extra[SH_OVAL0].p, hist);
+        hipLaunchKernelGGL(k_shard_owner_keys, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s, uit,
+                           (const uint32_t *)ctx->ukey[1].p, ubits, nl, world, T, (uint32_t *)ctx->extra[SH_OKEY0].p,
+                           (uint32_t *)ctx->extra[SH_OVAL0].p, hist);
         SLK_LAUNCH_CHECK(ctx, "k_shard_owner_keys");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[SH_OKEY0].p,
                                          (uint32_t *)ctx->extra[SH_OKEY1].p,
                                          (const uint32_t *)ctx->extra[SH_OVAL0].p,
-                                         (uint32_t *)ctx->extra[SH_OVAL1].p, nl, slk_bits_for(world - 1), s)))
+                                         (uint32_t *)ctx->extra[SH_OVAL1].p, nl, slk_bits_for((uint64_t)bins - 1), s)))
             return rc;
-        hipLaunchKernelGGL(k_shard_slots, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s, uit,
-                           (const uint32_t *)ctx->extra[SH_OVAL1].p, nl, world, d_send_ids,
-                           (uint32_t *)ctx->extra[SH_VSLOT].p);
-        SLK_LAUNCH_CHECK(ctx, "k_shard_slots");
         slk_prof_end(ctx, s);
-        ctx->shard_n = n;
     }
-    hipLaunchKernelGGL(k_shard_counts, dim3(1), dim3(SLK_MAX_WORLD), 0, s, (const unsigned long long *)hist, world,
-                       d_send_counts);
-    SLK_LAUNCH_CHECK(ctx, "k_shard_counts");
+    slk_prof_begin(ctx, SLK_K_PREP, s);
+    hipLaunchKernelGGL(k_shard_scan, dim3(1), dim3(256), 0, s, (const unsigned long long *)hist, world, T,
+                       (uint32_t *)ctx->extra[SH_SEGSTART].p, (uint32_t *)ctx->extra[SH_UNITBASE].p, d_send_counts);
+    SLK_LAUNCH_CHECK(ctx, "k_shard_scan");
+    if (n > 0) {
+        const uint32_t nl = 2 * (uint32_t)n;
+        hipLaunchKernelGGL(k_shard_slots, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s,
+                           (const uint32_t *)ctx->uval[1].p, (const uint32_t *)ctx->extra[SH_OKEY1].p,
+                           (const uint32_t *)ctx->extra[SH_OVAL1].p, nl, world,
+                           (const uint32_t *)ctx->extra[SH_SEGSTART].p, (const uint32_t *)ctx->extra[SH_UNITBASE].p,
+                           d_send_ids, (uint32_t *)ctx->extra[SH_VSLOT].p);
+        SLK_LAUNCH_CHECK(ctx, "k_shard_slots");
+    }
+    slk_prof_end(ctx, s);
     return SLK_OK;
 }
 
-SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, const int64_t *d_ids, int64_t n_ids,
-                                float *d_rows_out, void *stream) {
+SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                      const int64_t *h_send_counts, const int64_t *h_recv_counts,
+                                      const int32_t *d_recv_ids, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_shard(ctx, sh))) return rc;
+    if (ctx->sh_M < 1 || ctx->sh_world != sh->world) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: no chunk begun for this world size");
+    if (!h_send_counts || !h_recv_counts) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: NULL count matrix");
+    const int M = ctx->sh_M, S = ctx->sh_S, W = ctx->sh_world, T = M * S;
+    // ---- unit windows: user-sorted positions (requester) and received-lookup positions (owner)
+    ctx->sh_ustart.assign((size_t)T + 1, 0);
+    ctx->sh_rstart.assign((size_t)T + 1, 0);
+    for (int t = 0; t < T; ++t) {
+        int64_t sent = 0, recv = 0;
+        for (int r = 0; r < W; ++r) {
+            if (h_send_counts[(size_t)r * T + t] < 0 || h_recv_counts[(size_t)r * T + t] < 0)
+                return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: negative count");
+            sent += h_send_counts[(size_t)r * T + t];
+            recv += h_recv_counts[(size_t)r * T + t];
+        }
+        if (sent & 1) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: unit %d sends an odd number of lookups", t);
+        ctx->sh_ustart[t + 1] = ctx->sh_ustart[t] + sent / 2;
+        ctx->sh_rstart[t + 1] = ctx->sh_rstart[t] + recv;
+    }
+    if (ctx->sh_ustart[T] != ctx->sh_n)
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: send counts cover %lld interactions, chunk has %lld",
+                        (long long)ctx->sh_ustart[T], (long long)ctx->sh_n);
+    const int64_t nr = ctx->sh_rstart[T];
+    if (nr >= ((int64_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: %lld received lookups >= 2^31", (long long)nr);
+    if (nr > 0 && !d_recv_ids) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: d_recv_ids is NULL");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    if (nr > 0) {
+        const unsigned ibits = slk_bits_for((uint64_t)local->num_items - 1);
+        if (ibits + slk_bits_for((uint64_t)M - 1) > 32)
+            return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: %d minibatches do not fit beside %u item-row bits in a 32-bit key", M, ibits);
+        for (int b = 0; b < 2; ++b) {
+            if ((rc = slk_ensure(ctx, ctx->ikey[b], (size_t)nr * 4))) return rc;
+            if ((rc = slk_ensure(ctx, ctx->ipay[b], (size_t)nr * 4))) return rc;
+        }
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_RID], (size_t)nr * 4))) return rc;
+        const int nseg = W * T;
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGTAB], (size_t)nseg * 5 * 4))) return rc;
+        // received buffer order: [source][unit]; regrouped order: [unit][source]
+        ctx->sh_host2.resize(((size_t)nseg * 5 + 1) / 2 + 1);
+        uint32_t *tab = (uint32_t *)ctx->sh_host2.data();
+        int64_t from = 0;
+        for (int r = 0; r < W; ++r)
+            for (int t = 0; t < T; ++t) {
+                int64_t to = ctx->sh_rstart[t];
+                for (int r2 = 0; r2 < r; ++r2) to += h_recv_counts[(size_t)r2 * T + t];
+                uint32_t *sg = tab + 5 * ((size_t)r * T + t);
+                sg[0] = (uint32_t)from;
+                sg[1] = (uint32_t)to;
+                sg[2] = (uint32_t)h_recv_counts[(size_t)r * T + t];
+                sg[3] = (uint32_t)(t / S);
+                sg[4] = (uint32_t)ctx->sh_rstart[(size_t)(t / S) * S];
+                from += h_recv_counts[(size_t)r * T + t];
+            }
+        slk_prof_begin(ctx, SLK_K_PREP, s);
+        SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_SEGTAB].p, tab, (size_t)nseg * 5 * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_shard_regroup, dim3((unsigned)nseg), dim3(256), 0, s, d_recv_ids,
+                           (const uint32_t *)ctx->extra[SH_SEGTAB].p, ibits, (int32_t *)ctx->extra[SH_RID].p,
+                           (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+        SLK_LAUNCH_CHECK(ctx, "k_shard_regroup");
+        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
+                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, (size_t)nr,
+                                         ibits + slk_bits_for((uint64_t)M - 1), s)))
+            return rc;
+        slk_prof_end(ctx, s);
+    }
+    ctx->shard_n = ctx->sh_n;  // committed
+    return SLK_OK;
+}
+
+static int check_unit(slk_ctx *ctx, int32_t unit, const char *who) {
+    if (ctx->shard_n < 0 || ctx->sh_M < 1) return slk_fail(ctx, SLK_EINVAL, "%s: no committed chunk", who);
+    if (unit < 0 || unit >= ctx->sh_M * ctx->sh_S) return slk_fail(ctx, SLK_EINVAL, "%s: unit %d outside [0, %d)", who, unit, ctx->sh_M * ctx->sh_S);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, int32_t unit, float *d_rows_out,
+                                void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
-    if (n_ids < 0 || (n_ids > 0 && (!d_ids || !d_rows_out))) return slk_fail(ctx, SLK_EINVAL, "slk_shard_gather: bad arguments");
+    if ((rc = check_unit(ctx, unit, "slk_shard_gather"))) return rc;
+    const int64_t r0 = ctx->sh_rstart[unit], n_ids = ctx->sh_rstart[unit + 1] - r0;
     if (n_ids == 0) return SLK_OK;
+    if (!d_rows_out) return slk_fail(ctx, SLK_EINVAL, "slk_shard_gather: d_rows_out is NULL");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
+    const int32_t *d_ids = (const int32_t *)ctx->extra[SH_RID].p + r0;
     slk_prof_begin(ctx, SLK_K_EXCHANGE, s);
 #define SLK_GATHER(V_, G_)                                                                                  \
     hipLaunchKernelGGL((k_shard_gather<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n_ids, 256 / G_)), dim3(256), 0, s, \
@@ -301,17 +472,20 @@ static void fill_tables(slk_pass_args &a, slk_ctx *ctx, const slk_tables *local,
 }
 
 SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim,
-                                   const slk_shard *sh, int64_t n, int32_t loss, const float *d_rows_in,
-                                   float *d_grad_out, float *d_loss_out, void *stream) {
+                                   const slk_shard *sh, int32_t unit, int64_t global_batch, int32_t loss,
+                                   const float *d_rows_in, float *d_grad_out, float *d_loss_out, int32_t accumulate,
+                                   void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
+    if ((rc = check_unit(ctx, unit, "slk_shard_user_pass"))) return rc;
     if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_HINGE)
         return slk_fail(ctx, SLK_EINVAL, "row-sharded path supports pointwise/bpr/hinge (loss kind %d)", loss);
-    if (n != ctx->shard_n) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: n %lld does not match slk_shard_begin (%lld)", (long long)n, (long long)ctx->shard_n);
+    if (global_batch < 1) return slk_fail(ctx, SLK_EINVAL, "global_batch must be >= 1");
+    const int64_t p0 = ctx->sh_ustart[unit], n = ctx->sh_ustart[unit + 1] - p0;
     if (!d_loss_out || (n > 0 && (!d_rows_in || !d_grad_out))) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: NULL pointer");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
@@ -327,17 +501,17 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     slk_pass_args a;
     memset(&a, 0, sizeof(a));
     fill_tables(a, ctx, local, optim, dense);
-    a.begin = 0;
-    a.end = (uint32_t)n;
+    a.begin = (uint32_t)p0;
+    a.end = (uint32_t)(p0 + n);
     a.ukey = (const uint32_t *)ctx->ukey[1].p;
-    a.umask = 0xffffffffu;
+    a.umask = (uint32_t)((1ull << ctx->sh_ubits) - 1);
     a.vslot = (const uint32_t *)ctx->extra[SH_VSLOT].p;
     a.vrows = d_rows_in;
     a.grows = d_grad_out;
     a.RSV = shard_rsv(local->dim);
     a.loss_partial = (double *)ctx->losspart.p;
     a.loss_kind = loss;
-    a.inv_b = 1.0f / (float)sh->global_batch;
+    a.inv_b = 1.0f / (float)global_batch;
     const unsigned gpb = 256u / (unsigned)g;
     const unsigned ugrid = n > 0 ? slk_grid_for(ctx, (size_t)n, gpb) : 0;
     if (n > 0) {
@@ -352,20 +526,23 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
         slk_prof_end(ctx, s);
     }
     hipLaunchKernelGGL(k_shard_loss, dim3(1), dim3(256), 0, s, (const double *)ctx->losspart.p, (int)ugrid, a.inv_b,
-                       d_loss_out);
+                       d_loss_out, (int)accumulate);
     SLK_LAUNCH_CHECK(ctx, "k_shard_loss");
     return SLK_OK;
 }
 
-SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, const int64_t *d_ids,
-                                   const float *d_grad_in, int64_t n_ids, void *stream) {
+SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, int32_t minibatch,
+                                   const float *d_grad_in, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
-    if (n_ids < 0 || n_ids >= ((int64_t)1 << 31) || (n_ids > 0 && (!d_ids || !d_grad_in)))
-        return slk_fail(ctx, SLK_EINVAL, "slk_shard_item_pass: bad arguments");
+    if (ctx->shard_n < 0 || minibatch < 0 || minibatch >= ctx->sh_M)
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_item_pass: no committed chunk / minibatch %d out of range", minibatch);
+    const int S = ctx->sh_S;
+    const int64_t r0 = ctx->sh_rstart[(size_t)minibatch * S], nr = ctx->sh_rstart[(size_t)(minibatch + 1) * S] - r0;
+    if (nr > 0 && !d_grad_in) return slk_fail(ctx, SLK_EINVAL, "slk_shard_item_pass: d_grad_in is NULL");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
@@ -375,30 +552,18 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
                                  (size_t)local->num_users, (size_t)local->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
     }
-    if (n_ids > 0) {
-        const uint32_t nr = (uint32_t)n_ids;
-        for (int b = 0; b < 2; ++b) {
-            if ((rc = slk_ensure(ctx, ctx->ikey[b], (size_t)nr * 4))) return rc;
-            if ((rc = slk_ensure(ctx, ctx->ipay[b], (size_t)nr * 4))) return rc;
-        }
+    if (nr > 0) {
         const unsigned ibits = slk_bits_for((uint64_t)local->num_items - 1);
-        slk_prof_begin(ctx, SLK_K_PREP, s);
-        hipLaunchKernelGGL(k_shard_item_keys, dim3(slk_grid_for(ctx, nr, 256)), dim3(256), 0, s, d_ids, nr,
-                           (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
-        SLK_LAUNCH_CHECK(ctx, "k_shard_item_keys");
-        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
-                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nr, ibits, s)))
-            return rc;
-        slk_prof_end(ctx, s);
         slk_pass_args a;
         memset(&a, 0, sizeof(a));
         fill_tables(a, ctx, local, optim, dense);
-        a.snap = const_cast<float *>(d_grad_in);
+        a.snap = const_cast<float *>(d_grad_in);  // records indexed by the slot inside this minibatch
         a.RS = shard_rsv(local->dim);
-        a.ibegin = 0;
-        a.iend = nr;
+        a.begin = 0;
+        a.ibegin = (uint32_t)r0;
+        a.iend = (uint32_t)(r0 + nr);
         a.ikey = (const uint32_t *)ctx->ikey[1].p;
-        a.imask = 0xffffffffu;
+        a.imask = (uint32_t)((1ull << ibits) - 1);
         a.ipay = (const uint32_t *)ctx->ipay[1].p;
         a.mb_loss_out = nullptr;
         slk_pass_fn ipass = nullptr;
@@ -408,7 +573,7 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
 #undef SLK_PICK
         const unsigned gpb = 256u / (unsigned)g;
         slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-        hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, nr, 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)nr, 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
         SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW>");
         slk_prof_end(ctx, s);
     }

@@ -5,10 +5,18 @@ row-sharded across the GPUs of a node with RCCL all-to-all over xGMI for cross-s
 lookups.  One process per GPU.  Rows are sharded cyclically: owner(row) = row % world, local
 row = row // world, for the user AND the item tables (with their biases and optimizer state).
 A rank processes the interactions of each global minibatch whose user it owns, so user rows
-are always local; item rows travel in three all-to-all phases per minibatch (ids to the
-owners, rows back, gradient records to the owners).  Owners sum a row's gradient
-contributions before ONE optimizer update, so the semantics of the single-GPU step
-(factorization/implicit.py:229-243: pre-step forward, duplicates summed) are preserved.
+are always local; item rows travel by all-to-all (ids to the owners, rows back, gradient
+records to the owners).  Owners sum a row's gradient contributions before ONE optimizer
+update, so the semantics of the single-GPU step (factorization/implicit.py:229-243: pre-step
+forward, duplicates summed) are preserved.
+
+Everything that depends only on ids -- negatives, the sort by user, the bucketing of the
+lookups by owner, the id exchange, the owners' sort by row -- is done once per CHUNK of
+minibatches, so the minibatch loop issues kernels and collectives without ever waiting for
+the GPU: the split sizes of every exchange of the chunk come from one count exchange (the one
+host synchronisation per chunk).  Each minibatch is further cut into `slices` by user; the row
+and gradient exchanges of one slice run (async_op) while another slice computes, so xGMI and
+HBM work overlap.
 
 The compute phases are the slk_shard_* entry points of include/spotlight_hip.h; this module is
 the host side: buffers, split sizes and the collectives (torch.distributed = RCCL on ROCm).
@@ -24,6 +32,13 @@ def local_rows(num_rows, world, rank):
     return (int(num_rows) - rank + world - 1) // world
 
 
+def _bits(x):
+    b = 1
+    while x >> b:
+        b += 1
+    return b
+
+
 class ShardedBilinearTrainer(object):
     """One rank's half of the row-sharded training step.
 
@@ -36,9 +51,10 @@ class ShardedBilinearTrainer(object):
     num_items_global: total number of item rows (negatives are drawn over this range).
     group: process group (default: WORLD).
     stream: raw hipStream_t the kernels are enqueued on (torch's current stream).
+    slices: user-slices per minibatch (exchange/compute overlap); default 4 when world > 1.
     """
 
-    def __init__(self, engine, tables, optim, num_items_global, group=None, stream=0):
+    def __init__(self, engine, tables, optim, num_items_global, group=None, stream=0, slices=None):
         self.engine = engine
         self.tables = tables
         self.optim = optim
@@ -47,13 +63,26 @@ class ShardedBilinearTrainer(object):
         self.rank = dist.get_rank(group)
         self.num_items_global = int(num_items_global)
         self.stream = stream
+        self.slices = int(slices) if slices else (4 if self.world > 1 else 1)
         w = tables
         self.dim = w[0].shape[1]
         self.device = w[0].device
         self._tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0], self.dim)
+        self._shard = _native.make_shard(self.world, self.rank, self.num_items_global)
         self.rsv = engine.shard_row_floats(self.dim)
         self._bufs = {}
+        self.exchange_rows = 0
         self.last_exchange_rows = 0
+
+    def max_minibatches_per_chunk(self):
+        """Bound of one slk_shard_chunk_begin: (owner, unit) bins <= 2048 and 32-bit sort keys."""
+        s, w = self.slices, self.world
+        ub, ib = _bits(max(self.tables[0].shape[0] - 1, 1)), _bits(max(self.tables[1].shape[0] - 1, 1))
+        m = 2048 // (w * s)
+        m = min(m, (1 << (32 - ub)) // s, 1 << (32 - ib))
+        if m < 1:
+            raise ValueError('row-sharded chunk: %d slices x world %d do not fit the engine limits' % (s, w))
+        return m
 
     def _buf(self, name, rows, cols, dtype):
         """Persistent exchange buffer, grown geometrically (views of the first `rows` rows)."""
@@ -66,70 +95,97 @@ class ShardedBilinearTrainer(object):
             self._bufs[name] = b
         return b[:int(rows)]
 
-    def step(self, users_local, items, global_batch, loss='bpr', neg_in=None, neg_out=None):
-        """One global minibatch.  `users_local` / `items`: int64 device tensors holding this
-        rank's interactions (LOCAL user rows, GLOBAL item ids); may be empty.  Returns a
-        1-element tensor: this rank's share of loss.item() (sum over ranks = the loss)."""
-        eng, w = self.engine, self.world
-        n = int(users_local.numel())
-        sh = _native.make_shard(w, self.rank, self.num_items_global, global_batch)
-        send_ids = self._buf('send_ids', 2 * n, 0, torch.int64)
-        send_counts = self._buf('send_counts', w, 0, torch.int64)
-        eng.shard_begin(self._tables, sh, users_local.data_ptr() if n else None, items.data_ptr() if n else None,
-                        n, send_ids.data_ptr(), send_counts.data_ptr(),
-                        d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
-                        d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None,
-                        stream=self.stream)
-        # a2a #1: how many lookups each owner receives, then the owner-local row ids
-        recv_counts = self._buf('recv_counts', w, 0, torch.int64)
+    def run_chunk(self, users_local, items, mb_off, global_batches, loss='bpr', neg_in=None, neg_out=None):
+        """A chunk of M = len(mb_off) - 1 consecutive global minibatches.  `users_local` / `items`:
+        int64 device tensors with this rank's interactions of the chunk (LOCAL user rows, GLOBAL item
+        ids; may be empty), minibatch m = [mb_off[m], mb_off[m + 1]); `global_batches[m]`: size of the
+        GLOBAL minibatch (losses are means over it).  Negatives: `neg_in`, or one contiguous draw from
+        this rank's engine RNG.  Returns a [M] tensor: this rank's share of each loss.item() (sum
+        over ranks = the loss)."""
+        eng, w, s_n, st = self.engine, self.world, self.slices, self.stream
+        m_n = len(mb_off) - 1
+        t_n = m_n * s_n
+        n = int(mb_off[-1])
+        assert int(users_local.numel()) == n and int(mb_off[0]) == 0
+        send_ids = self._buf('send_ids', 2 * n, 0, torch.int32)
+        send_counts = self._buf('send_counts', w * t_n, 0, torch.int64)
+        eng.shard_chunk_begin(self._tables, self._shard, users_local.data_ptr() if n else None,
+                              items.data_ptr() if n else None, n, mb_off, s_n, send_ids.data_ptr(),
+                              send_counts.data_ptr(),
+                              d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
+                              d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None, stream=st)
+        # counts [owner][unit] -> [source][unit]; the chunk's only host synchronisation
+        recv_counts = self._buf('recv_counts', w * t_n, 0, torch.int64)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()  # one host sync per minibatch
-        n_recv = sum(rc)
-        recv_ids = self._buf('recv_ids', n_recv, 0, torch.int64)
-        dist.all_to_all_single(recv_ids, send_ids, rc, sc, group=self.group)
-        # a2a #2: owners gather the requested rows (+ bias) and send them back
-        rows_send = self._buf('rows_send', n_recv, self.rsv, torch.float32)
-        eng.shard_gather(self._tables, recv_ids.data_ptr() if n_recv else None, n_recv,
-                         rows_send.data_ptr() if n_recv else None, stream=self.stream)
-        rows_recv = self._buf('rows_recv', 2 * n, self.rsv, torch.float32)
-        dist.all_to_all_single(rows_recv, rows_send, sc, rc, group=self.group)
-        # forward / loss / backward / user update on the requester
-        grad_send = self._buf('grad_send', 2 * n, self.rsv, torch.float32)
-        loss_out = self._buf('loss_out', 1, 0, torch.float32)
-        eng.shard_user_pass(self._tables, self.optim, sh, n, loss, rows_recv.data_ptr() if n else None,
-                            grad_send.data_ptr() if n else None, loss_out.data_ptr(), stream=self.stream)
-        # a2a #3: gradient records to the owners, which sum per row and update once
-        grad_recv = self._buf('grad_recv', n_recv, self.rsv, torch.float32)
-        dist.all_to_all_single(grad_recv, grad_send, rc, sc, group=self.group)
-        eng.shard_item_pass(self._tables, self.optim, recv_ids.data_ptr() if n_recv else None,
-                            grad_recv.data_ptr() if n_recv else None, n_recv, stream=self.stream)
-        self.last_exchange_rows = 2 * n - sc[self.rank]  # lookups that crossed xGMI
-        return loss_out.clone()
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        sc_peer = [sum(sc[r * t_n:(r + 1) * t_n]) for r in range(w)]
+        rc_peer = [sum(rc[r * t_n:(r + 1) * t_n]) for r in range(w)]
+        recv_ids = self._buf('recv_ids', sum(rc_peer), 0, torch.int32)
+        dist.all_to_all_single(recv_ids, send_ids, rc_peer, sc_peer, group=self.group)
+        eng.shard_chunk_commit(self._tables, self._shard, sc, rc, recv_ids.data_ptr(), stream=st)
+        sc_unit = [[sc[r * t_n + t] for r in range(w)] for t in range(t_n)]
+        rc_unit = [[rc[r * t_n + t] for r in range(w)] for t in range(t_n)]
+        n_send = [sum(x) for x in sc_unit]  # = 2 * interactions of the unit
+        n_recv = [sum(x) for x in rc_unit]
+        self.last_exchange_rows = sum(n_send) - sc_peer[self.rank]  # lookups that crossed xGMI
+        self.exchange_rows += self.last_exchange_rows
+        loss_out = torch.zeros(m_n, dtype=torch.float32, device=self.device)
+        rsv = self.rsv
+        for m in range(m_n):
+            units = range(m * s_n, (m + 1) * s_n)
+            # owners: row records of every slice's requests; rows travel back (async)
+            rows_recv, h_rows = [], []
+            for k, t in enumerate(units):
+                rows_send = self._buf('rows_send%d' % k, n_recv[t], rsv, torch.float32)
+                eng.shard_gather(self._tables, t, rows_send.data_ptr(), stream=st)
+                rr = self._buf('rows_recv%d' % k, n_send[t], rsv, torch.float32)
+                rows_recv.append(rr)
+                h_rows.append(dist.all_to_all_single(rr, rows_send, sc_unit[t], rc_unit[t], group=self.group,
+                                                     async_op=True))
+            # requesters: forward / loss / backward / user update per slice; gradient records
+            # travel to the owners (async) while the next slice computes
+            grad_recv = self._buf('grad_recv', sum(n_recv[t] for t in units), rsv, torch.float32)
+            h_grad, off = [], 0
+            for k, t in enumerate(units):
+                h_rows[k].wait()
+                grad_send = self._buf('grad_send%d' % k, n_send[t], rsv, torch.float32)
+                eng.shard_user_pass(self._tables, self.optim, self._shard, t, global_batches[m], loss,
+                                    rows_recv[k].data_ptr(), grad_send.data_ptr(), loss_out[m:].data_ptr(),
+                                    accumulate=k > 0, stream=st)
+                h_grad.append(dist.all_to_all_single(grad_recv[off:off + n_recv[t]], grad_send, rc_unit[t],
+                                                     sc_unit[t], group=self.group, async_op=True))
+                off += n_recv[t]
+            for h in h_grad:
+                h.wait()
+            # owners: per unique row, sum of the minibatch's records, ONE optimizer update
+            eng.shard_item_pass(self._tables, self.optim, m, grad_recv.data_ptr(), stream=st)
+        return loss_out
+
+    def step(self, users_local, items, global_batch, loss='bpr', neg_in=None, neg_out=None):
+        """One global minibatch (a chunk of one).  Returns a 1-element tensor: this rank's share of
+        loss.item() (sum over ranks = the loss)."""
+        return self.run_chunk(users_local, items, [0, int(users_local.numel())], [global_batch], loss=loss,
+                              neg_in=neg_in, neg_out=neg_out)
 
     def train(self, users_local, items, batch_local, loss='bpr', mb_loss=None, sample_chunk=8):
         """Minibatch loop over this rank's interactions: global minibatch k consists of every
         rank's slice [k*batch_local, (k+1)*batch_local) (all ranks must hold the same number of
         interactions).  Negatives are drawn from this rank's engine RNG over the global item range,
-        `sample_chunk` minibatches per draw (one contiguous randint stream per rank, exactly as a
-        per-minibatch draw would produce: sampling.py:34 draws are independent per output).
+        one contiguous draw per chunk of `sample_chunk` minibatches (exactly what per-minibatch
+        draws would produce: sampling.py:34 draws are independent per output).
         Returns the per-minibatch loss shares (sum over ranks = loss.item())."""
         n = int(users_local.numel())
         n_mb = (n + batch_local - 1) // batch_local
         if mb_loss is None:
             mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=self.device)
         self.exchange_rows = 0
-        negs = None
-        for k in range(n_mb):
-            lo, hi = k * batch_local, min((k + 1) * batch_local, n)
-            if k % sample_chunk == 0:
-                c_hi = min((k + sample_chunk) * batch_local, n)
-                negs = self._buf('negs', c_hi - lo, 0, torch.int64)
-                self.engine.sample_items(self.num_items_global, c_hi - lo, negs.data_ptr(), stream=self.stream)
-                c_lo = lo
-            part = self.step(users_local[lo:hi], items[lo:hi], (hi - lo) * self.world, loss=loss,
-                             neg_in=negs[lo - c_lo:hi - c_lo])
-            mb_loss[k:k + 1].copy_(part)
-            self.exchange_rows += self.last_exchange_rows
+        per_chunk = max(1, min(int(sample_chunk), self.max_minibatches_per_chunk()))
+        for k0 in range(0, n_mb, per_chunk):
+            k1 = min(k0 + per_chunk, n_mb)
+            lo, hi = k0 * batch_local, min(k1 * batch_local, n)
+            off = [min(k * batch_local, n) - lo for k in range(k0, k1 + 1)]
+            gbs = [(off[i + 1] - off[i]) * self.world for i in range(k1 - k0)]
+            mb_loss[k0:k1].copy_(self.run_chunk(users_local[lo:hi], items[lo:hi], off, gbs, loss=loss))
         return mb_loss
 
 
@@ -246,10 +302,14 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
             trainer.optim = ostruct
             self._trainer = trainer
             mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=device)
-            for k in range(n_mb):
-                a, b = bounds[k], bounds[k + 1]
-                share = trainer.step(ul[a:b], il[a:b], min(B, n - k * B), loss=self._loss, neg_in=ng[a:b])
-                mb_loss[k:k + 1].copy_(share)
+            per_chunk = min(8, trainer.max_minibatches_per_chunk())
+            for k0 in range(0, n_mb, per_chunk):
+                k1 = min(k0 + per_chunk, n_mb)
+                a, b = bounds[k0], bounds[k1]
+                off = [bounds[k] - a for k in range(k0, k1 + 1)]
+                gbs = [min(B, n - k * B) for k in range(k0, k1)]
+                mb_loss[k0:k1].copy_(trainer.run_chunk(ul[a:b], il[a:b], off, gbs, loss=self._loss,
+                                                       neg_in=ng[a:b]))
             dist.all_reduce(mb_loss, group=self._group)
             binding.store_steps(ostruct.step)
             epoch_loss = float(mb_loss.double().mean().item())

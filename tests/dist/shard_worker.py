@@ -24,6 +24,8 @@ from spotlight_amd.factorization.sharded import ShardedBilinearTrainer, local_ro
 def main():
     backend, loss, opt, D = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     sample_on_device = len(sys.argv) > 5 and sys.argv[5] == 'sample'
+    chunk_mode = len(sys.argv) > 5 and sys.argv[5] == 'chunk'  # every minibatch in ONE run_chunk call
+    slices = int(sys.argv[6]) if len(sys.argv) > 6 else None
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     if backend == 'emu':
         from emu_backend import emu_lib
@@ -54,7 +56,7 @@ def main():
     s1 = [torch.zeros_like(t) for t in loc]
     s2 = [torch.zeros_like(t) for t in loc]
     optim = _native.make_optim(opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2], **hp)
-    trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream)
+    trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream, slices=slices)
     if sample_on_device:
         eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
 
@@ -67,7 +69,16 @@ def main():
         losses = [float(x) for x in shares.cpu().numpy()]
         # the draws: one contiguous stream, minibatch after minibatch
         used_negs = np.random.RandomState(1000 + rank).randint(0, I, N, dtype=np.int64)
-    for k in range(0 if use_train_loop else n_mb):
+    if chunk_mode:
+        mine = np.nonzero(users % world == rank)[0]
+        off = [int(np.searchsorted(mine, min(k * B, N))) for k in range(n_mb + 1)]
+        gbs = [min((k + 1) * B, N) - k * B for k in range(n_mb)]
+        shares = trainer.run_chunk(torch.from_numpy(users[mine] // world).to(dev), torch.from_numpy(items[mine]).to(dev),
+                                   off, gbs, loss=loss, neg_in=torch.from_numpy(negs[mine]).to(dev))
+        dist.all_reduce(shares)
+        losses = [float(x) for x in shares.cpu().numpy()]
+        used_negs[mine] = negs[mine]
+    for k in range(0 if (use_train_loop or chunk_mode) else n_mb):
         lo, hi = k * B, min((k + 1) * B, N)
         idx = np.nonzero(users[lo:hi] % world == rank)[0] + lo
         ul = torch.from_numpy(users[idx] // world).to(dev)

@@ -53,6 +53,14 @@ def test_sharded_world2_matches_oracle_and_single_device(loss, opt, D):
     run_world(2, [loss, opt, D])
 
 
+@pytest.mark.parametrize('world,slices,loss,opt', [(2, 1, 'bpr', 'adagrad'), (2, 3, 'pointwise', 'sparse_adam'),
+                                                   (3, 2, 'hinge', 'adam_dense'), (1, 2, 'bpr', 'adagrad')])
+def test_sharded_whole_chunk_with_slices(world, slices, loss, opt):
+    """Every minibatch of the run in ONE chunk (one count exchange, no per-minibatch host sync), each
+    minibatch cut into `slices` user-slices whose exchanges are issued asynchronously."""
+    run_world(world, [loss, opt, 8, 'chunk', slices])
+
+
 def test_sharded_world3_device_sampled_negatives():
     run_world(3, ['bpr', 'adagrad', 16, 'sample'])
 
@@ -85,6 +93,11 @@ def test_gpu_sharded_phases_world1_nccl(loss, opt, D):
     """The real gfx950 kernels of the four shard phases + RCCL all_to_all_single (a single rank:
     the exchange degenerates to a device copy), against the oracle and the fused one-GPU path."""
     run_world(1, [loss, opt, D], backend='hip')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_whole_chunk_with_slices_world1_nccl():
+    run_world(1, ['bpr', 'adagrad', 64, 'chunk', 4], backend='hip')
 
 
 @pytest.mark.gpu
