@@ -211,7 +211,10 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
         const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
         if (MODE == SLK_ITEM_SNAP) {
             gb = rec[D + s];
-            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+            // several negatives per interaction (adaptive hinge): only the positive and the selected
+            // negative carry a gradient, so the row is fetched only when dL/dscore != 0 (a dependent
+            // load; with one negative every occurrence is live and both loads are issued at once)
+            const slk_vec<VEC> u = (on && (NP <= 2 || gb != 0.0f)) ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
         } else {
@@ -243,6 +246,9 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 // bias (slot 3), or both.  They separate when the embedding rows are BloomEmbedding rows (keys =
 // hashed rows) while the bias table is indexed by the item id itself.
 enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
+#ifndef SLK_SPILL_BATCH
+#define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
+#endif
 
 // Row update with the parameter / first-state elements already in registers (loaded early, see
 // k_item_pass).  Same arithmetic, in the same order, as slk_apply_vec.
@@ -409,17 +415,45 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(6) void k_item_pass(slk_pass_
                 }
                 ++k;
             } while (k < tn && s_key[k + 1] == key);
-            if (k == tn) {  // the run may continue in the following tiles
-                for (uint32_t q = tb + tn; q < iend && a.ikey[q] == key; ++q) {
-                    slk_vec<VEC> cc;
-                    float gq;
-                    slk_item_contrib<VEC, MODE>(a, a.ipay[q], D, d0, rows_on, cc, gq);
-                    if (MODE != SLK_ITEM_SNAP || gq != 0.0f) {
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
-                        gb += gq;
-                        any = true;
+            if (k == tn) {
+                // The run may continue in the following tiles (long runs: BloomEmbedding rows shared
+                // by many ids, skewed items).  The group reads G keys + payloads at once (the keys are
+                // sorted, so the lanes that still match are a prefix), then takes the occurrences
+                // SLK_SPILL_BATCH at a time: independent loads in flight, summed in occurrence order.
+                uint32_t q = tb + tn;
+                bool more = q < iend;
+                while (more) {
+                    const uint32_t qi = q + (uint32_t)lane;
+                    uint32_t pq = 0u;
+                    int cnt = 0;
+                    if (qi < iend && a.ikey[qi] == key) {
+                        pq = a.ipay[qi];
+                        cnt = 1;
                     }
+#pragma unroll
+                    for (int m = G / 2; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, G);
+                    for (int j0 = 0; j0 < cnt; j0 += SLK_SPILL_BATCH) {
+                        slk_vec<VEC> cc[SLK_SPILL_BATCH];
+                        float gq[SLK_SPILL_BATCH];
+#pragma unroll
+                        for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
+                            gq[e] = 0.0f;
+                            cc[e] = slk_vzero<VEC>();
+                            const uint32_t pj = __shfl(pq, (j0 + e) & (G - 1), G);
+                            if (j0 + e < cnt) slk_item_contrib<VEC, MODE>(a, pj, D, d0, rows_on, cc[e], gq[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
+                            if (j0 + e < cnt && (MODE != SLK_ITEM_SNAP || gq[e] != 0.0f)) {
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) gv.v[i] += cc[e].v[i];
+                                gb += gq[e];
+                                any = true;
+                            }
+                        }
+                    }
+                    more = cnt == G;
+                    q += (uint32_t)G;
                 }
             }
             if (UPD != SLK_UPD_SPARSE_ADAM && !any) return;
