@@ -135,6 +135,9 @@ def bench_c4(args):
     I, D, L, K, W = args.items, args.dim, args.seq_len, args.steps, args.warmup
     B = args.batch if args.batch != (1 << 20) else 4096
     eng = _native.Engine(0)
+    for kv in args.set:
+        name, value = kv.split('=')
+        eng.set_option(name, int(value))
     gen = torch.Generator(device=dev)
     gen.manual_seed(99)
     E = torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen)

@@ -22,7 +22,7 @@
 
 #include "slk_kernels.h"
 
-enum { SQ_MCOUNT = 8, SQ_REP };  // ctx->extra slots (0..5 belong to slk_shard.hip)
+enum { SQ_MCOUNT = 12, SQ_REP };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
 
 struct slk_seq_args {
     const float *E;         // item_embeddings
@@ -244,6 +244,209 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
     if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot / (double)M;
 }
 
+// SEQUENCE PASS, register-resident variant: used when a row group's chunk of timesteps fits CMAX
+// rows of registers (L <= 256 and ceil(L / NG) <= 16: e.g. L = 200 at dim <= 64).  Same chunks,
+// same scans and the same summation order as k_seq_pass -- results are bit-identical -- but a
+// group keeps its chunk's item rows in VGPRs instead of staging the whole sequence in LDS:
+//   * LDS per workgroup drops from L*D*4 + 8 KB (59 KB at L=200, D=64: 2 workgroups per CU) to
+//     the 8 KB of chunk sums, so occupancy is set by registers (4 workgroups per CU);
+//   * the ids of the chunk are fetched by one coalesced load per group (lane k holds timestep
+//     t0 + k, broadcast by __shfl) and all of the chunk's row loads are issued back to back
+//     instead of one dependent (id -> row) pair per loop iteration.
+template <int VEC, int G, bool ADAPT, int CMAX>
+__global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
+    constexpr int NG = 256 / G;
+    constexpr int DL = G * VEC;
+    __shared__ double red[256];
+    __shared__ __attribute__((aligned(16))) float sT[NG * DL];  // per-chunk sums
+    __shared__ __attribute__((aligned(16))) float sC[NG * DL];  // per-chunk non-zero counts
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D, L = a.L;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const float M = (float)*a.mcount;
+    const uint32_t Bs = a.s_end - a.s_begin;
+    const int nn = a.NP - 1;
+    const int t0 = grp * a.C < L ? grp * a.C : L;
+    const int t1 = t0 + a.C < L ? t0 + a.C : L;
+    const int cnt = t1 - t0;  // <= CMAX <= G
+    double loss_acc = 0.0;
+
+    for (uint32_t s = a.s_begin + blockIdx.x; s < a.s_end; s += gridDim.x) {
+        const int64_t *seq = a.seqs + (size_t)s * L;
+        const uint32_t bl = s - a.s_begin;
+        float *recs = a.rec + (size_t)bl * L * a.RS;
+        // ---- (A) ids of the chunk: lane k holds timestep t0 + k; rows straight into registers
+        uint32_t my_it = 0u, my_neg = 0u;
+        if (lane < cnt) {
+            my_it = (uint32_t)seq[t0 + lane];
+            if (!ADAPT) my_neg = a.neg32[(size_t)bl * L + t0 + lane];
+        }
+        slk_vec<VEC> e[CMAX];
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k) {
+            const uint32_t id = __shfl(my_it, k, G);
+            e[k] = (on && k < cnt) ? slk_vload<VEC>(a.E + (size_t)id * D + d0) : slk_vzero<VEC>();
+        }
+        // ---- (B1) per-chunk sum and non-zero count (rows beyond the chunk are zero: exact no-ops)
+        {
+            slk_vec<VEC> sum = slk_vzero<VEC>(), cn = slk_vzero<VEC>();
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    sum.v[i] += e[k].v[i];
+                    cn.v[i] += (e[k].v[i] != 0.0f) ? 1.0f : 0.0f;
+                }
+            }
+            __syncthreads();  // chunk sums of the previous sequence no longer in use
+            slk_vstore<VEC>(sT + grp * DL + d0, sum);
+            slk_vstore<VEC>(sC + grp * DL + d0, cn);
+        }
+        __syncthreads();
+        // ---- (B2) exclusive prefix -> representation -> scores -> loss -> dL/d(prefix sum)
+        {
+            slk_vec<VEC> S = slk_vzero<VEC>(), Cn = slk_vzero<VEC>();
+            for (int gq = 0; gq < grp; ++gq) {
+                const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0), y = slk_vload<VEC>(sC + gq * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    S.v[i] += x.v[i];
+                    Cn.v[i] += y.v[i];
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < CMAX; kb += 4) {
+                if (kb >= cnt) continue;
+                // independent loads of up to 4 timesteps first (memory-level parallelism)
+                uint32_t it[4], nid[4];
+                slk_vec<VEC> nrow[4];
+                float pb[4], nb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    it[k] = __shfl(my_it, (kb + k) & (G - 1), G);
+                    nid[k] = __shfl(my_neg, (kb + k) & (G - 1), G);
+                    pb[k] = nb[k] = 0.0f;
+                    nrow[k] = slk_vzero<VEC>();
+                    if (kb + k < cnt) {
+                        pb[k] = a.bias[it[k]];
+                        if (!ADAPT) {
+                            if (on) nrow[k] = slk_vload<VEC>(a.E + (size_t)nid[k] * D + d0);
+                            nb[k] = a.bias[nid[k]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (kb + k < CMAX && kb + k < cnt) {
+                        const int t = t0 + kb + k;
+                        const slk_vec<VEC> ev = e[(kb + k) < CMAX ? (kb + k) : 0];
+                        slk_vec<VEC> rep, c1;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            c1.v[i] = Cn.v[i] + 1.0f;
+                            rep.v[i] = S.v[i] / c1.v[i];
+                        }
+                        const float sp = pb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, ev));
+                        float sn;
+                        int chosen = 0;
+                        slk_vec<VEC> nr = nrow[k];
+                        if (!ADAPT) {
+                            sn = nb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, nr));
+                        } else {
+                            // losses.py:164-166: the highest-scoring of the n candidates drawn for this
+                            // (sequence, timestep); row (r*B + b) of the (n*B, L) draw; first maximum wins
+                            sn = 0.0f;
+                            for (int rb = 0; rb < nn; rb += 4) {
+                                slk_vec<VEC> cr[4];
+                                float cb[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    cr[j] = slk_vzero<VEC>();
+                                    cb[j] = 0.0f;
+                                    if (rb + j < nn) {
+                                        const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
+                                        if (on) cr[j] = slk_vload<VEC>(a.E + (size_t)cid * D + d0);
+                                        cb[j] = a.bias[cid];
+                                    }
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    if (rb + j < nn) {
+                                        const float sc = cb[j] + slk_group_sum<G>(slk_vdot<VEC>(rep, cr[j]));
+                                        if (rb + j == 0 || sc > sn) {
+                                            sn = sc;
+                                            chosen = rb + j;
+                                            nr = cr[j];
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        float l, gp, gn;
+                        slk_pair_loss(a.loss_kind, sp, sn, 1.0f, l, gp, gn);
+                        const float mask = it[k] != 0u ? 1.0f : 0.0f;
+                        const float w = mask / M;  // d(sum(loss*mask)/sum(mask)) / d loss
+                        gp = gp * w;
+                        gn = gn * w;
+                        float *rec = recs + (size_t)t * a.RS;
+                        if (on) slk_vstore<VEC>(rec + d0, rep);
+                        if (lane == 0) {
+                            loss_acc += (double)(l * mask);
+                            rec[2 * D] = gp;
+                            if (!ADAPT) {
+                                rec[2 * D + 1] = gn;
+                            } else {
+                                for (int j = 0; j < nn; ++j) rec[2 * D + 1 + j] = (j == chosen) ? gn : 0.0f;
+                            }
+                        }
+                        // advance the running sums; the row's registers now hold dL/d(prefix sum)
+                        slk_vec<VEC> gs;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            gs.v[i] = (gp * ev.v[i] + gn * nr.v[i]) / c1.v[i];
+                            S.v[i] += ev.v[i];
+                            Cn.v[i] += (ev.v[i] != 0.0f) ? 1.0f : 0.0f;
+                        }
+                        e[(kb + k) < CMAX ? (kb + k) : 0] = gs;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every group has consumed the chunk sums
+        // ---- (C) cumsum backward: row j receives the sum of dL/d(prefix sum) over t > j
+        {
+            slk_vec<VEC> sum = slk_vzero<VEC>();
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) sum.v[i] += e[k].v[i];
+            }
+            slk_vstore<VEC>(sT + grp * DL + d0, sum);
+        }
+        __syncthreads();
+        {
+            slk_vec<VEC> suf = slk_vzero<VEC>();
+            for (int gq = NG - 1; gq > grp; --gq) {
+                const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
+            }
+#pragma unroll
+            for (int k = CMAX - 1; k >= 0; --k) {
+                if (k < cnt) {
+                    if (on) slk_vstore<VEC>(recs + (size_t)(t0 + k) * a.RS + D + d0, suf);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) suf.v[i] += e[k].v[i];
+                }
+            }
+        }
+    }
+    const double tot = slk_block_sum_256(loss_acc, red);
+    if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot / (double)M;
+}
+
 // occurrence r = pos * NP + s (pos = chunk-local timestep): key = (minibatch, item), value = r
 __global__ __launch_bounds__(256) void k_seq_item_keys(const int64_t *seqs, const uint32_t *neg32, uint32_t nocc,
                                                        uint32_t n_seq, uint32_t L, uint32_t NP, uint32_t bsz,
@@ -347,7 +550,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     const unsigned ibits = slk_bits_for((uint64_t)tables->num_items - 1);
     // minibatches per chunk: keys fit 32 bits, occurrences < 2^31, ~4M timesteps of scratch
     int64_t mb_per_chunk = (int64_t)1 << (32 - ibits);
-    const int64_t cap_ts = (int64_t)1 << 22;
+    const int64_t cap_ts = ctx->opt_chunk_interactions;  // timesteps of scratch per chunk (~8M)
     if (mb_per_chunk > 32768) mb_per_chunk = 32768;  // gridDim.y of the mask-count launch
     if (mb_per_chunk * bsz * L > cap_ts) mb_per_chunk = cap_ts / (bsz * L);
     while (mb_per_chunk > 1 && mb_per_chunk * bsz * L * NP >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
@@ -374,14 +577,20 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     const int upd = slk_upd_for(optim->kind);
     seq_pass_fn spass = nullptr;
     slk_pass_fn ipass = nullptr;
+    // register-resident sequence pass when a group's chunk of timesteps fits 16 rows of VGPRs
+    const bool reg_pass = L <= 256 && (L + NG - 1) / NG <= 16 && ctx->opt_seq_variant != 0;
 #define SLK_PICK(V_, G_)                                                                 \
     do {                                                                                 \
-        spass = adaptive ? k_seq_pass<V_, G_, true> : k_seq_pass<V_, G_, false>;         \
+        constexpr int CM_ = (G_) < 16 ? (G_) : 16;                                       \
+        if (reg_pass)                                                                    \
+            spass = adaptive ? k_seq_pass_reg<V_, G_, true, CM_> : k_seq_pass_reg<V_, G_, false, CM_>; \
+        else                                                                             \
+            spass = adaptive ? k_seq_pass<V_, G_, true> : k_seq_pass<V_, G_, false>;     \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ>(upd);                             \
     } while (0)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
-    if (lds_bytes > 48 * 1024)
+    if (!reg_pass && lds_bytes > 48 * 1024)
         SLK_HIP(ctx, hipFuncSetAttribute((const void *)spass, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
     const unsigned gpb = 256u / (unsigned)g;
@@ -451,7 +660,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             unsigned sgrid = b1 - b0;
             if (sgrid > max_grid) sgrid = max_grid;
             slk_prof_begin(ctx, SLK_K_SEQ_PASS, s);
-            hipLaunchKernelGGL(spass, dim3(sgrid), dim3(256), lds_bytes, s, q);
+            hipLaunchKernelGGL(spass, dim3(sgrid), dim3(256), reg_pass ? 0 : lds_bytes, s, q);
             SLK_LAUNCH_CHECK(ctx, "k_seq_pass");
             slk_prof_end(ctx, s);
 
