@@ -149,8 +149,13 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
 
 // one thread per column c of the [n, B] candidate matrix; k0 = chunk-local index of the
 // minibatch's first interaction.  gk must be zero on entry for this minibatch.
+//
+// qk / live (optional): the two occurrences of column c that carry a gradient -- the positive of
+// interaction k0 + c and the selected negative -- as item-pass payloads r = position * NP + pair
+// (qk: chunk-local interaction -> user-sorted position), or ~0u twice when the hinge is inactive.
 __global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float *gk, uint32_t k0, uint32_t bm,
-                                                         int nn, float inv_b, double *loss_partial) {
+                                                         int nn, float inv_b, double *loss_partial,
+                                                         const uint32_t *qk, uint32_t *live) {
     __shared__ double red[256];
     const int NP = nn + 1;
     double lsum = 0.0;
@@ -172,6 +177,11 @@ __global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float 
         const float g = x >= 0.0f ? inv_b : 0.0f;
         gk[(size_t)(k0 + c) * NP] = -g;
         gk[best_at] = g;
+        if (live) {
+            const uint32_t kb = (uint32_t)(best_at / (size_t)NP), sb = (uint32_t)(best_at - (size_t)kb * NP);
+            live[2 * (size_t)c] = g != 0.0f ? qk[k0 + c] * (uint32_t)NP : 0xffffffffu;
+            live[2 * (size_t)c + 1] = g != 0.0f ? qk[kb] * (uint32_t)NP + sb : 0xffffffffu;
+        }
     }
     const double tot = slk_block_sum_256(lsum, red);
     if (threadIdx.x == 0) loss_partial[blockIdx.x] = tot;
@@ -256,6 +266,27 @@ __global__ __launch_bounds__(256) void k_build_item_keys(const uint32_t *uit, ui
         const uint32_t q = r / (uint32_t)NP;
         key[r] = ((q / bsz) << ibits) | uit[r];
         val[r] = r;
+    }
+}
+
+// adaptive hinge, live occurrences only: qk[uk[q]] = q
+__global__ __launch_bounds__(256) void k_invert_perm(const uint32_t *uk, uint32_t nc, uint32_t *qk) {
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nc; q += gridDim.x * 256) qk[uk[q]] = q;
+}
+
+// keys of one minibatch's live list (k_adaptive_select): entry e -> (item of occurrence live[e], live[e]);
+// with a BloomEmbedding item layer (ib.n_hash > 0, hashed = true) entry e*H + h -> (row_h(item), live[e]).
+// Dead entries get the all-ones key: they sort to the end and the item pass skips them.
+__global__ __launch_bounds__(256) void k_build_live_keys(const uint32_t *live, const uint32_t *uit, uint32_t n_live,
+                                                         slk_bloom_dev ib, bool hashed, uint32_t *key, uint32_t *val) {
+    const uint32_t H = hashed ? (uint32_t)ib.n_hash : 1u;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n_live * H; e += gridDim.x * 256) {
+        const uint32_t l = e / H, h = e - l * H;
+        const uint32_t r = live[l];
+        uint32_t k = 0xffffffffu;
+        if (r != 0xffffffffu) k = hashed ? slk_bloom_row(ib, uit[r], (int)h) : uit[r];
+        key[e] = k;
+        val[e] = r;
     }
 }
 
@@ -539,6 +570,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return slk_fail(ctx, SLK_EINVAL, "batch_size * lookups per interaction must be < 2^31");
     const int64_t chunk_cap = mb_per_chunk * bsz;
 
+    // Adaptive hinge: only the positive and the selected negative of a column carry a gradient, so
+    // the item-side owner passes run over 2 live occurrences per interaction (sorted per minibatch,
+    // after the selection) instead of all 1+n.  Not for SparseAdam, which also decays the moments
+    // of looked-up rows whose gradient is zero.
+    const bool late = adaptive && optim->kind != SLK_OPT_SPARSE_ADAM;
     // scratch.  With the "overlap_prep" option the value-independent part of a chunk (negatives,
     // sort by user, sort by item) is prepared on a second HIP stream while the previous chunk's
     // passes run, and those buffers exist twice (ctx->pb[0|1]).  Off by default: measured on
@@ -552,10 +588,12 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         for (int b = 0; b < 2; ++b) {
             if ((rc = slk_ensure(ctx, pb.ukey[b], nc_max * 4))) return rc;
             if ((rc = slk_ensure(ctx, pb.uval[b], nc_max * 8))) return rc;
-            if ((rc = slk_ensure(ctx, pb.ikey[b], nc_max * NP * 4))) return rc;
-            if ((rc = slk_ensure(ctx, pb.ipay[b], nc_max * NP * 4))) return rc;
-            if (Hi && (rc = slk_ensure(ctx, pb.bik[b], nc_max * NP * Hi * 4))) return rc;
-            if (Hi && (rc = slk_ensure(ctx, pb.bip[b], nc_max * NP * Hi * 4))) return rc;
+            // `late`: the item-side lists are built per minibatch from the live occurrences only;
+            // ipay[0] then holds the interaction -> sorted-position map of the chunk
+            if (!late && (rc = slk_ensure(ctx, pb.ikey[b], nc_max * NP * 4))) return rc;
+            if (!(late && b == 1) && (rc = slk_ensure(ctx, pb.ipay[b], late ? nc_max * 4 : nc_max * NP * 4))) return rc;
+            if (!late && Hi && (rc = slk_ensure(ctx, pb.bik[b], nc_max * NP * Hi * 4))) return rc;
+            if (!late && Hi && (rc = slk_ensure(ctx, pb.bip[b], nc_max * NP * Hi * 4))) return rc;
             if (Hu && (rc = slk_ensure(ctx, pb.buk[b], nc_max * Hu * 4))) return rc;
             if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
         }
@@ -569,7 +607,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
-    enum { BL_UREC = 16 };
+    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1 };
+    if (late) {
+        const size_t nl = 2 * (size_t)bsz, nlh = nl * (size_t)(Hi ? Hi : 1);
+        if ((rc = slk_ensure(ctx, ctx->extra[BL_LIVE], nl * 4))) return rc;
+        for (int b = 0; b < 4; ++b)
+            if ((rc = slk_ensure(ctx, ctx->extra[BL_LK0 + b], nlh * 4))) return rc;
+    }
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     if (dense) {
@@ -640,7 +684,6 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const unsigned mbbits = slk_bits_for((uint64_t)((nc - 1) / (uint32_t)bsz));
         uint32_t *ukey_in = (uint32_t *)pb.ukey[0].p, *ukey = (uint32_t *)pb.ukey[1].p;
         const uint32_t *uit, *uk = nullptr;
-        (void)uk;
         if (!adaptive) {
             hipLaunchKernelGGL((k_build_user_keys<true>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
                                (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
@@ -662,14 +705,20 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             SLK_LAUNCH_CHECK(ctx, "k_pack_items");
             uit = (const uint32_t *)pb.uit.p;
         }
-        hipLaunchKernelGGL(k_build_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
-                           (uint32_t)bsz, ibits, (uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ipay[0].p);
-        SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
-        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p,
-                                         (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
-                                         ibits + mbbits, s)))
-            return rc;
-        if (Hi) {
+        if (late) {
+            hipLaunchKernelGGL(k_invert_perm, dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, nc,
+                               (uint32_t *)pb.ipay[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_invert_perm");
+        } else {
+            hipLaunchKernelGGL(k_build_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
+                               (uint32_t)bsz, ibits, (uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ipay[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p,
+                                             (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
+                                             ibits + mbbits, s)))
+                return rc;
+        }
+        if (Hi && !late) {
             hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,
                                uit, nocc, NP, (uint32_t)bsz, icbits, ibd, (uint32_t *)pb.bik[0].p,
                                (uint32_t *)pb.bip[0].p);
@@ -744,7 +793,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             slk_set_opt_coeffs(a, optim);
             a.nt = ctx->opt_nt;
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
-            const unsigned igrid = slk_grid_for(ctx, (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
+            const unsigned igrid = slk_grid_for(ctx, late ? (size_t)bm * 2 : (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
             if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
@@ -753,10 +802,33 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 SLK_LAUNCH_CHECK(ctx, "k_score_pass");
                 const unsigned sgrid = slk_grid_for(ctx, bm, 256);
                 hipLaunchKernelGGL(k_adaptive_select, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
-                                   (float *)ctx->gk.p, b0, bm, nn, a.inv_b, (double *)ctx->losspart.p);
+                                   (float *)ctx->gk.p, b0, bm, nn, a.inv_b, (double *)ctx->losspart.p,
+                                   late ? (const uint32_t *)pb.ipay[0].p : (const uint32_t *)nullptr,
+                                   late ? (uint32_t *)ctx->extra[BL_LIVE].p : (uint32_t *)nullptr);
                 SLK_LAUNCH_CHECK(ctx, "k_adaptive_select");
                 a.n_loss_partial = (int)sgrid;
                 slk_prof_end(ctx, s);
+                if (late) {
+                    // this minibatch's live occurrences, sorted by item (biases; rows of a plain table)
+                    slk_prof_begin(ctx, SLK_K_PREP, s);
+                    const uint32_t nl = 2 * bm;
+                    hipLaunchKernelGGL(k_build_live_keys, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s,
+                                       (const uint32_t *)ctx->extra[BL_LIVE].p, uit, nl, ibd, false,
+                                       (uint32_t *)ctx->extra[BL_LK0].p, (uint32_t *)ctx->extra[BL_LV0].p);
+                    SLK_LAUNCH_CHECK(ctx, "k_build_live_keys");
+                    if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_LK0].p,
+                                                     (uint32_t *)ctx->extra[BL_LK1].p,
+                                                     (const uint32_t *)ctx->extra[BL_LV0].p,
+                                                     (uint32_t *)ctx->extra[BL_LV1].p, nl, ibits + 1, s)))  // + the dead entries' bit
+                        return rc;
+                    slk_prof_end(ctx, s);
+                    a.ikey = (const uint32_t *)ctx->extra[BL_LK1].p;
+                    a.ipay = (const uint32_t *)ctx->extra[BL_LV1].p;
+                    a.imask = 0xffffffffu;
+                    a.ibegin = 0;
+                    a.iend = nl;
+                    // a.pad_item2 == ~0u: the dead entries' all-ones key is never updated
+                }
             } else {
                 a.n_loss_partial = (int)ugrid;
             }
@@ -782,6 +854,25 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 r.ibegin = a.ibegin * (uint32_t)Hi;
                 r.iend = a.iend * (uint32_t)Hi;
                 r.imask = (uint32_t)((1ull << icbits) - 1);
+                if (late) {
+                    // the live occurrences' hashed rows (the bias pass above has consumed LK1/LV1:
+                    // same stream, so the buffers can be reused)
+                    const uint32_t nlh = 2 * bm * (uint32_t)Hi;
+                    hipLaunchKernelGGL(k_build_live_keys, dim3(slk_grid_for(ctx, nlh, 256)), dim3(256), 0, s,
+                                       (const uint32_t *)ctx->extra[BL_LIVE].p, uit, 2 * bm, ibd, true,
+                                       (uint32_t *)ctx->extra[BL_LK0].p, (uint32_t *)ctx->extra[BL_LV0].p);
+                    SLK_LAUNCH_CHECK(ctx, "k_build_live_keys<hashed>");
+                    if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_LK0].p,
+                                                     (uint32_t *)ctx->extra[BL_LK1].p,
+                                                     (const uint32_t *)ctx->extra[BL_LV0].p,
+                                                     (uint32_t *)ctx->extra[BL_LV1].p, nlh, icbits + 1, s)))
+                        return rc;
+                    r.ikey = (const uint32_t *)ctx->extra[BL_LK1].p;
+                    r.ipay = (const uint32_t *)ctx->extra[BL_LV1].p;
+                    r.ibegin = 0;
+                    r.iend = nlh;
+                    r.imask = 0xffffffffu;
+                }
                 r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
                 hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
                                    0, s, r);

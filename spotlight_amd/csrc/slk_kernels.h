@@ -381,7 +381,13 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(6) void k_item_pass(slk_pass_
             g[it] = 0.0f;
             c[it] = slk_vzero<VEC>();
             // rows of the run inherited from the previous tile belong to that tile's owner
-            const bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
+            bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
+            if (mine) {
+                // never-updated keys (padding_idx rows, the dead entries of a live list) have no
+                // record worth reading -- a dead entry's payload is not even a valid reference
+                const uint32_t item = s_key[j + 1] & a.imask;
+                mine = item != a.pad_item && item != a.pad_item2;
+            }
             if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, rows_on, c[it], g[it]);
         }
 #pragma unroll
