@@ -42,15 +42,26 @@ def run_reference(case):
     seqs = make_sequences(rs, case['N'], case['L'], case['I'], case.get('pad_frac', 0.5))
     inter = SequenceInteractions(seqs, num_items=case['I'])
     model_rs = np.random.RandomState(case['seed'])
+    names = list(NAMES)
+    representation = 'pooling'
+    if case.get('bloom'):
+        # PoolNet over a BloomEmbedding item layer (sequence/representations.py:62-68, layers.py:74-244)
+        from spotlight.layers import BloomEmbedding
+        from spotlight.sequence.representations import PoolNet
+        torch.manual_seed(int(case['seed']))
+        representation = PoolNet(case['I'], case['D'], item_embedding_layer=BloomEmbedding(
+            case['I'], case['D'], compression_ratio=case['ratio'], num_hash_functions=int(case['bloom']),
+            padding_idx=0))
+        names[0] = 'item_embeddings.embeddings.weight'
     model = ref_seq.ImplicitSequenceModel(
-        loss=case['loss'], representation='pooling', embedding_dim=case['D'], n_iter=case['n_iter'],
+        loss=case['loss'], representation=representation, embedding_dim=case['D'], n_iter=case['n_iter'],
         batch_size=case['B'], l2=case.get('l2', 0.0), learning_rate=case.get('lr', 1e-2),
         optimizer_func=optimizer_factory(case['opt']),
         sparse=case['opt'] in ('adagrad_sparse', 'sparse_adam'),
         random_state=model_rs, num_negative_samples=case.get('n_neg', 5))
     model._initialize(inter)
     params = dict(model._net.named_parameters())
-    rec = {'init_%d' % t: params[nm].detach().numpy().copy() for t, nm in enumerate(NAMES)}
+    rec = {'init_%d' % t: params[nm].detach().numpy().copy() for t, nm in enumerate(names)}
     rec['rng_key_before_fit'] = model_rs.get_state()[1].copy()
     rec['rng_pos_before_fit'] = np.int64(model_rs.get_state()[2])
     shuffled, negatives, losses, first_grads = [], [], [], []
@@ -77,7 +88,7 @@ def run_reference(case):
 
     def rec_step(*a, **kw):
         if not first_grads:
-            for nm in NAMES:
+            for nm in names:
                 g = params[nm].grad
                 first_grads.append((g.to_dense() if g.is_sparse else g).detach().numpy().copy())
         return orig_step(*a, **kw)
@@ -94,7 +105,7 @@ def run_reference(case):
     rec['negatives'] = np.concatenate(negatives)
     rec['losses'] = np.array(losses, dtype=np.float32)
     st = model._optimizer.state
-    for t, nm in enumerate(NAMES):
+    for t, nm in enumerate(names):
         rec['grad0_%d' % t] = first_grads[t]
         rec['final_%d' % t] = params[nm].detach().numpy().copy()
         s = st[params[nm]]
@@ -129,10 +140,24 @@ def cases():
     return out
 
 
+def bloom_cases():
+    """PoolNet over a BloomEmbedding item layer (dense gradients only: the inner table is not sparse)."""
+    out = []
+    for loss, opt in (('bpr', 'adagrad'), ('pointwise', 'adam_default'), ('hinge', 'adagrad'),
+                      ('adaptive_hinge', 'adagrad')):
+        out.append(dict(name='seq_bloom_%s_%s' % (loss, opt), loss=loss, opt=opt, I=60, N=50, L=7, D=8, B=16,
+                        n_iter=2, seed=42, data_seed=7, l2=1e-6 if opt == 'adam_default' else 0.0, lr=1e-2,
+                        n_neg=3, bloom=2, ratio=0.4))
+    out.append(dict(name='seq_bloom_d64_bpr_adagrad', loss='bpr', opt='adagrad', I=400, N=120, L=20, D=64, B=32,
+                    n_iter=2, seed=1, data_seed=0, pad_frac=0.3, frac_tol=0.15, bloom=4, ratio=0.2))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
-    for case in cases():
+    which = bloom_cases() if 'bloom' in sys.argv[1:] else cases()
+    for case in which:
         rec = run_reference(case)
         errs, fr = replay_seq_with_oracle(case, rec)
         step_keys = [k for k in errs if k.startswith('grad0') or k == 'loss0']

@@ -185,12 +185,18 @@ class BilinearOracle(object):
         return (mb_loss, neg_out) if want_negs else mb_loss
 
 
+class _Bloom(C.Structure):
+    _fields_ = [('rows', C.c_int64), ('n_hash', C.c_int32), ('pad_', C.c_int32), ('padding_idx', C.c_int64),
+                ('skip_row', C.c_int64), ('seeds', C.c_uint32 * 8)]
+
+
 class _SeqModel(C.Structure):
     _fields_ = [('p', C.c_void_p * 2), ('s1', C.c_void_p * 2), ('s2', C.c_void_p * 2),
                 ('num_items', C.c_int64), ('dim', C.c_int32), ('opt_kind', C.c_int32),
                 ('padding_idx', C.c_int64), ('step', C.c_int64),
                 ('lr', C.c_double), ('eps', C.c_double), ('beta1', C.c_double),
-                ('beta2', C.c_double), ('weight_decay', C.c_double), ('lr_decay', C.c_double)]
+                ('beta2', C.c_double), ('weight_decay', C.c_double), ('lr_decay', C.c_double),
+                ('bloom', _Bloom)]
 
 
 class PoolNetOracle(object):
@@ -198,7 +204,9 @@ class PoolNetOracle(object):
     state; restates spotlight/sequence/implicit.py:193-340 with sequence/representations.py:76-144."""
 
     def __init__(self, item_emb, item_bias, opt='adagrad', lr=1e-2, eps=None, betas=(0.9, 0.999),
-                 weight_decay=0.0, lr_decay=0.0, step=0, state1=None, state2=None, padding_idx=0):
+                 weight_decay=0.0, lr_decay=0.0, step=0, state1=None, state2=None, padding_idx=0, item_bloom=None):
+        """`item_bloom`: bloom_desc(...) when item_embeddings is a BloomEmbedding(num_items, D, padding_idx=0)
+        (item_emb is then the compressed table; num_items = len(item_bias))."""
         assert lib().slko_sizeof_seq_model() == C.sizeof(_SeqModel)
         f = lambda a: np.array(a, dtype=np.float32, order='C', copy=True)
         self.p = [f(item_emb), f(item_bias).reshape(-1)]
@@ -211,7 +219,9 @@ class PoolNetOracle(object):
             self.m.p[t] = self.p[t].ctypes.data
             self.m.s1[t] = self.s1[t].ctypes.data
             self.m.s2[t] = self.s2[t].ctypes.data
-        self.m.num_items, self.m.dim = self.p[0].shape
+        self.m.num_items, self.m.dim = self.p[1].shape[0], self.p[0].shape[1]
+        if item_bloom is not None:
+            self.m.bloom = _fill_bloom(item_bloom, self.p[0].shape[0])
         self.m.opt_kind = OPTS[opt]
         self.m.padding_idx = -1 if padding_idx is None else int(padding_idx)
         self.m.lr, self.m.eps = lr, eps
@@ -271,11 +281,6 @@ BLOOM_SEEDS = [179424941, 179425457, 179425907, 179426369,
                179424977, 179425517, 179425943, 179426407]  # spotlight/layers.py:13-20, first eight
 
 
-class _Bloom(C.Structure):
-    _fields_ = [('rows', C.c_int64), ('n_hash', C.c_int32), ('pad_', C.c_int32), ('padding_idx', C.c_int64),
-                ('skip_row', C.c_int64), ('seeds', C.c_uint32 * 8)]
-
-
 class _BModel(C.Structure):
     _fields_ = [('p', C.c_void_p * 4), ('s1', C.c_void_p * 4), ('s2', C.c_void_p * 4),
                 ('num_users', C.c_int64), ('num_items', C.c_int64), ('dim', C.c_int32), ('opt_kind', C.c_int32),
@@ -289,6 +294,15 @@ def bloom_desc(n_hash=4, padding_idx=0, bag=False, seeds=None):
     the table itself."""
     return dict(n_hash=n_hash, padding_idx=padding_idx, skip_row=-1 if bag else padding_idx,
                 seeds=list(seeds if seeds is not None else BLOOM_SEEDS[:n_hash]))
+
+
+def _fill_bloom(desc, rows):
+    b = _Bloom()
+    b.rows, b.n_hash = int(rows), desc['n_hash']
+    b.padding_idx, b.skip_row = desc['padding_idx'], desc['skip_row']
+    for h, s in enumerate(desc['seeds']):
+        b.seeds[h] = s
+    return b
 
 
 class BloomBilinearOracle(object):

@@ -103,9 +103,10 @@ def case_from_rec(rec):
 
 def replay_seq_with_oracle(case, rec):
     """Replays a recorded ImplicitSequenceModel(PoolNet) run through the C oracle."""
-    from oracle.oracle import PoolNetOracle
+    from oracle.oracle import PoolNetOracle, bloom_desc
     hp = _oracle_hparams(case)
-    mk = lambda: PoolNetOracle(rec['init_0'], rec['init_1'], opt=ORACLE_OPT[case['opt']], **hp)
+    bloom = bloom_desc(int(case['bloom'])) if ('bloom' in case and int(case['bloom'])) else None
+    mk = lambda: PoolNetOracle(rec['init_0'], rec['init_1'], opt=ORACLE_OPT[case['opt']], item_bloom=bloom, **hp)
     o = mk()
     rng = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
     nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
@@ -141,7 +142,7 @@ def replay_seq_with_oracle(case, rec):
     st = rng.get_state()
     assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
     # predictions from the reference's own final tables (the trajectory may legitimately drift)
-    po = PoolNetOracle(rec['final_0'], rec['final_1'])
+    po = PoolNetOracle(rec['final_0'], rec['final_1'], item_bloom=bloom)
     errs['predict_all'] = rel_inf(po.predict(rec['predict_seq']), rec['predict_all'])
     errs['predict_some'] = rel_inf(po.predict(rec['predict_seq2'], rec['predict_items']), rec['predict_some'])
     return errs, fr

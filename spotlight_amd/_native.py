@@ -274,12 +274,15 @@ def make_tables(ptrs, num_users, num_items, dim, user_bloom=None, item_bloom=Non
     return t
 
 
-def make_seq_tables(item_emb_ptr, item_bias_ptr, num_items, dim):
-    """slk_tables for the PoolNet entry points: only slots 1 (item embeddings) and 3 (item
-    biases) are populated."""
+def make_seq_tables(item_emb_ptr, item_bias_ptr, num_items, dim, item_bloom=None):
+    """slk_tables of a PoolNet: slots 1 (item embeddings) and 3 (item biases); `item_bloom`: SlkBloom
+    descriptor when the embedding layer is a BloomEmbedding (kept alive by the returned struct)."""
     t = SlkTables()
     t.d_param[1], t.d_param[3] = item_emb_ptr, item_bias_ptr
     t.num_users, t.num_items, t.dim = 0, int(num_items), int(dim)
+    t._keep = (None, item_bloom)
+    if item_bloom is not None:
+        t.item_bloom = C.pointer(item_bloom)
     return t
 
 

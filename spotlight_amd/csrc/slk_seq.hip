@@ -22,7 +22,7 @@
 
 #include "slk_kernels.h"
 
-enum { SQ_MCOUNT = 12, SQ_REP };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
+enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1 };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
 
 struct slk_seq_args {
     const float *E;         // item_embeddings
@@ -37,6 +37,7 @@ struct slk_seq_args {
     double *loss_partial;
     int loss_kind;
     int C;                  // timesteps per row-group chunk
+    slk_bloom_dev ib;       // item_embedding_layer = BloomEmbedding (n_hash == 0: plain table)
 };
 
 // non-zero sequence entries per minibatch (mask.sum(), losses.py:45-48)
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
         __syncthreads();  // LDS of the previous sequence no longer in use
         // ---- (A) stage the sequence's item rows
         for (int t = grp; t < L; t += NG) {
-            const slk_vec<VEC> e = on ? slk_vload<VEC>(a.E + (size_t)seq[t] * D + d0) : slk_vzero<VEC>();
+            const slk_vec<VEC> e = slk_emb_vec<VEC>(a.E, a.ib, (uint32_t)seq[t], D, d0, on);
             slk_vstore<VEC>(sE + t * DL + d0, e);
         }
         __syncthreads();
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                         pb[k] = a.bias[it[k]];
                         if (!ADAPT) {
                             nid[k] = a.neg32[(size_t)bl * L + t];
-                            if (on) nrow[k] = slk_vload<VEC>(a.E + (size_t)nid[k] * D + d0);
+                            nrow[k] = slk_emb_vec<VEC>(a.E, a.ib, nid[k], D, d0, on);
                             nb[k] = a.bias[nid[k]];
                         }
                     }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                                 cb[j] = 0.0f;
                                 if (rb + j < nn) {
                                     const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
-                                    if (on) cr[j] = slk_vload<VEC>(a.E + (size_t)cid * D + d0);
+                                    cr[j] = slk_emb_vec<VEC>(a.E, a.ib, cid, D, d0, on);
                                     cb[j] = a.bias[cid];
                                 }
                             }
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
 #pragma unroll
         for (int k = 0; k < CMAX; ++k) {
             const uint32_t id = __shfl(my_it, k, G);
-            e[k] = (on && k < cnt) ? slk_vload<VEC>(a.E + (size_t)id * D + d0) : slk_vzero<VEC>();
+            e[k] = slk_emb_vec<VEC>(a.E, a.ib, id, D, d0, on && k < cnt);
         }
         // ---- (B1) per-chunk sum and non-zero count (rows beyond the chunk are zero: exact no-ops)
         {
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
                     if (kb + k < cnt) {
                         pb[k] = a.bias[it[k]];
                         if (!ADAPT) {
-                            if (on) nrow[k] = slk_vload<VEC>(a.E + (size_t)nid[k] * D + d0);
+                            nrow[k] = slk_emb_vec<VEC>(a.E, a.ib, nid[k], D, d0, on);
                             nb[k] = a.bias[nid[k]];
                         }
                     }
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
                                     cb[j] = 0.0f;
                                     if (rb + j < nn) {
                                         const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
-                                        if (on) cr[j] = slk_vload<VEC>(a.E + (size_t)cid * D + d0);
+                                        cr[j] = slk_emb_vec<VEC>(a.E, a.ib, cid, D, d0, on);
                                         cb[j] = a.bias[cid];
                                     }
                                 }
@@ -447,37 +448,59 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
     if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot / (double)M;
 }
 
-// occurrence r = pos * NP + s (pos = chunk-local timestep): key = (minibatch, item), value = r
+// item of occurrence r = pos * NP + s (pos = chunk-local timestep; s = 0: the sequence's own item,
+// s > 0: candidate s - 1 in the draw layout of sequence/implicit.py:266-286) and its minibatch
+__device__ __forceinline__ uint32_t slk_seq_occ_item(const int64_t *seqs, const uint32_t *neg32, uint32_t r,
+                                                     uint32_t n_seq, uint32_t L, uint32_t NP, uint32_t bsz,
+                                                     uint32_t *mb_out) {
+    const uint32_t nn = NP - 1;
+    const uint32_t pos = r / NP, s = r - pos * NP;
+    const uint32_t sc = pos / L, t = pos - sc * L;
+    const uint32_t mb = sc / bsz;
+    *mb_out = mb;
+    if (s == 0) return (uint32_t)seqs[pos];
+    const uint32_t b0 = mb * bsz, bl = sc - b0;
+    const uint32_t Bs = (n_seq - b0 < bsz) ? n_seq - b0 : bsz;
+    return neg32[(size_t)b0 * nn * L + ((size_t)(s - 1) * Bs + bl) * L + t];
+}
+
+// key = (minibatch, item), value = r
 __global__ __launch_bounds__(256) void k_seq_item_keys(const int64_t *seqs, const uint32_t *neg32, uint32_t nocc,
                                                        uint32_t n_seq, uint32_t L, uint32_t NP, uint32_t bsz,
                                                        unsigned ibits, uint32_t *key, uint32_t *val) {
-    const uint32_t nn = NP - 1;
     for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nocc; r += gridDim.x * 256) {
-        const uint32_t pos = r / NP, s = r - pos * NP;
-        const uint32_t sc = pos / L, t = pos - sc * L;
-        const uint32_t mb = sc / bsz;
-        uint32_t item;
-        if (s == 0) {
-            item = (uint32_t)seqs[pos];
-        } else {
-            const uint32_t b0 = mb * bsz, bl = sc - b0;
-            const uint32_t Bs = (n_seq - b0 < bsz) ? n_seq - b0 : bsz;
-            item = neg32[(size_t)b0 * nn * L + ((size_t)(s - 1) * Bs + bl) * L + t];
-        }
+        uint32_t mb;
+        const uint32_t item = slk_seq_occ_item(seqs, neg32, r, n_seq, L, NP, bsz, &mb);
         key[r] = (mb << ibits) | item;
         val[r] = r;
     }
 }
 
+// BloomEmbedding item layer: occurrence r feeds the n_hash hashed rows of its item:
+// key[r*H + h] = (minibatch, row_h(item)), value = r (same record as the plain occurrence)
+__global__ __launch_bounds__(256) void k_seq_item_bloom_keys(const int64_t *seqs, const uint32_t *neg32,
+                                                             uint32_t nocc, uint32_t n_seq, uint32_t L, uint32_t NP,
+                                                             uint32_t bsz, unsigned cbits, slk_bloom_dev ib,
+                                                             uint32_t *key, uint32_t *val) {
+    const uint32_t H = (uint32_t)ib.n_hash;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nocc * H; e += gridDim.x * 256) {
+        const uint32_t r = e / H, h = e - r * H;
+        uint32_t mb;
+        const uint32_t item = slk_seq_occ_item(seqs, neg32, r, n_seq, L, NP, bsz, &mb);
+        key[e] = (mb << cbits) | slk_bloom_row(ib, item, (int)h);
+        val[e] = r;
+    }
+}
+
 // PoolNet.user_representation's final state for ONE sequence (sequence/implicit.py:331-335)
 template <int VEC, int G>
-__global__ void k_seq_final_repr(const float *E, int D, const int64_t *seq, int L, float *rep) {
+__global__ void k_seq_final_repr(const float *E, slk_bloom_dev ib, int D, const int64_t *seq, int L, float *rep) {
     const int lane = threadIdx.x;
     const int d0 = lane * VEC;
     if (d0 >= D) return;
     slk_vec<VEC> S = slk_vzero<VEC>(), Cn = slk_vzero<VEC>();
     for (int t = 0; t < L; ++t) {
-        const slk_vec<VEC> e = slk_vload<VEC>(E + (size_t)seq[t] * D + d0);
+        const slk_vec<VEC> e = slk_emb_vec<VEC>(E, ib, (uint32_t)seq[t], D, d0, true);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             S.v[i] += e.v[i];
@@ -491,8 +514,9 @@ __global__ void k_seq_final_repr(const float *E, int D, const int64_t *seq, int 
 
 // PoolNet.forward of one representation against many items (sequence/representations.py:136-144)
 template <int VEC, int G>
-__global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const float *V, const float *bi, int D,
-                                                     const int64_t *items, int64_t n, float *out) {
+__global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const float *V, const float *bi,
+                                                     slk_bloom_dev ib, int D, const int64_t *items, int64_t n,
+                                                     float *out) {
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const flo
     const slk_vec<VEC> r = on ? slk_vload<VEC>(rep + d0) : slk_vzero<VEC>();
     for (int64_t k = (int64_t)blockIdx.x * GPB + grp; k < n; k += (int64_t)gridDim.x * GPB) {
         const int64_t i = items ? items[k] : k;
-        const slk_vec<VEC> b = on ? slk_vload<VEC>(V + (size_t)i * D + d0) : slk_vzero<VEC>();
+        const slk_vec<VEC> b = slk_emb_vec<VEC>(V, ib, (uint32_t)i, D, d0, on);
         const float s = bi[i] + slk_group_sum<G>(slk_vdot<VEC>(r, b));
         if (lane == 0) out[k] = s;
     }
@@ -517,8 +541,6 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     int vec, g, rc;
     const unsigned TM = 10u;  // tables 1 (item_embeddings) and 3 (item_biases)
     if ((rc = slk_check_tables(ctx, tables, TM, &vec, &g))) return rc;
-    if (tables->item_bloom)
-        return slk_fail(ctx, SLK_EINVAL, "BloomEmbedding item tables are not supported by the PoolNet path yet");
     if ((rc = slk_check_optim(ctx, optim, TM))) return rc;
     if (n_seq < 0 || batch_size < 1 || seq_len < 1)
         return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: n_seq %lld batch_size %lld seq_len %lld", (long long)n_seq,
@@ -541,19 +563,26 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
         return slk_fail(ctx, SLK_EINVAL, "sequence length %lld x dim %d does not fit the 160 KB LDS of a CU",
                         (long long)L, D);
     const int64_t bsz = batch_size < n_seq ? batch_size : n_seq;
-    if (bsz * L * NP >= ((int64_t)1 << 31))
-        return slk_fail(ctx, SLK_EINVAL, "batch_size * seq_len * (1 + negatives) must be < 2^31");
+    if (bsz * L * NP * (tables->item_bloom ? tables->item_bloom->n_hash : 1) >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "batch_size * seq_len * lookups per timestep must be < 2^31");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
 
     const unsigned ibits = slk_bits_for((uint64_t)tables->num_items - 1);
-    // minibatches per chunk: keys fit 32 bits, occurrences < 2^31, ~4M timesteps of scratch
-    int64_t mb_per_chunk = (int64_t)1 << (32 - ibits);
+    // item_embedding_layer = BloomEmbedding (sequence/representations.py:62-68): hashed-row owner pass
+    slk_bloom_dev ibd;
+    slk_bloom_to_dev(tables->item_bloom, &ibd);
+    const int Hi = ibd.n_hash;
+    const unsigned icbits = Hi ? slk_bits_for((uint64_t)ibd.rows - 1) : 0;
+    const unsigned kbits = icbits > ibits ? icbits : ibits;
+    // minibatches per chunk: keys fit 32 bits, occurrences < 2^31, ~8M timesteps of scratch
+    int64_t mb_per_chunk = (int64_t)1 << (32 - kbits);
     const int64_t cap_ts = ctx->opt_chunk_interactions;  // timesteps of scratch per chunk (~8M)
     if (mb_per_chunk > 32768) mb_per_chunk = 32768;  // gridDim.y of the mask-count launch
     if (mb_per_chunk * bsz * L > cap_ts) mb_per_chunk = cap_ts / (bsz * L);
-    while (mb_per_chunk > 1 && mb_per_chunk * bsz * L * NP >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
+    const int64_t occ_mult = (int64_t)NP * (Hi ? Hi : 1);
+    while (mb_per_chunk > 1 && mb_per_chunk * bsz * L * occ_mult >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
     if (mb_per_chunk < 1) mb_per_chunk = 1;
     const int64_t chunk_seqs = mb_per_chunk * bsz;
     const size_t ns_max = (size_t)(chunk_seqs < n_seq ? chunk_seqs : n_seq);
@@ -563,6 +592,8 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     for (int b = 0; b < 2; ++b) {
         if ((rc = slk_ensure(ctx, ctx->ikey[b], nts_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->ipay[b], nts_max * NP * 4))) return rc;
+        if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIK0 + b], nts_max * NP * Hi * 4))) return rc;
+        if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIP0 + b], nts_max * NP * Hi * 4))) return rc;
     }
     const int RS = 2 * D + ((NP + 3) / 4) * 4;
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * L * RS * 4))) return rc;
@@ -571,12 +602,12 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     if ((rc = slk_ensure(ctx, ctx->extra[SQ_MCOUNT], (size_t)mb_per_chunk * 4))) return rc;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (dense) {
-        const size_t elems[4] = {0, (size_t)tables->num_items * D, 0, (size_t)tables->num_items};
+        const size_t elems[4] = {0, (size_t)(Hi ? ibd.rows : tables->num_items) * D, 0, (size_t)tables->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, TM, s))) return rc;
     }
     const int upd = slk_upd_for(optim->kind);
     seq_pass_fn spass = nullptr;
-    slk_pass_fn ipass = nullptr;
+    slk_pass_fn ipass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr;
     // register-resident sequence pass when a group's chunk of timesteps fits 16 rows of VGPRs
     const bool reg_pass = L <= 256 && (L + NG - 1) / NG <= 16 && ctx->opt_seq_variant != 0;
 #define SLK_PICK(V_, G_)                                                                 \
@@ -587,6 +618,10 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
         else                                                                             \
             spass = adaptive ? k_seq_pass<V_, G_, true> : k_seq_pass<V_, G_, false>;     \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ>(upd);                             \
+        if (Hi) {                                                                        \
+            ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ, SLK_PART_ROWS>(upd);     \
+            ipass_bias = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ, SLK_PART_BIAS>(upd);     \
+        }                                                                                \
     } while (0)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
@@ -636,6 +671,17 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
                                          (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
                                          ibits + mbbits, s)))
             return rc;
+        if (Hi) {
+            hipLaunchKernelGGL(k_seq_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s, cs,
+                               (const uint32_t *)neg32, nocc, ns, (uint32_t)L, (uint32_t)NP, (uint32_t)bsz, icbits, ibd,
+                               (uint32_t *)ctx->extra[SQ_BIK0].p, (uint32_t *)ctx->extra[SQ_BIP0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_seq_item_bloom_keys");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[SQ_BIK0].p,
+                                             (uint32_t *)ctx->extra[SQ_BIK1].p,
+                                             (const uint32_t *)ctx->extra[SQ_BIP0].p,
+                                             (uint32_t *)ctx->extra[SQ_BIP1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+                return rc;
+        }
         slk_prof_end(ctx, s);
 
         for (uint32_t b0 = 0, mb = 0; b0 < ns; b0 += (uint32_t)bsz, ++mb, ++mb_global) {
@@ -657,6 +703,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             q.loss_partial = (double *)ctx->losspart.p;
             q.loss_kind = loss;
             q.C = (int)((L + NG - 1) / NG);
+            q.ib = ibd;
             unsigned sgrid = b1 - b0;
             if (sgrid > max_grid) sgrid = max_grid;
             slk_prof_begin(ctx, SLK_K_SEQ_PASS, s);
@@ -692,9 +739,28 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
             slk_set_opt_coeffs(a, optim);
             a.nt = ctx->opt_nt;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-            hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s,
-                               a);
-            SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ>");
+            if (!Hi) {
+                hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s,
+                                   a);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ>");
+            } else {
+                // item biases are indexed by the item id: plain occurrence list, bias only ...
+                hipLaunchKernelGGL(ipass_bias, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
+                                   0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ,BIAS>");
+                // ... while every occurrence feeds the n_hash hashed rows of the compressed table
+                slk_pass_args r = a;
+                r.mb_loss_out = nullptr;
+                r.ikey = (const uint32_t *)ctx->extra[SQ_BIK1].p;
+                r.ipay = (const uint32_t *)ctx->extra[SQ_BIP1].p;
+                r.ibegin = a.ibegin * (uint32_t)Hi;
+                r.iend = a.iend * (uint32_t)Hi;
+                r.imask = (uint32_t)((1ull << icbits) - 1);
+                r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
+                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
+                                   0, s, r);
+                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ,ROWS>");
+            }
             slk_prof_end(ctx, s);
             if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, TM, s))) return rc;
             optim->step += 1;
@@ -708,8 +774,8 @@ SLK_EXPORT int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, tables, 10u, &vec, &g))) return rc;
-    if (tables->item_bloom)
-        return slk_fail(ctx, SLK_EINVAL, "BloomEmbedding item tables are not supported by the PoolNet path yet");
+    slk_bloom_dev ibd;
+    slk_bloom_to_dev(tables->item_bloom, &ibd);
     if (n < 0 || seq_len < 1 || !d_sequence || (n > 0 && !d_out))
         return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_predict: bad arguments");
     if (n == 0) return SLK_OK;
@@ -722,10 +788,10 @@ SLK_EXPORT int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const
 #define SLK_SEQ_PREDICT(V_, G_)                                                                                  \
     do {                                                                                                         \
         hipLaunchKernelGGL((k_seq_final_repr<V_, G_>), dim3(1), dim3(64), 0, s, (const float *)tables->d_param[1], \
-                           (int)tables->dim, d_sequence, (int)seq_len, rep);                                     \
+                           ibd, (int)tables->dim, d_sequence, (int)seq_len, rep);                                \
         hipLaunchKernelGGL((k_seq_predict<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
                            (const float *)rep, (const float *)tables->d_param[1],                                \
-                           (const float *)tables->d_param[3], (int)tables->dim, d_items, n, d_out);              \
+                           (const float *)tables->d_param[3], ibd, (int)tables->dim, d_items, n, d_out);         \
     } while (0)
     SLK_FOR_LAYOUT(vec, g, SLK_SEQ_PREDICT);
 #undef SLK_SEQ_PREDICT

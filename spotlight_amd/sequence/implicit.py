@@ -14,6 +14,7 @@ from spotlight_amd import _native
 from spotlight_amd.factorization import implicit as _host
 from spotlight_amd.factorization.implicit import _OptimizerBinding
 from spotlight_amd.helpers import _repr_model
+from spotlight_amd.layers import BloomEmbedding
 from spotlight_amd.sequence.representations import PADDING_IDX, PoolNet
 from spotlight_amd.torch_utils import set_seed, shuffle
 
@@ -31,7 +32,7 @@ class ImplicitSequenceModel(object):
     """Implicit-feedback sequence model (next-item prediction from the items seen so far).
 
     Parameters follow spotlight/sequence/implicit.py:85-97.  `representation` must be
-    'pooling' or a :class:`PoolNet`; the reference's 'cnn' / 'lstm' / 'mixture' encoders are
+    'pooling' or a :class:`PoolNet` (whose item_embedding_layer may be a BloomEmbedding); the reference's 'cnn' / 'lstm' / 'mixture' encoders are
     outside this package's scope and raise NotImplementedError.  `use_cuda` is accepted for
     signature compatibility; the model always lives on the HIP device.
     """
@@ -89,8 +90,6 @@ class ImplicitSequenceModel(object):
             raise NotImplementedError(
                 'representation {!r}: only the pooling (PoolNet) representation has a fused gfx950 '
                 'path; the cnn / lstm / mixture encoders are out of scope'.format(self._representation))
-        if type(net.item_embeddings).__name__ == 'BloomEmbedding':
-            raise NotImplementedError('BloomEmbedding item layers are not supported by the PoolNet kernels yet')
         self._net = net.to(_host._model_device())
 
         if self._optimizer_func is None:
@@ -121,7 +120,10 @@ class ImplicitSequenceModel(object):
 
     def _slk_tables(self):
         w = self._net.tables()
-        return _native.make_seq_tables(w[0].data_ptr(), w[1].data_ptr(), w[0].shape[0], w[0].shape[1])
+        layer = self._net.item_embeddings
+        bloom = layer.descriptor() if isinstance(layer, BloomEmbedding) else None
+        return _native.make_seq_tables(w[0].data_ptr(), w[1].data_ptr(), w[1].shape[0], w[0].shape[1],
+                                       item_bloom=bloom)
 
     def _padding_idx(self):
         return self._net.item_embeddings.padding_idx

@@ -11,7 +11,7 @@ package's embedding hot path.
 import torch
 import torch.nn as nn
 
-from spotlight_amd.layers import ScaledEmbedding, ZeroEmbedding
+from spotlight_amd.layers import BloomEmbedding, ScaledEmbedding, ZeroEmbedding
 
 PADDING_IDX = 0
 
@@ -32,12 +32,27 @@ class PoolNet(nn.Module):
         """[item_embeddings.weight, item_biases.weight] (ABI slots 1 and 3 of slk_tables)."""
         return [self.item_embeddings.weight, self.item_biases.weight]
 
+    def _embed(self, ids):
+        """Embedding vectors of `ids` (any shape) -> [..., D]; a BloomEmbedding layer sums its hashed rows
+        (layers.py:236-242), computed here with plain torch ops for prediction-time API parity."""
+        layer = self.item_embeddings
+        if not isinstance(layer, BloomEmbedding):
+            return layer.weight[ids]
+        import numpy as np
+        from sklearn.utils import murmurhash3_32
+        flat = ids.reshape(-1).cpu().numpy().astype(np.int32)
+        rows = np.stack([murmurhash3_32(flat, seed=seed) % layer.compressed_num_embeddings
+                         for seed in layer._masks], axis=1).astype(np.int64)
+        rows[flat == layer.padding_idx] = 0
+        w = layer.weight
+        return w[torch.from_numpy(rows).to(w.device)].sum(1).reshape(tuple(ids.shape) + (w.shape[1],))
+
     def user_representation(self, item_sequences):
         """(all_representations [B, D, L], final_representation [B, D]) as in the reference
         (:76-114): running sums of the item embeddings divided by (per-dimension non-zero
         count + 1).  Plain torch ops on the tables' device; not differentiable here."""
         with torch.no_grad():
-            emb = self.item_embeddings.weight[item_sequences].permute(0, 2, 1)  # [B, D, L]
+            emb = self._embed(item_sequences).permute(0, 2, 1)  # [B, D, L]
             emb = torch.nn.functional.pad(emb, (1, 0))
             sums = torch.cumsum(emb, 2)
             counts = torch.cumsum((emb != 0.0).float(), 2)
@@ -47,7 +62,7 @@ class PoolNet(nn.Module):
     def forward(self, user_representations, targets):
         """predictions[b, t] = bias[target] + <representation[b, :, t], E[target]> (:116-144)."""
         with torch.no_grad():
-            w = self.item_embeddings.weight[targets]          # [B, L, D] or [B, 1, D]
+            w = self._embed(targets)                          # [B, L, D] or [B, 1, D]
             b = self.item_biases.weight[targets].squeeze(-1)  # [B, L]
             if user_representations.dim() == 2:
                 user_representations = user_representations.unsqueeze(2)

@@ -50,13 +50,15 @@ class _Model(object):
 class _SeqModel(object):
     """PoolNet tables (item_embeddings, item_biases) + optimizer state in ABI slots 1 and 3."""
 
-    def __init__(self, be, params, opt='adagrad', **hp):
+    def __init__(self, be, params, opt='adagrad', item_bloom=None, **hp):
         f = lambda x: be.alloc(np.array(x, dtype=np.float32, order='C'))
         self.p = [f(params[0]), f(np.asarray(params[1]).reshape(-1))]
         self.s1 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
         self.s2 = [be.alloc(np.zeros(be.get(x).shape, np.float32)) for x in self.p]
-        I, D = be.get(self.p[0]).shape
-        self.tables = _native.make_seq_tables(be.ptr(self.p[0]), be.ptr(self.p[1]), I, D)
+        rows, D = be.get(self.p[0]).shape
+        I = be.get(self.p[1]).shape[0]  # id range = bias rows (the embedding table may be a compressed one)
+        self.tables = _native.make_seq_tables(be.ptr(self.p[0]), be.ptr(self.p[1]), I, D,
+                                              item_bloom=_bloom_struct(item_bloom, rows))
         slot = lambda xs: [None, be.ptr(xs[0]), None, be.ptr(xs[1])]
         self.optim = _native.make_optim(opt, slot(self.s1), slot(self.s2), **hp)
 

@@ -208,9 +208,10 @@ def make_sequences(rs, n_seq, L, num_items, pad_frac=0.5):
     return seqs
 
 
-def _seq_params(rs, I, D):
+def _seq_params(rs, I, D, rows=None):
+    """`rows`: compressed rows when the item embedding layer is a BloomEmbedding."""
     sc = min(0.3, 1.0 / np.sqrt(D))
-    E = rs.normal(0, sc, (I, D)).astype(np.float32)
+    E = rs.normal(0, sc, (rows or I, D)).astype(np.float32)
     bias = rs.normal(0, 0.1, I).astype(np.float32)
     E[0] = 0.0   # padding row (ScaledEmbedding/ZeroEmbedding with padding_idx=0, layers.py:35-37,54-56)
     bias[0] = 0.0
@@ -218,15 +219,17 @@ def _seq_params(rs, I, D):
 
 
 def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3, epochs=2, tol=2e-5, seed=5,
-                                   pad_frac=0.5):
-    from oracle.oracle import PoolNetOracle
+                                   pad_frac=0.5, bloom=0, ratio=0.4):
+    """`bloom` > 0: PoolNet over a BloomEmbedding item layer with that many hash functions."""
+    from oracle.oracle import PoolNetOracle, bloom_desc
     eng = be.engine
     rs = np.random.RandomState(seed)
     seqs = make_sequences(rs, N, L, I, pad_frac)
-    params = _seq_params(rs, I, D)
+    desc = bloom_desc(n_hash=bloom) if bloom else None
+    params = _seq_params(rs, I, D, rows=int(ratio * I) if bloom else None)
     hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
-    ora = PoolNetOracle(*params, opt=opt, **hp)
-    dev = be.seq_model(params, opt=opt, **hp)
+    ora = PoolNetOracle(*params, opt=opt, item_bloom=desc, **hp)
+    dev = be.seq_model(params, opt=opt, item_bloom=desc, **hp)
     state = np.random.RandomState(9).get_state()
     orng = Rng(state=state)
     eng.rng_set_state(state)
@@ -251,7 +254,7 @@ def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3
     got, ref = eng.rng_get_state(), orng.get_state()
     assert (got[1] == ref[1]).all() and got[2] == ref[2]
     # predict on the engine's own tables (sequence/implicit.py:288-340)
-    po = PoolNetOracle(be.get(dev.p[0]), be.get(dev.p[1]))
+    po = PoolNetOracle(be.get(dev.p[0]), be.get(dev.p[1]), item_bloom=desc)
     out = be.alloc(np.empty(I, dtype=np.float32))
     d_seq = be.alloc(seqs[1])
     eng.poolnet_predict(dev.tables, be.ptr(d_seq), L, None, I, be.ptr(out), be.stream)
@@ -263,18 +266,20 @@ def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3
     assert rel_inf(be.get(out), po.predict(seqs[1], some)) < 1e-5
 
 
-def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11):
+def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11, bloom=0, ratio=0.4):
     """Identical minibatch and parameters: loss within 1e-5 rel, summed gradients within 1e-5 of
     each table's inf-norm; read back through ADAM_DENSE with lr = 0, beta1 = 0."""
-    from oracle.oracle import PoolNetOracle
+    from oracle.oracle import PoolNetOracle, bloom_desc
     eng = be.engine
     rs = np.random.RandomState(seed)
     seqs = make_sequences(rs, B, L, I)
     n_draw = B * L * (nn if loss == 'adaptive_hinge' else 1)
     negs = rs.randint(0, I, n_draw).astype(np.int64)
-    params = _seq_params(rs, I, D)
-    want_loss, want_g = PoolNetOracle(*params, opt='adagrad').step(seqs, negs, loss=loss, n_neg=nn, want_grads=True)
-    dev = be.seq_model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999))
+    desc = bloom_desc(n_hash=bloom) if bloom else None
+    params = _seq_params(rs, I, D, rows=int(ratio * I) if bloom else None)
+    want_loss, want_g = PoolNetOracle(*params, opt='adagrad', item_bloom=desc).step(seqs, negs, loss=loss, n_neg=nn,
+                                                                                   want_grads=True)
+    dev = be.seq_model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999), item_bloom=desc)
     mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
     d_seqs, d_negs = be.alloc(seqs), be.alloc(negs)
     eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), B, L, B, loss, nn, be.ptr(mb_loss),
@@ -288,11 +293,14 @@ def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11
 
 def check_seq_replays_reference_fixture(be, golden_dir, name):
     """Sequence fixtures recorded from the live reference (oracle/make_golden_seq.py)."""
+    from oracle.oracle import bloom_desc
     from oracle.replay import case_from_rec, _oracle_hparams
     eng = be.engine
     rec = np.load(os.path.join(golden_dir, name + '.npz'))
     case = case_from_rec(rec)
-    dev = be.seq_model([rec['init_0'], rec['init_1']], opt=ORACLE_OPT[str(case['opt'])], **_oracle_hparams(case))
+    desc = bloom_desc(n_hash=int(case['bloom'])) if int(case.get('bloom', 0)) else None
+    dev = be.seq_model([rec['init_0'], rec['init_1']], opt=ORACLE_OPT[str(case['opt'])], item_bloom=desc,
+                       **_oracle_hparams(case))
     state = ('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit']))
     eng.rng_set_state(state)
     host = Rng(state=state)
@@ -324,7 +332,7 @@ def check_seq_replays_reference_fixture(be, golden_dir, name):
         bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
         assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
     # predictions on the reference's final tables
-    fin = be.seq_model([rec['final_0'], rec['final_1']])
+    fin = be.seq_model([rec['final_0'], rec['final_1']], item_bloom=desc)
     out = be.alloc(np.empty(int(case['I']), dtype=np.float32))
     d_seq = be.alloc(rec['predict_seq'].astype(np.int64))
     eng.poolnet_predict(fin.tables, be.ptr(d_seq), L, None, int(case['I']), be.ptr(out), be.stream)
@@ -332,7 +340,10 @@ def check_seq_replays_reference_fixture(be, golden_dir, name):
 
 
 SEQ_FIXTURES = ['seq_bpr_adagrad_sparse', 'seq_hinge_sparse_adam', 'seq_pointwise_adam_default',
-                'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam']
+                'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam',
+                # PoolNet over a BloomEmbedding item layer (oracle/make_golden_seq.py bloom)
+                'seq_bloom_bpr_adagrad', 'seq_bloom_pointwise_adam_default', 'seq_bloom_hinge_adagrad',
+                'seq_bloom_adaptive_hinge_adagrad', 'seq_bloom_d64_bpr_adagrad']
 
 
 # ---------------------------------------------------------------------------------------

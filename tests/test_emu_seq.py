@@ -39,6 +39,21 @@ def test_seq_single_step_loss_and_gradients(be, loss):
     ec.check_seq_single_step_gradients(be, loss, 16)
 
 
+@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
+@pytest.mark.parametrize('opt', ['adagrad', 'sparse_adam', 'adam_dense'])
+def test_seq_bloom_item_layer_matches_oracle(be, loss, opt):
+    """PoolNet over a BloomEmbedding item layer (sequence/representations.py:62-68 + layers.py:74-244):
+    in-kernel hashing, sums of hashed rows, hashed-row owner pass + plain bias pass."""
+    ec.check_seq_train_matches_oracle(be, loss, opt, 8, I=60, bloom=2)
+    ec.check_seq_single_step_gradients(be, loss, 16, I=80, bloom=4, ratio=0.25)
+
+
+def test_seq_bloom_other_layouts(be):
+    ec.check_seq_train_matches_oracle(be, 'bpr', 'adagrad', 64, I=300, N=20, L=33, B=8, epochs=1, bloom=4, ratio=0.2)
+    ec.check_seq_train_matches_oracle(be, 'pointwise', 'adagrad', 128, I=90, N=11, L=5, B=8, epochs=1, bloom=3)
+    ec.check_seq_train_matches_oracle(be, 'hinge', 'adagrad', 6, I=50, N=6, L=300, B=3, epochs=1, bloom=2)
+
+
 @pytest.mark.parametrize('name', ec.SEQ_FIXTURES)
 def test_seq_replays_reference_fixture(be, name):
     ec.check_seq_replays_reference_fixture(be, GOLDEN, name)

@@ -101,6 +101,17 @@ def test_seq_single_step_loss_and_gradients(be, loss, D):
     ec.check_seq_single_step_gradients(be, loss, D, I=3000, B=200, L=40, seed=3)
 
 
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('adaptive_hinge', 'adam_dense'), ('pointwise', 'sparse_adam'),
+                                      ('hinge', 'adagrad')])
+def test_seq_bloom_item_layer_matches_oracle(be, loss, opt):
+    """PoolNet over a BloomEmbedding item layer: small case, single-step gradients, and a case with many
+    workgroups / minibatches per chunk (C4-like rows: D=64, 4 hash functions, ratio 0.2)."""
+    ec.check_seq_train_matches_oracle(be, loss, opt, 8, I=60, bloom=2)
+    ec.check_seq_single_step_gradients(be, loss, 64, I=3000, B=200, L=40, seed=3, bloom=4, ratio=0.2)
+    ec.check_seq_train_matches_oracle(be, loss, opt, 64, I=2000, N=600, L=50, B=128, nn=5, epochs=1, tol=1e-4,
+                                      pad_frac=0.2, bloom=4, ratio=0.2)
+
+
 @pytest.mark.parametrize('name', ec.SEQ_FIXTURES)
 def test_seq_replays_reference_fixture(be, name):
     ec.check_seq_replays_reference_fixture(be, GOLDEN, name)

@@ -101,7 +101,8 @@ def test_training_learns_planted_structure():
 
 
 @pytest.mark.parametrize('name', ['seq_bpr_adam_default', 'seq_hinge_adagrad_sparse', 'seq_pointwise_sparse_adam',
-                                  'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam'])
+                                  'seq_adaptive_hinge_adagrad', 'seq_d64_bpr_adagrad', 'seq_d32_adaptive_adam',
+                                  'seq_bloom_bpr_adagrad', 'seq_bloom_adaptive_hinge_adagrad', 'seq_bloom_d64_bpr_adagrad'])
 def test_sequence_model_fit_predict_match_reference_run(name):
     """ImplicitSequenceModel (PoolNet) drop-in API on cuda:0 against the reference's recordings."""
     from test_host_seq_model import check_fit_predict_against_fixture
