@@ -40,6 +40,15 @@ struct slk_seq_args {
     slk_bloom_dev ib;       // item_embedding_layer = BloomEmbedding (n_hash == 0: plain table)
 };
 
+// item vector of `id` in the sequence passes: BLOOM is a compile-time property there, so that the
+// plain path keeps straight-line loads the compiler can batch (a runtime n_hash test cost the
+// register-resident pass its memory-level parallelism: 0.20 -> 0.40 ms)
+template <int VEC, bool BLOOM>
+__device__ __forceinline__ slk_vec<VEC> slk_seq_vec(const slk_seq_args &a, uint32_t id, int D, int d0, bool on) {
+    if (BLOOM) return slk_emb_vec<VEC>(a.E, a.ib, id, D, d0, on);
+    return on ? slk_vload<VEC>(a.E + (size_t)id * D + d0) : slk_vzero<VEC>();
+}
+
 // non-zero sequence entries per minibatch (mask.sum(), losses.py:45-48)
 __global__ __launch_bounds__(256) void k_seq_count(const int64_t *seqs, uint32_t n_seq, uint32_t L, uint32_t bsz,
                                                    uint32_t *mcount) {
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256) void k_seq_count(const int64_t *seqs, uint32_t
     if (threadIdx.x == 0 && red[0]) atomicAdd(&mcount[mb], red[0]);
 }
 
-template <int VEC, int G, bool ADAPT>
+template <int VEC, int G, bool ADAPT, bool BLOOM>
 __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
     HIP_DYNAMIC_SHARED(float, lds)
     __shared__ double red[256];
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
         __syncthreads();  // LDS of the previous sequence no longer in use
         // ---- (A) stage the sequence's item rows
         for (int t = grp; t < L; t += NG) {
-            const slk_vec<VEC> e = slk_emb_vec<VEC>(a.E, a.ib, (uint32_t)seq[t], D, d0, on);
+            const slk_vec<VEC> e = slk_seq_vec<VEC, BLOOM>(a, (uint32_t)seq[t], D, d0, on);
             slk_vstore<VEC>(sE + t * DL + d0, e);
         }
         __syncthreads();
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                         pb[k] = a.bias[it[k]];
                         if (!ADAPT) {
                             nid[k] = a.neg32[(size_t)bl * L + t];
-                            nrow[k] = slk_emb_vec<VEC>(a.E, a.ib, nid[k], D, d0, on);
+                            nrow[k] = slk_seq_vec<VEC, BLOOM>(a, nid[k], D, d0, on);
                             nb[k] = a.bias[nid[k]];
                         }
                     }
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                                 cb[j] = 0.0f;
                                 if (rb + j < nn) {
                                     const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
-                                    cr[j] = slk_emb_vec<VEC>(a.E, a.ib, cid, D, d0, on);
+                                    cr[j] = slk_seq_vec<VEC, BLOOM>(a, cid, D, d0, on);
                                     cb[j] = a.bias[cid];
                                 }
                             }
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
 //   * the ids of the chunk are fetched by one coalesced load per group (lane k holds timestep
 //     t0 + k, broadcast by __shfl) and all of the chunk's row loads are issued back to back
 //     instead of one dependent (id -> row) pair per loop iteration.
-template <int VEC, int G, bool ADAPT, int CMAX>
+template <int VEC, int G, bool ADAPT, bool BLOOM, int CMAX>
 __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
     constexpr int NG = 256 / G;
     constexpr int DL = G * VEC;
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
 #pragma unroll
         for (int k = 0; k < CMAX; ++k) {
             const uint32_t id = __shfl(my_it, k, G);
-            e[k] = slk_emb_vec<VEC>(a.E, a.ib, id, D, d0, on && k < cnt);
+            e[k] = slk_seq_vec<VEC, BLOOM>(a, id, D, d0, on && k < cnt);
         }
         // ---- (B1) per-chunk sum and non-zero count (rows beyond the chunk are zero: exact no-ops)
         {
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
                     if (kb + k < cnt) {
                         pb[k] = a.bias[it[k]];
                         if (!ADAPT) {
-                            nrow[k] = slk_emb_vec<VEC>(a.E, a.ib, nid[k], D, d0, on);
+                            nrow[k] = slk_seq_vec<VEC, BLOOM>(a, nid[k], D, d0, on);
                             nb[k] = a.bias[nid[k]];
                         }
                     }
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
                                     cb[j] = 0.0f;
                                     if (rb + j < nn) {
                                         const uint32_t cid = a.neg32[((size_t)(rb + j) * Bs + bl) * L + t];
-                                        cr[j] = slk_emb_vec<VEC>(a.E, a.ib, cid, D, d0, on);
+                                        cr[j] = slk_seq_vec<VEC, BLOOM>(a, cid, D, d0, on);
                                         cb[j] = a.bias[cid];
                                     }
                                 }
@@ -613,10 +622,14 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
 #define SLK_PICK(V_, G_)                                                                 \
     do {                                                                                 \
         constexpr int CM_ = (G_) < 16 ? (G_) : 16;                                       \
-        if (reg_pass)                                                                    \
-            spass = adaptive ? k_seq_pass_reg<V_, G_, true, CM_> : k_seq_pass_reg<V_, G_, false, CM_>; \
+        if (reg_pass && Hi)                                                              \
+            spass = adaptive ? k_seq_pass_reg<V_, G_, true, true, CM_> : k_seq_pass_reg<V_, G_, false, true, CM_>; \
+        else if (reg_pass)                                                               \
+            spass = adaptive ? k_seq_pass_reg<V_, G_, true, false, CM_> : k_seq_pass_reg<V_, G_, false, false, CM_>; \
+        else if (Hi)                                                                     \
+            spass = adaptive ? k_seq_pass<V_, G_, true, true> : k_seq_pass<V_, G_, false, true>; \
         else                                                                             \
-            spass = adaptive ? k_seq_pass<V_, G_, true> : k_seq_pass<V_, G_, false>;     \
+            spass = adaptive ? k_seq_pass<V_, G_, true, false> : k_seq_pass<V_, G_, false, false>; \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ>(upd);                             \
         if (Hi) {                                                                        \
             ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SEQ, SLK_PART_ROWS>(upd);     \
