@@ -191,6 +191,24 @@ int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d
                         int64_t seq_len, const int64_t *d_items, int64_t n, float *d_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Evaluation side of the path (spotlight/evaluation.py:9-109: mrr_score / sequence_mrr_score call
+ * predict() once per user or sequence and rank on the host with scipy.stats.rankdata).
+ * slk_bilinear_scores: d_out[r * num_items + i] = score of item i for user d_users[r] -- the rows
+ * predict(user) returns (factorization/implicit.py:277-311), a tile of users per pass over the item
+ * table.  slk_poolnet_scores: the same for sequences d_sequences[n_seq][seq_len]
+ * (sequence/implicit.py:288-340).  slk_rank_targets: first d_scores[row][item] = -FLT_MAX for the
+ * (row, item) pairs to exclude (the reference's predictions[train items] = FLOAT_MAX on the negated
+ * scores), then d_rank_out[t] = rankdata(-d_scores[row_t])[item_t] with 'average' ties. */
+int slk_bilinear_scores(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_users, int64_t n_users,
+                        float *d_out, void *stream);
+int slk_poolnet_scores(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_sequences, int64_t n_seq,
+                       int64_t seq_len, float *d_out, void *stream);
+int slk_rank_targets(slk_ctx *ctx, float *d_scores, int64_t n_rows, int64_t num_items,
+                     const int64_t *d_exc_rows, const int64_t *d_exc_items, int64_t n_exc,
+                     const int64_t *d_tgt_rows, const int64_t *d_tgt_items, int64_t n_tgt,
+                     double *d_rank_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Row-sharded BilinearNet training (the reference has no multi-GPU code, the
  * boundary is fixed by BASELINE.json's north star).  One process per GPU; user and item
  * tables (+ biases, optimizer state) are row-sharded cyclically: owner(row) = row % world,

@@ -66,6 +66,11 @@ _PROTOTYPES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_poolnet_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_poolnet_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_void_p]),
+    'slk_rank_targets': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shard_row_floats': (C.c_int, [C.c_int32]),
     'slk_shard_chunk_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
                                         C.c_int64, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
@@ -196,6 +201,20 @@ class Engine(object):
     def poolnet_predict(self, tables, d_sequence, seq_len, d_items, n, d_out, stream=0):
         self._check(self._lib.slk_poolnet_predict(self._ctx, C.byref(tables), d_sequence, int(seq_len), d_items,
                                                   int(n), d_out, stream))
+
+    # -- evaluation: batched predict + on-GPU ranking (include/spotlight_hip.h) -----------
+    def bilinear_scores(self, tables, d_users, n_users, d_out, stream=0):
+        self._check(self._lib.slk_bilinear_scores(self._ctx, C.byref(tables), d_users, int(n_users), d_out, stream))
+
+    def poolnet_scores(self, tables, d_sequences, n_seq, seq_len, d_out, stream=0):
+        self._check(self._lib.slk_poolnet_scores(self._ctx, C.byref(tables), d_sequences, int(n_seq), int(seq_len),
+                                                 d_out, stream))
+
+    def rank_targets(self, d_scores, n_rows, num_items, d_exc_rows, d_exc_items, n_exc, d_tgt_rows, d_tgt_items,
+                     n_tgt, d_rank_out, stream=0):
+        self._check(self._lib.slk_rank_targets(self._ctx, d_scores, int(n_rows), int(num_items), d_exc_rows,
+                                               d_exc_items, int(n_exc), d_tgt_rows, d_tgt_items, int(n_tgt),
+                                               d_rank_out, stream))
 
     # -- row-sharded training phases (include/spotlight_hip.h: slk_shard_*) --------------
     def shard_row_floats(self, dim):

@@ -1,0 +1,128 @@
+"""Ranking / accuracy metrics -- the callers on the far side of predict(), with the signatures and
+semantics of spotlight/evaluation.py:9-244.
+
+mrr_score and sequence_mrr_score have a fast path for this package's models: instead of one
+predict() (a full pass over the item table) and one host scipy.stats.rankdata per user, users are
+scored a tile at a time on the GPU and the rank of every held-out item is counted there
+(csrc/slk_eval.hip: slk_bilinear_scores / slk_poolnet_scores / slk_rank_targets).  Any other model
+object (anything with the reference's predict()) takes the generic per-user route, which is also
+what the tests compare the fast path with.
+"""
+import numpy as np
+import scipy.stats as st
+
+FLOAT_MAX = np.finfo(np.float32).max
+
+_SCORE_BYTES = 256 << 20  # device memory for one tile of score rows
+
+
+def _device_ranks(model, keys, num_items, exclude, targets):
+    """ranks[k] = rankdata(-scores(keys[k]) with exclude[k] pushed last)[targets[k]], computed on
+    the GPU.  keys: array of users (1-D) or sequences (2-D); exclude / targets: lists of index arrays."""
+    import torch
+    from spotlight_amd.factorization import implicit as host
+    per_tile = max(1, _SCORE_BYTES // (4 * num_items))
+    out = []
+    for lo in range(0, len(keys), per_tile):
+        hi = min(lo + per_tile, len(keys))
+        scores = model._batch_scores(keys[lo:hi])
+        device = scores.device
+        flat = lambda lists: (np.repeat(np.arange(hi - lo), [len(x) for x in lists]).astype(np.int64),
+                              np.concatenate(lists).astype(np.int64) if lists else np.zeros(0, np.int64))
+        er, ei = flat([np.asarray(x).reshape(-1) for x in exclude[lo:hi]])
+        tr, ti = flat([np.asarray(x).reshape(-1) for x in targets[lo:hi]])
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        d_er, d_ei, d_tr, d_ti = dev(er), dev(ei), dev(tr), dev(ti)
+        ranks = torch.empty(len(tr), dtype=torch.float64, device=device)
+        host._engine_for(device).rank_targets(scores.data_ptr(), hi - lo, num_items, d_er.data_ptr(), d_ei.data_ptr(),
+                                              len(er), d_tr.data_ptr(), d_ti.data_ptr(), len(tr), ranks.data_ptr(),
+                                              host._stream_for(device))
+        ranks = ranks.cpu().numpy()
+        bounds = np.cumsum([0] + [len(np.asarray(x).reshape(-1)) for x in targets[lo:hi]])
+        out.extend(ranks[bounds[k]:bounds[k + 1]] for k in range(hi - lo))
+    return out
+
+
+def mrr_score(model, test, train=None):
+    """Mean reciprocal rank of each test user's held-out items among all items, train items pushed
+    to the end of the ranking (evaluation.py:9-56).  One score per user with test interactions."""
+    test = test.tocsr()
+    train = train.tocsr() if train is not None else None
+    users = np.array([u for u in range(test.shape[0]) if test.indptr[u + 1] > test.indptr[u]], dtype=np.int64)
+    if hasattr(model, '_batch_scores') and len(users):
+        targets = [test[u].indices for u in users]
+        exclude = [train[u].indices if train is not None else np.zeros(0, np.int64) for u in users]
+        ranks = _device_ranks(model, users, test.shape[1], exclude, targets)
+        return np.array([(1.0 / r).mean() for r in ranks])
+    mrrs = []
+    for user_id in users:
+        predictions = -model.predict(int(user_id))
+        if train is not None:
+            predictions[train[user_id].indices] = FLOAT_MAX
+        mrrs.append((1.0 / st.rankdata(predictions)[test[user_id].indices]).mean())
+    return np.array(mrrs)
+
+
+def sequence_mrr_score(model, test, exclude_preceding=False):
+    """Reciprocal rank of the last element of every test sequence, predicted from the elements
+    before it (evaluation.py:59-109)."""
+    sequences = test.sequences[:, :-1]
+    targets = test.sequences[:, -1:]
+    if hasattr(model, '_batch_scores') and len(sequences):
+        exclude = [sequences[i] if exclude_preceding else np.zeros(0, np.int64) for i in range(len(sequences))]
+        ranks = _device_ranks(model, sequences, model._num_items, exclude, [targets[i] for i in range(len(sequences))])
+        return np.array([(1.0 / r).mean() for r in ranks])
+    mrrs = []
+    for i in range(len(sequences)):
+        predictions = -model.predict(sequences[i])
+        if exclude_preceding:
+            predictions[sequences[i]] = FLOAT_MAX
+        mrrs.append((1.0 / st.rankdata(predictions)[targets[i]]).mean())
+    return np.array(mrrs)
+
+
+def _get_precision_recall(predictions, targets, k):
+    top = predictions[:k]
+    hits = len(set(top).intersection(set(targets)))
+    return float(hits) / len(top), float(hits) / len(targets)
+
+
+def sequence_precision_recall_score(model, test, k=10, exclude_preceding=False):
+    """Precision@k / recall@k of the last k elements of every test sequence, predicted from the
+    elements before them (evaluation.py:112-162)."""
+    sequences = test.sequences[:, :-k]
+    targets = test.sequences[:, -k:]
+    pairs = []
+    for i in range(len(sequences)):
+        predictions = -model.predict(sequences[i])
+        if exclude_preceding:
+            predictions[sequences[i]] = FLOAT_MAX
+        pairs.append(_get_precision_recall(predictions.argsort()[:k], targets[i], k))
+    pairs = np.array(pairs)
+    return pairs[:, 0], pairs[:, 1]
+
+
+def precision_recall_score(model, test, train=None, k=10):
+    """Precision@k and recall@k per test user; k may be an array, giving one column per value
+    (evaluation.py:172-223)."""
+    test = test.tocsr()
+    train = train.tocsr() if train is not None else None
+    ks = np.array([k]) if np.isscalar(k) else k
+    precision, recall = [], []
+    for user_id, row in enumerate(test):
+        if not len(row.indices):
+            continue
+        predictions = -model.predict(user_id)
+        if train is not None:
+            predictions[train[user_id].indices] = FLOAT_MAX
+        order = predictions.argsort()
+        p, r = zip(*[_get_precision_recall(order, row.indices, x) for x in ks])
+        precision.append(p)
+        recall.append(r)
+    return np.array(precision).squeeze(), np.array(recall).squeeze()
+
+
+def rmse_score(model, test):
+    """Root mean squared error of predict(user_ids, item_ids) against test.ratings (evaluation.py:226-244)."""
+    predictions = model.predict(test.user_ids, test.item_ids)
+    return np.sqrt(((test.ratings - predictions) ** 2).mean())

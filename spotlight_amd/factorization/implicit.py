@@ -281,3 +281,16 @@ class ImplicitFactorizationModel(object):
                                 d_items.data_ptr() if d_items is not None else None, n,
                                 out.data_ptr(), _stream_for(device))
         return out.cpu().numpy().flatten()
+
+    def _batch_scores(self, user_ids):
+        """[len(user_ids), num_items] device tensor: row r == predict(user_ids[r]) (bit-identical), a
+        tile of users per pass over the item table (csrc/slk_eval.hip); used by evaluation.mrr_score."""
+        users = np.ascontiguousarray(np.asarray(user_ids).reshape(-1), dtype=np.int64)
+        self._check_input(users, None, allow_items_none=True)
+        self._net.train(False)
+        device = self._net.tables()[0].device
+        d_users = torch.from_numpy(users).to(device)
+        out = torch.empty((users.size, self._num_items), dtype=torch.float32, device=device)
+        _engine_for(device).bilinear_scores(self._slk_tables(), d_users.data_ptr(), users.size, out.data_ptr(),
+                                            _stream_for(device))
+        return out

@@ -193,3 +193,17 @@ class ImplicitSequenceModel(object):
         engine.poolnet_predict(self._slk_tables(), d_seq.data_ptr(), seq.size, d_items.data_ptr(), items.size,
                                out.data_ptr(), _host._stream_for(device))
         return out.cpu().numpy().flatten()
+
+    def _batch_scores(self, sequences):
+        """[n_sequences, num_items] device tensor: row r == predict(sequences[r]) (bit-identical), a tile
+        of sequences per pass over the item table (csrc/slk_eval.hip); used by evaluation.sequence_mrr_score."""
+        self._net.train(False)
+        sequences = np.atleast_2d(sequences)
+        self._check_input(sequences)
+        seqs = np.ascontiguousarray(sequences.astype(np.int64))
+        device = self._net.tables()[0].device
+        d_seqs = torch.from_numpy(seqs).to(device)
+        out = torch.empty((seqs.shape[0], self._num_items), dtype=torch.float32, device=device)
+        _host._engine_for(device).poolnet_scores(self._slk_tables(), d_seqs.data_ptr(), seqs.shape[0], seqs.shape[1],
+                                                 out.data_ptr(), _host._stream_for(device))
+        return out

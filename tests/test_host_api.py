@@ -1,0 +1,159 @@
+"""Host-side callers around the training path -- cross_validation, datasets.synthetic, evaluation --
+against values recorded from the live reference (oracle/make_golden_host.py -> golden/host_api.npz),
+and the GPU fast path of the ranking metrics (csrc/slk_eval.hip through the emulator build) against
+the generic per-user scipy route."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from emu_backend import emu_lib
+from spotlight_amd import _native
+from spotlight_amd import evaluation as ev
+from spotlight_amd.cross_validation import random_train_test_split, shuffle_interactions, user_based_train_test_split
+from spotlight_amd.datasets.synthetic import generate_sequential
+from spotlight_amd.factorization import implicit as host
+from spotlight_amd.factorization.implicit import ImplicitFactorizationModel
+from spotlight_amd.interactions import Interactions
+from spotlight_amd.layers import BloomEmbedding
+from spotlight_amd.sequence.implicit import ImplicitSequenceModel
+from spotlight_amd.sequence.representations import PoolNet
+
+
+class FixedScores(object):
+    """As in oracle/make_golden_host.py."""
+
+    def __init__(self, num_users, num_items, seed):
+        rs = np.random.RandomState(seed)
+        self.table = rs.normal(size=(num_users, num_items)).astype(np.float32)
+        self.table[:, ::7] = 0.25
+        self._num_items = num_items
+
+    def predict(self, user_ids, item_ids=None):
+        if item_ids is None:
+            if np.ndim(user_ids) == 0:
+                return self.table[int(user_ids)].copy()
+            return self.table[int(np.asarray(user_ids).sum()) % len(self.table)].copy()
+        return self.table[np.asarray(user_ids).reshape(-1), np.asarray(item_ids).reshape(-1)].copy()
+
+
+class OnlyPredict(object):
+    """Hides a model's fast-path hook: evaluation then takes the generic per-user route."""
+
+    def __init__(self, model):
+        self._model, self._num_items = model, model._num_items
+
+    def predict(self, *a, **kw):
+        return self._model.predict(*a, **kw)
+
+
+@pytest.fixture(scope='module')
+def rec():
+    return np.load(os.path.join(GOLDEN, 'host_api.npz'))
+
+
+@pytest.fixture(scope='module')
+def data():
+    return generate_sequential(num_users=30, num_items=60, num_interactions=900, concentration_parameter=0.1, order=3,
+                               random_state=np.random.RandomState(11))
+
+
+def test_synthetic_generator_and_splits_match_the_reference(rec, data):
+    assert np.array_equal(data.user_ids, rec['gen_users']) and np.array_equal(data.item_ids, rec['gen_items'])
+    assert np.array_equal(data.timestamps, rec['gen_ts']) and np.array_equal(data.ratings, rec['gen_ratings'])
+    assert data.user_ids.dtype == rec['gen_users'].dtype and data.item_ids.dtype == rec['gen_items'].dtype
+    sh = shuffle_interactions(data, random_state=np.random.RandomState(12))
+    assert np.array_equal(sh.user_ids, rec['shuffle_users']) and np.array_equal(sh.item_ids, rec['shuffle_items'])
+    tr, te = random_train_test_split(data, test_percentage=0.25, random_state=np.random.RandomState(13))
+    assert np.array_equal(tr.user_ids, rec['rs_train_users']) and np.array_equal(tr.item_ids, rec['rs_train_items'])
+    assert np.array_equal(te.user_ids, rec['rs_test_users']) and np.array_equal(te.item_ids, rec['rs_test_items'])
+    assert (tr.num_users, tr.num_items) == (30, 60) and len(tr) + len(te) == len(data)
+    utr, ute = user_based_train_test_split(data, test_percentage=0.3, random_state=np.random.RandomState(14))
+    assert np.array_equal(utr.user_ids, rec['us_train_users']) and np.array_equal(ute.user_ids, rec['us_test_users'])
+    assert np.array_equal(ute.item_ids, rec['us_test_items'])
+    assert not set(utr.user_ids) & set(ute.user_ids)
+    seq = te.to_sequence(max_sequence_length=6, min_sequence_length=2, step_size=2)
+    assert np.array_equal(seq.sequences, rec['to_seq'])
+
+
+def test_metrics_match_the_reference_on_fixed_scores(rec, data):
+    tr, te = random_train_test_split(data, test_percentage=0.25, random_state=np.random.RandomState(13))
+    seq = te.to_sequence(max_sequence_length=6, min_sequence_length=2, step_size=2)
+    model = FixedScores(30, 60, 15)
+    assert np.allclose(ev.mrr_score(model, te), rec['mrr'], rtol=1e-12)
+    assert np.allclose(ev.mrr_score(model, te, train=tr), rec['mrr_train'], rtol=1e-12)
+    assert np.allclose(ev.sequence_mrr_score(model, seq), rec['seq_mrr'], rtol=1e-12)
+    assert np.allclose(ev.sequence_mrr_score(model, seq, exclude_preceding=True), rec['seq_mrr_excl'], rtol=1e-12)
+    p, r = ev.precision_recall_score(model, te, train=tr, k=5)
+    assert np.array_equal(p, rec['prec5']) and np.array_equal(r, rec['rec5'])
+    p, r = ev.precision_recall_score(model, te, k=np.array([1, 3, 10]))
+    assert np.array_equal(p, rec['prec_multi']) and np.array_equal(r, rec['rec_multi'])
+    p, r = ev.sequence_precision_recall_score(model, seq, k=2, exclude_preceding=True)
+    assert np.array_equal(p, rec['seq_prec2']) and np.array_equal(r, rec['seq_rec2'])
+    assert abs(ev.rmse_score(model, te) - float(rec['rmse'])) < 1e-12
+
+
+@pytest.fixture()
+def emu_device(monkeypatch):
+    eng = _native.Engine(0, lib=emu_lib())
+    monkeypatch.setattr(host, '_engine_for', lambda device: eng)
+    monkeypatch.setattr(host, '_stream_for', lambda device: 0)
+    monkeypatch.setattr(host, '_model_device', lambda: torch.device('cpu'))
+    yield eng
+    eng.close()
+
+
+def check_factorization_fast_path(bloom=False, **kw):
+    data = generate_sequential(num_users=40, num_items=70, num_interactions=1500, random_state=np.random.RandomState(3))
+    tr, te = random_train_test_split(data, random_state=np.random.RandomState(4))
+    extra = {}
+    if bloom:
+        from spotlight_amd.factorization.representations import BilinearNet
+        extra['representation'] = BilinearNet(40, 70, 16, item_embedding_layer=BloomEmbedding(70, 16, 0.5, 2))
+    model = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=2, batch_size=128,
+                                       random_state=np.random.RandomState(5), **extra, **kw)
+    model.fit(tr)
+    users = np.array([0, 7, 39, 7], dtype=np.int64)
+    rows = model._batch_scores(users).cpu().numpy()
+    for r, u in enumerate(users):
+        assert np.array_equal(rows[r], model.predict(int(u)))  # bit-identical to predict(user)
+    # duplicate scores in a row: ties must take scipy's 'average' rank
+    with torch.no_grad():
+        model._net.item_embeddings.weight[5] = model._net.item_embeddings.weight[6]
+        model._net.item_biases.weight[5] = model._net.item_biases.weight[6]
+    for train in (None, tr):
+        fast = ev.mrr_score(model, te, train=train)
+        slow = ev.mrr_score(OnlyPredict(model), te, train=train)
+        assert fast.shape == slow.shape and np.allclose(fast, slow, rtol=1e-12, atol=0)
+    return model
+
+
+def check_sequence_fast_path(bloom=False, **kw):
+    data = generate_sequential(num_users=40, num_items=70, num_interactions=1500, random_state=np.random.RandomState(3))
+    seq = data.to_sequence(max_sequence_length=8, min_sequence_length=3, step_size=2)
+    rep = 'pooling'
+    if bloom:
+        rep = PoolNet(70, 16, item_embedding_layer=BloomEmbedding(70, 16, 0.5, 2))
+    model = ImplicitSequenceModel(loss='bpr', representation=rep, embedding_dim=16, n_iter=2, batch_size=64,
+                                  random_state=np.random.RandomState(5), **kw)
+    model.fit(seq)
+    rows = model._batch_scores(seq.sequences[:5]).cpu().numpy()
+    for r in range(5):
+        assert np.array_equal(rows[r], model.predict(seq.sequences[r]))
+    for excl in (False, True):
+        fast = ev.sequence_mrr_score(model, seq, exclude_preceding=excl)
+        slow = ev.sequence_mrr_score(OnlyPredict(model), seq, exclude_preceding=excl)
+        assert fast.shape == slow.shape and np.allclose(fast, slow, rtol=1e-12, atol=0)
+    return model
+
+
+@pytest.mark.parametrize('bloom', [False, True])
+def test_mrr_fast_path_matches_per_user_route(emu_device, bloom):
+    check_factorization_fast_path(bloom)
+
+
+@pytest.mark.parametrize('bloom', [False, True])
+def test_sequence_mrr_fast_path_matches_per_sequence_route(emu_device, bloom):
+    check_sequence_fast_path(bloom)
