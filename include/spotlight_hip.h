@@ -190,6 +190,15 @@ int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, 
 int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_sequence,
                         int64_t seq_len, const int64_t *d_items, int64_t n, float *d_out, void *stream);
 
+/* spotlight/torch_utils.py:35-52 (shuffle): d_perm_out[0..n) = the array numpy's legacy
+ * RandomState.shuffle(arange(n)) produces from the ctx RNG state, bit for bit (Fisher-Yates with
+ * masked-rejection draws over the MT19937 stream), computed on the GPU; the RNG state afterwards is
+ * numpy's.  Synchronises the stream a few dozen times (once per power-of-two range of the draw).
+ * slk_gather_rows_i64: d_dst[r][:] = d_src[d_perm[r]][:] (the x[shuffle_indices] that follows). */
+int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, void *stream);
+int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int64_t *d_perm, int64_t n, int64_t row_len,
+                        int64_t *d_dst, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Evaluation side of the path (spotlight/evaluation.py:9-109: mrr_score / sequence_mrr_score call
  * predict() once per user or sequence and rank on the host with scipy.stats.rankdata).

@@ -66,6 +66,8 @@ _PROTOTYPES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_poolnet_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_shuffle_perm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_gather_rows_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_bilinear_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_poolnet_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_void_p]),
@@ -201,6 +203,13 @@ class Engine(object):
     def poolnet_predict(self, tables, d_sequence, seq_len, d_items, n, d_out, stream=0):
         self._check(self._lib.slk_poolnet_predict(self._ctx, C.byref(tables), d_sequence, int(seq_len), d_items,
                                                   int(n), d_out, stream))
+
+    # -- epoch shuffle on the device (include/spotlight_hip.h: slk_shuffle_perm) ----------
+    def shuffle_perm(self, n, d_perm_out, stream=0):
+        self._check(self._lib.slk_shuffle_perm(self._ctx, int(n), d_perm_out, stream))
+
+    def gather_rows_i64(self, d_src, d_perm, n, row_len, d_dst, stream=0):
+        self._check(self._lib.slk_gather_rows_i64(self._ctx, d_src, d_perm, int(n), int(row_len), d_dst, stream))
 
     # -- evaluation: batched predict + on-GPU ranking (include/spotlight_hip.h) -----------
     def bilinear_scores(self, tables, d_users, n_users, d_out, stream=0):

@@ -81,6 +81,8 @@ struct slk_ctx {
     std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
     std::vector<uint64_t> sh_host, sh_host2;     // host staging for small H2D tables (begin / commit)
 
+    int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
+
     // profiling
     bool prof_on = false;
     std::vector<slk_prof_span> spans;
@@ -135,6 +137,8 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
 int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 int slk_sort_reserve(slk_ctx *ctx, size_t n);
+// slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
+int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
 
 static inline unsigned slk_bits_for(uint64_t max_value) {

@@ -233,6 +233,44 @@ __global__ __launch_bounds__(256) void k_fill_zero(uint32_t *out32, int64_t *out
     }
 }
 
+// ctx->raw[b*624 ..] = state block b (untempered) for b = 0 .. nblocks-1, block 0 = the ctx's
+// current key block (ctx->raw must hold nblocks*624 words).
+int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s) {
+    uint32_t *raw = (uint32_t *)ctx->raw.p;
+    {
+        // block 0 of every launch is its input key block; further launches (> 10.2 M words)
+        // restart from the last block of the previous one
+        const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS;
+        const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_generate_jump,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        unsigned long long start = 0;  // index of the launch's block 0
+        const uint32_t *key_src = ctx->d_rng->key;
+        while (true) {
+            const unsigned long long nb_l = (nblocks - start < cap) ? nblocks - start : cap;
+            const unsigned wgs = (unsigned)((nb_l + SLK_MT_JUMP_BLOCKS - 1) / SLK_MT_JUMP_BLOCKS);
+            if (wgs > 1 && !ctx->d_jump) {
+                const uint32_t *tab = slk_mt_jump_table(ctx);
+                if (!tab) return SLK_EIO;
+                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
+                SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
+                SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
+            }
+            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(SLK_MT_THREADS), lds_bytes, s, key_src,
+                               (const uint32_t *)ctx->d_jump, raw + start * SLK_MT_N, (int)nb_l);
+            SLK_LAUNCH_CHECK(ctx, "k_mt_generate_jump");
+            if (start + nb_l >= nblocks) break;
+            start += nb_l - 1;
+            key_src = raw + start * SLK_MT_N;
+        }
+    }
+    return SLK_OK;
+}
+
 int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,
                    hipStream_t s) {
     if (num_items < 1 || num_items > (int64_t)1 << 32)
@@ -268,37 +306,7 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
     unsigned long long *off = (unsigned long long *)ctx->cnt.p;
     uint32_t *cnt = (uint32_t *)(off + nb);
 
-    {
-        // block 0 of every launch is its input key block; further launches (> 10.2 M words)
-        // restart from the last block of the previous one
-        const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS;
-        const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_generate_jump,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set = true;
-        }
-        unsigned long long start = 0;  // index of the launch's block 0
-        const uint32_t *key_src = ctx->d_rng->key;
-        while (true) {
-            const unsigned long long nb_l = (nblocks - start < cap) ? nblocks - start : cap;
-            const unsigned wgs = (unsigned)((nb_l + SLK_MT_JUMP_BLOCKS - 1) / SLK_MT_JUMP_BLOCKS);
-            if (wgs > 1 && !ctx->d_jump) {
-                const uint32_t *tab = slk_mt_jump_table(ctx);
-                if (!tab) return SLK_EIO;
-                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
-                SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
-                SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
-            }
-            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(SLK_MT_THREADS), lds_bytes, s, key_src,
-                               (const uint32_t *)ctx->d_jump, raw + start * SLK_MT_N, (int)nb_l);
-            SLK_LAUNCH_CHECK(ctx, "k_mt_generate_jump");
-            if (start + nb_l >= nblocks) break;
-            start += nb_l - 1;
-            key_src = raw + start * SLK_MT_N;
-        }
-    }
+    if ((rc = slk_mt_generate_blocks(ctx, nblocks, s))) return rc;
     slk_accept_args a;
     a.raw = raw;
     a.st = ctx->d_rng;

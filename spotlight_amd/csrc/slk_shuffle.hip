@@ -1,0 +1,404 @@
+// slk_shuffle.hip -- numpy's legacy RandomState.shuffle(arange(n)) on the GPU, bit-exact.
+//
+// Replaces the host half of spotlight/torch_utils.py:35-52 (shuffle): the reference permutes the
+// epoch's ids with numpy's serial Fisher-Yates,
+//     for i = n-1 .. 1:  j = rk_interval(i)  (v = next32() & mask(i) until v <= i);  swap(x[i], x[j])
+// which costs 20-30 ns per interaction on the host -- 50-100x the time the GPU needs to TRAIN on
+// that interaction.  Both halves of the loop are sequential as written; both
+// have an exact parallel form:
+//
+//  (1) THE DRAWS.  Whether raw word t is accepted depends on how many words before it were
+//      (i = n-1 - #accepted).  Per power-of-two range of i (constant mask) the decisions
+//      d(t) = [A(t) < need  and  v_t <= hi - A(t)],  A = exclusive prefix sum of d
+//      are found by fixpoint iteration from the expected curve A(t) = (hi+1)(1 - exp(-t/(mask+1))):
+//      if A is right on [0, t) then so is the next iterate on [0, t], so the first wrong index
+//      advances every sweep (no cycles), and because shifting A by delta flips only ~0.7 delta
+//      decisions the error contracts geometrically -- ~20 sweeps of an 8-byte-per-word scan
+//      instead of 1e8 dependent steps.  The last 4095 draws are taken by one thread.
+//  (2) THE SWAPS.  Step i makes x[i] final and moves the value that sat at i into j_i.  Hence, with
+//      T_p = the steps i' > p with j_i' = p in time order:  X[p] (the value at p when step p
+//      runs) = X[last of T_p] or p if none -- a forest of pointers to larger indices, resolved by
+//      pointer doubling -- and  final[first of T_p] = p,  final[next of T_p] = X[previous of T_p],
+//      final[i] = X[i] for self-swaps and for position 0.  T_p = one stable radix sort of (j_i, i).
+//
+// The RNG state afterwards is exactly numpy's (block of the last consumed word, pos = offset + 1),
+// so the negatives drawn next continue the same stream.
+#include <math.h>
+
+#include "slk_common.h"
+
+#define SLK_MT_N 624
+#define FY_TILE 2048       // words per workgroup in the scan kernels (256 threads x 8)
+#define FY_TAIL 4096       // draws for i < FY_TAIL are taken sequentially
+
+enum { FY_B0 = 26, FY_B1, FY_B2, FY_B3, FY_B4, FY_SMALL };  // ctx->extra slots
+
+__device__ __forceinline__ uint32_t fy_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+struct fy_args {
+    const uint32_t *raw;     // untempered stream, word 0 = first word of the ctx's key block
+    unsigned long long w0;   // absolute index of the window's first word
+    uint32_t W;              // window length
+    uint32_t mask, hi, need; // this range: draws for i = hi, hi-1, ..., hi-need+1 (all share mask)
+    const uint32_t *A_old;   // exclusive count of accepted words before t (current iterate)
+    uint32_t *A_new;
+};
+
+__device__ __forceinline__ bool fy_decide(const fy_args &a, uint32_t t, uint32_t *v) {
+    if (t >= a.W) return false;
+    const uint32_t acc = a.A_old[t];
+    if (acc >= a.need) return false;  // the range is complete: later words belong to the next one
+    *v = fy_temper(a.raw[a.w0 + t]) & a.mask;
+    return *v <= a.hi - acc;
+}
+
+__global__ __launch_bounds__(256) void k_fy_init(uint32_t *A, uint32_t W, uint32_t need, uint32_t hi, uint32_t mask) {
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < W; t += gridDim.x * 256) {
+        const double x = ((double)hi + 1.0) * (1.0 - exp(-(double)t / ((double)mask + 1.0)));
+        A[t] = x >= (double)need ? need : (uint32_t)x;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fy_count(fy_args a, uint32_t *cnt) {
+    __shared__ unsigned s[256];
+    const uint32_t base = blockIdx.x * FY_TILE + threadIdx.x * 8;
+    unsigned c = 0;
+    for (int j = 0; j < 8; ++j) {
+        uint32_t v;
+        c += fy_decide(a, base + j, &v) ? 1u : 0u;
+    }
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s[0];
+}
+
+// exclusive scan of cnt[nb] -> off[nb]
+__global__ __launch_bounds__(256) void k_fy_scan(const uint32_t *cnt, uint32_t *off, int nb) {
+    __shared__ uint32_t s[256];
+    __shared__ uint32_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + t;
+        const uint32_t v = (i < nb) ? cnt[i] : 0u;
+        s[t] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint32_t x = (t >= d) ? s[t - d] : 0u;
+            __syncthreads();
+            s[t] += x;
+            __syncthreads();
+        }
+        if (i < nb) off[i] = carry + s[t] - v;
+        __syncthreads();
+        if (t == 255) carry += s[255];
+        __syncthreads();
+    }
+}
+
+// A_new = exclusive prefix sum of the decisions taken with A_old; *changed |= (A_new != A_old)
+__global__ __launch_bounds__(256) void k_fy_apply(fy_args a, const uint32_t *off, int *changed) {
+    __shared__ unsigned s[256];
+    const int t = threadIdx.x;
+    const uint32_t base = blockIdx.x * FY_TILE + t * 8;
+    bool ok[8];
+    unsigned c = 0;
+    for (int j = 0; j < 8; ++j) {
+        uint32_t v;
+        ok[j] = fy_decide(a, base + j, &v);
+        c += ok[j] ? 1u : 0u;
+    }
+    s[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned x = (t >= d) ? s[t - d] : 0u;
+        __syncthreads();
+        s[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = off[blockIdx.x] + (s[t] - c);
+    bool diff = false;
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < a.W) {
+            diff |= a.A_old[base + j] != run;
+            a.A_new[base + j] = run;
+        }
+        run += ok[j] ? 1u : 0u;
+    }
+    if (diff) *changed = 1;
+}
+
+// the converged decisions: J[g0 + A(t)] = v_t for the accepted words; *consumed = words used by the range
+__global__ __launch_bounds__(256) void k_fy_emit(fy_args a, uint32_t *J, uint32_t g0, uint32_t *consumed) {
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < a.W; t += gridDim.x * 256) {
+        uint32_t v;
+        if (fy_decide(a, t, &v)) {
+            const uint32_t acc = a.A_old[t];
+            J[g0 + acc] = v;
+            if (acc == a.need - 1) *consumed = t + 1;
+        }
+    }
+}
+
+// the last draws (i = i_start .. 1), one thread: rk_interval(i) for each
+__global__ void k_fy_tail(const uint32_t *raw, unsigned long long w0, unsigned long long total_words,
+                          uint32_t i_start, uint32_t *J, uint32_t g0, uint32_t *consumed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long w = w0;
+    uint32_t g = g0;
+    bool ok = true;
+    for (uint32_t i = i_start; i >= 1 && ok; --i) {
+        uint32_t mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do {
+            if (w >= total_words) { ok = false; break; }
+            v = fy_temper(raw[w++]) & mask;
+        } while (v > i);
+        if (ok) J[g++] = v;
+    }
+    *consumed = ok ? (uint32_t)(w - w0) : 0xffffffffu;
+}
+
+// step g (i = n-1-g) writes position j: key = j, value = i; self-swaps get the sentinel key n
+__global__ __launch_bounds__(256) void k_fy_keys(const uint32_t *J, uint32_t n, uint32_t *key, uint32_t *val) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g + 1 < n; g += gridDim.x * 256) {
+        const uint32_t i = n - 1 - g, j = J[g];
+        key[g] = (j == i) ? n : j;
+        val[g] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fy_iota(uint32_t *R, uint32_t n) {
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) R[p] = p;
+}
+
+// R[p] = the LAST step (smallest i' > p) that wrote position p, if any
+__global__ __launch_bounds__(256) void k_fy_pred(const uint32_t *key, const uint32_t *val, uint32_t m, uint32_t n,
+                                                 uint32_t *R) {
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < m; e += gridDim.x * 256) {
+        const uint32_t k = key[e];
+        if (k != n && (e + 1 == m || key[e + 1] != k)) R[k] = val[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fy_jump(const uint32_t *R0, uint32_t *R1, uint32_t n, int *changed) {
+    bool diff = false;
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const uint32_t r = R0[p], rr = R0[r];
+        R1[p] = rr;
+        diff |= rr != r;
+    }
+    if (diff) *changed = 1;
+}
+
+__global__ __launch_bounds__(256) void k_fy_final(const uint32_t *key, const uint32_t *val, uint32_t m, uint32_t n,
+                                                  const uint32_t *X, int64_t *perm) {
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < m; e += gridDim.x * 256) {
+        const uint32_t k = key[e], i = val[e];
+        uint32_t out;
+        if (k == n) out = X[i];                                  // swap with itself
+        else if (e == 0 || key[e - 1] != k) out = k;             // first writer of p takes p's own value
+        else out = X[val[e - 1]];                                // ... the next one what the previous moved in
+        perm[i] = (int64_t)out;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) perm[0] = (int64_t)X[0];
+}
+
+__global__ __launch_bounds__(256) void k_fy_rng_finalize(slk_rng_dev *st, const uint32_t *raw, unsigned long long t_last) {
+    const unsigned long long blk = t_last / SLK_MT_N;
+    for (int i = threadIdx.x; i < SLK_MT_N; i += 256) st->key[i] = raw[blk * SLK_MT_N + i];
+    __syncthreads();
+    if (threadIdx.x == 0) st->pos = (int32_t)(t_last % SLK_MT_N) + 1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T *src, const int64_t *perm, int64_t n, int64_t row_len,
+                                                     T *dst) {
+    const int64_t total = n * row_len;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / row_len, c = e - r * row_len;
+        dst[e] = src[perm[r] * row_len + c];
+    }
+}
+
+static inline unsigned fy_grid(const slk_ctx *ctx, size_t n) {
+    size_t b = (n + 255) / 256, cap = (size_t)ctx->num_cus * 16;
+    if (b > cap) b = cap;
+    return (unsigned)(b ? b : 1);
+}
+
+// expected raw words for the draws i = hi .. lo (one mask): sum (mask+1)/(i+1)
+static double fy_expected_words(double mask, double lo, double hi) { return (mask + 1.0) * log((hi + 1.0) / lo); }
+
+SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (n < 0 || n >= ((int64_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "slk_shuffle_perm: n %lld outside [0, 2^31)", (long long)n);
+    if (n == 0) return SLK_OK;
+    if (!d_perm_out) return slk_fail(ctx, SLK_EINVAL, "slk_shuffle_perm: d_perm_out is NULL");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    const uint32_t N = (uint32_t)n;
+    int rc;
+    if (N == 1) {  // nothing to draw
+        SLK_HIP(ctx, hipMemsetAsync(d_perm_out, 0, 8, s));
+        return SLK_OK;
+    }
+    slk_prof_begin(ctx, SLK_K_SAMPLE, s);
+    // ---- raw words: expected count of every range + 12 sigma (variance per draw <= 2) + slack
+    double need_words = 0.0;
+    for (uint32_t hi = N - 1; hi >= 1;) {
+        uint32_t mask = hi;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t lo = (mask >> 1) + 1;  // 2^k
+        need_words += fy_expected_words((double)mask, (double)lo, (double)hi);
+        hi = lo - 1;
+    }
+    need_words += 12.0 * sqrt(2.0 * (double)N) + 4096.0;
+    int32_t pos0 = 0;
+    SLK_HIP(ctx, hipStreamSynchronize(s));
+    SLK_HIP(ctx, hipMemcpy(&pos0, &ctx->d_rng->pos, sizeof(pos0), hipMemcpyDeviceToHost));
+    const unsigned long long nblocks = 1ull + (unsigned long long)((need_words + (double)pos0) / SLK_MT_N) + 1ull;
+    const unsigned long long total_words = nblocks * SLK_MT_N;
+    if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
+    for (int b = 0; b < 5; ++b)
+        if ((rc = slk_ensure(ctx, ctx->extra[FY_B0 + b], (size_t)N * 4 + 64))) return rc;
+    const size_t nb_max = ((size_t)N * 2 + FY_TILE - 1) / FY_TILE + 2;
+    if ((rc = slk_ensure(ctx, ctx->extra[FY_SMALL], nb_max * 8 + 64))) return rc;
+    if ((rc = slk_mt_generate_blocks(ctx, nblocks, s))) return rc;
+    const uint32_t *raw = (const uint32_t *)ctx->raw.p;
+    uint32_t *J = (uint32_t *)ctx->extra[FY_B0].p;
+    uint32_t *Abuf[2] = {(uint32_t *)ctx->extra[FY_B1].p, (uint32_t *)ctx->extra[FY_B2].p};
+    uint32_t *cnt = (uint32_t *)ctx->extra[FY_SMALL].p, *off = cnt + nb_max;
+    int *d_flag = (int *)(off + nb_max);
+    uint32_t *d_consumed = (uint32_t *)(d_flag + 1);
+
+    // ---- (1) the draws, range by range (constant mask), largest i first
+    unsigned long long w = (unsigned long long)pos0;  // next unconsumed word
+    uint32_t g = 0;                                   // draws emitted so far (draw g <-> i = N-1-g)
+    uint32_t hi = N - 1;
+    int total_sweeps = 0;
+    while (hi >= FY_TAIL) {
+        uint32_t mask = hi;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t lo = (mask >> 1) + 1;
+        if (lo < FY_TAIL) lo = FY_TAIL;
+        const uint32_t need = hi - lo + 1;
+        double wd = fy_expected_words((double)mask, (double)lo, (double)hi) + 12.0 * sqrt(2.0 * (double)need) + 64.0;
+        if (wd > (double)(total_words - w)) wd = (double)(total_words - w);
+        if (wd >= 4294967295.0) return slk_fail(ctx, SLK_EINVAL, "slk_shuffle_perm: window too large");
+        fy_args a;
+        a.raw = raw;
+        a.w0 = w;
+        a.W = (uint32_t)wd;
+        a.mask = mask;
+        a.hi = hi;
+        a.need = need;
+        const unsigned nb = (a.W + FY_TILE - 1) / FY_TILE;
+        int cur = 0;
+        hipLaunchKernelGGL(k_fy_init, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, Abuf[0], a.W, need, hi, mask);
+        SLK_LAUNCH_CHECK(ctx, "k_fy_init");
+        const int check_every = a.W > (1u << 20) ? 1 : 3;
+        int sweeps = 0, flag = 1;
+        while (flag) {
+            for (int k = 0; k < check_every; ++k) {
+                a.A_old = Abuf[cur];
+                a.A_new = Abuf[cur ^ 1];
+                if (k == check_every - 1) SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_fy_count, dim3(nb), dim3(256), 0, s, a, cnt);
+                hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb);
+                hipLaunchKernelGGL(k_fy_apply, dim3(nb), dim3(256), 0, s, a, (const uint32_t *)off, d_flag);
+                SLK_LAUNCH_CHECK(ctx, "k_fy_apply");
+                cur ^= 1;
+                ++sweeps;
+            }
+            SLK_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            SLK_HIP(ctx, hipStreamSynchronize(s));
+            if (sweeps > 2000) return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: acceptance fixpoint did not converge");
+        }
+        total_sweeps += sweeps;
+        a.A_old = Abuf[cur];
+        uint32_t consumed = 0;
+        SLK_HIP(ctx, hipMemsetAsync(d_consumed, 0, 4, s));
+        hipLaunchKernelGGL(k_fy_emit, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, a, J, g, d_consumed);
+        SLK_LAUNCH_CHECK(ctx, "k_fy_emit");
+        SLK_HIP(ctx, hipMemcpyAsync(&consumed, d_consumed, 4, hipMemcpyDeviceToHost, s));
+        SLK_HIP(ctx, hipStreamSynchronize(s));
+        if (consumed == 0)
+            return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: ran out of generated words (rejection tail > 12 sigma)");
+        w += consumed;
+        g += need;
+        hi = lo - 1;
+    }
+    if (hi >= 1) {
+        uint32_t consumed = 0;
+        hipLaunchKernelGGL(k_fy_tail, dim3(1), dim3(64), 0, s, raw, w, total_words, hi, J, g, d_consumed);
+        SLK_LAUNCH_CHECK(ctx, "k_fy_tail");
+        SLK_HIP(ctx, hipMemcpyAsync(&consumed, d_consumed, 4, hipMemcpyDeviceToHost, s));
+        SLK_HIP(ctx, hipStreamSynchronize(s));
+        if (consumed == 0xffffffffu)
+            return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: ran out of generated words (rejection tail > 12 sigma)");
+        w += consumed;
+    }
+    ctx->fy_sweeps = total_sweeps;
+    hipLaunchKernelGGL(k_fy_rng_finalize, dim3(1), dim3(256), 0, s, ctx->d_rng, raw, w - 1);
+    SLK_LAUNCH_CHECK(ctx, "k_fy_rng_finalize");
+    slk_prof_end(ctx, s);
+
+    // ---- (2) the swaps
+    slk_prof_begin(ctx, SLK_K_PREP, s);
+    const uint32_t m = N - 1;
+    uint32_t *key0 = (uint32_t *)ctx->extra[FY_B1].p, *val0 = (uint32_t *)ctx->extra[FY_B2].p;
+    uint32_t *key1 = (uint32_t *)ctx->extra[FY_B3].p, *val1 = (uint32_t *)ctx->extra[FY_B4].p;
+    hipLaunchKernelGGL(k_fy_keys, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)J, N, key0, val0);
+    SLK_LAUNCH_CHECK(ctx, "k_fy_keys");
+    if ((rc = slk_sort_pairs_u32_u32(ctx, key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s))) return rc;
+    uint32_t *R[2] = {key0, val0};  // the sort's inputs are free again
+    hipLaunchKernelGGL(k_fy_iota, dim3(fy_grid(ctx, N)), dim3(256), 0, s, R[0], N);
+    hipLaunchKernelGGL(k_fy_pred, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
+                       m, N, R[0]);
+    SLK_LAUNCH_CHECK(ctx, "k_fy_pred");
+    int cur = 0, flag = 1, rounds = 0;
+    while (flag) {
+        SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_fy_jump, dim3(fy_grid(ctx, N)), dim3(256), 0, s, (const uint32_t *)R[cur], R[cur ^ 1], N,
+                           d_flag);
+        SLK_LAUNCH_CHECK(ctx, "k_fy_jump");
+        cur ^= 1;
+        SLK_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        SLK_HIP(ctx, hipStreamSynchronize(s));
+        if (++rounds > 64) return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: pointer doubling did not terminate");
+    }
+    hipLaunchKernelGGL(k_fy_final, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
+                       m, N, (const uint32_t *)R[cur], d_perm_out);
+    SLK_LAUNCH_CHECK(ctx, "k_fy_final");
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int64_t *d_perm, int64_t n,
+                                   int64_t row_len, int64_t *d_dst, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (n < 0 || row_len < 1 || (n > 0 && (!d_src || !d_perm || !d_dst)))
+        return slk_fail(ctx, SLK_EINVAL, "slk_gather_rows_i64: bad arguments");
+    if (n == 0) return SLK_OK;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    hipLaunchKernelGGL((k_gather_rows<int64_t>), dim3(fy_grid(ctx, (size_t)(n * row_len))), dim3(256), 0, s, d_src, d_perm,
+                       n, row_len, d_dst);
+    SLK_LAUNCH_CHECK(ctx, "k_gather_rows");
+    return SLK_OK;
+}

@@ -46,6 +46,23 @@ def _state_tensor(state, key, like):
     return state[key]
 
 
+def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
+    """d_dst = d_src[numpy-exact shuffle of arange(n)] for every (d_src, d_dst, row_len) of `arrays`,
+    drawn from the engine's RNG state (slk_shuffle_perm: the reference's `shuffle`, torch_utils.py:35-52).
+    If the device shuffle reports a failure (it cannot, short of a 12-sigma rejection tail) the
+    permutation is drawn by numpy on the host from `random_state`, as the reference does, and the
+    engine's RNG state is re-synchronised -- the results are identical either way."""
+    try:
+        engine.shuffle_perm(n, d_perm.data_ptr(), stream=stream)
+    except _native.SlkError:
+        order = np.arange(n)
+        random_state.shuffle(order)
+        d_perm.copy_(torch.from_numpy(order))
+        engine.rng_set_state(random_state.get_state())
+    for d_src, d_dst, row_len in arrays:
+        engine.gather_rows_i64(d_src.data_ptr(), d_perm.data_ptr(), n, row_len, d_dst.data_ptr(), stream=stream)
+
+
 class _OptimizerBinding(object):
     """Maps a torch.optim object onto slk_optim.  The torch optimizer stays the owner of
     hyper-parameters and state tensors (so state_dict / pickle / resuming fit() behave as
@@ -241,14 +258,18 @@ class ImplicitFactorizationModel(object):
 
         engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
                                 self._num_negative_samples, stream=stream)
+        # ids go to the device once; every epoch's permutation x[shuffle_indices] of them
+        # (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
+        d_users0 = torch.from_numpy(user_ids).to(device)
+        d_items0 = torch.from_numpy(item_ids).to(device)
+        d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
+        d_perm = torch.empty(n, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):
-            # host shuffle: numpy Fisher-Yates on the model's RandomState (torch_utils.py:35-52)
-            users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
-            d_users = torch.from_numpy(users).to(device)
-            d_items = torch.from_numpy(items).to(device)
-
-            # the negatives continue the same MT19937 stream on the GPU
+            # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as
+            # numpy would consume it on the host
             engine.rng_set_state(self._random_state.get_state())
+            device_epoch_shuffle(engine, self._random_state, n, d_perm, [(d_users0, d_users, 1), (d_items0, d_items, 1)],
+                                 stream)
             ostruct = binding.as_struct()
             engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
                                   self._batch_size, self._loss, self._num_negative_samples,

@@ -147,17 +147,21 @@ class ImplicitSequenceModel(object):
         n_minibatches = (n_seq + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 
+        # the sequences go to the device once; `sequences` is rebound to its shuffled copy every epoch,
+        # so successive epochs' permutations compose exactly as in the reference (:215-216) -- here by
+        # gathering from the previous epoch's device array with a numpy-exact device permutation
+        d_prev = torch.from_numpy(np.ascontiguousarray(sequences)).to(device)
+        d_sequences = torch.empty_like(d_prev)
+        d_perm = torch.empty(n_seq, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):
-            # host shuffle on the model's RandomState; `sequences` is rebound, so successive
-            # epochs' permutations compose exactly as in the reference (:215-216)
-            sequences = shuffle(sequences, random_state=self._random_state)
-            d_sequences = torch.from_numpy(np.ascontiguousarray(sequences)).to(device)
-
             engine.rng_set_state(self._random_state.get_state())
+            _host.device_epoch_shuffle(engine, self._random_state, n_seq, d_perm, [(d_prev, d_sequences, seq_len)],
+                                       stream)
             ostruct = binding.as_struct()
             engine.poolnet_train(tables, ostruct, self._padding_idx(), d_sequences.data_ptr(), n_seq, seq_len,
                                  self._batch_size, self._loss, self._num_negative_samples,
                                  mb_loss.data_ptr(), stream=stream)
+            d_prev, d_sequences = d_sequences, d_prev
             binding.store_steps(ostruct.step)
             self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
 

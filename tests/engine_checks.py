@@ -516,3 +516,33 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
     for k, (a, b) in enumerate(zip(*results)):
         assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined run' % k,
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
+
+
+# ---------------------------------------------------------------------------------------
+# epoch shuffle on the device (slk_shuffle_perm)
+# ---------------------------------------------------------------------------------------
+def check_shuffle_matches_numpy(be, n, seed, burn=7, rows=0):
+    """d_perm == numpy's RandomState.shuffle(arange(n)) bit for bit, same RandomState afterwards
+    (torch_utils.py:35-52); `rows` > 0 also checks slk_gather_rows_i64 on an [n, rows] array."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    if burn:
+        rs.randint(0, 1000, burn)  # leave the block start
+    eng.rng_set_state(rs.get_state())
+    want = np.arange(n)
+    rs.shuffle(want)
+    d_perm = be.alloc(np.full(max(n, 1), -1, dtype=np.int64))
+    eng.shuffle_perm(n, be.ptr(d_perm), stream=be.stream)
+    got = be.get(d_perm)[:n]
+    st, ref = eng.rng_get_state(), rs.get_state()
+    assert np.array_equal(got, want), (n, int((got != want).sum()))
+    assert (st[1] == ref[1]).all() and st[2] == ref[2], 'RandomState after the shuffle differs'
+    if rows and n:
+        src = np.arange(n * rows, dtype=np.int64).reshape(n, rows) * 3 + 1
+        d_src, d_dst = be.alloc(src), be.alloc(np.zeros_like(src))
+        eng.gather_rows_i64(be.ptr(d_src), be.ptr(d_perm), n, rows, be.ptr(d_dst), stream=be.stream)
+        assert np.array_equal(be.get(d_dst), src[want])
+    # the negatives drawn next continue the same stream
+    d_neg = be.alloc(np.zeros(64, dtype=np.int64))
+    eng.sample_items(1000, 64, be.ptr(d_neg), stream=be.stream)
+    assert np.array_equal(be.get(d_neg), rs.randint(0, 1000, 64, dtype=np.int64))

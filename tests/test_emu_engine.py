@@ -111,3 +111,10 @@ def test_pipelined_chunks_match_single_chunk(be):
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100, overlap=0, nt=0)
     with pytest.raises(_native.SlkError):
         eng.set_option('no_such_option', 1)
+
+
+@pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 623, 4095, 4096, 4097, 8191, 8192, 8193, 12345, 70001])
+def test_device_shuffle_is_numpy_exact(be, n):
+    """slk_shuffle_perm: sizes around the sequential tail (4096), the power-of-two range edges and the
+    MT19937 block size; RandomState continuity checked through the next randint."""
+    ec.check_shuffle_matches_numpy(be, n, seed=n + 1, burn=n % 5, rows=3 if n in (10, 4097) else 0)
