@@ -281,13 +281,17 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
         n = len(user_ids)
         n_mb = (n + B - 1) // B
 
+        d_users0 = torch.from_numpy(user_ids).to(device)
+        d_items0 = torch.from_numpy(item_ids).to(device)
+        d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
+        d_perm = torch.empty(n, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):
-            users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
-            d_users = torch.from_numpy(users).to(device)
-            d_items = torch.from_numpy(items).to(device)
+            # every rank computes the same numpy-exact permutation and negatives on its own GPU
+            engine.rng_set_state(self._random_state.get_state())
+            _host.device_epoch_shuffle(engine, self._random_state, n, d_perm,
+                                       [(d_users0, d_users, 1), (d_items0, d_items, 1)], stream)
             # the epoch's negatives: one randint per minibatch == one contiguous draw over the epoch
             negs = torch.empty(n, dtype=torch.int64, device=device)
-            engine.rng_set_state(self._random_state.get_state())
             engine.sample_items(self._num_items, n, negs.data_ptr(), stream=stream)
             self._random_state.set_state(engine.rng_get_state())
             # this rank's interactions, minibatch membership unchanged
