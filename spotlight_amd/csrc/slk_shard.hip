@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         uint32_t q = p;
         do {
             const size_t sp_ = (size_t)a.vslot[2 * (size_t)q] * a.RSV, sn_ = (size_t)a.vslot[2 * (size_t)q + 1] * a.RSV;
-            const slk_vec<VEC> vi = on ? slk_vload<VEC>(a.vrows + sp_ + d0) : slk_vzero<VEC>();
-            const slk_vec<VEC> vj = on ? slk_vload<VEC>(a.vrows + sn_ + d0) : slk_vzero<VEC>();
+            // exchange buffers are read / written exactly once: streaming hints (ctx option "nt" bit 0)
+            const bool nt = (a.nt & 1) != 0;
+            const slk_vec<VEC> vi = on ? slk_vload_if_nt<VEC>(a.vrows + sp_ + d0, nt) : slk_vzero<VEC>();
+            const slk_vec<VEC> vj = on ? slk_vload_if_nt<VEC>(a.vrows + sn_ + d0, nt) : slk_vzero<VEC>();
             const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.vrows[sp_ + D];
             const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.vrows[sn_ + D];
             float l, gp, gn;
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
             }
             gbu += gp + gn;
             if (on) {
-                slk_vstore<VEC>(a.grows + sp_ + d0, cp);
-                slk_vstore<VEC>(a.grows + sn_ + d0, cn);
+                slk_vstore_if_nt<VEC>(a.grows + sp_ + d0, cp, nt);
+                slk_vstore_if_nt<VEC>(a.grows + sn_ + d0, cn, nt);
             }
             if (lane == 0) {
                 a.grows[sp_ + D] = gp;
