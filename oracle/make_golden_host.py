@@ -65,6 +65,27 @@ def main():
     p, r = sequence_precision_recall_score(model, seq, k=2, exclude_preceding=True)
     rec['seq_prec2'], rec['seq_rec2'] = p, r
     rec['rmse'] = np.float64(rmse_score(model, te))
+    # end-to-end, the level the reference's own tests work at (tests/factorization/test_implicit.py,
+    # tests/sequence/test_sequence_implicit.py: MRR floors): train the reference's models on the synthetic
+    # data above and record the MRRs a drop-in run with the same seeds should reproduce
+    import torch
+    from spotlight.factorization.implicit import ImplicitFactorizationModel
+    from spotlight.sequence.implicit import ImplicitSequenceModel
+    torch.set_num_threads(1)
+    big = generate_sequential(num_users=60, num_items=200, num_interactions=6000, concentration_parameter=0.01,
+                              order=2, random_state=np.random.RandomState(21))
+    btr, bte = random_train_test_split(big, test_percentage=0.2, random_state=np.random.RandomState(22))
+    fm = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=4, batch_size=256, learning_rate=1e-2,
+                                    l2=1e-6, random_state=np.random.RandomState(23))
+    fm.fit(btr)
+    rec['e2e_mrr_factorization'] = mrr_score(fm, bte, train=btr)
+    str_, ste = user_based_train_test_split(big, test_percentage=0.3, random_state=np.random.RandomState(24))
+    sq_tr = str_.to_sequence(max_sequence_length=10, min_sequence_length=3, step_size=1)
+    sq_te = ste.to_sequence(max_sequence_length=10, min_sequence_length=3, step_size=1)
+    sm = ImplicitSequenceModel(loss='bpr', representation='pooling', embedding_dim=16, n_iter=4, batch_size=64,
+                               learning_rate=1e-2, l2=1e-6, random_state=np.random.RandomState(25))
+    sm.fit(sq_tr)
+    rec['e2e_mrr_sequence'] = sequence_mrr_score(sm, sq_te)
     np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'host_api.npz'), **rec)
     print('host_api.npz written:', {k: np.asarray(v).shape for k, v in rec.items()})
 

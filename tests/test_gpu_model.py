@@ -177,3 +177,9 @@ def test_mrr_fast_path_speed_at_movielens_100k_shape():
     assert np.allclose(fast, slow, rtol=1e-12, atol=0)
     print('mrr_score 943x1682: batched %.1f ms, per-user route %.1f ms' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
     assert (t1 - t0) < (t2 - t1)
+
+
+def test_end_to_end_mrr_matches_reference_on_gpu():
+    from test_host_api import check_end_to_end_mrr_matches_reference
+    rec = np.load(os.path.join(GOLDEN, 'host_api.npz'))
+    check_end_to_end_mrr_matches_reference(rec, use_cuda=True)

@@ -157,3 +157,31 @@ def test_mrr_fast_path_matches_per_user_route(emu_device, bloom):
 @pytest.mark.parametrize('bloom', [False, True])
 def test_sequence_mrr_fast_path_matches_per_sequence_route(emu_device, bloom):
     check_sequence_fast_path(bloom)
+
+
+def check_end_to_end_mrr_matches_reference(rec, **kw):
+    """The level the reference's own tests work at: train on the same synthetic data with the same seeds
+    (=> same init, shuffles and negatives) and compare the per-user / per-sequence MRRs with those of the
+    reference's run (oracle/make_golden_host.py)."""
+    big = generate_sequential(num_users=60, num_items=200, num_interactions=6000, concentration_parameter=0.01,
+                              order=2, random_state=np.random.RandomState(21))
+    btr, bte = random_train_test_split(big, test_percentage=0.2, random_state=np.random.RandomState(22))
+    fm = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=4, batch_size=256, learning_rate=1e-2,
+                                    l2=1e-6, random_state=np.random.RandomState(23), **kw)
+    fm.fit(btr)
+    got, want = ev.mrr_score(fm, bte, train=btr), rec['e2e_mrr_factorization']
+    assert got.shape == want.shape
+    assert abs(got.mean() - want.mean()) <= 0.02 * want.mean() and np.abs(got - want).mean() <= 0.05 * want.mean()
+    str_, ste = user_based_train_test_split(big, test_percentage=0.3, random_state=np.random.RandomState(24))
+    sq_tr = str_.to_sequence(max_sequence_length=10, min_sequence_length=3, step_size=1)
+    sq_te = ste.to_sequence(max_sequence_length=10, min_sequence_length=3, step_size=1)
+    sm = ImplicitSequenceModel(loss='bpr', representation='pooling', embedding_dim=16, n_iter=4, batch_size=64,
+                               learning_rate=1e-2, l2=1e-6, random_state=np.random.RandomState(25), **kw)
+    sm.fit(sq_tr)
+    got, want = ev.sequence_mrr_score(sm, sq_te), rec['e2e_mrr_sequence']
+    assert got.shape == want.shape
+    assert abs(got.mean() - want.mean()) <= 0.02 * want.mean() and np.abs(got - want).mean() <= 0.05 * want.mean()
+
+
+def test_end_to_end_mrr_matches_reference(emu_device, rec):
+    check_end_to_end_mrr_matches_reference(rec)
