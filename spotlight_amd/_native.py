@@ -112,6 +112,10 @@ def load():
     """Loads csrc/libspotlight_hip.so; raises ImportError (never falls back) if it is absent."""
     global _LIB
     if _LIB is None:
+        path = os.environ.get('SPOTLIGHT_HIP_LIB', LIB_PATH)  # another build of the same ABI (A/B measurements)
+        if path != LIB_PATH:
+            _LIB = bind(C.CDLL(path))
+            return _LIB
         if not os.path.exists(LIB_PATH):
             raise ImportError('%s not found: build it with `python -m spotlight_amd.build` '
                               '(hipcc --offload-arch=gfx950).  spotlight_amd has no CPU fallback.'

@@ -234,7 +234,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 // A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
 // list.  Per tile: (1) keys + payloads -> LDS; wave 0 compacts the heads of the runs of equal keys
 // that START in the tile into a list, head r belongs to row group r mod GPB (an even 1-2 heads per
-// group); (2) a group issues the loads of its first two heads' item rows + optimizer state TOGETHER
+// group); (2) a group issues the loads of its first head's item row + optimizer state TOGETHER
 // with its four record gathers (every load independent: one HBM round trip covers both) and parks
 // the contributions in LDS; (3) each run is summed from LDS by its owner group (runs that spill
 // past the tile end are finished from global memory; rows of a run that started in an earlier
@@ -246,6 +246,13 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 // bias (slot 3), or both.  They separate when the embedding rows are BloomEmbedding rows (keys =
 // hashed rows) while the bias table is indexed by the item id itself.
 enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
+#ifndef SLK_ITEM_WAVES
+#define SLK_ITEM_WAVES 7  // occupancy target of the item pass (waves per SIMD): 72 VGPRs, no spills with NPRE 1
+#endif
+#ifndef SLK_ITEM_NPRE
+#define SLK_ITEM_NPRE 1  // heads per group whose row + state loads ride along with the record gather; measured
+                         // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
+#endif
 #ifndef SLK_SPILL_BATCH
 #define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
 #endif
@@ -283,11 +290,11 @@ __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t,
 }
 
 template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH>
-__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(6) void k_item_pass(slk_pass_args a) {
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
     constexpr int DL = G * VEC;  // LDS row length (>= D)
-    constexpr int NPRE = 2;      // heads per group whose rows are loaded early
+    constexpr int NPRE = SLK_ITEM_NPRE;  // heads per group whose rows are loaded early
     __shared__ double red[256];
     __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
     __shared__ uint32_t s_pay[T];
