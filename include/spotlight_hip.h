@@ -42,7 +42,11 @@ enum slk_loss {
     SLK_LOSS_POINTWISE = 0,
     SLK_LOSS_BPR = 1,
     SLK_LOSS_HINGE = 2,
-    SLK_LOSS_ADAPTIVE_HINGE = 3
+    SLK_LOSS_ADAPTIVE_HINGE = 3,
+    /* explicit feedback (spotlight/losses.py:169-244), slk_bilinear_train_explicit only */
+    SLK_LOSS_REGRESSION = 4,
+    SLK_LOSS_POISSON = 5,
+    SLK_LOSS_LOGISTIC = 6
 };
 
 /* Optimizers the reference can instantiate (factorization/implicit.py:143-150):
@@ -155,6 +159,15 @@ int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
  * optimizer kind, n, batch_size, loss, n_neg) will need, so that the training call itself
  * performs no allocation (torch's caching allocator plays this role for the reference).  Optional:
  * slk_bilinear_train grows its scratch on demand. */
+/* ExplicitFactorizationModel.fit's minibatch loop (spotlight/factorization/explicit.py:213-236) for one
+ * epoch of already shuffled (user, item, rating) triples: forward (BilinearNet, exp() of the score under
+ * the poisson loss), regression / poisson / logistic loss (losses.py:169-244), backward with duplicate
+ * rows summed, optimizer step.  No negatives are drawn; d_mb_loss[m] = loss.item() of minibatch m.
+ * predict() is slk_bilinear_predict followed by exp (poisson) / sigmoid (logistic) (explicit.py:277-282). */
+int slk_bilinear_train_explicit(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                                const int64_t *d_users, const int64_t *d_items, const float *d_ratings,
+                                int64_t n, int64_t batch_size, int32_t loss, float *d_mb_loss, void *stream);
+
 int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n,
                          int64_t batch_size, int32_t loss, int32_t n_neg, void *stream);
 

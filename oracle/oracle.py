@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, '_build', 'libslk_oracle.so')
 
+EXPLICIT_LOSSES = {'regression': 4, 'poisson': 5, 'logistic': 6}
 LOSSES = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
 OPTS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
 
@@ -183,6 +184,41 @@ class BilinearOracle(object):
                                        _ptr(neg_in), _ptr(neg_out), _ptr(mb_loss))
         assert rc == 0
         return (mb_loss, neg_out) if want_negs else mb_loss
+
+    # -- explicit feedback (spotlight/factorization/explicit.py:173-243, losses.py:169-244) --------
+    def explicit_step(self, users, items, ratings, loss='regression', want_grads=False):
+        users = np.ascontiguousarray(users, dtype=np.int64)
+        items = np.ascontiguousarray(items, dtype=np.int64)
+        ratings = np.ascontiguousarray(ratings, dtype=np.float32)
+        loss_out = C.c_float()
+        dg, dgp = None, None
+        if want_grads:
+            dg = [np.zeros_like(p) for p in self.p]
+            dgp = (C.c_void_p * 4)(*[g.ctypes.data for g in dg])
+        rc = lib().slko_explicit_step(C.byref(self.m), _ptr(users), _ptr(items), _ptr(ratings), C.c_int64(users.size),
+                                      C.c_int(EXPLICIT_LOSSES[loss]), C.byref(loss_out), dgp)
+        assert rc == 0
+        return (float(loss_out.value), dg) if want_grads else float(loss_out.value)
+
+    def explicit_train(self, users, items, ratings, batch_size, loss='regression'):
+        users = np.ascontiguousarray(users, dtype=np.int64)
+        items = np.ascontiguousarray(items, dtype=np.int64)
+        ratings = np.ascontiguousarray(ratings, dtype=np.float32)
+        n = users.size
+        mb_loss = np.empty((n + batch_size - 1) // batch_size, dtype=np.float32)
+        rc = lib().slko_explicit_train(C.byref(self.m), _ptr(users), _ptr(items), _ptr(ratings), C.c_int64(n),
+                                       C.c_int64(batch_size), C.c_int(EXPLICIT_LOSSES[loss]), _ptr(mb_loss))
+        assert rc == 0
+        return mb_loss
+
+    def explicit_predict(self, users, items=None, loss='regression'):
+        """explicit.py:245-284: exp() of the score for poisson, sigmoid() for logistic."""
+        out = self.predict(users, items)
+        if loss == 'poisson':
+            return np.exp(out)
+        if loss == 'logistic':
+            return (1.0 / (1.0 + np.exp(-out.astype(np.float32)))).astype(np.float32)
+        return out
 
 
 class _Bloom(C.Structure):

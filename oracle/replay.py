@@ -194,3 +194,44 @@ def replay_bloom_with_oracle(case, rec):
     errs['predict_all'] = rel_inf(po.predict(3), rec['predict_user3_all'])
     errs['predict_pairs'] = rel_inf(po.predict(rec['predict_pairs_u'], rec['predict_pairs_i']), rec['predict_pairs'])
     return errs, fr
+
+
+def replay_explicit_with_oracle(case, rec):
+    """Replays a recorded ExplicitFactorizationModel run (factorization/explicit.py:173-284)."""
+    loss = str(case['loss'])
+    hp = oracle_hparams(case)
+    mk = lambda: BilinearOracle(rec['init_0'], rec['init_1'], rec['init_2'], rec['init_3'],
+                                opt=ORACLE_OPT[str(case['opt'])], **hp)
+    o = mk()
+    rng = Rng(state=('MT19937', rec['rng_key_before_fit'], int(rec['rng_pos_before_fit'])))
+    N, B = int(case['N']), int(case['B'])
+    users64, items64 = rec['users'].astype(np.int64), rec['items'].astype(np.int64)
+    losses, errs = [], {}
+    for e in range(int(case['n_iter'])):
+        perm = rng.shuffle_perm(N)  # one permutation for the three arrays (torch_utils.py:35-52)
+        su, si, sr = users64[perm], items64[perm], rec['ratings'][perm]
+        assert (su == rec['shuffled_users'][e]).all() and (si == rec['shuffled_items'][e]).all()
+        assert (sr == rec['shuffled_ratings'][e]).all()
+        if e == 0:
+            B0 = min(B, N)
+            l0, dg = mk().explicit_step(su[:B0], si[:B0], sr[:B0], loss=loss, want_grads=True)
+            errs['loss0'] = abs(l0 - rec['losses'][0]) / abs(rec['losses'][0])
+            bscale = max(np.abs(rec['grad0_2']).max(), np.abs(rec['grad0_3']).max())
+            for t in range(4):
+                ref = rec['grad0_%d' % t]
+                errs['grad0_%d' % t] = (rel_inf(dg[t].reshape(ref.shape), ref) if t < 2
+                                        else np.abs(dg[t].reshape(ref.shape) - ref).max() / bscale)
+        losses.append(o.explicit_train(su, si, sr, B, loss=loss))
+    errs['loss'] = np.max(np.abs(np.concatenate(losses) - rec['losses']) / np.abs(rec['losses']))
+    fr = {}
+    for t in range(4):
+        ref = rec['final_%d' % t]
+        errs['final_%d' % t] = rel_inf(o.p[t].reshape(ref.shape), ref)
+        fr['final_%d' % t] = frac_outside(o.p[t].reshape(ref.shape), ref)
+    st = rng.get_state()
+    assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
+    po = BilinearOracle(rec['final_0'], rec['final_1'], rec['final_2'], rec['final_3'])
+    errs['predict_all'] = rel_inf(po.explicit_predict(3, None, loss=loss), rec['predict_all'])
+    errs['predict_pairs'] = rel_inf(po.explicit_predict(rec['predict_users'], rec['predict_items'], loss=loss),
+                                    rec['predict_pairs'])
+    return errs, fr

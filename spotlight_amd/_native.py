@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 SLK_ABI_VERSION = 3
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
-LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
+LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
+              'regression': 4, 'poisson': 5, 'logistic': 6}
 OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
 KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5,
                   'exchange': 6, 'seq_pass': 7}
@@ -57,6 +58,8 @@ _PROTOTYPES = {
     'slk_bilinear_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
                                      C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_train_explicit': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     'slk_bilinear_reserve': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int64,
                                        C.c_int32, C.c_int32, C.c_void_p]),
     'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
@@ -185,6 +188,12 @@ class Engine(object):
             self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, int(n), int(batch_size),
             LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), d_neg_in, d_neg_out,
             d_mb_loss, stream))
+
+    def bilinear_train_explicit(self, tables, optim, d_users, d_items, d_ratings, n, batch_size, loss, d_mb_loss,
+                                stream=0):
+        self._check(self._lib.slk_bilinear_train_explicit(
+            self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, d_ratings, int(n), int(batch_size),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_mb_loss, stream))
 
     def bilinear_reserve(self, tables, optim, n, batch_size, loss, n_neg, stream=0):
         self._check(self._lib.slk_bilinear_reserve(

@@ -188,6 +188,39 @@ __global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float 
 }
 
 // ---------------------------------------------------------------------------------------
+// explicit feedback (spotlight/factorization/explicit.py:223-234, losses.py:169-244): per interaction
+// the loss of its ONE predicted score against the observed rating and dL/dscore, formed in fp32
+// operation by operation as autograd forms them.  One thread per interaction of the minibatch.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_explicit_loss(const float *sk, const float *ratings, float *gk, uint32_t k0,
+                                                       uint32_t bm, int loss_kind, float inv_b, double *loss_partial) {
+    __shared__ double red[256];
+    double lsum = 0.0;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < bm; c += gridDim.x * 256) {
+        const float sc = sk[k0 + c], r = ratings[k0 + c];
+        float l, g;
+        if (loss_kind == SLK_LOSS_REGRESSION) {  // ((r - p) ** 2).mean()
+            const float diff = r - sc;
+            l = diff * diff;
+            g = -(inv_b * (2.0f * diff));
+        } else if (loss_kind == SLK_LOSS_POISSON) {  // p = exp(score); (p - r * log(p)).mean()
+            const float p = expf(sc);
+            l = p - r * logf(p);
+            g = (inv_b + ((-inv_b) * r) / p) * p;
+        } else {  // binary_cross_entropy_with_logits(score, clamp(r, 0, 1)), mean reduction
+            const float t = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            const float mx = -sc > 0.0f ? -sc : 0.0f;
+            l = (1.0f - t) * sc + (mx + logf(expf(-mx) + expf(-sc - mx)));
+            g = (slk_sigmoid(sc) - t) / (float)bm;
+        }
+        gk[k0 + c] = g;
+        lsum += (double)l;
+    }
+    const double tot = slk_block_sum_256(lsum, red);
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------
 // dense sweeps (reference default optimizer: Adam with weight_decay = l2 over EVERY row)
 // ---------------------------------------------------------------------------------------
 struct slk_sweep_args {
@@ -495,7 +528,8 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
 static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                                const int64_t *d_users, const int64_t *d_items, int64_t n,
                                int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
-                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only);
+                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only,
+                               const float *d_ratings = nullptr);
 
 SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                                   const int64_t *d_users, const int64_t *d_items, int64_t n,
@@ -514,21 +548,39 @@ SLK_EXPORT int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, cons
                                nullptr, stream, true);
 }
 
+// ExplicitFactorizationModel.fit's minibatch loop (spotlight/factorization/explicit.py:213-236): the same
+// passes with ONE pair per interaction, dL/dscore from k_explicit_loss (the PRE route of the user pass)
+SLK_EXPORT int slk_bilinear_train_explicit(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
+                                           const int64_t *d_users, const int64_t *d_items, const float *d_ratings,
+                                           int64_t n, int64_t batch_size, int32_t loss, float *d_mb_loss,
+                                           void *stream) {
+    if (ctx && (loss < SLK_LOSS_REGRESSION || loss > SLK_LOSS_LOGISTIC))
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train_explicit: loss kind %d is not regression/poisson/logistic", loss);
+    if (ctx && n > 0 && !d_ratings) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train_explicit: d_ratings is NULL");
+    return bilinear_train_impl(ctx, tables, optim, d_users, d_items, n, batch_size, loss, 0, nullptr, nullptr,
+                               d_mb_loss, stream, false, d_ratings);
+}
+
 static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                                const int64_t *d_users, const int64_t *d_items, int64_t n,
                                int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
-                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only) {
+                               int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only,
+                               const float *d_ratings) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (n < 0 || batch_size < 1) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: n %lld batch_size %lld",
                                                  (long long)n, (long long)batch_size);
-    if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_ADAPTIVE_HINGE)
+    if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_LOGISTIC)
         return slk_fail(ctx, SLK_EINVAL, "unknown loss kind %d", loss);
     const bool adaptive = loss == SLK_LOSS_ADAPTIVE_HINGE;
-    const int nn = adaptive ? n_neg : 1;
-    if (nn < 1 || nn > 1024) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", nn);
+    const bool expl = loss >= SLK_LOSS_REGRESSION;  // explicit feedback: ratings, no negatives
+    if (expl != (d_ratings != nullptr) && !reserve_only)
+        return slk_fail(ctx, SLK_EINVAL, "ratings go with (and only with) the regression/poisson/logistic losses");
+    const bool pre = adaptive || expl;  // dL/dscore is computed before the user pass
+    const int nn = adaptive ? n_neg : (expl ? 0 : 1);
+    if (!expl && (nn < 1 || nn > 1024)) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", nn);
     const int NP = nn + 1;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (n == 0) return SLK_OK;
@@ -597,13 +649,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (Hu && (rc = slk_ensure(ctx, pb.buk[b], nc_max * Hu * 4))) return rc;
             if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
         }
-        if (adaptive && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
+        if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
     }
     const int RS = D + ((NP + 3) / 4) * 4;  // record = user row + NP dL/dscore, 16-B granular
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
     const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
-    if (adaptive) {
+    if (pre) {
         if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
@@ -635,7 +687,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             rpass_rows = nullptr;
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
-        upass = user_pass_fn<V_, G_>(upd, adaptive, bloom);                               \
+        upass = user_pass_fn<V_, G_>(upd, pre, bloom);                               \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
         spass = k_score_pass<V_, G_>;                                                     \
         if (bloom) {                                                                      \
@@ -656,6 +708,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         uint32_t *neg32 = (uint32_t *)pb.neg32.p;
 
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
+        if (nn == 0) return SLK_OK;  // explicit feedback draws none
         if (d_neg_in) {
             slk_prof_begin(ctx, SLK_K_SAMPLE, s);
             hipLaunchKernelGGL(k_i64_to_u32, dim3(slk_grid_for(ctx, (size_t)nc * nn, 256)), dim3(256), 0, s,
@@ -684,7 +737,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const unsigned mbbits = slk_bits_for((uint64_t)((nc - 1) / (uint32_t)bsz));
         uint32_t *ukey_in = (uint32_t *)pb.ukey[0].p, *ukey = (uint32_t *)pb.ukey[1].p;
         const uint32_t *uit, *uk = nullptr;
-        if (!adaptive) {
+        if (!pre) {
             hipLaunchKernelGGL((k_build_user_keys<true>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
                                (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
@@ -751,8 +804,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         int rc;
         const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
         const uint32_t *ukey = (const uint32_t *)pb.ukey[1].p;
-        const uint32_t *uit = adaptive ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
-        const uint32_t *uk = adaptive ? (const uint32_t *)pb.uval[1].p : nullptr;
+        const uint32_t *uit = pre ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
+        const uint32_t *uk = pre ? (const uint32_t *)pb.uval[1].p : nullptr;
         // ---- minibatches, in order
         for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
             const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
@@ -795,7 +848,18 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
             const unsigned igrid = slk_grid_for(ctx, late ? (size_t)bm * 2 : (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
-            if (adaptive) {
+            if (expl) {
+                slk_prof_begin(ctx, SLK_K_SCORE, s);
+                hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_score_pass");
+                const unsigned sgrid = slk_grid_for(ctx, bm, 256);
+                hipLaunchKernelGGL(k_explicit_loss, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
+                                   d_ratings + c0, (float *)ctx->gk.p, b0, bm, (int)loss, a.inv_b,
+                                   (double *)ctx->losspart.p);
+                SLK_LAUNCH_CHECK(ctx, "k_explicit_loss");
+                a.n_loss_partial = (int)sgrid;
+                slk_prof_end(ctx, s);
+            } else if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
                 SLK_HIP(ctx, hipMemsetAsync((float *)ctx->gk.p + (size_t)b0 * NP, 0, (size_t)bm * NP * 4, s));
                 hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);

@@ -19,10 +19,13 @@ def golden_names(kind='bilinear'):
     """Fixtures recorded from the live reference: 'bilinear' = plain BilinearNet runs
     (oracle/make_golden.py), 'seq' = ImplicitSequenceModel/PoolNet (oracle/make_golden_seq.py),
     'bloom' = BilinearNet with BloomEmbedding layers (oracle/make_golden_bloom.py), 'host' = outputs of
-    the host-side callers (oracle/make_golden_host.py)."""
+    the host-side callers (oracle/make_golden_host.py), 'explicit' = ExplicitFactorizationModel runs
+    (oracle/make_golden_explicit.py)."""
     def kind_of(f):
         if f.startswith('host_'):
             return 'host'
+        if f.startswith('explicit_'):
+            return 'explicit'
         return 'seq' if f.startswith('seq_') else 'bloom' if f.startswith('bloom_') else 'bilinear'
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz') and kind_of(f) == kind)
 

@@ -546,3 +546,102 @@ def check_shuffle_matches_numpy(be, n, seed, burn=7, rows=0):
     d_neg = be.alloc(np.zeros(64, dtype=np.int64))
     eng.sample_items(1000, 64, be.ptr(d_neg), stream=be.stream)
     assert np.array_equal(be.get(d_neg), rs.randint(0, 1000, 64, dtype=np.int64))
+
+
+# ---------------------------------------------------------------------------------------
+# explicit feedback (slk_bilinear_train_explicit)
+# ---------------------------------------------------------------------------------------
+EXPLICIT_LOSSES = ('regression', 'poisson', 'logistic')
+EXPLICIT_FIXTURES = ['explicit_regression_adam_default', 'explicit_regression_adagrad', 'explicit_poisson_adagrad',
+                     'explicit_poisson_sparse_adam', 'explicit_logistic_adam_default', 'explicit_logistic_sparse_adam',
+                     'explicit_d64_regression_adagrad']
+
+
+def _ratings_for(rs, loss, n):
+    if loss == 'logistic':
+        return rs.choice([-1.0, 1.0], n).astype(np.float32)
+    if loss == 'poisson':
+        return rs.poisson(2.0, n).astype(np.float32)
+    return rs.randint(1, 6, n).astype(np.float32)
+
+
+def check_explicit_train_matches_oracle(be, loss, opt, D, U=37, I=29, N=300, B=64, epochs=2, tol=2e-5, seed=5,
+                                        user_bloom=0, item_bloom=0):
+    """ExplicitFactorizationModel's minibatch loop (factorization/explicit.py:213-236) against the oracle:
+    per-minibatch losses, tables and optimizer state; no RNG draws are made."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    ratings = _ratings_for(rs, loss, N)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)).astype(np.float32), rs.normal(0, sc, (I, D)).astype(np.float32),
+              rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    ora = BilinearOracle(*params, opt=opt, sparse_grads=True, **hp)
+    dev = be.model(params, opt=opt, **hp)
+    state = np.random.RandomState(9).get_state()
+    eng.rng_set_state(state)
+    n_mb = (N + B - 1) // B
+    d_users, d_items, d_ratings = be.alloc(users), be.alloc(items), be.alloc(ratings)
+    for epoch in range(epochs):
+        want = ora.explicit_train(users, items, ratings, B, loss=loss)
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), N, B,
+                                    loss, be.ptr(mb_loss), stream=be.stream)
+        got = be.get(mb_loss)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-5, (got, want)
+    assert dev.optim.step == ora.step_count == epochs * n_mb
+    for t in range(4):
+        assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t))
+        assert_close_table(be.get(dev.s1[t]), ora.s1[t], tol, ('state1', t))
+    st = eng.rng_get_state()
+    assert (st[1] == state[1]).all() and st[2] == state[2]  # the explicit path draws nothing
+
+
+def check_explicit_single_step_gradients(be, loss, D, U=50, I=40, B=128, seed=11):
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, B).astype(np.int64)
+    items = rs.randint(0, I, B).astype(np.int64)
+    ratings = _ratings_for(rs, loss, B)
+    params = [rs.normal(0, 0.3, (U, D)), rs.normal(0, 0.3, (I, D)), rs.normal(0, 0.2, U), rs.normal(0, 0.2, I)]
+    want_loss, want_g = BilinearOracle(*params, opt='adagrad', sparse_grads=True).explicit_step(
+        users, items, ratings, loss=loss, want_grads=True)
+    dev = be.model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999))
+    mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+    d_users, d_items, d_ratings = be.alloc(users), be.alloc(items), be.alloc(ratings)
+    eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), B, B, loss,
+                                be.ptr(mb_loss), stream=be.stream)
+    assert abs(float(be.get(mb_loss)[0]) - want_loss) / abs(want_loss) < 1e-5
+    for t in range(4):
+        got = be.get(dev.s1[t])
+        assert np.abs(got.ravel() - want_g[t].ravel()).max() <= 1e-5 * np.abs(want_g[t]).max(), t
+
+
+def check_explicit_replays_reference_fixture(be, golden_dir, name):
+    """Explicit-feedback fixtures recorded from the live reference (oracle/make_golden_explicit.py)."""
+    from oracle.replay import case_from_rec, _oracle_hparams
+    eng = be.engine
+    rec = np.load(os.path.join(golden_dir, name + '.npz'))
+    case = case_from_rec(rec)
+    loss = str(case['loss'])
+    dev = be.model([rec['init_%d' % t] for t in range(4)], opt=ORACLE_OPT[str(case['opt'])], **_oracle_hparams(case))
+    N, B = int(case['N']), int(case['B'])
+    n_mb = (N + B - 1) // B
+    losses = []
+    for e in range(int(case['n_iter'])):
+        d_u = be.alloc(rec['shuffled_users'][e].astype(np.int64))
+        d_i = be.alloc(rec['shuffled_items'][e].astype(np.int64))
+        d_r = be.alloc(rec['shuffled_ratings'][e].astype(np.float32))
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_u), be.ptr(d_i), be.ptr(d_r), N, B, loss,
+                                    be.ptr(mb_loss), stream=be.stream)
+        losses.append(be.get(mb_loss))
+    losses = np.concatenate(losses)
+    assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
+    assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
+    for t in range(4):
+        ref = rec['final_%d' % t]
+        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
+        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())

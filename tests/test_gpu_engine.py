@@ -181,3 +181,16 @@ def test_pipelined_chunks_match_oracle(be):
 def test_device_shuffle_is_numpy_exact(be, n):
     """slk_shuffle_perm on the real device, up to 3e7 elements (every power-of-two range up to 2^25)."""
     ec.check_shuffle_matches_numpy(be, n, seed=n % 1000 + 3, burn=n % 7, rows=2 if n == 5000 else 0)
+
+
+# ---- explicit feedback (slk_bilinear_train_explicit) ----
+@pytest.mark.parametrize('loss', ec.EXPLICIT_LOSSES)
+def test_explicit_train_and_gradients(be, loss):
+    ec.check_explicit_train_matches_oracle(be, loss, 'adagrad', 8)
+    ec.check_explicit_train_matches_oracle(be, loss, 'adam_dense', 64, U=3000, I=1000, N=50000, B=4096, epochs=1, tol=1e-4)
+    ec.check_explicit_single_step_gradients(be, loss, 64, U=4000, I=6000, B=20000, seed=3)
+
+
+@pytest.mark.parametrize('name', ec.EXPLICIT_FIXTURES)
+def test_explicit_replays_reference_fixture(be, name):
+    ec.check_explicit_replays_reference_fixture(be, GOLDEN, name)

@@ -183,3 +183,12 @@ def test_end_to_end_mrr_matches_reference_on_gpu():
     from test_host_api import check_end_to_end_mrr_matches_reference
     rec = np.load(os.path.join(GOLDEN, 'host_api.npz'))
     check_end_to_end_mrr_matches_reference(rec, use_cuda=True)
+
+
+@pytest.mark.parametrize('name', ['explicit_regression_adam_default', 'explicit_poisson_adagrad',
+                                  'explicit_logistic_sparse_adam', 'explicit_d64_regression_adagrad'])
+def test_explicit_model_fit_predict_match_reference_run(name):
+    """ExplicitFactorizationModel drop-in API on cuda:0 against the reference's recordings."""
+    from test_host_explicit_model import check_fit_predict_against_fixture
+    model = check_fit_predict_against_fixture(name, to_numpy=lambda w: w.detach().cpu().numpy(), use_cuda=True)
+    assert all(w.is_cuda for w in model._net.tables())

@@ -7,7 +7,8 @@ import pytest
 
 from conftest import GOLDEN, golden_names
 from oracle.oracle import Rng, bloom_indices, murmur3_32
-from oracle.replay import case_from_rec, replay_bloom_with_oracle, replay_seq_with_oracle, replay_with_oracle
+from oracle.replay import (case_from_rec, replay_bloom_with_oracle, replay_explicit_with_oracle, replay_seq_with_oracle,
+                           replay_with_oracle)
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -78,3 +79,15 @@ def test_murmur_and_bloom_indices_match_sklearn():
     want[0] = 0  # padding_idx
     got = bloom_indices(ids.astype(np.int64), seeds, comp, padding_idx=0)
     assert (got == want).all()
+
+
+@pytest.mark.parametrize('name', golden_names('explicit'))
+def test_oracle_replays_reference_explicit_run(name):
+    """ExplicitFactorizationModel (factorization/explicit.py:173-284, losses.py:169-244) fixtures."""
+    rec = np.load(os.path.join(GOLDEN, name + '.npz'))
+    case = case_from_rec(rec)
+    errs, frac = replay_explicit_with_oracle(case, rec)  # asserts bit-exact shuffles / rng state
+    step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
+    assert step < 1e-5, errs
+    assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_pairs'] < 1e-5
+    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
