@@ -306,6 +306,7 @@ def main():
     if dist is not None:
         from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
         trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
+        trainer.reserve(B, 8)  # exchange buffers of the timed loop's chunks (8 minibatches) up front
     xgmi_rows = [0]
 
     def run(first_mb, n_mb):

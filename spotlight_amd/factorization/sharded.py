@@ -95,6 +95,21 @@ class ShardedBilinearTrainer(object):
             self._bufs[name] = b
         return b[:int(rows)]
 
+    def reserve(self, batch_local, minibatches):
+        """Pre-allocates the exchange buffers of chunks of `minibatches` x `batch_local` local interactions
+        (uniformly spread lookups assumed, 25 % headroom), so that a timed loop allocates nothing."""
+        n = int(batch_local) * int(minibatches)
+        per_unit = 2 * int(batch_local) // self.slices + 1
+        slack = lambda x: x + x // 4 + 1024
+        self._buf('send_ids', 2 * n, 0, torch.int32)
+        self._buf('recv_ids', slack(2 * n), 0, torch.int32)
+        self._buf('send_counts', self.world * minibatches * self.slices, 0, torch.int64)
+        self._buf('recv_counts', self.world * minibatches * self.slices, 0, torch.int64)
+        self._buf('grad_recv', slack(2 * int(batch_local)), self.rsv, torch.float32)
+        for k in range(self.slices):
+            for name in ('rows_send%d', 'rows_recv%d', 'grad_send%d'):
+                self._buf(name % k, slack(per_unit), self.rsv, torch.float32)
+
     def run_chunk(self, users_local, items, mb_off, global_batches, loss='bpr', neg_in=None, neg_out=None):
         """A chunk of M = len(mb_off) - 1 consecutive global minibatches.  `users_local` / `items`:
         int64 device tensors with this rank's interactions of the chunk (LOCAL user rows, GLOBAL item
