@@ -25,6 +25,7 @@ def main():
     backend, loss, opt, D = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     sample_on_device = len(sys.argv) > 5 and sys.argv[5] == 'sample'
     chunk_mode = len(sys.argv) > 5 and sys.argv[5] == 'chunk'  # every minibatch in ONE run_chunk call
+    train_mode = len(sys.argv) > 5 and sys.argv[5] == 'train'  # bench.py's loop: trainer.train, device negatives
     slices = int(sys.argv[6]) if len(sys.argv) > 6 else None
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     if backend == 'emu':
@@ -46,6 +47,14 @@ def main():
     users = rs.randint(0, U, N).astype(np.int64)
     items = rs.randint(0, I, N).astype(np.int64)
     negs = rs.randint(0, I, N).astype(np.int64)
+    if train_mode:
+        # every rank holds the same number of interactions of every global minibatch (as in bench.py):
+        # interaction k belongs to rank k % world
+        B = 24 * world
+        N = B * n_mb - 2 * world  # short last minibatch, still evenly split
+        users = (rs.randint(0, U // world, N) * world + np.arange(N) % world).astype(np.int64)
+        items = rs.randint(0, I, N).astype(np.int64)
+        negs = np.zeros(N, dtype=np.int64)
     sc = min(0.3, 1.0 / np.sqrt(D))
     params = [rs.normal(0, sc, (U, D)).astype(np.float32), rs.normal(0, sc, (I, D)).astype(np.float32),
               rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
@@ -57,7 +66,7 @@ def main():
     s2 = [torch.zeros_like(t) for t in loc]
     optim = _native.make_optim(opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2], **hp)
     trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream, slices=slices)
-    if sample_on_device:
+    if sample_on_device or train_mode:
         eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
 
     losses, used_negs = [], np.full(N, -1, dtype=np.int64)
@@ -69,6 +78,13 @@ def main():
         losses = [float(x) for x in shares.cpu().numpy()]
         # the draws: one contiguous stream, minibatch after minibatch
         used_negs = np.random.RandomState(1000 + rank).randint(0, I, N, dtype=np.int64)
+    if train_mode:
+        mine = np.nonzero(users % world == rank)[0]
+        shares = trainer.train(torch.from_numpy(users[mine] // world).to(dev), torch.from_numpy(items[mine]).to(dev),
+                               B // world, loss=loss, sample_chunk=2)
+        dist.all_reduce(shares)
+        losses = [float(x) for x in shares.cpu().numpy()]
+        used_negs[mine] = np.random.RandomState(1000 + rank).randint(0, I, len(mine), dtype=np.int64)
     if chunk_mode:
         mine = np.nonzero(users % world == rank)[0]
         off = [int(np.searchsorted(mine, min(k * B, N))) for k in range(n_mb + 1)]
@@ -78,7 +94,7 @@ def main():
         dist.all_reduce(shares)
         losses = [float(x) for x in shares.cpu().numpy()]
         used_negs[mine] = negs[mine]
-    for k in range(0 if (use_train_loop or chunk_mode) else n_mb):
+    for k in range(0 if (use_train_loop or chunk_mode or train_mode) else n_mb):
         lo, hi = k * B, min((k + 1) * B, N)
         idx = np.nonzero(users[lo:hi] % world == rank)[0] + lo
         ul = torch.from_numpy(users[idx] // world).to(dev)

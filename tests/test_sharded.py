@@ -61,6 +61,13 @@ def test_sharded_whole_chunk_with_slices(world, slices, loss, opt):
     run_world(world, [loss, opt, 8, 'chunk', slices])
 
 
+@pytest.mark.parametrize('world,slices', [(2, 4), (3, 2)])
+def test_sharded_bench_loop_equal_shares(world, slices):
+    """The loop bench.py runs at N > 1: ShardedBilinearTrainer.train over equal per-rank shares of every
+    global minibatch, negatives drawn on each rank's device, several minibatches per chunk."""
+    run_world(world, ['bpr', 'adagrad', 16, 'train', slices])
+
+
 def test_sharded_world3_device_sampled_negatives():
     run_world(3, ['bpr', 'adagrad', 16, 'sample'])
 
