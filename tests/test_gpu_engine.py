@@ -177,7 +177,7 @@ def test_pipelined_chunks_match_oracle(be):
     ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=0, nt=15)
 
 
-@pytest.mark.parametrize('n', [0, 1, 2, 5000, 65536, 65537, 1000003, (1 << 24) + 1, 30000000])
+@pytest.mark.parametrize('n', [0, 1, 2, 5000, 65536, 65537, 1000003, (1 << 24) + 1, 30000000, (1 << 27) + 12345])
 def test_device_shuffle_is_numpy_exact(be, n):
     """slk_shuffle_perm on the real device, up to 3e7 elements (every power-of-two range up to 2^25)."""
     ec.check_shuffle_matches_numpy(be, n, seed=n % 1000 + 3, burn=n % 7, rows=2 if n == 5000 else 0)
