@@ -645,3 +645,49 @@ def check_explicit_replays_reference_fixture(be, golden_dir, name):
         ref = rec['final_%d' % t]
         bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
         assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+
+
+def check_high_row_ids(be, U=(1 << 25) + 3, I=(1 << 21) + 1, D=4, N=4000, B=1024, seed=2):
+    """Ids near the top of tables with more than 2^24 (users) / 2^21 (items) rows: the (minibatch, row)
+    sort keys, the uint32 narrowing and the row addressing must hold beyond 24 bits.  Rows are zero except
+    the touched ones, which the check compares with the oracle run on a compacted copy of the tables."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    hot_u = np.concatenate([np.array([0, 1, U - 1, U - 2, min((1 << 24) + 1, U - 3)]), rs.randint(0, U, 200)])
+    hot_i = np.concatenate([np.array([0, I - 1, min((1 << 20) + 7, I - 2)]), rs.randint(0, I, 100)])
+    users = rs.choice(hot_u, N).astype(np.int64)
+    items = rs.choice(hot_i, N).astype(np.int64)
+    negs = rs.choice(hot_i, N).astype(np.int64)
+    # compacted problem for the oracle: rank of each id among the ids in use
+    uu, ui = np.unique(users), np.unique(np.concatenate([items, negs]))
+    pu = rs.normal(0, 0.3, (len(uu), D)).astype(np.float32)
+    pi = rs.normal(0, 0.3, (len(ui), D)).astype(np.float32)
+    bu, bi = rs.normal(0, 0.1, len(uu)).astype(np.float32), rs.normal(0, 0.1, len(ui)).astype(np.float32)
+    ora = BilinearOracle(pu, pi, bu, bi, opt='adagrad', lr=0.05, sparse_grads=True)
+    want_loss = ora.train(None, np.searchsorted(uu, users), np.searchsorted(ui, items), B, loss='bpr',
+                          neg_in=np.searchsorted(ui, negs))
+    full = [np.zeros((U, D), np.float32), np.zeros((I, D), np.float32), np.zeros(U, np.float32), np.zeros(I, np.float32)]
+    full[0][uu], full[1][ui], full[2][uu], full[3][ui] = pu, pi, bu, bi
+    dev = be.model(full, opt='adagrad', lr=0.05)
+    del full
+    n_mb = (N + B - 1) // B
+    mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+    d_users, d_items, d_negs = be.alloc(users), be.alloc(items), be.alloc(negs)
+    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, 'bpr', 1, be.ptr(mb_loss),
+                       d_neg_in=be.ptr(d_negs), stream=be.stream)
+    assert np.abs(be.get(mb_loss) - want_loss).max() / np.abs(want_loss).max() < 1e-5
+    got = [be.get(t) for t in dev.p]
+    assert_close_table(got[0][uu], ora.p[0], 2e-5, 'user rows')
+    assert_close_table(got[1][ui], ora.p[1], 2e-5, 'item rows')
+    assert_close_table(got[2][uu], ora.p[2], 2e-5, 'user bias')
+    assert_close_table(got[3][ui], ora.p[3], 2e-5, 'item bias')
+    untouched = np.ones(U, dtype=bool)
+    untouched[uu] = False
+    assert not got[0][untouched].any() and not got[2][untouched].any()
+    # predict for the top user row
+    out = be.alloc(np.empty(len(ui), dtype=np.float32))
+    d_u, d_it = be.alloc(np.array([U - 1], dtype=np.int64)), be.alloc(ui.astype(np.int64))
+    eng.bilinear_predict(dev.tables, be.ptr(d_u), 1, be.ptr(d_it), len(ui), be.ptr(out), be.stream)
+    k = int(np.searchsorted(uu, U - 1))
+    ref = (ora.p[0][k] * ora.p[1]).sum(1) + ora.p[2][k] + ora.p[3]
+    assert rel_inf(be.get(out), ref) < 1e-5

@@ -118,3 +118,14 @@ def test_device_shuffle_is_numpy_exact(be, n):
     """slk_shuffle_perm: sizes around the sequential tail (4096), the power-of-two range edges and the
     MT19937 block size; RandomState continuity checked through the next randint."""
     ec.check_shuffle_matches_numpy(be, n, seed=n + 1, burn=n % 5, rows=3 if n in (10, 4097) else 0)
+
+
+def test_minibatch_of_one_interaction(be):
+    """batch_size 1 (the reference crashes there: squeeze() collapses [1, D]) and a
+    last minibatch of one interaction."""
+    ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 16, U=9, I=7, N=5, B=1, epochs=1)
+    ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, U=9, I=7, N=65, B=64, epochs=1)
+
+
+def test_row_ids_near_the_top_of_the_tables(be):
+    ec.check_high_row_ids(be, U=(1 << 17) + 3, I=(1 << 16) + 1, N=600, B=256)

@@ -194,3 +194,15 @@ def test_explicit_train_and_gradients(be, loss):
 @pytest.mark.parametrize('name', ec.EXPLICIT_FIXTURES)
 def test_explicit_replays_reference_fixture(be, name):
     ec.check_explicit_replays_reference_fixture(be, GOLDEN, name)
+
+
+def test_row_ids_beyond_24_bits(be):
+    """Tables with 2^25 + 3 user rows and 2^21 + 1 item rows, ids at both ends of the range."""
+    ec.check_high_row_ids(be)
+
+
+def test_minibatch_of_one_interaction(be):
+    """batch_size 1 (the reference crashes there: squeeze() collapses [1, D]) and a
+    last minibatch of one interaction."""
+    ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 16, U=9, I=7, N=5, B=1, epochs=1)
+    ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, U=9, I=7, N=65, B=64, epochs=1)
