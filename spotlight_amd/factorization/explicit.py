@@ -52,8 +52,7 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
     def fit(self, interactions, verbose=False):
         """Fit the model on interactions that carry ratings; repeated calls resume
         (explicit.py:173-243)."""
-        user_ids = interactions.user_ids.astype(np.int64)
-        item_ids = interactions.item_ids.astype(np.int64)
+        user_ids, item_ids = interactions.user_ids, interactions.item_ids
 
         if not self._initialized:
             self._initialize(interactions)
@@ -75,8 +74,8 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
         # ids and ratings go to the device once; the ratings ride through the shuffle as int64 bit
         # patterns (slk_gather_rows_i64 moves 8-byte elements)
         ratings = np.ascontiguousarray(interactions.ratings, dtype=np.float32)
-        d_users0 = torch.from_numpy(user_ids).to(device)
-        d_items0 = torch.from_numpy(item_ids).to(device)
+        d_users0 = _host.ids_to_device(user_ids, device)
+        d_items0 = _host.ids_to_device(item_ids, device)
         d_ratings0 = torch.from_numpy(ratings).to(device).view(torch.int32).to(torch.int64)
         d_users, d_items, d_rbits = (torch.empty_like(d_users0), torch.empty_like(d_items0),
                                      torch.empty_like(d_ratings0))

@@ -46,6 +46,15 @@ def _state_tensor(state, key, like):
     return state[key]
 
 
+def ids_to_device(ids, device):
+    """int64 device tensor of a host id array: uploaded in the array's own dtype (int32 in the reference's
+    datasets: half the PCIe bytes) and widened on the device, instead of widening on the host first."""
+    ids = np.ascontiguousarray(ids)
+    if ids.dtype not in (np.int32, np.int64):
+        ids = ids.astype(np.int64)
+    return torch.from_numpy(ids).to(device).to(torch.int64)
+
+
 def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
     """d_dst = d_src[numpy-exact shuffle of arange(n)] for every (d_src, d_dst, row_len) of `arrays`,
     drawn from the engine's RNG state (slk_shuffle_perm: the reference's `shuffle`, torch_utils.py:35-52).
@@ -239,8 +248,7 @@ class ImplicitFactorizationModel(object):
     def fit(self, interactions, verbose=False):
         """Fit the model; repeated calls resume from the current parameters and optimizer
         state (implicit.py:184-252)."""
-        user_ids = interactions.user_ids.astype(np.int64)
-        item_ids = interactions.item_ids.astype(np.int64)
+        user_ids, item_ids = interactions.user_ids, interactions.item_ids
 
         if not self._initialized:
             self._initialize(interactions)
@@ -260,8 +268,8 @@ class ImplicitFactorizationModel(object):
                                 self._num_negative_samples, stream=stream)
         # ids go to the device once; every epoch's permutation x[shuffle_indices] of them
         # (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
-        d_users0 = torch.from_numpy(user_ids).to(device)
-        d_items0 = torch.from_numpy(item_ids).to(device)
+        d_users0 = ids_to_device(user_ids, device)
+        d_items0 = ids_to_device(item_ids, device)
         d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):

@@ -281,8 +281,7 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
         self._trainer = None
 
     def fit(self, interactions, verbose=False):
-        user_ids = interactions.user_ids.astype(np.int64)
-        item_ids = interactions.item_ids.astype(np.int64)
+        user_ids, item_ids = interactions.user_ids, interactions.item_ids
         if not self._initialized:
             self._initialize(interactions)
         self._check_input(user_ids, item_ids)
@@ -296,8 +295,8 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
         n = len(user_ids)
         n_mb = (n + B - 1) // B
 
-        d_users0 = torch.from_numpy(user_ids).to(device)
-        d_items0 = torch.from_numpy(item_ids).to(device)
+        d_users0 = _host.ids_to_device(user_ids, device)
+        d_items0 = _host.ids_to_device(item_ids, device)
         d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):

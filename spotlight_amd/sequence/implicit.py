@@ -131,7 +131,7 @@ class ImplicitSequenceModel(object):
     def fit(self, interactions, verbose=False):
         """Fit the model on a SequenceInteractions dataset; repeated calls resume
         (sequence/implicit.py:193-264)."""
-        sequences = interactions.sequences.astype(np.int64)
+        sequences = interactions.sequences
 
         if not self._initialized:
             self._initialize(interactions)
@@ -150,7 +150,7 @@ class ImplicitSequenceModel(object):
         # the sequences go to the device once; `sequences` is rebound to its shuffled copy every epoch,
         # so successive epochs' permutations compose exactly as in the reference (:215-216) -- here by
         # gathering from the previous epoch's device array with a numpy-exact device permutation
-        d_prev = torch.from_numpy(np.ascontiguousarray(sequences)).to(device)
+        d_prev = _host.ids_to_device(sequences, device)
         d_sequences = torch.empty_like(d_prev)
         d_perm = torch.empty(n_seq, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):
