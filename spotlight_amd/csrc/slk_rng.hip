@@ -54,8 +54,9 @@ __device__ __forceinline__ void mt_regen_block(const uint32_t *o, uint32_t *n, i
 }
 
 #define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
-// LDS: prefix X[33*624] | zero block [624] (target of the padding exponent) | ping | pong
-#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 3) * SLK_MT_N)
+// LDS: prefix X[33*624] | zero block [624] (target of the padding exponent) | ping | pong |
+// the workgroup's exponent list as uint16 (SLK_MT_JUMP_TERMS / 2 words)
+#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 3) * SLK_MT_N + SLK_MT_JUMP_TERMS / 2)
 
 // raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.
 // Workgroup w owns blocks [w*L, (w+1)*L).  w > 0 first jumps to block w*L:
@@ -86,25 +87,22 @@ __global__ __launch_bounds__(SLK_MT_THREADS) void k_mt_generate_jump(const uint3
             mt_regen_block(X + (b - 1) * SLK_MT_N, X + b * SLK_MT_N, t);
         const uint32_t *e = polys + (size_t)(blockIdx.x - 1) * SLK_MT_JUMP_TERMS;
         const uint32_t *xj = X + 1 + (t < SLK_MT_N ? t : 0);
-        // the exponent list is wave-uniform: scalar loads, fetched one group of 16 ahead of the
-        // LDS reads that consume it; padding exponents hit the zero block
+        // The exponent list (every workgroup its own 40 KB: no reuse in the scalar cache, and a
+        // dependent scalar load per group of terms cost more than the LDS reads it fed) is staged
+        // in LDS as 16-bit values by coalesced vector loads; the loop then reads eight exponents
+        // with one broadcast ds_read_b128.  Padding exponents hit the zero block.
         const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];  // list length rounded up to 16
-        uint32_t c[16], n[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) c[i] = e[i];
+        uint16_t *sx = reinterpret_cast<uint16_t *>(pp1 + SLK_MT_N);
+        for (int i = t; i < nterms; i += SLK_MT_THREADS) sx[i] = (uint16_t)e[i];
+        __syncthreads();
         uint32_t acc = 0;
-        for (int k = 0; k < nterms; k += 16) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) n[i] = e[k + 16 + i];  // (list has 16 spare entries)
-            uint32_t a0 = 0, a1 = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                a0 ^= xj[c[i]];
-                a1 ^= xj[c[i + 1]];
-            }
+        for (int k = 0; k < nterms; k += 8) {
+            const uint4 ev = *reinterpret_cast<const uint4 *>(sx + k);
+            uint32_t a0 = xj[ev.x & 0xffffu] ^ xj[ev.y & 0xffffu];
+            uint32_t a1 = xj[ev.x >> 16] ^ xj[ev.y >> 16];
+            a0 ^= xj[ev.z & 0xffffu] ^ xj[ev.w & 0xffffu];
+            a1 ^= xj[ev.z >> 16] ^ xj[ev.w >> 16];
             acc ^= a0 ^ a1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) c[i] = n[i];
         }
         if (t < SLK_MT_N) pp0[t] = acc;
         cur = pp0;
