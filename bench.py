@@ -154,6 +154,7 @@ def bench_c4(args):
     def run(first, n_mb):
         eng.poolnet_train(tb, op, 0, seqs[first * B:].data_ptr(), n_mb * B, L, B, 'bpr', 1,
                           mb_loss[first:].data_ptr(), stream=stream)
+    eng.poolnet_reserve(tb, op, K * B, L, B, 'bpr', 1, stream=stream)  # scratch of the timed call's shape
     run(0, W)
     torch.cuda.synchronize(dev)
     eng.profile_reset()

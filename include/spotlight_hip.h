@@ -198,6 +198,10 @@ int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, 
                       int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
                       float *d_mb_loss, void *stream);
 
+/* Pre-allocates the scratch of a later slk_poolnet_train of the same shape (no hipMalloc in the epoch loop). */
+int slk_poolnet_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n_seq,
+                        int64_t seq_len, int64_t batch_size, int32_t loss, int32_t n_neg, void *stream);
+
 /* ImplicitSequenceModel.predict (sequence/implicit.py:288-340): d_out[k] = score of item
  * d_items[k] (NULL: item k) as the next item after d_sequence[seq_len]. */
 int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_sequence,

@@ -67,6 +67,8 @@ _PROTOTYPES = {
     'slk_poolnet_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_void_p,
                                     C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_poolnet_reserve': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int64, C.c_int64,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
     'slk_poolnet_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shuffle_perm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -212,6 +214,11 @@ class Engine(object):
             d_sequences, int(n_seq), int(seq_len), int(batch_size),
             LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg), d_neg_in, d_neg_out,
             d_mb_loss, stream))
+
+    def poolnet_reserve(self, tables, optim, n_seq, seq_len, batch_size, loss, n_neg, stream=0):
+        self._check(self._lib.slk_poolnet_reserve(self._ctx, C.byref(tables), C.byref(optim), int(n_seq), int(seq_len),
+                                                  int(batch_size), LOSS_KINDS[loss] if isinstance(loss, str) else int(loss),
+                                                  int(n_neg), stream))
 
     def poolnet_predict(self, tables, d_sequence, seq_len, d_items, n, d_out, stream=0):
         self._check(self._lib.slk_poolnet_predict(self._ctx, C.byref(tables), d_sequence, int(seq_len), d_items,

@@ -542,10 +542,31 @@ __global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const flo
 
 typedef void (*seq_pass_fn)(slk_seq_args);
 
+static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, int64_t padding_idx,
+                              const int64_t *d_sequences, int64_t n_seq, int64_t seq_len, int64_t batch_size,
+                              int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
+                              float *d_mb_loss, void *stream, bool reserve_only);
+
 SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, int64_t padding_idx,
                                  const int64_t *d_sequences, int64_t n_seq, int64_t seq_len, int64_t batch_size,
                                  int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
                                  float *d_mb_loss, void *stream) {
+    return poolnet_train_impl(ctx, tables, optim, padding_idx, d_sequences, n_seq, seq_len, batch_size, loss, n_neg,
+                              d_neg_in, d_neg_out, d_mb_loss, stream, false);
+}
+
+SLK_EXPORT int slk_poolnet_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n_seq,
+                                   int64_t seq_len, int64_t batch_size, int32_t loss, int32_t n_neg, void *stream) {
+    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    slk_optim o = *optim;
+    return poolnet_train_impl(ctx, tables, &o, 0, nullptr, n_seq, seq_len, batch_size, loss, n_neg, nullptr, nullptr,
+                              nullptr, stream, true);
+}
+
+static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, int64_t padding_idx,
+                              const int64_t *d_sequences, int64_t n_seq, int64_t seq_len, int64_t batch_size,
+                              int32_t loss, int32_t n_neg, const int64_t *d_neg_in, int64_t *d_neg_out,
+                              float *d_mb_loss, void *stream, bool reserve_only) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     const unsigned TM = 10u;  // tables 1 (item_embeddings) and 3 (item_biases)
@@ -563,7 +584,7 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
     if (padding_idx < -1 || padding_idx >= tables->num_items)
         return slk_fail(ctx, SLK_EINVAL, "padding_idx %lld outside [-1, num_items)", (long long)padding_idx);
     if (n_seq == 0) return SLK_OK;
-    if (!d_sequences || !d_mb_loss) return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: NULL pointer");
+    if (!reserve_only && (!d_sequences || !d_mb_loss)) return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_train: NULL pointer");
     const int D = tables->dim;
     const int64_t L = seq_len;
     const int NG = 256 / g, DL = g * vec;
@@ -643,6 +664,11 @@ SLK_EXPORT int slk_poolnet_train(slk_ctx *ctx, const slk_tables *tables, slk_opt
                                          (int)lds_bytes));
     const unsigned gpb = 256u / (unsigned)g;
 
+    if (reserve_only) {
+        // sampler and sort scratch of the largest chunk, so that the training call allocates nothing
+        if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nts_max * nn))) return rc;
+        return slk_sort_reserve(ctx, nts_max * (size_t)occ_mult);
+    }
     int64_t mb_global = 0;
     for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs) {
         const uint32_t ns = (uint32_t)((n_seq - c0 < chunk_seqs) ? (n_seq - c0) : chunk_seqs);

@@ -147,6 +147,8 @@ class ImplicitSequenceModel(object):
         n_minibatches = (n_seq + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 
+        engine.poolnet_reserve(tables, binding.as_struct(), n_seq, seq_len, self._batch_size, self._loss,
+                               self._num_negative_samples, stream=stream)
         # the sequences go to the device once; `sequences` is rebound to its shuffled copy every epoch,
         # so successive epochs' permutations compose exactly as in the reference (:215-216) -- here by
         # gathering from the previous epoch's device array with a numpy-exact device permutation
