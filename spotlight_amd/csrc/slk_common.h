@@ -36,7 +36,7 @@ struct slk_rng_dev {
     unsigned long long accepted;
 };
 
-#define SLK_EXTRA_BUFS 32
+#define SLK_EXTRA_BUFS 40
 
 // buffers filled by the value-independent prep of one chunk of minibatches (slk_bilinear.hip)
 struct slk_prep_bufs {
@@ -129,6 +129,8 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
 // sort wrapper (slk_sort.hip)
 int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                            uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+int slk_sort_pairs_u32_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s);
 

@@ -31,7 +31,7 @@
 #define FY_TILE 2048       // words per workgroup in the scan kernels (256 threads x 8)
 #define FY_TAIL 4096       // draws for i < FY_TAIL are taken sequentially
 
-enum { FY_B0 = 26, FY_B1, FY_B2, FY_B3, FY_B4, FY_SMALL };  // ctx->extra slots
+enum { FY_B0 = 26, FY_B1, FY_B2, FY_B3, FY_B4, FY_SMALL, FY_SORT };  // ctx->extra slots (32 in all)
 
 __device__ __forceinline__ uint32_t fy_temper(uint32_t y) {
     y ^= (y >> 11);
@@ -364,7 +364,9 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     uint32_t *key1 = (uint32_t *)ctx->extra[FY_B3].p, *val1 = (uint32_t *)ctx->extra[FY_B4].p;
     hipLaunchKernelGGL(k_fy_keys, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)J, N, key0, val0);
     SLK_LAUNCH_CHECK(ctx, "k_fy_keys");
-    if ((rc = slk_sort_pairs_u32_u32(ctx, key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s))) return rc;
+    // own temporary storage: the shuffle may be prepared on another stream than the training passes
+    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[FY_SORT], key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s)))
+        return rc;
     uint32_t *R[2] = {key0, val0};  // the sort's inputs are free again
     hipLaunchKernelGGL(k_fy_iota, dim3(fy_grid(ctx, N)), dim3(256), 0, s, R[0], N);
     hipLaunchKernelGGL(k_fy_pred, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,

@@ -8,15 +8,23 @@
 
 template <class V>
 static int sort_impl(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
-                     unsigned end_bit, hipStream_t s) {
+                     unsigned end_bit, hipStream_t s, slk_buf *scratch = nullptr) {
     if (n == 0) return SLK_OK;
     if (end_bit > 32) end_bit = 32;
+    slk_buf &buf = scratch ? *scratch : ctx->sort_tmp;
     size_t tmp = 0;
     SLK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
-    int rc = slk_ensure(ctx, ctx->sort_tmp, tmp);
+    int rc = slk_ensure(ctx, buf, tmp);
     if (rc) return rc;
-    SLK_HIP(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
+    SLK_HIP(ctx, rocprim::radix_sort_pairs(buf.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
     return SLK_OK;
+}
+
+// same, with the caller's temporary storage: for sorts that may run on another stream than the
+// training passes' sorts (the epoch shuffle prepared ahead, slk_shuffle.hip)
+int slk_sort_pairs_u32_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
+    return sort_impl<uint32_t>(ctx, kin, kout, vin, vout, n, end_bit, s, &scratch);
 }
 
 int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
