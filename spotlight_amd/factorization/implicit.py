@@ -64,69 +64,12 @@ def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
     try:
         engine.shuffle_perm(n, d_perm.data_ptr(), stream=stream)
     except _native.SlkError:
-        if random_state is None:  # running ahead of the host's RandomState: nothing to fall back on
-            raise
         order = np.arange(n)
         random_state.shuffle(order)
         d_perm.copy_(torch.from_numpy(order))
         engine.rng_set_state(random_state.get_state())
     for d_src, d_dst, row_len in arrays:
         engine.gather_rows_i64(d_src.data_ptr(), d_perm.data_ptr(), n, row_len, d_dst.data_ptr(), stream=stream)
-
-
-class _EpochPrep(object):
-    """The value-independent half of an epoch -- the shuffle of the ids and the negatives -- drawn on the
-    device from one MT19937 stream in the reference's order (shuffle(e), negatives(e), shuffle(e+1), ...;
-    implicit.py:212-219, 256-275), one epoch AHEAD of the training kernels on a second HIP stream
-    (double-buffered outputs).  On the GPU-less test harness (no streams) everything runs in order."""
-
-    def __init__(self, engine, random_state, device, d_users0, d_items0, num_items, n_draws, ahead):
-        self.engine, self.random_state, self.device = engine, random_state, device
-        self.src = (d_users0, d_items0)
-        self.n, self.num_items, self.n_draws = int(d_users0.numel()), int(num_items), int(n_draws)
-        # running ahead costs a second set of buffers; keep it for sizes where that is small change
-        self.ahead = bool(ahead) and device.type == 'cuda' and (16 * self.n + 8 * self.n_draws) <= (16 << 30)
-        sets = 2 if self.ahead else 1
-        self.bufs = [(torch.empty_like(d_users0), torch.empty_like(d_items0),
-                      torch.empty(self.n_draws, dtype=torch.int64, device=device)) for _ in range(sets)]
-        self.perm = torch.empty(self.n, dtype=torch.int64, device=device)
-        self.side = torch.cuda.Stream(device) if self.ahead else None
-        self.states = {}
-        self.prepared = -1
-        self.next_epoch = 0
-        self.want_more = False
-        engine.rng_set_state(random_state.get_state())
-
-    def _prepare(self, epoch):
-        bufs = self.bufs[epoch % len(self.bufs)]
-        if self.side is not None:
-            # the id arrays were produced on the current stream (ordered once, before the first epoch); the
-            # outputs' previous readers -- the training of epoch - 2 -- finished before the host read that
-            # epoch's loss, so later preparations wait for nothing and overlap the training in flight
-            if epoch == 0 or self.prepared < 0:
-                self.side.wait_stream(torch.cuda.current_stream(self.device))
-            stream = self.side.cuda_stream
-        else:
-            stream = _stream_for(self.device)
-        device_epoch_shuffle(self.engine, self.random_state if self.side is None else None, self.n, self.perm,
-                             [(self.src[0], bufs[0], 1), (self.src[1], bufs[1], 1)], stream)
-        self.engine.sample_items(self.num_items, self.n_draws, bufs[2].data_ptr(), stream=stream)
-        self.states[epoch] = self.engine.rng_get_state()  # synchronises `stream`: the outputs are complete
-        self.prepared = epoch
-
-    def take(self, epoch, last):
-        if self.prepared < epoch:
-            self._prepare(epoch)
-        self.next_epoch, self.want_more = epoch + 1, not last
-        return self.bufs[epoch % len(self.bufs)]
-
-    def after_enqueue(self):
-        if self.ahead and self.want_more:
-            self._prepare(self.next_epoch)
-
-    def state_after(self, epoch):
-        """numpy RandomState.get_state() as it stands after `epoch`'s shuffle and negatives."""
-        return self.states.pop(epoch)
 
 
 class _OptimizerBinding(object):
@@ -321,51 +264,35 @@ class ImplicitFactorizationModel(object):
         n_minibatches = (n + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 
+        engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
+                                self._num_negative_samples, stream=stream)
         # ids go to the device once; every epoch's permutation x[shuffle_indices] of them
         # (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
         d_users0 = ids_to_device(user_ids, device)
         d_items0 = ids_to_device(item_ids, device)
-        nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
-        prep = _EpochPrep(engine, self._random_state, device, d_users0, d_items0, self._num_items, n * nn,
-                          ahead=self._n_iter > 1)
-        # When the next epoch is prepared ahead, the training runs on its own (non-default) stream: the
-        # engine's small synchronous read-backs go through the NULL stream, which would otherwise wait
-        # for the training kernels enqueued on torch's default stream.
-        caller_stream = work_stream = None
-        if prep.ahead:
-            caller_stream = torch.cuda.current_stream(device)
-            work_stream = torch.cuda.Stream(device)
-            work_stream.wait_stream(caller_stream)
-            torch.cuda.set_stream(work_stream)
-        try:
-            stream = _stream_for(device)
-            engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
-                                    self._num_negative_samples, stream=stream)
-            for epoch_num in range(self._n_iter):
-                # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as numpy
-                # would consume it on the host.  Both depend on ids only, so epoch e+1's are prepared on a
-                # second stream while epoch e trains.
-                d_users, d_items, d_negs = prep.take(epoch_num, last=epoch_num + 1 == self._n_iter)
-                ostruct = binding.as_struct()
-                engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
-                                      self._batch_size, self._loss, self._num_negative_samples,
-                                      mb_loss.data_ptr(), d_neg_in=d_negs.data_ptr(), stream=stream)
-                binding.store_steps(ostruct.step)
-                prep.after_enqueue()  # epoch e+1's shuffle + negatives, while the GPU trains on epoch e
+        d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
+        d_perm = torch.empty(n, dtype=torch.int64, device=device)
+        for epoch_num in range(self._n_iter):
+            # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as
+            # numpy would consume it on the host
+            engine.rng_set_state(self._random_state.get_state())
+            device_epoch_shuffle(engine, self._random_state, n, d_perm, [(d_users0, d_users, 1), (d_items0, d_items, 1)],
+                                 stream)
+            ostruct = binding.as_struct()
+            engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
+                                  self._batch_size, self._loss, self._num_negative_samples,
+                                  mb_loss.data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
 
-                # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch
-                epoch_loss = float(mb_loss.double().mean().item())
-                self._random_state.set_state(prep.state_after(epoch_num))
+            # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch
+            epoch_loss = float(mb_loss.double().mean().item())
 
-                if verbose:
-                    print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
-                if np.isnan(epoch_loss) or epoch_loss == 0.0:
-                    raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
-        finally:
-            if work_stream is not None:
-                caller_stream.wait_stream(work_stream)
-                torch.cuda.set_stream(caller_stream)
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
     def predict(self, user_ids, item_ids=None):
         """Scores for one user against all/some items, or for explicit (user, item) pairs;

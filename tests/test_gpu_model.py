@@ -192,33 +192,3 @@ def test_explicit_model_fit_predict_match_reference_run(name):
     from test_host_explicit_model import check_fit_predict_against_fixture
     model = check_fit_predict_against_fixture(name, to_numpy=lambda w: w.detach().cpu().numpy(), use_cuda=True)
     assert all(w.is_cuda for w in model._net.tables())
-
-
-def test_epoch_prep_ahead_is_bit_neutral(monkeypatch):
-    """fit() prepares epoch e+1's shuffle and negatives on a second stream while epoch e trains: tables,
-    optimizer state and RandomState must equal the in-order run bit for bit (a missing dependency between
-    the two streams shows up here)."""
-    from spotlight_amd.factorization import implicit as mod
-    rs = np.random.RandomState(8)
-    inter = Interactions(rs.randint(0, 20000, 600000).astype(np.int32), rs.randint(0, 5000, 600000).astype(np.int32),
-                         num_users=20000, num_items=5000)
-
-    def run(ahead):
-        orig = mod._EpochPrep.__init__
-
-        def init(self, *a, **kw):
-            kw['ahead'] = kw['ahead'] and ahead
-            orig(self, *a, **kw)
-        monkeypatch.setattr(mod._EpochPrep, '__init__', init)
-        model = ImplicitFactorizationModel(loss='bpr', embedding_dim=32, n_iter=4, batch_size=65536, use_cuda=True,
-                                           optimizer_func=lambda p: torch.optim.Adagrad(p, lr=0.05),
-                                           random_state=np.random.RandomState(3))
-        model.fit(inter)
-        monkeypatch.setattr(mod._EpochPrep, '__init__', orig)
-        st = model._random_state.get_state()
-        return [w.detach().cpu().numpy() for w in model._net.tables()], st
-
-    (ta, sa), (tb, sb) = run(True), run(False)
-    for x, y in zip(ta, tb):
-        assert np.array_equal(x, y)
-    assert (sa[1] == sb[1]).all() and sa[2] == sb[2]
