@@ -18,7 +18,7 @@
 //  (2) THE SWAPS.  Step i makes x[i] final and moves the value that sat at i into j_i.  Hence, with
 //      T_p = the steps i' > p with j_i' = p in time order:  X[p] (the value at p when step p
 //      runs) = X[last of T_p] or p if none -- a forest of pointers to larger indices, resolved by
-//      pointer doubling -- and  final[first of T_p] = p,  final[next of T_p] = X[previous of T_p],
+//      walking each (short) chain -- and  final[first of T_p] = p,  final[next of T_p] = X[previous of T_p],
 //      final[i] = X[i] for self-swaps and for position 0.  T_p = one stable radix sort of (j_i, i).
 //
 // The RNG state afterwards is exactly numpy's (block of the last consumed word, pos = offset + 1),
@@ -107,16 +107,19 @@ __global__ __launch_bounds__(256) void k_fy_scan(const uint32_t *cnt, uint32_t *
     }
 }
 
-// A_new = exclusive prefix sum of the decisions taken with A_old; *changed |= (A_new != A_old)
-__global__ __launch_bounds__(256) void k_fy_apply(fy_args a, const uint32_t *off, int *changed) {
+// A_new = exclusive prefix sum of the decisions taken with A_old; *changed |= (A_new != A_old).
+// The same pass counts, per tile, the decisions A_new itself implies -- the next sweep's tile counts --
+// so a sweep is one scan of nb counters plus this kernel (12 bytes per word instead of 20).
+__global__ __launch_bounds__(256) void k_fy_apply(fy_args a, const uint32_t *off, uint32_t *cnt_next, int *changed) {
     __shared__ unsigned s[256];
     const int t = threadIdx.x;
     const uint32_t base = blockIdx.x * FY_TILE + t * 8;
     bool ok[8];
+    uint32_t vals[8];
     unsigned c = 0;
     for (int j = 0; j < 8; ++j) {
-        uint32_t v;
-        ok[j] = fy_decide(a, base + j, &v);
+        vals[j] = 0u;
+        ok[j] = fy_decide(a, base + j, &vals[j]);
         c += ok[j] ? 1u : 0u;
     }
     s[t] = c;
@@ -129,14 +132,26 @@ __global__ __launch_bounds__(256) void k_fy_apply(fy_args a, const uint32_t *off
     }
     uint32_t run = off[blockIdx.x] + (s[t] - c);
     bool diff = false;
+    unsigned cn = 0;
     for (int j = 0; j < 8; ++j) {
         if (base + j < a.W) {
             diff |= a.A_old[base + j] != run;
             a.A_new[base + j] = run;
+            // the decision the next sweep will take for this word (same word, new count)
+            const uint32_t v = fy_temper(a.raw[a.w0 + base + j]) & a.mask;
+            cn += (run < a.need && v <= a.hi - run) ? 1u : 0u;
         }
         run += ok[j] ? 1u : 0u;
     }
     if (diff) *changed = 1;
+    __syncthreads();
+    s[t] = cn;
+    __syncthreads();
+    for (int offn = 128; offn >= 1; offn >>= 1) {
+        if (t < offn) s[t] += s[t + offn];
+        __syncthreads();
+    }
+    if (t == 0) cnt_next[blockIdx.x] = s[0];
 }
 
 // the converged decisions: J[g0 + A(t)] = v_t for the accepted words; *consumed = words used by the range
@@ -193,14 +208,22 @@ __global__ __launch_bounds__(256) void k_fy_pred(const uint32_t *key, const uint
     }
 }
 
-__global__ __launch_bounds__(256) void k_fy_jump(const uint32_t *R0, uint32_t *R1, uint32_t n, int *changed) {
-    bool diff = false;
+// X[p] = the value standing at p when step p runs = the end of the chain p -> R[p] -> R[R[p]] -> ...
+// (R[q] > q unless q is terminal, R[q] == q).  The chains are short (a position is the target of
+// ln(n/p) later steps on average and the chain hops to ever larger indices), so every position
+// simply walks its own: one pass instead of log-many pointer-doubling rounds over all n.
+__global__ __launch_bounds__(256) void k_fy_resolve(const uint32_t *R, uint32_t *X, uint32_t n) {
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        const uint32_t r = R0[p], rr = R0[r];
-        R1[p] = rr;
-        diff |= rr != r;
+        uint32_t r = R[p];
+        if (r != p) {
+            uint32_t nx = R[r];
+            while (nx != r) {
+                r = nx;
+                nx = R[r];
+            }
+        }
+        X[p] = r;
     }
-    if (diff) *changed = 1;
 }
 
 __global__ __launch_bounds__(256) void k_fy_final(const uint32_t *key, const uint32_t *val, uint32_t m, uint32_t n,
@@ -312,14 +335,16 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
         SLK_LAUNCH_CHECK(ctx, "k_fy_init");
         const int check_every = a.W > (1u << 20) ? 1 : 3;
         int sweeps = 0, flag = 1;
+        a.A_old = Abuf[0];
+        hipLaunchKernelGGL(k_fy_count, dim3(nb), dim3(256), 0, s, a, cnt);  // later counts come from k_fy_apply
+        SLK_LAUNCH_CHECK(ctx, "k_fy_count");
         while (flag) {
             for (int k = 0; k < check_every; ++k) {
                 a.A_old = Abuf[cur];
                 a.A_new = Abuf[cur ^ 1];
                 if (k == check_every - 1) SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
-                hipLaunchKernelGGL(k_fy_count, dim3(nb), dim3(256), 0, s, a, cnt);
                 hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb);
-                hipLaunchKernelGGL(k_fy_apply, dim3(nb), dim3(256), 0, s, a, (const uint32_t *)off, d_flag);
+                hipLaunchKernelGGL(k_fy_apply, dim3(nb), dim3(256), 0, s, a, (const uint32_t *)off, cnt, d_flag);
                 SLK_LAUNCH_CHECK(ctx, "k_fy_apply");
                 cur ^= 1;
                 ++sweeps;
@@ -372,17 +397,9 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     hipLaunchKernelGGL(k_fy_pred, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
                        m, N, R[0]);
     SLK_LAUNCH_CHECK(ctx, "k_fy_pred");
-    int cur = 0, flag = 1, rounds = 0;
-    while (flag) {
-        SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_fy_jump, dim3(fy_grid(ctx, N)), dim3(256), 0, s, (const uint32_t *)R[cur], R[cur ^ 1], N,
-                           d_flag);
-        SLK_LAUNCH_CHECK(ctx, "k_fy_jump");
-        cur ^= 1;
-        SLK_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-        SLK_HIP(ctx, hipStreamSynchronize(s));
-        if (++rounds > 64) return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: pointer doubling did not terminate");
-    }
+    hipLaunchKernelGGL(k_fy_resolve, dim3(fy_grid(ctx, N)), dim3(256), 0, s, (const uint32_t *)R[0], R[1], N);
+    SLK_LAUNCH_CHECK(ctx, "k_fy_resolve");
+    const int cur = 1;
     hipLaunchKernelGGL(k_fy_final, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
                        m, N, (const uint32_t *)R[cur], d_perm_out);
     SLK_LAUNCH_CHECK(ctx, "k_fy_final");
