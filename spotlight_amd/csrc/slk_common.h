@@ -56,6 +56,7 @@ struct slk_ctx {
     hipStream_t last_stream = nullptr;
     slk_rng_dev *d_rng = nullptr;
     uint32_t *d_jump = nullptr;  // device copy of the jump polynomial table
+    bool mt_attr_set = false;    // k_mt_generate_jump's dynamic-LDS limit raised on this device
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,

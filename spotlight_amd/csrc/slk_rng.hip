@@ -240,11 +240,10 @@ int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t
         // restart from the last block of the previous one
         const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS;
         const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (!ctx->mt_attr_set) {  // per ctx, i.e. per device: function attributes live in the device's context
             SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_generate_jump,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set = true;
+            ctx->mt_attr_set = true;
         }
         unsigned long long start = 0;  // index of the launch's block 0
         const uint32_t *key_src = ctx->d_rng->key;
