@@ -223,34 +223,45 @@ __global__ __launch_bounds__(256) void k_explicit_loss(const float *sk, const fl
 // ---------------------------------------------------------------------------------------
 // dense sweeps (reference default optimizer: Adam with weight_decay = l2 over EVERY row)
 // ---------------------------------------------------------------------------------------
-struct slk_sweep_args {
-    float *p, *s1, *s2, *g;
-    size_t numel;
+
+// One launch sweeps up to four tables: block b belongs to the table t with first[t] <= b < first[t + 1]
+// and strides over that table with the blocks of its own range (a minibatch of the reference's default
+// optimizer is then user pass + item pass + ONE sweep launch instead of four).
+struct slk_sweep_all_args {
+    float *p[4], *s1[4], *s2[4], *g[4];
+    size_t numel[4];
+    unsigned first[5];
+    int adam;
     float wd, w1, beta2, omb2, step_size, bc2_sqrt, eps, clr;
 };
 
-__global__ __launch_bounds__(256) void k_adam_dense_sweep(slk_sweep_args a) {
-    // torch/optim/adam.py:414-546 (single-tensor): g += wd*p; m.lerp_(g, 1-b1);
-    // v = b2*v + (1-b2) g^2; p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < a.numel; e += (size_t)gridDim.x * 256) {
-        const float gv = a.g[e] + a.wd * a.p[e];
-        a.g[e] = 0.0f;
-        const float m = a.s1[e] + a.w1 * (gv - a.s1[e]);
-        const float v = a.s2[e] * a.beta2 + a.omb2 * (gv * gv);
-        a.s1[e] = m;
-        a.s2[e] = v;
-        a.p[e] += -a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
-    }
-}
-
-__global__ __launch_bounds__(256) void k_adagrad_dense_sweep(slk_sweep_args a) {
-    // torch/optim/adagrad.py:350-385 dense branch with weight_decay
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < a.numel; e += (size_t)gridDim.x * 256) {
-        const float gv = a.g[e] + a.wd * a.p[e];
-        a.g[e] = 0.0f;
-        const float s = a.s1[e] + gv * gv;
-        a.s1[e] = s;
-        a.p[e] += -a.clr * (gv / (sqrtf(s) + a.eps));
+__global__ __launch_bounds__(256) void k_dense_sweep_all(slk_sweep_all_args a) {
+    int t = 0;
+    while (t < 3 && blockIdx.x >= a.first[t + 1]) ++t;
+    const size_t local = blockIdx.x - a.first[t], nblk = a.first[t + 1] - a.first[t];
+    float *p = a.p[t], *s1 = a.s1[t], *s2 = a.s2[t], *g = a.g[t];
+    const size_t numel = a.numel[t];
+    if (a.adam) {
+        // torch/optim/adam.py:414-546 (single-tensor): g += wd*p; m.lerp_(g, 1-b1);
+        // v = b2*v + (1-b2) g^2; p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+        for (size_t e = local * 256 + threadIdx.x; e < numel; e += nblk * 256) {
+            const float gv = g[e] + a.wd * p[e];
+            g[e] = 0.0f;
+            const float m = s1[e] + a.w1 * (gv - s1[e]);
+            const float v = s2[e] * a.beta2 + a.omb2 * (gv * gv);
+            s1[e] = m;
+            s2[e] = v;
+            p[e] += -a.step_size * (m / (sqrtf(v) / a.bc2_sqrt + a.eps));
+        }
+    } else {
+        // torch/optim/adagrad.py:350-385 dense branch with weight_decay
+        for (size_t e = local * 256 + threadIdx.x; e < numel; e += nblk * 256) {
+            const float gv = g[e] + a.wd * p[e];
+            g[e] = 0.0f;
+            const float s = s1[e] + gv * gv;
+            s1[e] = s;
+            p[e] += -a.clr * (gv / (sqrtf(s) + a.eps));
+        }
     }
 }
 
@@ -457,11 +468,12 @@ int slk_dense_sweeps(slk_ctx *ctx, float *const params[4], const slk_optim *opti
                      hipStream_t s) {
     const double step = (double)(optim->step + 1);
     slk_prof_begin(ctx, SLK_K_DENSE_SWEEP, s);
-    slk_sweep_args w;
+    slk_sweep_all_args w;
     memset(&w, 0, sizeof(w));
     w.wd = (float)optim->weight_decay;
     w.eps = (float)optim->eps;
-    if (optim->kind == SLK_OPT_ADAM_DENSE) {
+    w.adam = optim->kind == SLK_OPT_ADAM_DENSE;
+    if (w.adam) {
         const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
         w.w1 = (float)(1.0 - optim->beta1);
         w.beta2 = (float)optim->beta2;
@@ -471,19 +483,21 @@ int slk_dense_sweeps(slk_ctx *ctx, float *const params[4], const slk_optim *opti
     } else {
         w.clr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
     }
+    unsigned blocks = 0;
     for (int t = 0; t < 4; ++t) {
+        w.first[t] = blocks;
         if (!((table_mask >> t) & 1u)) continue;
-        w.p = params[t];
-        w.s1 = optim->d_state1[t];
-        w.s2 = optim->d_state2[t];
-        w.g = (float *)ctx->dgrad[t].p;
-        w.numel = ctx->dgrad_elems[t];
-        const unsigned wgrid = slk_grid_for(ctx, w.numel, 256);
-        if (optim->kind == SLK_OPT_ADAM_DENSE)
-            hipLaunchKernelGGL(k_adam_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
-        else
-            hipLaunchKernelGGL(k_adagrad_dense_sweep, dim3(wgrid), dim3(256), 0, s, w);
-        SLK_LAUNCH_CHECK(ctx, "dense sweep");
+        w.p[t] = params[t];
+        w.s1[t] = optim->d_state1[t];
+        w.s2[t] = optim->d_state2[t];
+        w.g[t] = (float *)ctx->dgrad[t].p;
+        w.numel[t] = ctx->dgrad_elems[t];
+        blocks += slk_grid_for(ctx, w.numel[t], 256);
+    }
+    w.first[4] = blocks;
+    if (blocks) {
+        hipLaunchKernelGGL(k_dense_sweep_all, dim3(blocks), dim3(256), 0, s, w);
+        SLK_LAUNCH_CHECK(ctx, "k_dense_sweep_all");
     }
     slk_prof_end(ctx, s);
     return SLK_OK;
