@@ -14,7 +14,7 @@
 //      if A is right on [0, t) then so is the next iterate on [0, t], so the first wrong index
 //      advances every sweep (no cycles), and because shifting A by delta flips only ~0.7 delta
 //      decisions the error contracts geometrically -- ~20 sweeps of an 8-byte-per-word scan
-//      instead of 1e8 dependent steps.  The last 65535 draws are taken in order by one wavefront.
+//      instead of 1e8 dependent steps.  The last 4095 draws are taken in order by one lane.
 //  (2) THE SWAPS.  Step i makes x[i] final and moves the value that sat at i into j_i.  Hence, with
 //      T_p = the steps i' > p with j_i' = p in time order:  X[p] (the value at p when step p
 //      runs) = X[last of T_p] or p if none -- a forest of pointers to larger indices, resolved by
@@ -29,7 +29,8 @@
 
 #define SLK_MT_N 624
 #define FY_TILE 2048       // words per workgroup in the scan kernels (256 threads x 8)
-#define FY_TAIL 65536      // draws for i < FY_TAIL are taken in order by one wavefront (k_fy_tail)
+#define FY_TAIL 4096       // draws for i < FY_TAIL are taken in order by one lane (k_fy_tail): serial code costs
+                           // ~100 ns per word on this machine, so the tail is kept short (65536 measured +8 ms)
 
 enum { FY_B0 = 26, FY_B1, FY_B2, FY_B3, FY_B4, FY_SMALL, FY_SORT };  // ctx->extra slots (32 in all)
 
@@ -166,37 +167,51 @@ __global__ __launch_bounds__(256) void k_fy_emit(fy_args a, uint32_t *J, uint32_
     }
 }
 
-// the last draws (i = i_start .. 1) by ONE wavefront: 64 words are tempered at once, then the wave walks
-// them in order (every lane runs the same scalar decision: is word l <= the current i under its mask?),
-// i.e. numpy's rk_interval loop at ~6 ns per word instead of one dependent global load per word.
+// the last draws (i = i_start .. 1) by ONE wavefront: 256 words are tempered at once into LDS, then lane 0
+// walks them in order (is word l <= the current i under its mask?): numpy's rk_interval loop without a
+// dependent global load per word.
 __global__ __launch_bounds__(64) void k_fy_tail(const uint32_t *raw, unsigned long long w0,
                                                 unsigned long long total_words, uint32_t i_start, uint32_t *J,
                                                 uint32_t g0, uint32_t *consumed) {
+    __shared__ uint32_t sv[256];
     const int lane = threadIdx.x;
     unsigned long long w = w0;
     uint32_t i = i_start, g = g0;
     uint32_t result = 0xffffffffu;  // words consumed; ~0u = ran out of generated words
     while (i >= 1) {
         if (w >= total_words) break;
-        const unsigned long long idx = w + (unsigned long long)lane;
-        const uint32_t mine = idx < total_words ? fy_temper(raw[idx]) : 0u;
-        const int avail = (total_words - w < 64ull) ? (int)(total_words - w) : 64;
+        // 256 words per round: tempered by the 64 lanes, parked in LDS, then walked in order from
+        // LDS (plain loads the compiler can batch ahead of the dependent decision chain)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long idx = w + (unsigned long long)(r * 64 + lane);
+            sv[r * 64 + lane] = idx < total_words ? fy_temper(raw[idx]) : 0u;
+        }
+        __syncthreads();
+        const int avail = (total_words - w < 256ull) ? (int)(total_words - w) : 256;
         int l = 0;
-        for (; l < avail && i >= 1; ++l) {
-            uint32_t mask = i;
-            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-            const uint32_t v = __shfl(mine, l, 64) & mask;
-            if (v <= i) {
-                if (lane == 0) J[g] = v;
-                ++g;
-                --i;
+        if (lane == 0) {
+            for (; l < avail && i >= 1; ++l) {
+                uint32_t mask = i;
+                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                const uint32_t v = sv[l] & mask;
+                if (v <= i) {
+                    J[g] = v;
+                    ++g;
+                    --i;
+                }
             }
         }
+        // lane 0's progress to the whole wave
+        i = __shfl(i, 0, 64);
+        g = __shfl(g, 0, 64);
+        l = __shfl(l, 0, 64);
         if (i == 0) {
             result = (uint32_t)(w + (unsigned long long)l - w0);
             break;
         }
-        w += 64;
+        w += 256;
     }
     if (lane == 0) *consumed = result;
 }

@@ -116,7 +116,7 @@ def test_pipelined_chunks_match_single_chunk(be):
 @pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 623, 4095, 4096, 4097, 8192, 12345, 65535, 65536, 65537, 65538, 70001,
                                131073])
 def test_device_shuffle_is_numpy_exact(be, n):
-    """slk_shuffle_perm: sizes around the in-order tail (65536), the power-of-two range edges and the
+    """slk_shuffle_perm: sizes around the in-order tail (4096), the power-of-two range edges and the
     MT19937 block size; RandomState continuity checked through the next randint."""
     ec.check_shuffle_matches_numpy(be, n, seed=n + 1, burn=n % 5, rows=3 if n in (10, 4097) else 0)
 
