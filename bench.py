@@ -390,6 +390,13 @@ def main():
                             'slices_per_minibatch': trainer.slices,
                             'kernel_ms_per_step': kern_ms,
                             'exchange_and_host_ms_per_step': elapsed / K * 1e3 - kern_ms}
+            # the exchange bound: every byte leaves through one of the (world - 1) direct xGMI links of
+            # this GPU (point-to-point mesh, ~76.8 GB/s per link and direction)
+            xb = roof['xgmi']['bytes_per_step_per_gpu_each_way']
+            peak = max(world - 1, 1) * 76.8
+            roof['xgmi'].update({'link_peak_GBs_each_way': peak,
+                                 'achieved_GBs_each_way_over_the_whole_step': xb / (elapsed / K) / 1e9,
+                                 'min_ms_per_step_at_link_peak': xb / (peak * 1e9) * 1e3 if world > 1 else 0.0})
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
