@@ -216,6 +216,20 @@ int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, void *stream)
 int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int64_t *d_perm, int64_t n, int64_t row_len,
                         int64_t *d_dst, void *stream);
 
+/* Interactions.to_sequence (spotlight/interactions.py:170-266): the interactions ordered by
+ * np.lexsort((timestamps, user_ids)) and cut, per user, into left-zero-padded windows of
+ * max_sequence_length items ending at positions count, count - step_size, ... of the user's history
+ * (newest window first, users ascending); windows shorter than min_length are dropped (pass 1 for
+ * min_sequence_length=None).  d_timestamps: int64 (ts_kind 0) or float64 (ts_kind 1; NaN last).
+ * slk_to_sequence_plan sorts and counts (synchronises; *num_sequences_out is a HOST int64), the
+ * caller allocates, slk_to_sequence_fill writes d_sequences[num_sequences][max_sequence_length]
+ * (int32, as the reference) and d_sequence_users[num_sequences].  num_users bounds the user ids
+ * (<= 0: unknown, 32 bits sorted). */
+int slk_to_sequence_plan(slk_ctx *ctx, const int64_t *d_users, const int64_t *d_items, const void *d_timestamps,
+                         int32_t ts_kind, int64_t n, int64_t num_users, int32_t max_sequence_length,
+                         int32_t step_size, int32_t min_length, int64_t *num_sequences_out, void *stream);
+int slk_to_sequence_fill(slk_ctx *ctx, int32_t *d_sequences, int32_t *d_sequence_users, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Evaluation side of the path (spotlight/evaluation.py:9-109: mrr_score / sequence_mrr_score call
  * predict() once per user or sequence and rank on the host with scipy.stats.rankdata).

@@ -73,6 +73,9 @@ _PROTOTYPES = {
                                       C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shuffle_perm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_gather_rows_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_to_sequence_plan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
+    'slk_to_sequence_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_bilinear_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_poolnet_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_void_p]),
@@ -230,6 +233,19 @@ class Engine(object):
 
     def gather_rows_i64(self, d_src, d_perm, n, row_len, d_dst, stream=0):
         self._check(self._lib.slk_gather_rows_i64(self._ctx, d_src, d_perm, int(n), int(row_len), d_dst, stream))
+
+    # -- Interactions.to_sequence on the device (include/spotlight_hip.h: slk_to_sequence_*) --
+    def to_sequence_plan(self, d_users, d_items, d_timestamps, ts_kind, n, num_users, max_sequence_length,
+                         step_size, min_length, stream=0):
+        """Sorts and counts; returns the number of sequences the following to_sequence_fill writes."""
+        rows = C.c_int64(0)
+        self._check(self._lib.slk_to_sequence_plan(self._ctx, d_users, d_items, d_timestamps, int(ts_kind), int(n),
+                                                   int(num_users), int(max_sequence_length), int(step_size),
+                                                   int(min_length), C.byref(rows), stream))
+        return int(rows.value)
+
+    def to_sequence_fill(self, d_sequences, d_sequence_users, stream=0):
+        self._check(self._lib.slk_to_sequence_fill(self._ctx, d_sequences, d_sequence_users, stream))
 
     # -- evaluation: batched predict + on-GPU ranking (include/spotlight_hip.h) -----------
     def bilinear_scores(self, tables, d_users, n_users, d_out, stream=0):

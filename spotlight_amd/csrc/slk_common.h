@@ -82,6 +82,10 @@ struct slk_ctx {
     std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
     std::vector<uint64_t> sh_host, sh_host2;     // host staging for small H2D tables (begin / commit)
 
+    // Interactions.to_sequence plan (slk_seqprep.hip): rows pending a slk_to_sequence_fill (-1: none)
+    int64_t ts_rows = -1, ts_nseg = 0;
+    int ts_L = 0, ts_step = 0;
+
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
 
     // profiling
@@ -131,6 +135,8 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
 int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                            uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
 int slk_sort_pairs_u32_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+int slk_sort_pairs_u64_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
                               uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s);

@@ -6,11 +6,11 @@
 
 #include "slk_common.h"
 
-template <class V>
-static int sort_impl(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const V *vin, V *vout, size_t n,
+template <class V, class K = uint32_t>
+static int sort_impl(slk_ctx *ctx, const K *kin, K *kout, const V *vin, V *vout, size_t n,
                      unsigned end_bit, hipStream_t s, slk_buf *scratch = nullptr) {
     if (n == 0) return SLK_OK;
-    if (end_bit > 32) end_bit = 32;
+    if (end_bit > 8 * sizeof(K)) end_bit = 8 * sizeof(K);
     slk_buf &buf = scratch ? *scratch : ctx->sort_tmp;
     size_t tmp = 0;
     SLK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
@@ -25,6 +25,12 @@ static int sort_impl(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const V 
 int slk_sort_pairs_u32_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                               uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
     return sort_impl<uint32_t>(ctx, kin, kout, vin, vout, n, end_bit, s, &scratch);
+}
+
+// 64-bit keys (timestamps whose range needs more than 32 bits, slk_seqprep.hip)
+int slk_sort_pairs_u64_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
+    return sort_impl<uint32_t, uint64_t>(ctx, kin, kout, vin, vout, n, end_bit, s, &scratch);
 }
 
 int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,

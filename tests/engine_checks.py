@@ -691,3 +691,95 @@ def check_high_row_ids(be, U=(1 << 25) + 3, I=(1 << 21) + 1, D=4, N=4000, B=1024
     k = int(np.searchsorted(uu, U - 1))
     ref = (ora.p[0][k] * ora.p[1]).sum(1) + ora.p[2][k] + ora.p[3]
     assert rel_inf(be.get(out), ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# Interactions.to_sequence on the device (slk_to_sequence_plan / slk_to_sequence_fill)
+# ---------------------------------------------------------------------------------------
+def to_sequence_case(rs, n, num_users, num_items, ts_mode):
+    """Synthetic interactions with duplicate timestamps (stability matters) in the flavour `ts_mode`."""
+    from spotlight_amd.interactions import Interactions
+    users = rs.randint(0, num_users, n).astype(np.int32)
+    items = rs.randint(1, num_items, n).astype(np.int32)
+    if ts_mode == 'int32':
+        ts = rs.randint(0, max(n // 3, 2), n).astype(np.int32)
+    elif ts_mode == 'int64_wide':      # range needs more than 32 bits: the 64-bit key sort
+        ts = rs.randint(0, 50, n).astype(np.int64) * (1 << 37) - (1 << 40)
+    elif ts_mode == 'negative':
+        ts = rs.randint(-1000, 1000, n).astype(np.int64)
+    elif ts_mode == 'float':
+        ts = rs.randint(-40, 40, n).astype(np.float64) / 8.0
+        ts[rs.rand(n) < 0.05] = -0.0
+        ts[rs.rand(n) < 0.05] = np.inf
+    elif ts_mode == 'float32':
+        ts = (rs.randint(0, 200, n) * 0.25).astype(np.float32)
+    elif ts_mode == 'constant':
+        ts = np.full(n, 7, dtype=np.int64)
+    else:
+        raise ValueError(ts_mode)
+    return Interactions(users, items, timestamps=ts, num_users=num_users, num_items=num_items)
+
+
+def device_to_sequence(be, inter, max_sequence_length, min_sequence_length, step_size):
+    """The engine calls Interactions._to_sequence_device makes, through the backend `be`."""
+    eng = be.engine
+    L = max_sequence_length
+    step = L if step_size is None else step_size
+    if min_sequence_length is None:
+        thr = 1
+    else:
+        thr = min_sequence_length if min_sequence_length > 0 else L + min_sequence_length
+    ts = inter.timestamps
+    kind = 0 if ts.dtype.kind in 'iu' else 1
+    ts = ts.astype(np.int64 if kind == 0 else np.float64)
+    d_u, d_i, d_t = be.alloc(inter.user_ids.astype(np.int64)), be.alloc(inter.item_ids.astype(np.int64)), be.alloc(ts)
+    rows = eng.to_sequence_plan(be.ptr(d_u), be.ptr(d_i), be.ptr(d_t), kind, len(inter), inter.num_users, L, step, thr,
+                                stream=be.stream)
+    d_seq = be.alloc(np.full((max(rows, 1), L), -7, dtype=np.int32))
+    d_su = be.alloc(np.full(max(rows, 1), -7, dtype=np.int32))
+    eng.to_sequence_fill(be.ptr(d_seq), be.ptr(d_su), stream=be.stream)
+    return be.get(d_seq)[:rows], be.get(d_su)[:rows]
+
+
+def check_to_sequence(be, n, num_users, num_items, ts_mode, max_sequence_length, min_sequence_length, step_size, seed=0):
+    """Device to_sequence == the host to_sequence (interactions.py:170-266; the host one is pinned to the
+    reference's golden vectors in test_host_api.py / test_interactions.py), cell for cell."""
+    rs = np.random.RandomState(seed)
+    inter = to_sequence_case(rs, n, num_users, num_items, ts_mode)
+    want = inter.to_sequence(max_sequence_length, min_sequence_length, step_size)
+    seq, seq_users = device_to_sequence(be, inter, max_sequence_length, min_sequence_length, step_size)
+    assert seq.shape == want.sequences.shape, (seq.shape, want.sequences.shape)
+    assert np.array_equal(seq, want.sequences)
+    assert np.array_equal(seq_users, want.user_ids)
+    return seq.shape[0]
+
+
+def vectorized_to_sequence(inter, L, min_len, step):
+    """numpy restatement of interactions.py:170-266 without the Python double loop (so that 10^7 interactions
+    can be checked); itself checked against the host loop at small sizes (test_emu_engine.py)."""
+    step = L if step is None else step
+    order = np.lexsort((inter.timestamps, inter.user_ids))
+    users, items = inter.user_ids[order], inter.item_ids[order]
+    uniq, starts, counts = np.unique(users, return_index=True, return_counts=True)
+    per_user = -(-counts // step)
+    seg = np.repeat(np.arange(len(uniq)), per_user)
+    first = np.concatenate([[0], np.cumsum(per_user)[:-1]])
+    w = np.arange(len(seg)) - first[seg]
+    end = counts[seg] - w * step
+    pos = end[:, None] - L + np.arange(L)[None, :]
+    seq = np.where(pos >= 0, items[np.clip(starts[seg][:, None] + pos, 0, len(items) - 1)], 0).astype(np.int32)
+    seq_users = uniq[seg].astype(np.int32)
+    if min_len is not None:
+        keep = seq[:, -min_len] != 0
+        seq, seq_users = seq[keep], seq_users[keep]
+    return seq, seq_users
+
+
+def check_to_sequence_large(be, n, num_users, num_items, ts_mode, L, min_len, step, seed=0):
+    rs = np.random.RandomState(seed)
+    inter = to_sequence_case(rs, n, num_users, num_items, ts_mode)
+    want, want_users = vectorized_to_sequence(inter, L, min_len, step)
+    seq, seq_users = device_to_sequence(be, inter, L, min_len, step)
+    assert seq.shape == want.shape, (seq.shape, want.shape)
+    assert np.array_equal(seq, want) and np.array_equal(seq_users, want_users)
+    return seq.shape[0]

@@ -130,3 +130,51 @@ def test_minibatch_of_one_interaction(be):
 
 def test_row_ids_near_the_top_of_the_tables(be):
     ec.check_high_row_ids(be, U=(1 << 17) + 3, I=(1 << 16) + 1, N=600, B=256)
+
+
+TO_SEQUENCE_CASES = [
+    # n, users, items, timestamps, max_len, min_len, step
+    (1, 5, 9, 'int32', 4, None, None),
+    (57, 1, 9, 'int32', 5, None, 1),            # one user: every prefix is a window
+    (200, 11, 50, 'int32', 5, None, None),
+    (200, 11, 50, 'int32', 5, None, 1),
+    (200, 11, 50, 'int32', 5, 3, 2),
+    (200, 11, 50, 'int32', 5, 5, 1),            # only full windows
+    (200, 11, 50, 'int32', 5, 0, 1),            # sequences[:, -0] is column 0: full windows again
+    (200, 11, 50, 'int32', 5, -2, 1),           # negative index: column 2 non-zero
+    (300, 40, 50, 'negative', 3, None, 2),
+    (300, 40, 50, 'int64_wide', 7, 2, 3),
+    (300, 40, 50, 'float', 4, None, 1),
+    (300, 40, 50, 'float32', 20, None, 7),      # windows longer than most histories
+    (300, 40, 50, 'constant', 6, None, 4),      # all timestamps equal: input order kept
+    (5000, 300, 1000, 'int32', 10, None, None),  # several scan tiles
+    (5000, 2, 1000, 'int32', 16, 4, 1),          # long histories, many rows per user
+    (4500, 3000, 1000, 'int32', 4, 2, 1),        # most users dropped by the minimum length
+]
+
+
+@pytest.mark.parametrize('case', TO_SEQUENCE_CASES, ids=lambda c: '-'.join(str(x) for x in c))
+def test_device_to_sequence_matches_host(be, case):
+    """slk_to_sequence_plan / _fill == Interactions.to_sequence (interactions.py:170-266), cell for cell."""
+    n, users, items, ts_mode, L, min_len, step = case
+    ec.check_to_sequence(be, n, users, items, ts_mode, L, min_len, step, seed=n + L)
+    # the loop-free restatement the large GPU cases are checked with agrees with the host loop
+    inter = ec.to_sequence_case(np.random.RandomState(n + L), n, users, items, ts_mode)
+    want = inter.to_sequence(L, min_len, step)
+    got, got_users = ec.vectorized_to_sequence(inter, L, min_len, step)
+    assert np.array_equal(got, want.sequences) and np.array_equal(got_users, want.user_ids)
+
+
+def test_device_to_sequence_argument_errors(be):
+    eng = be.engine
+    d = be.alloc(np.zeros(4, dtype=np.int64))
+    for bad in (dict(L=0), dict(step=0), dict(thr=0), dict(thr=5), dict(kind=2)):
+        kw = dict(L=4, step=1, thr=1, kind=0)
+        kw.update(bad)
+        with pytest.raises(_native.SlkError):
+            eng.to_sequence_plan(be.ptr(d), be.ptr(d), be.ptr(d), kw['kind'], 4, 3, kw['L'], kw['step'], kw['thr'],
+                                 stream=be.stream)
+    assert eng.to_sequence_plan(be.ptr(d), be.ptr(d), be.ptr(d), 0, 0, 3, 4, 1, 1, stream=be.stream) == 0  # empty
+    eng.to_sequence_fill(be.ptr(d), be.ptr(d), stream=be.stream)
+    with pytest.raises(_native.SlkError):  # no plan pending
+        eng.to_sequence_fill(be.ptr(d), be.ptr(d), stream=be.stream)

@@ -183,6 +183,27 @@ def test_device_shuffle_is_numpy_exact(be, n):
     ec.check_shuffle_matches_numpy(be, n, seed=n % 1000 + 3, burn=n % 7, rows=2 if n == 5000 else 0)
 
 
+# ---- Interactions.to_sequence on the device (slk_seqprep.hip) ----
+@pytest.mark.parametrize('case', [
+    (1, 5, 9, 'int32', 4, None, None), (200, 11, 50, 'int32', 5, 3, 2), (300, 40, 50, 'float', 4, None, 1),
+    (300, 40, 50, 'int64_wide', 7, 2, 3), (300, 40, 50, 'constant', 6, None, 4), (5000, 2, 1000, 'int32', 16, 4, 1),
+    (70000, 3000, 1000, 'negative', 10, None, None)], ids=lambda c: '-'.join(str(x) for x in c))
+def test_device_to_sequence_matches_host(be, case):
+    n, users, items, ts_mode, L, min_len, step = case
+    ec.check_to_sequence(be, n, users, items, ts_mode, L, min_len, step, seed=n + L)
+
+
+@pytest.mark.parametrize('case', [
+    (3000000, 200000, 1000000, 'int32', 10, None, None), (3000000, 200000, 1000000, 'int64_wide', 20, 5, 3),
+    (2000000, 1500000, 50000, 'float', 8, 2, 1), (10000000, 1000000, 1000000, 'int32', 50, 3, 25)],
+    ids=lambda c: '-'.join(str(x) for x in c))
+def test_device_to_sequence_large(be, case):
+    """Millions of interactions against the loop-free numpy restatement (the host double loop takes minutes there)."""
+    n, users, items, ts_mode, L, min_len, step = case
+    rows = ec.check_to_sequence_large(be, n, users, items, ts_mode, L, min_len, step, seed=L)
+    assert rows > 0
+
+
 # ---- explicit feedback (slk_bilinear_train_explicit) ----
 @pytest.mark.parametrize('loss', ec.EXPLICIT_LOSSES)
 def test_explicit_train_and_gradients(be, loss):

@@ -192,3 +192,21 @@ def test_explicit_model_fit_predict_match_reference_run(name):
     from test_host_explicit_model import check_fit_predict_against_fixture
     model = check_fit_predict_against_fixture(name, to_numpy=lambda w: w.detach().cpu().numpy(), use_cuda=True)
     assert all(w.is_cuda for w in model._net.tables())
+
+
+def test_to_sequence_device_route_on_gpu():
+    """Interactions.to_sequence(device='cuda') == the host route, then feeds the sequence model."""
+    from spotlight_amd.interactions import Interactions
+    from spotlight_amd.sequence.implicit import ImplicitSequenceModel
+    rs = np.random.RandomState(9)
+    n = 60000
+    inter = Interactions(rs.randint(0, 900, n).astype(np.int32), rs.randint(1, 1500, n).astype(np.int32),
+                         timestamps=rs.randint(0, 5000, n).astype(np.int32), num_users=900, num_items=1500)
+    for kw in (dict(), dict(max_sequence_length=20, step_size=1), dict(max_sequence_length=7, min_sequence_length=3, step_size=2)):
+        a, b = inter.to_sequence(**kw), inter.to_sequence(device='cuda', **kw)
+        assert np.array_equal(a.sequences, b.sequences) and np.array_equal(a.user_ids, b.user_ids), kw
+    seq = inter.to_sequence(max_sequence_length=12, min_sequence_length=4, step_size=3, device='cuda:0')
+    model = ImplicitSequenceModel(loss='bpr', embedding_dim=16, n_iter=1, batch_size=256, use_cuda=True,
+                                  random_state=np.random.RandomState(1))
+    model.fit(seq)
+    assert model.predict(seq.sequences[0]).shape == (1500,)

@@ -146,3 +146,41 @@ def test_to_sequence_feeds_the_model(emu_device):
                               random_state=np.random.RandomState(2))
     m.fit(seq)
     assert m.predict(seq.sequences[0]).shape == (50,)
+
+
+def test_to_sequence_device_route(emu_device):
+    """Interactions.to_sequence(device='cuda') (slk_seqprep.hip) returns what the host route returns -- on the
+    reference-recorded split of tests/golden/host_api.npz, on the worked example of the reference's own test
+    (tests/test_interactions.py:67-100: every window ends where the docstring says) and with the argument
+    forms the reference accepts."""
+    import os
+
+    from conftest import GOLDEN
+    from spotlight_amd.cross_validation import random_train_test_split
+    from spotlight_amd.datasets.synthetic import generate_sequential
+    rec = np.load(os.path.join(GOLDEN, 'host_api.npz'))
+    data = generate_sequential(num_users=30, num_items=60, num_interactions=900, concentration_parameter=0.1, order=3,
+                               random_state=np.random.RandomState(11))
+    _, te = random_train_test_split(data, test_percentage=0.25, random_state=np.random.RandomState(13))
+    seq = te.to_sequence(max_sequence_length=6, min_sequence_length=2, step_size=2, device='cuda')
+    assert np.array_equal(seq.sequences, rec['to_seq']) and seq.sequences.dtype == np.int32
+    assert seq.num_items == te.num_items and seq.max_sequence_length == 6
+
+    rs = np.random.RandomState(5)
+    n = 700
+    inter = Interactions(rs.randint(0, 25, n).astype(np.int32), rs.randint(1, 80, n).astype(np.int32),
+                         timestamps=rs.randint(0, 300, n).astype(np.int32), num_users=25, num_items=80)
+    for kw in (dict(), dict(max_sequence_length=4), dict(max_sequence_length=5, step_size=1),
+               dict(max_sequence_length=7, min_sequence_length=3, step_size=2), dict(max_sequence_length=3, min_sequence_length=0)):
+        a, b = inter.to_sequence(**kw), inter.to_sequence(device='cuda', **kw)
+        assert np.array_equal(a.sequences, b.sequences) and np.array_equal(a.user_ids, b.user_ids), kw
+        assert b.user_ids.dtype == np.int32
+    with pytest.raises(IndexError):
+        inter.to_sequence(max_sequence_length=4, min_sequence_length=5, device='cuda')
+    with pytest.raises(ValueError):
+        inter.to_sequence(device='cpu')
+    no_ts = Interactions(inter.user_ids, inter.item_ids)
+    with pytest.raises(ValueError):
+        no_ts.to_sequence(device='cuda')
+    m = ImplicitSequenceModel(loss='bpr', n_iter=1, embedding_dim=8, batch_size=32, random_state=np.random.RandomState(2))
+    m.fit(inter.to_sequence(max_sequence_length=8, min_sequence_length=2, step_size=3, device='cuda'))
