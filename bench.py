@@ -22,8 +22,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -231,6 +231,26 @@ int slk_to_sequence_plan(slk_ctx *ctx, const int64_t *d_users, const int64_t *d_
 int slk_to_sequence_fill(slk_ctx *ctx, int32_t *d_sequences, int32_t *d_sequence_users, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Embedding front-end for encoders whose body stays on stock PyTorch (LSTMNet / CNNNet /
+ * MixtureLSTMNet, spotlight/sequence/representations.py:147-596): the lookups
+ * `self.item_embeddings(ids)` / `self.item_biases(ids)` and their autograd backward.
+ * slk_embedding_forward: d_out[k][:] = d_weight[d_ids[k]][:] (layers.py:23-56), or, with a bloom
+ *   descriptor, the sum of the n_hash hashed rows (layers.py:236-242).
+ * slk_embedding_backward_plan / _fill: gradient of that lookup w.r.t. the table from
+ *   d_grad_out[n][dim]: per distinct row the sum of its gradient rows in ascending lookup order
+ *   (torch's CPU embedding backward order; no atomics), rows equal to padding_idx (bloom: skip_row)
+ *   excluded like nn.Embedding(padding_idx=...).  Dense output: pass d_grad_dense[rows][dim] (fully
+ *   overwritten).  Coalesced COO output (sparse=True layers): pass num_rows_out to the plan (a HOST
+ *   int64; synchronises), allocate, then pass d_rows_out[num_rows] (ascending) and
+ *   d_values_out[num_rows][dim] with d_grad_dense = NULL. */
+int slk_embedding_forward(slk_ctx *ctx, const float *d_weight, int64_t rows, int32_t dim, const slk_bloom *bloom,
+                          const int64_t *d_ids, int64_t n, float *d_out, void *stream);
+int slk_embedding_backward_plan(slk_ctx *ctx, int64_t rows, int32_t dim, const slk_bloom *bloom, int64_t padding_idx,
+                                const int64_t *d_ids, int64_t n, int64_t *num_rows_out, void *stream);
+int slk_embedding_backward_fill(slk_ctx *ctx, const float *d_grad_out, float *d_grad_dense, int64_t *d_rows_out,
+                                float *d_values_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Evaluation side of the path (spotlight/evaluation.py:9-109: mrr_score / sequence_mrr_score call
  * predict() once per user or sequence and rank on the host with scipy.stats.rankdata).
  * slk_bilinear_scores: d_out[r * num_items + i] = score of item i for user d_users[r] -- the rows

@@ -76,6 +76,11 @@ _PROTOTYPES = {
     'slk_to_sequence_plan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     'slk_to_sequence_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_embedding_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p]),
+    'slk_embedding_backward_plan': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                              C.POINTER(C.c_int64), C.c_void_p]),
+    'slk_embedding_backward_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_bilinear_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_poolnet_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_void_p]),
@@ -246,6 +251,25 @@ class Engine(object):
 
     def to_sequence_fill(self, d_sequences, d_sequence_users, stream=0):
         self._check(self._lib.slk_to_sequence_fill(self._ctx, d_sequences, d_sequence_users, stream))
+
+    # -- embedding front-end for the torch-side encoders (include/spotlight_hip.h: slk_embedding_*) --
+    def embedding_forward(self, d_weight, rows, dim, bloom, d_ids, n, d_out, stream=0):
+        self._check(self._lib.slk_embedding_forward(self._ctx, d_weight, int(rows), int(dim),
+                                                    C.byref(bloom) if bloom is not None else None, d_ids, int(n),
+                                                    d_out, stream))
+
+    def embedding_backward_plan(self, rows, dim, bloom, padding_idx, d_ids, n, count_rows=False, stream=0):
+        """Sorts the lookups by table row; with count_rows returns the number of distinct rows that
+        receive a gradient (the size of the COO output of embedding_backward_fill)."""
+        out = C.c_int64(0)
+        self._check(self._lib.slk_embedding_backward_plan(
+            self._ctx, int(rows), int(dim), C.byref(bloom) if bloom is not None else None,
+            -1 if padding_idx is None else int(padding_idx), d_ids, int(n), C.byref(out) if count_rows else None, stream))
+        return int(out.value)
+
+    def embedding_backward_fill(self, d_grad_out, d_grad_dense=None, d_rows_out=None, d_values_out=None, stream=0):
+        self._check(self._lib.slk_embedding_backward_fill(self._ctx, d_grad_out, d_grad_dense, d_rows_out,
+                                                          d_values_out, stream))
 
     # -- evaluation: batched predict + on-GPU ranking (include/spotlight_hip.h) -----------
     def bilinear_scores(self, tables, d_users, n_users, d_out, stream=0):

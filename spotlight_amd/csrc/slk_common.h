@@ -36,7 +36,7 @@ struct slk_rng_dev {
     unsigned long long accepted;
 };
 
-#define SLK_EXTRA_BUFS 40
+#define SLK_EXTRA_BUFS 48
 
 // buffers filled by the value-independent prep of one chunk of minibatches (slk_bilinear.hip)
 struct slk_prep_bufs {
@@ -85,6 +85,10 @@ struct slk_ctx {
     // Interactions.to_sequence plan (slk_seqprep.hip): rows pending a slk_to_sequence_fill (-1: none)
     int64_t ts_rows = -1, ts_nseg = 0;
     int ts_L = 0, ts_step = 0;
+
+    // embedding front-end (slk_embed.hip): occurrences staged by slk_embedding_backward_plan (-1: none)
+    int64_t em_occ = -1, em_rows = 0, em_segments = -1;
+    int em_dim = 0;
 
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
 
@@ -146,6 +150,9 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
 int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 int slk_sort_reserve(slk_ctx *ctx, size_t n);
+// positions where a sorted key array changes value -> d_heads[0..nseg), d_heads[nseg] = n (slk_seqprep.hip);
+// synchronises the stream (nseg is returned to the host)
+int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *nseg_out, hipStream_t s);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);

@@ -240,6 +240,18 @@ static int ts_scan(slk_ctx *ctx, ts_scan_args a, uint32_t *d_total, uint32_t *to
     return SLK_OK;
 }
 
+int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *nseg_out, hipStream_t s) {
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[TS_SMALL], 64))) return rc;
+    ts_scan_args a;
+    memset(&a, 0, sizeof(a));
+    a.su = d_sorted;
+    a.n = n;
+    a.out = d_heads;
+    a.total_n = n;
+    return ts_scan<0>(ctx, a, (uint32_t *)((char *)ctx->extra[TS_SMALL].p + 32), nseg_out, s);
+}
+
 SLK_EXPORT int slk_to_sequence_plan(slk_ctx *ctx, const int64_t *d_users, const int64_t *d_items, const void *d_timestamps,
                                     int32_t ts_kind, int64_t n, int64_t num_users, int32_t max_sequence_length,
                                     int32_t step_size, int32_t min_length, int64_t *num_sequences_out, void *stream) {

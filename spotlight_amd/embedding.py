@@ -1,0 +1,66 @@
+"""Embedding front-end for encoders whose body runs on stock PyTorch-ROCm.
+
+`lookup(weight, ids, ...)` is what `ScaledEmbedding` / `ZeroEmbedding` / `BloomEmbedding` call in their
+`forward`: the gather (or hashed-row sum) and its autograd backward are the gfx950 kernels of
+csrc/slk_embed.hip -- one stable radix sort of the looked-up rows, one owner group per distinct row adding
+its gradient rows in ascending lookup order -- instead of torch's index_select / embedding_backward
+(and, for bloom layers, instead of the reference's cached hash table + gather + sum,
+spotlight/layers.py:177-242).  The recurrent / convolutional body of LSTMNet, CNNNet and MixtureLSTMNet
+(spotlight/sequence/representations.py:147-596) stays on MIOpen through torch.
+
+The gradient comes back dense (zero where untouched) for ordinary layers and as a coalesced sparse COO
+tensor for `sparse=True` layers, so torch.optim's Adam / Adagrad / SparseAdam consume it unchanged.
+There is no CPU path: the tables must live on the HIP device.
+"""
+import torch
+
+
+def _hooks():
+    # resolved at call time: the GPU-less test harness substitutes these hooks (tests/emu)
+    from spotlight_amd.factorization import implicit as _host
+    return _host
+
+
+class _Lookup(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, weight, ids, bloom, padding_idx, sparse):
+        host = _hooks()
+        if weight.dtype != torch.float32 or not weight.is_contiguous() or weight.dim() != 2:
+            raise RuntimeError('embedding tables must be contiguous 2-D fp32 tensors')
+        engine = host._engine_for(weight.device)
+        stream = host._stream_for(weight.device)
+        flat = ids.reshape(-1).to(device=weight.device, dtype=torch.int64).contiguous()
+        rows, dim = weight.shape
+        out = torch.empty((flat.numel(), dim), dtype=torch.float32, device=weight.device)
+        engine.embedding_forward(weight.data_ptr(), rows, dim, bloom, flat.data_ptr(), flat.numel(), out.data_ptr(),
+                                 stream)
+        ctx.save_for_backward(flat)
+        ctx.lookup = (rows, dim, bloom, padding_idx, sparse, weight.device)
+        return out.view(tuple(ids.shape) + (dim,))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (flat,) = ctx.saved_tensors
+        rows, dim, bloom, padding_idx, sparse, device = ctx.lookup
+        host = _hooks()
+        engine = host._engine_for(device)
+        stream = host._stream_for(device)
+        g = grad_out.reshape(flat.numel(), dim).to(torch.float32).contiguous()
+        n_rows = engine.embedding_backward_plan(rows, dim, bloom, padding_idx, flat.data_ptr(), flat.numel(),
+                                                count_rows=sparse, stream=stream)
+        if sparse:
+            idx = torch.empty((1, n_rows), dtype=torch.int64, device=device)
+            val = torch.empty((n_rows, dim), dtype=torch.float32, device=device)
+            engine.embedding_backward_fill(g.data_ptr(), None, idx.data_ptr(), val.data_ptr(), stream=stream)
+            grad = torch.sparse_coo_tensor(idx, val, (rows, dim), is_coalesced=True)
+        else:
+            grad = torch.empty((rows, dim), dtype=torch.float32, device=device)
+            engine.embedding_backward_fill(g.data_ptr(), grad.data_ptr(), stream=stream)
+        return grad, None, None, None, None
+
+
+def lookup(weight, ids, bloom=None, padding_idx=None, sparse=False):
+    """weight[ids] (or the bloom layer's hashed-row sum) with shape ids.shape + (dim,), differentiable
+    w.r.t. `weight`.  `bloom`: the layer's slk_bloom descriptor (BloomEmbedding.descriptor())."""
+    return _Lookup.apply(weight, ids, bloom, padding_idx, bool(sparse))

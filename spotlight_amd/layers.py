@@ -1,11 +1,15 @@
 """Embedding layers (mirror spotlight/layers.py:23-56).
 
-They are plain parameter holders: torch owns the fp32 tables (so state_dict / pickle /
-repr behave as in the reference) and the gfx950 kernels read and update them in place
-through their data_ptr().  Initial values come from torch's CPU generator in the same order
-as the reference, so the same seed gives the same initial tables.
+They are parameter holders: torch owns the fp32 tables (so state_dict / pickle / repr behave
+as in the reference) and the fused training kernels read and update them in place through
+their data_ptr().  Initial values come from torch's CPU generator in the same order as the
+reference, so the same seed gives the same initial tables.  Calling a layer (`layer(ids)`, what
+the LSTM / CNN / mixture encoders do) goes through spotlight_amd.embedding.lookup: the gather,
+the bloom hashed-row sum and their autograd backward are gfx950 kernels (csrc/slk_embed.hip).
 """
 import torch.nn as nn
+
+from spotlight_amd.embedding import lookup
 
 
 class ScaledEmbedding(nn.Embedding):
@@ -16,6 +20,9 @@ class ScaledEmbedding(nn.Embedding):
         if self.padding_idx is not None:
             self.weight.data[self.padding_idx].fill_(0)
 
+    def forward(self, indices):
+        return lookup(self.weight, indices, padding_idx=self.padding_idx, sparse=self.sparse)
+
 
 class ZeroEmbedding(nn.Embedding):
     """Zero-initialised embedding used for biases (layers.py:40-56)."""
@@ -24,6 +31,9 @@ class ZeroEmbedding(nn.Embedding):
         self.weight.data.zero_()
         if self.padding_idx is not None:
             self.weight.data[self.padding_idx].fill_(0)
+
+    def forward(self, indices):
+        return lookup(self.weight, indices, padding_idx=self.padding_idx, sparse=self.sparse)
 
 
 SEEDS = [
@@ -80,6 +90,17 @@ class BloomEmbedding(nn.Module):
     def weight(self):
         """The compressed table (what the kernels read and update in place)."""
         return self.embeddings.weight
+
+    def forward(self, indices):
+        """[batch] -> [batch, 1, dim]; [batch, seq] -> [batch, seq, dim]: sums of the hashed rows
+        (layers.py:200-244), hashed in-kernel."""
+        if indices.dim() == 2:
+            batch_size, seq_size = indices.size()
+        else:
+            batch_size, seq_size = indices.size(0), 1
+        out = lookup(self.embeddings.weight, indices.reshape(batch_size * seq_size), bloom=self.descriptor(),
+                     padding_idx=self.padding_idx, sparse=self.embeddings.sparse)
+        return out.view(batch_size, seq_size, -1)
 
     def descriptor(self):
         """include/spotlight_hip.h: slk_bloom for this layer."""

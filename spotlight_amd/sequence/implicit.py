@@ -1,10 +1,13 @@
-"""ImplicitSequenceModel -- drop-in for spotlight/sequence/implicit.py:23-340 with the
-'pooling' (PoolNet) representation.
+"""ImplicitSequenceModel -- drop-in for spotlight/sequence/implicit.py:23-340.
 
 Same constructor, fit(), predict(), error behaviour and random-state consumption as the
-reference; everything inside the epoch loop (negative sampling, PoolNet forward for the
-sequence and the negatives, masked loss, backward, optimizer update) is one C-ABI call into
-csrc/libspotlight_hip.so per epoch (include/spotlight_hip.h: slk_poolnet_train).
+reference.  With the 'pooling' (PoolNet) representation everything inside the epoch loop
+(negative sampling, PoolNet forward for the sequence and the negatives, masked loss, backward,
+optimizer update) is one C-ABI call into csrc/libspotlight_hip.so per epoch
+(include/spotlight_hip.h: slk_poolnet_train).  With 'lstm' / 'cnn' / 'mixture' (or any module
+with the same two methods) the encoder body trains through torch autograd on MIOpen, fed by this
+package's embedding front-end (spotlight_amd/embedding.py, csrc/slk_embed.hip); the epoch shuffle
+and the negatives still come from the on-device numpy-exact MT19937 stream.
 """
 import numpy as np
 import torch
@@ -15,8 +18,12 @@ from spotlight_amd.factorization import implicit as _host
 from spotlight_amd.factorization.implicit import _OptimizerBinding
 from spotlight_amd.helpers import _repr_model
 from spotlight_amd.layers import BloomEmbedding
-from spotlight_amd.sequence.representations import PADDING_IDX, PoolNet
+from spotlight_amd.losses import adaptive_hinge_loss, bpr_loss, hinge_loss, pointwise_loss
+from spotlight_amd.sequence.representations import PADDING_IDX, CNNNet, LSTMNet, MixtureLSTMNet, PoolNet
 from spotlight_amd.torch_utils import set_seed, shuffle
+
+_LOSS_FUNCTIONS = {'pointwise': pointwise_loss, 'bpr': bpr_loss, 'hinge': hinge_loss,
+                   'adaptive_hinge': adaptive_hinge_loss}
 
 
 class _SeqOptimizerBinding(_OptimizerBinding):
@@ -31,10 +38,11 @@ class _SeqOptimizerBinding(_OptimizerBinding):
 class ImplicitSequenceModel(object):
     """Implicit-feedback sequence model (next-item prediction from the items seen so far).
 
-    Parameters follow spotlight/sequence/implicit.py:85-97.  `representation` must be
-    'pooling' or a :class:`PoolNet` (whose item_embedding_layer may be a BloomEmbedding); the reference's 'cnn' / 'lstm' / 'mixture' encoders are
-    outside this package's scope and raise NotImplementedError.  `use_cuda` is accepted for
-    signature compatibility; the model always lives on the HIP device.
+    Parameters follow spotlight/sequence/implicit.py:85-97.  `representation`: 'pooling' or a
+    :class:`PoolNet` (fused kernels end to end; item_embedding_layer may be a BloomEmbedding), or
+    'cnn' / 'lstm' / 'mixture' / a module with user_representation + forward (encoder body on
+    torch autograd, embedding lookups and their backward on this package's kernels).  `use_cuda`
+    is accepted for signature compatibility; the model always lives on the HIP device.
     """
 
     def __init__(self, loss='pointwise', representation='pooling', embedding_dim=32, n_iter=10,
@@ -86,10 +94,14 @@ class ImplicitSequenceModel(object):
             net = PoolNet(self._num_items, self._embedding_dim, sparse=self._sparse)
         elif isinstance(self._representation, PoolNet):
             net = self._representation
+        elif self._representation == 'cnn':
+            net = CNNNet(self._num_items, self._embedding_dim, sparse=self._sparse)
+        elif self._representation == 'lstm':
+            net = LSTMNet(self._num_items, self._embedding_dim, sparse=self._sparse)
+        elif self._representation == 'mixture':
+            net = MixtureLSTMNet(self._num_items, self._embedding_dim, sparse=self._sparse)
         else:
-            raise NotImplementedError(
-                'representation {!r}: only the pooling (PoolNet) representation has a fused gfx950 '
-                'path; the cnn / lstm / mixture encoders are out of scope'.format(self._representation))
+            net = self._representation
         self._net = net.to(_host._model_device())
 
         if self._optimizer_func is None:
@@ -97,7 +109,8 @@ class ImplicitSequenceModel(object):
                                          lr=self._learning_rate)
         else:
             self._optimizer = self._optimizer_func(self._net.parameters())
-        self._loss_func = self._loss  # fused into the kernel; kept for introspection
+        # PoolNet: fused into the kernel, the name is kept for introspection; other encoders call it
+        self._loss_func = self._loss if isinstance(net, PoolNet) else _LOSS_FUNCTIONS[self._loss]
         self._binding = None
 
     def _bind(self):
@@ -138,6 +151,9 @@ class ImplicitSequenceModel(object):
 
         self._check_input(sequences)
 
+        if not isinstance(self._net, PoolNet):
+            return self._fit_autograd(sequences, verbose)
+
         binding = self._bind()
         device = self._net.tables()[0].device
         engine = _host._engine_for(device)
@@ -175,6 +191,66 @@ class ImplicitSequenceModel(object):
             if np.isnan(epoch_loss) or epoch_loss == 0.0:
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
+    def _fit_autograd(self, sequences, verbose):
+        """The reference's epoch loop (sequence/implicit.py:213-264) for encoders whose body is a torch
+        module: forward of the encoder, positive and negative scores, masked loss, backward and
+        optimizer step are torch autograd; the embedding lookups inside (and their backward) are this
+        package's kernels, and the shuffle + the negatives (`sample_items`, :266-276) come from the
+        device MT19937 stream, bit-identical to numpy's under the same RandomState."""
+        device = next(self._net.parameters()).device
+        engine = _host._engine_for(device)
+        stream = _host._stream_for(device)
+        n_seq, seq_len = sequences.shape
+        d_prev = _host.ids_to_device(sequences, device)
+        d_sequences = torch.empty_like(d_prev)
+        d_perm = torch.empty(n_seq, dtype=torch.int64, device=device)
+        n_neg = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
+        d_negatives = torch.empty(n_neg * self._batch_size * seq_len, dtype=torch.int64, device=device)
+        self._net.train(True)
+        for epoch_num in range(self._n_iter):
+            engine.rng_set_state(self._random_state.get_state())
+            _host.device_epoch_shuffle(engine, self._random_state, n_seq, d_perm, [(d_prev, d_sequences, seq_len)],
+                                       stream)
+            losses = []
+            for lo in range(0, n_seq, self._batch_size):
+                batch = d_sequences[lo:lo + self._batch_size]
+                rows = batch.shape[0]
+                representation, _ = self._net.user_representation(batch)
+                positive = self._net(representation, batch)
+                count = n_neg * rows * seq_len
+                engine.sample_items(self._num_items, count, d_negatives.data_ptr(), stream=stream)
+                negative_items = d_negatives[:count].view(n_neg * rows, seq_len)
+                if self._loss == 'adaptive_hinge':
+                    tiled = representation.repeat(*((n_neg,) + (1,) * (representation.dim() - 1)))
+                    negative = self._net(tiled, negative_items).view(n_neg, rows, seq_len)
+                else:
+                    negative = self._net(representation, negative_items)
+                self._optimizer.zero_grad()
+                loss = self._loss_func(positive, negative, mask=(batch != PADDING_IDX))
+                losses.append(loss.detach())
+                loss.backward()
+                self._optimizer.step()
+            d_prev, d_sequences = d_sequences, d_prev
+            self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
+            epoch_loss = float(torch.stack(losses).double().mean().item())
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def _predict_autograd_free(self, sequences, item_ids):
+        """predict() for the torch-side encoders (sequence/implicit.py:322-340)."""
+        device = next(self._net.parameters()).device
+        with torch.no_grad():
+            sequence_var = torch.from_numpy(sequences.astype(np.int64).reshape(1, -1)).to(device)
+            item_var = torch.from_numpy(np.asarray(item_ids).astype(np.int64)).to(device)
+            _, final = self._net.user_representation(sequence_var)
+            size = (len(item_var),) + final.size()[1:]
+            out = self._net(final.expand(*size), item_var)
+        return out.cpu().numpy().flatten()
+
     def predict(self, sequences, item_ids=None):
         """Scores of the next item after `sequences` (one sequence) for all items or for
         `item_ids`; flat np.float32 array (sequence/implicit.py:288-340)."""
@@ -187,6 +263,9 @@ class ImplicitSequenceModel(object):
 
         self._check_input(item_ids)
         self._check_input(sequences)
+
+        if not isinstance(self._net, PoolNet):
+            return self._predict_autograd_free(sequences, item_ids)
 
         seq = np.ascontiguousarray(sequences.astype(np.int64).reshape(-1))
         items = np.ascontiguousarray(np.asarray(item_ids).astype(np.int64).reshape(-1))
@@ -206,6 +285,9 @@ class ImplicitSequenceModel(object):
         self._net.train(False)
         sequences = np.atleast_2d(sequences)
         self._check_input(sequences)
+        if not isinstance(self._net, PoolNet):  # torch-side encoders: one predict() per sequence
+            device = next(self._net.parameters()).device
+            return torch.stack([torch.from_numpy(self.predict(row)) for row in sequences]).to(device)
         seqs = np.ascontiguousarray(sequences.astype(np.int64))
         device = self._net.tables()[0].device
         d_seqs = torch.from_numpy(seqs).to(device)

@@ -20,10 +20,13 @@ def golden_names(kind='bilinear'):
     (oracle/make_golden.py), 'seq' = ImplicitSequenceModel/PoolNet (oracle/make_golden_seq.py),
     'bloom' = BilinearNet with BloomEmbedding layers (oracle/make_golden_bloom.py), 'host' = outputs of
     the host-side callers (oracle/make_golden_host.py), 'explicit' = ExplicitFactorizationModel runs
-    (oracle/make_golden_explicit.py)."""
+    (oracle/make_golden_explicit.py), 'enc' = ImplicitSequenceModel with the LSTM / CNN / mixture encoders
+    (oracle/make_golden_encoders.py)."""
     def kind_of(f):
         if f.startswith('host_'):
             return 'host'
+        if f.startswith('enc_'):
+            return 'enc'
         if f.startswith('explicit_'):
             return 'explicit'
         return 'seq' if f.startswith('seq_') else 'bloom' if f.startswith('bloom_') else 'bilinear'

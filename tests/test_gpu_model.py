@@ -210,3 +210,48 @@ def test_to_sequence_device_route_on_gpu():
                                   random_state=np.random.RandomState(1))
     model.fit(seq)
     assert model.predict(seq.sequences[0]).shape == (1500,)
+
+
+# ---- torch-side encoders fed by the embedding front-end (csrc/slk_embed.hip) ----
+@pytest.mark.parametrize('name', ['enc_lstm_bpr_adam_default', 'enc_lstm_hinge_adagrad_sparse',
+                                  'enc_lstm_adaptive_hinge_adagrad', 'enc_cnn_pointwise_adam_default',
+                                  'enc_cnn_deep_bpr_adagrad', 'enc_mixture_bpr_adam_default',
+                                  'enc_lstm_bloom_bpr_adagrad', 'enc_cnn_bloom_pointwise_adam_default',
+                                  'enc_lstm_d32_bpr_adam_default'])
+def test_encoder_models_match_reference_run_on_gpu(name):
+    """LSTM / CNN / mixture representations on cuda:0 (encoder body on MIOpen, lookups + their backward on the
+    package's kernels) against the reference's CPU recordings: identical initialisation and RandomState
+    consumption, first-step gradients and losses within 1e-4, trained parameters within the trajectory band."""
+    from test_host_encoders import check_against_fixture
+    model = check_against_fixture(name, to_numpy=lambda t: t.detach().cpu().numpy(), tol=1e-4, traj_tol=5e-3, use_cuda=True)
+    assert all(p.is_cuda for p in model._net.parameters())
+
+
+@pytest.mark.parametrize('dim,sparse', [(1, False), (64, False), (64, True), (128, False), (20, True)])
+def test_lookup_matches_torch_embedding_on_gpu(dim, sparse):
+    """Front-end vs torch's own embedding autograd on the device at a training-sized batch (4096 x 50 lookups
+    over 100 000 rows, Zipf-skewed so that some rows collect thousands of gradient rows)."""
+    from spotlight_amd.embedding import lookup
+    dev = torch.device('cuda', 0)
+    rs = np.random.RandomState(dim)
+    rows, shape = 100000, (4096, 50)
+    w0 = torch.from_numpy(rs.normal(size=(rows, dim)).astype(np.float32)).to(dev)
+    ids_np = np.minimum(rs.zipf(1.3, shape) - 1, rows - 1)
+    ids = torch.from_numpy(ids_np).to(dev)
+    upstream = torch.from_numpy(rs.normal(size=shape + (dim,)).astype(np.float32)).to(dev)
+    w_ref = w0.clone().requires_grad_(True)
+    out_ref = torch.nn.functional.embedding(ids, w_ref, padding_idx=0)
+    (out_ref * upstream).sum().backward()
+    w = w0.clone().requires_grad_(True)
+    out = lookup(w, ids, padding_idx=0, sparse=sparse)
+    assert torch.equal(out, out_ref)
+    (out * upstream).sum().backward()
+    g = w.grad.to_dense() if sparse else w.grad
+    assert w.grad.is_sparse == sparse and float(g[0].abs().sum()) == 0.0
+    # float64 reference of the same sums: both implementations must be within fp32 summation error of it
+    exact = torch.zeros(rows, dim, dtype=torch.float64, device=dev)
+    exact.index_add_(0, ids.reshape(-1), upstream.reshape(-1, dim).double())
+    exact[0] = 0
+    scale = exact.abs().max()
+    assert float((g.double() - exact).abs().max() / scale) < 1e-5
+    assert float((w_ref.grad.double() - exact).abs().max() / scale) < 1e-4

@@ -121,8 +121,11 @@ def test_errors_and_validation(emu_device):
     inter = SequenceInteractions(seqs, num_items=6)
     with pytest.raises(AssertionError):
         ImplicitSequenceModel(loss='nope')
-    with pytest.raises(NotImplementedError):
-        ImplicitSequenceModel(representation='lstm', n_iter=1).fit(inter)
+    with pytest.raises(AssertionError):
+        ImplicitSequenceModel(representation='transformer')
+    lstm = ImplicitSequenceModel(representation='lstm', n_iter=1, embedding_dim=8, random_state=np.random.RandomState(1))
+    lstm.fit(inter)  # torch-side encoder over the embedding front-end (tests/test_host_encoders.py)
+    assert lstm.predict(seqs[0]).shape == (6,)
     m = ImplicitSequenceModel(loss='bpr', n_iter=1, embedding_dim=8, random_state=np.random.RandomState(1))
     m.fit(inter)
     with pytest.raises(ValueError):
