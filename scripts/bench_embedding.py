@@ -85,5 +85,6 @@ out['bloom'] = {'front_end_ms': timed(bloom_ours), 'reference_route_ms': timed(b
 line = json.dumps(out)
 print(line)
 if os.environ.get('GRAFT_OUT'):
+    os.makedirs(os.path.dirname(os.path.abspath(os.environ['GRAFT_OUT'])), exist_ok=True)
     with open(os.environ['GRAFT_OUT'], 'w') as f:
         f.write(line + '\n')

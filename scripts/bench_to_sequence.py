@@ -65,5 +65,6 @@ out = {'n': n, 'max_sequence_length': L, 'step_size': step, 'num_users': U, 'seq
 line = json.dumps(out)
 print(line)
 if os.environ.get('GRAFT_OUT'):
+    os.makedirs(os.path.dirname(os.path.abspath(os.environ['GRAFT_OUT'])), exist_ok=True)
     with open(os.environ['GRAFT_OUT'], 'w') as f:
         f.write(line + '\n')

@@ -150,9 +150,11 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
 int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 int slk_sort_reserve(slk_ctx *ctx, size_t n);
-// positions where a sorted key array changes value -> d_heads[0..nseg), d_heads[nseg] = n (slk_seqprep.hip);
-// synchronises the stream (nseg is returned to the host)
-int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *nseg_out, hipStream_t s);
+// positions where a sorted key array changes value -> d_heads[0..nseg), d_heads[nseg] = n; optionally the
+// segment index of every position -> d_segid[n] (slk_seqprep.hip).  Synchronises the stream (nseg is
+// returned to the host).
+int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *d_segid,
+                      uint32_t *nseg_out, hipStream_t s);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);

@@ -4,15 +4,15 @@
 // forward : out[k][:] = W[ids[k]][:]  (ScaledEmbedding / ZeroEmbedding, layers.py:23-56), or the sum of the
 //           H hashed rows of a BloomEmbedding (layers.py:236-242), hashes computed in-kernel.
 // backward: the gradient w.r.t. W of that gather, given dL/dout.  Occurrences are sorted by table row with a
-//           stable radix sort and ONE group of lanes owns each distinct row: it adds the row's gradient rows
-//           in ascending occurrence order (the order torch's CPU embedding backward adds them in) -- no
-//           atomics, bit-reproducible.  Rows equal to padding_idx get no gradient, like nn.Embedding.
+//           stable radix sort and every distinct row receives the sum of its gradient rows through a chunked
+//           multi-level segmented reduction (k_emb_reduce) -- no atomics, bit-reproducible, balanced under
+//           skew.  Rows equal to padding_idx get no gradient, like nn.Embedding.
 //           Output either dense [rows, D] (zero where untouched) or coalesced COO (distinct rows + sums)
 //           for sparse=True layers feeding SparseAdam / sparse Adagrad.
 #include "slk_common.h"
 #include "slk_kernels.h"
 
-enum { EM_SORT = 32, EM_KEY0 = 40, EM_KEY1, EM_PAY0, EM_PAY1, EM_HEADS };  // ctx->extra slots
+enum { EM_SORT = 32, EM_KEY0 = 40, EM_KEY1, EM_PAY0, EM_PAY1, EM_HEADS, EM_PART0, EM_PART1 };  // ctx->extra slots
 
 static int em_threads_per_row(int D, int VEC) {
     int need = (D + VEC - 1) / VEC, t = 1;
@@ -54,39 +54,62 @@ __global__ __launch_bounds__(256) void k_emb_keys(slk_bloom_dev b, uint32_t rows
     }
 }
 
-// SPARSE: group s owns segment s of the compacted heads; dense: every sorted position that starts a run
-template <int VEC, bool SPARSE>
-__global__ __launch_bounds__(256) void k_emb_backward(const uint32_t *key, const uint32_t *pay, const uint32_t *heads,
-                                                       uint32_t n_occ, uint32_t n_groups, uint32_t rows, int D, int T,
-                                                       const float *gout, float *dense, int64_t *rows_out, float *values) {
+// Segmented sums over the row-sorted occurrences, balanced for skewed ids (one hot item can own a sixth of a
+// Zipf batch): the sorted list is cut into chunks of EM_CHUNK consecutive occurrences, one lane group per chunk.
+// A run of equal rows that lies strictly inside a chunk is summed and written to its destination; the chunk's
+// first and last run may continue in the neighbouring chunks, so their partial sums go, with their row, into
+// entries 2c and 2c + 1 of the next level's list -- which is again sorted by row and is reduced by the same
+// kernel, EM_CHUNK / 2 times shorter per level, until one chunk remains.  Summation order is fixed by the
+// positions alone: bit-reproducible, no atomics.
+#define EM_CHUNK 16
+// `key` is the destination row of `dst` ([rows][D]): the table row for the dense gradient, the segment index
+// for the COO values; keys >= rows (the run of lookups without a gradient) are dropped.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_emb_reduce(const uint32_t *key, const uint32_t *pay, uint32_t n, uint32_t nchunks,
+                                                     uint32_t rows, int D, int T, const float *gin, float *dst,
+                                                     uint32_t *key_next, float *part_next) {
     const int lane = threadIdx.x % T;
     const uint32_t grp = threadIdx.x / T, gpb = 256 / T;
-    for (uint32_t g = blockIdx.x * gpb + grp; g < n_groups; g += gridDim.x * gpb) {
-        uint32_t p, end;
-        if (SPARSE) {
-            p = heads[g];
-            end = heads[g + 1];
-        } else {
-            p = g;
-            if (p > 0 && key[p - 1] == key[p]) continue;
-            end = n_occ;
-        }
-        const uint32_t row = key[p];
-        if (row >= rows) continue;  // the run of occurrences without a gradient (padding)
+    for (uint32_t c = blockIdx.x * gpb + grp; c < nchunks; c += gridDim.x * gpb) {
+        const uint32_t start = c * EM_CHUNK;
+        const uint32_t end = start + EM_CHUNK < n ? start + EM_CHUNK : n;
         for (int d0 = lane * VEC; d0 < D; d0 += T * VEC) {
+            uint32_t row = key[start];
+            bool first = true;
             slk_vec<VEC> acc = slk_vzero<VEC>();
-            for (uint32_t q = p; q < end && (SPARSE || key[q] == row); ++q) {
-                const slk_vec<VEC> x = slk_vload<VEC>(gout + (size_t)pay[q] * D + d0);
+            for (uint32_t q = start; q <= end; ++q) {
+                const uint32_t r = q < end ? key[q] : 0xffffffffu;
+                if (r != row) {  // the run of `row` ends at q
+                    const bool last = q == end;
+                    if (nchunks == 1 || (!first && !last)) {
+                        if (row < rows) slk_vstore<VEC>(dst + (size_t)row * D + d0, acc);
+                    } else {
+                        const uint32_t slot = 2 * c + (first ? 0u : 1u);
+                        slk_vstore<VEC>(part_next + (size_t)slot * D + d0, acc);
+                        if (d0 == 0) key_next[slot] = row;
+                        if (first && last) {  // one run fills the chunk: the second entry is an exact zero
+                            slk_vstore<VEC>(part_next + (size_t)(slot + 1) * D + d0, slk_vzero<VEC>());
+                            if (d0 == 0) key_next[slot + 1] = row;
+                        }
+                    }
+                    first = false;
+                    row = r;
+                    acc = slk_vzero<VEC>();
+                }
+                if (q < end) {
+                    const slk_vec<VEC> x = slk_vload<VEC>(gin + (size_t)(pay ? pay[q] : q) * D + d0);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) acc.v[i] += x.v[i];
+                    for (int i = 0; i < VEC; ++i) acc.v[i] += x.v[i];
+                }
             }
-            if (SPARSE)
-                slk_vstore<VEC>(values + (size_t)g * D + d0, acc);
-            else
-                slk_vstore<VEC>(dense + (size_t)row * D + d0, acc);
         }
-        if (SPARSE && lane == 0) rows_out[g] = (int64_t)row;
     }
+}
+
+// rows_out[s] = the row of segment s (ascending): the indices of the coalesced COO gradient
+__global__ __launch_bounds__(256) void k_emb_segment_rows(const uint32_t *key, const uint32_t *heads, uint32_t n_rows,
+                                                           int64_t *rows_out) {
+    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < n_rows; s += gridDim.x * 256) rows_out[s] = (int64_t)key[heads[s]];
 }
 
 static int em_check(slk_ctx *ctx, const char *who, int64_t rows, int32_t D, const slk_bloom *bloom, int64_t n) {
@@ -167,7 +190,9 @@ SLK_EXPORT int slk_embedding_backward_plan(slk_ctx *ctx, int64_t rows, int32_t d
     if (num_rows_out) {
         if ((rc = slk_ensure(ctx, E[EM_HEADS], (occ + 1) * 4))) return rc;
         uint32_t nseg = 0, last = 0;
-        if ((rc = slk_compact_heads(ctx, k1, (uint32_t)occ, (uint32_t *)E[EM_HEADS].p, &nseg, s))) return rc;
+        // segment index of every sorted lookup -> EM_PAY0 (the sort's input payload, free by now): the key the
+        // reduction files the COO values under
+        if ((rc = slk_compact_heads(ctx, k1, (uint32_t)occ, (uint32_t *)E[EM_HEADS].p, p0, &nseg, s))) return rc;
         SLK_HIP(ctx, hipMemcpyAsync(&last, k1 + occ - 1, 4, hipMemcpyDeviceToHost, s));
         SLK_HIP(ctx, hipStreamSynchronize(s));
         if (last >= (uint32_t)rows) --nseg;  // the trailing run of occurrences without a gradient
@@ -192,30 +217,48 @@ SLK_EXPORT int slk_embedding_backward_fill(slk_ctx *ctx, const float *d_grad_out
     const int D = ctx->em_dim;
     ctx->em_occ = -1;
     if (!sparse) SLK_HIP(ctx, hipMemsetAsync(d_grad_dense, 0, (size_t)rows * D * sizeof(float), s));
-    const uint32_t groups = sparse ? (uint32_t)ctx->em_segments : (uint32_t)occ;
-    if (groups == 0) return SLK_OK;
+    if (occ == 0 || (sparse && ctx->em_segments == 0)) return SLK_OK;
     if (!d_grad_out || (sparse && (!d_rows_out || !d_values_out)))
         return slk_fail(ctx, SLK_EINVAL, "slk_embedding_backward_fill: NULL argument");
     slk_buf *E = ctx->extra;
-    const uint32_t *key = (const uint32_t *)E[EM_KEY1].p, *pay = (const uint32_t *)E[EM_PAY1].p;
-    const uint32_t *heads = (const uint32_t *)E[EM_HEADS].p;
+    const uint32_t n_rows = sparse ? (uint32_t)ctx->em_segments : 0u;
     const int VEC = D % 4 == 0 ? 4 : 1;
     const int T = em_threads_per_row(D, VEC);
-    const dim3 grid(em_grid(ctx, groups, 256 / T));
+    int rc;
+    const uint32_t chunks1 = ((uint32_t)occ + EM_CHUNK - 1) / EM_CHUNK;
+    for (int b = 0; b < 2; ++b)
+        if ((rc = slk_ensure(ctx, E[EM_PART0 + b], (size_t)2 * (b ? (chunks1 + EM_CHUNK - 1) / EM_CHUNK * 2 : chunks1) * D * sizeof(float) + 64)))
+            return rc;
     slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-#define EM_LAUNCH(V, SP)                                                                                             \
-    hipLaunchKernelGGL((k_emb_backward<V, SP>), grid, dim3(256), 0, s, key, pay, heads, (uint32_t)occ, groups,      \
-                       (uint32_t)rows, D, T, d_grad_out, d_grad_dense, d_rows_out, d_values_out)
-    if (VEC == 4 && sparse)
-        EM_LAUNCH(4, true);
-    else if (VEC == 4)
-        EM_LAUNCH(4, false);
-    else if (sparse)
-        EM_LAUNCH(1, true);
-    else
-        EM_LAUNCH(1, false);
-#undef EM_LAUNCH
-    SLK_LAUNCH_CHECK(ctx, "k_emb_backward");
+    if (sparse) {
+        hipLaunchKernelGGL(k_emb_segment_rows, dim3(em_grid(ctx, n_rows, 256)), dim3(256), 0, s, (const uint32_t *)E[EM_KEY1].p,
+                           (const uint32_t *)E[EM_HEADS].p, n_rows, d_rows_out);
+        SLK_LAUNCH_CHECK(ctx, "k_emb_segment_rows");
+    }
+    // level 1 reads the sorted (row | segment, lookup) pairs and the caller's gradient rows; deeper levels read
+    // the previous level's (key, partial sum) entries.  Key buffers: the sort's input arrays are free by now
+    // (EM_PAY0 holds the segment ids only until level 1 has consumed them).
+    const uint32_t *key = (const uint32_t *)E[sparse ? EM_PAY0 : EM_KEY1].p, *pay = (const uint32_t *)E[EM_PAY1].p;
+    const float *gin = d_grad_out;
+    float *dst = sparse ? d_values_out : d_grad_dense;
+    const uint32_t bound = sparse ? n_rows : (uint32_t)rows;
+    uint32_t n = (uint32_t)occ;
+    for (int level = 0;; ++level) {
+        const uint32_t nchunks = (n + EM_CHUNK - 1) / EM_CHUNK;
+        uint32_t *key_next = (uint32_t *)E[(level & 1) ? EM_PAY0 : EM_KEY0].p;
+        float *part_next = (float *)E[EM_PART0 + (level & 1)].p;
+        const dim3 grid(em_grid(ctx, nchunks, 256 / T));
+        if (VEC == 4)
+            hipLaunchKernelGGL(k_emb_reduce<4>, grid, dim3(256), 0, s, key, pay, n, nchunks, bound, D, T, gin, dst, key_next, part_next);
+        else
+            hipLaunchKernelGGL(k_emb_reduce<1>, grid, dim3(256), 0, s, key, pay, n, nchunks, bound, D, T, gin, dst, key_next, part_next);
+        if (nchunks == 1) break;
+        key = key_next;
+        pay = nullptr;
+        gin = part_next;
+        n = 2 * nchunks;
+    }
+    SLK_LAUNCH_CHECK(ctx, "k_emb_reduce");
     slk_prof_end(ctx, s);
     return SLK_OK;
 }

@@ -94,6 +94,7 @@ struct ts_scan_args {
     uint32_t step, thr;     // ROWS
     uint32_t *out;          // HEADS: heads[rank] = k ; ROWS: rowoff[s]
     uint32_t total_n;       // HEADS: n, written at heads[nseg]
+    uint32_t *segid;        // HEADS, optional: segid[k] = index of the segment position k belongs to
 };
 
 template <int ROWS>
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void k_ts_tile_apply(ts_scan_args a, const uin
                 a.out[k] = run;
             else if (v[j])
                 a.out[run] = k;
+            if (!ROWS && a.segid) a.segid[k] = v[j] ? run : run - 1;
         }
         run += v[j];
     }
@@ -240,7 +242,8 @@ static int ts_scan(slk_ctx *ctx, ts_scan_args a, uint32_t *d_total, uint32_t *to
     return SLK_OK;
 }
 
-int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *nseg_out, hipStream_t s) {
+int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *d_segid,
+                      uint32_t *nseg_out, hipStream_t s) {
     int rc;
     if ((rc = slk_ensure(ctx, ctx->extra[TS_SMALL], 64))) return rc;
     ts_scan_args a;
@@ -249,6 +252,7 @@ int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32
     a.n = n;
     a.out = d_heads;
     a.total_n = n;
+    a.segid = d_segid;
     return ts_scan<0>(ctx, a, (uint32_t *)((char *)ctx->extra[TS_SMALL].p + 32), nseg_out, s);
 }
 

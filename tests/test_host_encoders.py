@@ -187,3 +187,27 @@ def test_front_end_argument_errors(emu_device):
     with pytest.raises(_native.SlkError):  # fill without a plan
         eng.embedding_backward_fill(w.data_ptr(), w.data_ptr())
     assert lookup(w, torch.zeros((0,), dtype=torch.int64)).shape == (0, 4)
+
+
+@pytest.mark.parametrize('sparse', [False, True])
+@pytest.mark.parametrize('n', [15, 16, 17, 33, 257, 6000])
+def test_lookup_backward_under_skew(emu_device, n, sparse):
+    """Runs much longer than a reduction chunk (one row owns 60 % of the lookups) go through several levels of
+    the segmented reduction; sizes around the chunk edges."""
+    rs = np.random.RandomState(n)
+    rows, dim = 50, 8
+    ids_np = rs.randint(0, rows, n)
+    ids_np[rs.rand(n) < 0.6] = 7
+    ids = torch.from_numpy(ids_np)
+    up = torch.from_numpy(rs.normal(size=(n, dim)).astype(np.float32))
+    w = torch.zeros(rows, dim, requires_grad=True)
+    (lookup(w, ids, padding_idx=0, sparse=sparse) * up).sum().backward()
+    g = w.grad.to_dense() if sparse else w.grad
+    exact = torch.zeros(rows, dim, dtype=torch.float64)
+    exact.index_add_(0, ids, up.double())
+    exact[0] = 0
+    assert float((g.double() - exact).abs().max()) <= 1e-5 * float(exact.abs().max())
+    # bit-reproducible
+    w2 = torch.zeros(rows, dim, requires_grad=True)
+    (lookup(w2, ids, padding_idx=0, sparse=sparse) * up).sum().backward()
+    assert torch.equal(w2.grad.to_dense() if sparse else w2.grad, g)
