@@ -13,9 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spotlight_amd import _native  # noqa: E402
 
 loss = sys.argv[1] if len(sys.argv) > 1 else 'regression'
+fused = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 0: staged route (score pass + loss kernel before the user pass)
 U, I, D, B, K, W = 10_000_000, 1_000_000, 64, 1 << 20, 16, 4
 dev = torch.device('cuda', 0)
 eng = _native.Engine(0)
+eng.set_option('explicit_fused', fused)
 gen = torch.Generator(device=dev)
 gen.manual_seed(3)
 tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen),
@@ -46,7 +48,7 @@ run(W, K)
 torch.cuda.synchronize()
 eng.profile_enable(False)
 prof = eng.profile_read()
-print(json.dumps({'workload': 'explicit %s, %d users x %d items, dim %d, adagrad, batch %d' % (loss, U, I, D, B),
+print(json.dumps({'workload': 'explicit %s, %d users x %d items, dim %d, adagrad, batch %d' % (loss, U, I, D, B), 'fused': fused,
                   'interactions_per_s': K * B / dt, 'ms_per_step': dt / K * 1e3,
                   'ms_per_step_by_class': {k: prof[k][1] / K for k in ('prep', 'score', 'user_pass', 'item_pass')},
                   'final_loss': float(mb[-1].item())}))

@@ -157,6 +157,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_user_grid_mult = (int)value;
     } else if (!strcmp(name, "seq_variant") && (value == 0 || value == 1)) {
         ctx->opt_seq_variant = (int)value;
+    } else if (!strcmp(name, "explicit_fused") && (value == 0 || value == 1)) {
+        ctx->opt_explicit_fused = (int)value;
     } else if (!strcmp(name, "nt") && value >= 0 && value <= 15) {
         ctx->opt_nt = (int)value;
     } else {

@@ -29,14 +29,38 @@
 
 #include "slk_kernels.h"
 
+// loss of ONE predicted score against the observed rating and dL/dscore (losses.py:169-244), formed in fp32
+// operation by operation as autograd forms them; bm = minibatch size, inv_b = 1 / bm.
+__device__ __forceinline__ void slk_explicit_loss(int loss_kind, float sc, float r, float inv_b, uint32_t bm, float &l,
+                                                  float &g) {
+    if (loss_kind == SLK_LOSS_REGRESSION) {  // ((r - p) ** 2).mean()
+        const float diff = r - sc;
+        l = diff * diff;
+        g = -(inv_b * (2.0f * diff));
+    } else if (loss_kind == SLK_LOSS_POISSON) {  // p = exp(score); (p - r * log(p)).mean()
+        const float p = expf(sc);
+        l = p - r * logf(p);
+        g = (inv_b + ((-inv_b) * r) / p) * p;
+    } else {  // binary_cross_entropy_with_logits(score, clamp(r, 0, 1)), mean reduction
+        const float t = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+        const float mx = -sc > 0.0f ? -sc : 0.0f;
+        l = (1.0f - t) * sc + (mx + logf(expf(-mx) + expf(-sc - mx)));
+        g = (slk_sigmoid(sc) - t) / (float)bm;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // USER PASS
 // ---------------------------------------------------------------------------------------
 // BLOOM: the user and/or item embedding layer is a BloomEmbedding (slk_kernels.h).  Item vectors
 // are then sums of hashed rows; a bloom USER vector is shared between users, so its gradient is
 // not applied here but parked in a.urec for a ROW-mode owner pass over the hashed user rows.
-template <int VEC, int G, int UPD, bool PRE, bool BLOOM>
+// UMODE: 0 = the (positive, negative) pair's scores, loss and dL/dscore formed here; 1 = dL/dscore read from a.gk
+// (adaptive hinge, staged explicit route); 2 = explicit feedback, fused: one pair, score + loss against a.ratings
+template <int VEC, int G, int UPD, int UMODE, bool BLOOM>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
+    constexpr bool PRE = UMODE != 0;
+    constexpr bool EXPL = UMODE == 2;
     __shared__ double red[256];
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
@@ -59,11 +83,31 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         else
             u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (a.nt & 1) != 0) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
+        // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
+        // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
+        // fetching early there only lengthens register lifetimes)
+        constexpr bool EARLY_STATE = EXPL && !BLOOM && UPD == SLK_UPD_ADAGRAD;
+        slk_vec<VEC> su = slk_vzero<VEC>();
+        if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (a.nt & 1) != 0);
+        float sbu = 0.0f;
+        if (EARLY_STATE) sbu = a.S1[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
         uint32_t q = p;
+        // the key after the current position travels one iteration ahead of its use (the segment-end test)
+        // (latency-bound modes only: same-box A/B, +5 % on the adaptive pass, -1 % on the bandwidth-bound pair pass)
+        constexpr bool NEXT_KEY = UMODE != 0;
+        uint32_t next_key = 0;
+        if (NEXT_KEY) next_key = (q + 1 < a.end) ? a.ukey[q + 1] : ~key;
         do {
             float *rec = a.snap + (size_t)(q - a.begin) * a.RS;
+            // explicit feedback: the rating's gather is issued first so that it overlaps the item row's
+            uint32_t e_item = 0;
+            float e_rating = 0.0f;
+            if (EXPL) {
+                e_item = a.uit[q];
+                e_rating = a.ratings[a.uk[q]];
+            }
             if (on) slk_vstore<VEC>(rec + d0, u);
             if (!PRE) {
                 const uint32_t ip = slk_ld_u32(a.uit + 2 * (size_t)q, nt_keys), in = slk_ld_u32(a.uit + 2 * (size_t)q + 1, nt_keys);
@@ -87,6 +131,26 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     rec[D + 1] = gn;
                     loss_acc += l;
                 }
+            } else if (EXPL) {
+                // explicit feedback (one pair per interaction): score, loss and dL/dscore formed here
+                const uint32_t it = e_item;
+                const float bi = a.P[3][it];  // issued with the row, not after the dot's shuffles
+                slk_vec<VEC> v;
+                if (BLOOM)
+                    v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
+                else
+                    v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
+                const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v)) + bu + bi;
+                float l, g;
+                slk_explicit_loss(a.loss_kind, sc, e_rating, a.inv_b, a.end - a.begin, l, g);
+                if (lane == 0) {
+                    rec[D] = g;
+                    loss_acc += l;
+                }
+                if (g != 0.0f) {
+                    slk_vaxpy<VEC>(gu, g, v);
+                    gbu += g;
+                }
             } else {
                 const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
                 for (int s = 0; s < a.NP; ++s) {
@@ -105,16 +169,35 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 }
             }
             ++q;
-        } while (q < a.end && a.ukey[q] == key);
+            if (NEXT_KEY) {
+                if (next_key != key) break;
+                next_key = (q + 1 < a.end) ? a.ukey[q + 1] : ~key;
+            } else if (!(q < a.end && a.ukey[q] == key)) {
+                break;
+            }
+        } while (true);
 
         if (BLOOM && a.ub.n_hash) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
-            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
+            if (EARLY_STATE)
+                slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (a.nt & 1) != 0);
+            else
+                slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
         }
-        if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
+        if (EARLY_STATE) {
+            if (lane == 0 && gbu != 0.0f) {  // gbu == 0 is an exact no-op for Adagrad (slk_apply_bias)
+                slk_vec<1> bpv, bsv, gbv;
+                bpv.v[0] = bu;
+                bsv.v[0] = sbu;
+                gbv.v[0] = gbu;
+                slk_apply_vec_pre<1, UPD>(a, 2, user, bpv, bsv, gbv);
+            }
+        } else if (lane == 0) {
+            slk_apply_bias<UPD>(a, 2, user, gbu);
+        }
     }
-    if (!PRE) {
+    if (!PRE || EXPL) {
         const double tot = slk_block_sum_256((double)loss_acc, red);
         if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot;
     }
@@ -199,20 +282,7 @@ __global__ __launch_bounds__(256) void k_explicit_loss(const float *sk, const fl
     for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < bm; c += gridDim.x * 256) {
         const float sc = sk[k0 + c], r = ratings[k0 + c];
         float l, g;
-        if (loss_kind == SLK_LOSS_REGRESSION) {  // ((r - p) ** 2).mean()
-            const float diff = r - sc;
-            l = diff * diff;
-            g = -(inv_b * (2.0f * diff));
-        } else if (loss_kind == SLK_LOSS_POISSON) {  // p = exp(score); (p - r * log(p)).mean()
-            const float p = expf(sc);
-            l = p - r * logf(p);
-            g = (inv_b + ((-inv_b) * r) / p) * p;
-        } else {  // binary_cross_entropy_with_logits(score, clamp(r, 0, 1)), mean reduction
-            const float t = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
-            const float mx = -sc > 0.0f ? -sc : 0.0f;
-            l = (1.0f - t) * sc + (mx + logf(expf(-mx) + expf(-sc - mx)));
-            g = (slk_sigmoid(sc) - t) / (float)bm;
-        }
+        slk_explicit_loss(loss_kind, sc, r, inv_b, bm, l, g);
         gk[k0 + c] = g;
         lsum += (double)l;
     }
@@ -393,20 +463,25 @@ __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V,
 typedef slk_pass_fn pass_fn;
 
 template <int VEC, int G, bool BLOOM>
-static pass_fn user_pass_fn2(int upd, bool pre) {
-    if (pre) {
-        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, true, BLOOM>;
-        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, true, BLOOM>;
-        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, true, BLOOM>;
+static pass_fn user_pass_fn2(int upd, int umode) {
+    if (umode == 2) {
+        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 2, BLOOM>;
+        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 2, BLOOM>;
+        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 2, BLOOM>;
     }
-    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, false, BLOOM>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, false, BLOOM>;
-    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, false, BLOOM>;
+    if (umode == 1) {
+        if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 1, BLOOM>;
+        if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 1, BLOOM>;
+        return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 1, BLOOM>;
+    }
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, BLOOM>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, BLOOM>;
+    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, BLOOM>;
 }
 
 template <int VEC, int G>
-static pass_fn user_pass_fn(int upd, bool pre, bool bloom) {
-    return bloom ? user_pass_fn2<VEC, G, true>(upd, pre) : user_pass_fn2<VEC, G, false>(upd, pre);
+static pass_fn user_pass_fn(int upd, int umode, bool bloom) {
+    return bloom ? user_pass_fn2<VEC, G, true>(upd, umode) : user_pass_fn2<VEC, G, false>(upd, umode);
 }
 
 
@@ -699,9 +774,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int upd = slk_upd_for(optim->kind);
     pass_fn upass = nullptr, ipass = nullptr, spass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr,
             rpass_rows = nullptr;
+    const int umode = (expl && ctx->opt_explicit_fused) ? 2 : (pre ? 1 : 0);
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
-        upass = user_pass_fn<V_, G_>(upd, pre, bloom);                               \
+        upass = user_pass_fn<V_, G_>(upd, umode, bloom);                                  \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
         spass = k_score_pass<V_, G_>;                                                     \
         if (bloom) {                                                                      \
@@ -862,7 +938,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
             const unsigned igrid = slk_grid_for(ctx, late ? (size_t)bm * 2 : (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
-            if (expl) {
+            if (expl && ctx->opt_explicit_fused) {
+                // the user pass forms score, loss and dL/dscore itself (one pair per interaction)
+                a.ratings = d_ratings + c0;
+                a.n_loss_partial = (int)ugrid;
+            } else if (expl) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
                 hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_score_pass");

@@ -68,6 +68,7 @@ struct slk_ctx {
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
+    int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)

@@ -87,6 +87,8 @@ struct slk_pass_args {
     const uint32_t *uit;     // [pos*NP + s] item of pair s at sorted position pos
     const uint32_t *uk;      // sorted position -> chunk-local interaction index (PRE mode)
     const float *gk;         // PRE mode: dL/dscore per (interaction, pair)
+    const float *ratings;    // explicit feedback, fused route: ratings[chunk-local interaction]; the user pass forms
+                             // the score, the loss and dL/dscore itself (NP == 1) instead of reading gk
     float *sk;               // PRE mode: scores per (interaction, pair)
     float *snap;             // records, see slk_item_mode
     int RS;                  // record stride in floats

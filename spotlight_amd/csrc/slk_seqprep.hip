@@ -188,14 +188,17 @@ __global__ __launch_bounds__(256) void k_ts_tile_apply(ts_scan_args a, const uin
 }
 
 // ---- (3) the windows ------------------------------------------------------------------------
-#define TS_G 16  // lanes per output row
+#define TS_G 16     // lanes per output row
+#define TS_ROWS 16  // consecutive rows per lane group: one binary search, then a linear walk over the segments
 __global__ __launch_bounds__(256) void k_ts_fill(const uint32_t *su, const int32_t *it, const uint32_t *heads,
                                                   const uint32_t *rowoff, uint32_t nseg, uint32_t rows, int L, uint32_t step,
                                                   int32_t *seq, int32_t *seq_users) {
     const int lane = threadIdx.x % TS_G;
     const uint32_t grp = threadIdx.x / TS_G;
-    const uint32_t stride = gridDim.x * (256 / TS_G);
-    for (uint32_t r = blockIdx.x * (256 / TS_G) + grp; r < rows; r += stride) {
+    const uint32_t nblk = (rows + TS_ROWS - 1) / TS_ROWS;
+    for (uint32_t blk = blockIdx.x * (256 / TS_G) + grp; blk < nblk; blk += gridDim.x * (256 / TS_G)) {
+        uint32_t r = blk * TS_ROWS;
+        const uint32_t r_end = r + TS_ROWS < rows ? r + TS_ROWS : rows;
         // last segment whose first row is <= r (segments without rows share their successor's offset)
         uint32_t lo = 0, hi = nseg;  // invariant: rowoff[lo] <= r < rowoff[hi]
         while (hi - lo > 1) {
@@ -205,15 +208,19 @@ __global__ __launch_bounds__(256) void k_ts_fill(const uint32_t *su, const int32
             else
                 hi = mid;
         }
-        const uint32_t start = heads[lo];
-        const uint32_t count = heads[lo + 1] - start;
-        const int64_t end = (int64_t)count - (int64_t)(r - rowoff[lo]) * step;
-        int32_t *dst = seq + (size_t)r * L;
-        for (int c = lane; c < L; c += TS_G) {
-            const int64_t pos = end - L + c;
-            dst[c] = pos >= 0 ? it[start + pos] : 0;
+        uint32_t next = rowoff[lo + 1];
+        for (; r < r_end; ++r) {
+            while (next <= r) next = rowoff[++lo + 1];
+            const uint32_t start = heads[lo];
+            const uint32_t count = heads[lo + 1] - start;
+            const int64_t end = (int64_t)count - (int64_t)(r - rowoff[lo]) * step;
+            int32_t *dst = seq + (size_t)r * L;
+            for (int c = lane; c < L; c += TS_G) {
+                const int64_t pos = end - L + c;
+                dst[c] = pos >= 0 ? it[start + pos] : 0;
+            }
+            if (lane == 0) seq_users[r] = (int32_t)su[start];
         }
-        if (lane == 0) seq_users[r] = (int32_t)su[start];
     }
 }
 
@@ -374,7 +381,7 @@ SLK_EXPORT int slk_to_sequence_fill(slk_ctx *ctx, int32_t *d_sequences, int32_t 
     if (!d_sequences || !d_sequence_users) return slk_fail(ctx, SLK_EINVAL, "slk_to_sequence_fill: NULL output");
     slk_buf *E = ctx->extra;
     slk_prof_begin(ctx, SLK_K_PREP, s);
-    hipLaunchKernelGGL(k_ts_fill, dim3(ts_grid(ctx, (uint64_t)rows, 256 / TS_G)), dim3(256), 0, s, (const uint32_t *)E[TS_USERS].p,
+    hipLaunchKernelGGL(k_ts_fill, dim3(ts_grid(ctx, ((uint64_t)rows + TS_ROWS - 1) / TS_ROWS, 256 / TS_G)), dim3(256), 0, s, (const uint32_t *)E[TS_USERS].p,
                        (const int32_t *)E[TS_ITEMS].p, (const uint32_t *)E[TS_HEADS].p, (const uint32_t *)E[TS_ROWOFF].p,
                        (uint32_t)ctx->ts_nseg, (uint32_t)rows, (int)ctx->ts_L, (uint32_t)ctx->ts_step, d_sequences,
                        d_sequence_users);

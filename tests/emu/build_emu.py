@@ -12,7 +12,18 @@ LIB = os.path.join(OUT, 'libspotlight_emu.so')
 
 
 def build(force=False):
+    """Serialised across processes (pytest-xdist workers would otherwise compile into the same files at once)."""
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
     deps = srcs + [os.path.join(CSRC, 'slk_common.h'), os.path.join(CSRC, 'slk_kernels.h'), os.path.join(ROOT, 'include', 'spotlight_hip.h'),
                    os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'),

@@ -783,3 +783,36 @@ def check_to_sequence_large(be, n, num_users, num_items, ts_mode, L, min_len, st
     assert seq.shape == want.shape, (seq.shape, want.shape)
     assert np.array_equal(seq, want) and np.array_equal(seq_users, want_users)
     return seq.shape[0]
+
+
+def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=5, user_bloom=0, item_bloom=0):
+    """The fused explicit route (score + loss inside the user pass) and the staged one (score pass, loss kernel,
+    then the user pass) form dL/dscore with the same fp32 operations: identical tables and optimizer state; the
+    minibatch losses differ only in summation order."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    ratings = _ratings_for(rs, loss, N)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)).astype(np.float32), rs.normal(0, sc, (I, D)).astype(np.float32),
+              rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    n_mb = (N + B - 1) // B
+    d_users, d_items, d_ratings = be.alloc(users), be.alloc(items), be.alloc(ratings)
+    runs = []
+    try:
+        for fused in (1, 0):
+            eng.set_option('explicit_fused', fused)
+            dev = be.model(params, opt=opt, **hp)
+            mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+            for _ in range(2):
+                eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), N,
+                                            B, loss, be.ptr(mb_loss), stream=be.stream)
+            runs.append(([be.get(t).copy() for t in dev.p], [be.get(t).copy() for t in dev.s1], be.get(mb_loss).copy()))
+    finally:
+        eng.set_option('explicit_fused', 1)
+    for t in range(4):
+        assert np.array_equal(runs[0][0][t], runs[1][0][t]), ('param', t)
+        assert np.array_equal(runs[0][1][t], runs[1][1][t]), ('state', t)
+    assert np.allclose(runs[0][2], runs[1][2], rtol=1e-6)

@@ -35,3 +35,9 @@ def test_explicit_other_layouts(be):
 @pytest.mark.parametrize('name', ec.EXPLICIT_FIXTURES)
 def test_explicit_replays_reference_fixture(be, name):
     ec.check_explicit_replays_reference_fixture(be, GOLDEN, name)
+
+
+@pytest.mark.parametrize('loss', ec.EXPLICIT_LOSSES)
+def test_explicit_fused_and_staged_routes_agree(be, loss):
+    ec.check_explicit_routes_agree(be, loss, 'adagrad', 8)
+    ec.check_explicit_routes_agree(be, loss, 'adam_dense', 16, U=11, I=60, N=200, B=48)

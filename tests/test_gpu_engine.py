@@ -212,6 +212,12 @@ def test_explicit_train_and_gradients(be, loss):
     ec.check_explicit_single_step_gradients(be, loss, 64, U=4000, I=6000, B=20000, seed=3)
 
 
+@pytest.mark.parametrize('loss', ec.EXPLICIT_LOSSES)
+def test_explicit_fused_and_staged_routes_agree(be, loss):
+    ec.check_explicit_routes_agree(be, loss, 'adagrad', 64, U=30000, I=8000, N=200000, B=32768)
+    ec.check_explicit_routes_agree(be, loss, 'sparse_adam', 32, U=3000, I=800, N=20000, B=4096)
+
+
 @pytest.mark.parametrize('name', ec.EXPLICIT_FIXTURES)
 def test_explicit_replays_reference_fixture(be, name):
     ec.check_explicit_replays_reference_fixture(be, GOLDEN, name)
