@@ -36,6 +36,15 @@ class ZeroEmbedding(nn.Embedding):
         return lookup(self.weight, indices, padding_idx=self.padding_idx, sparse=self.sparse)
 
 
+class ScaledEmbeddingBag(nn.EmbeddingBag):
+    """N(0, 1/embedding_dim) initialised EmbeddingBag (layers.py:59-71).  Only the reference's
+    BloomEmbedding(bag=True) uses it, a mode this package rejects (see BloomEmbedding); the class is kept
+    for code that names it.  It is a stock torch module: no kernel of this package is involved."""
+
+    def reset_parameters(self):
+        self.weight.data.normal_(0, 1.0 / self.embedding_dim)
+
+
 SEEDS = [
     179424941, 179425457, 179425907, 179426369,
     179424977, 179425517, 179425943, 179426407,

@@ -1,0 +1,27 @@
+"""A few of the reference's end-to-end accuracy floors (tests/reference_floors.py) through the GPU-less harness:
+the fused PoolNet path, an autograd encoder over the embedding front-end, and a bloom item layer.  The whole
+table runs on the GPU (tests/test_gpu_reference_floors.py)."""
+import pytest
+import torch
+
+import reference_floors as rf
+from emu_backend import emu_lib
+from spotlight_amd import _native
+from spotlight_amd.factorization import implicit as host
+
+SUBSET = ('pooling-0.001', 'pooling-loss-adaptive_hinge', 'cnn-0.001', 'bloom-lstm-0.5')
+
+
+@pytest.fixture()
+def emu_device(monkeypatch):
+    eng = _native.Engine(0, lib=emu_lib())
+    monkeypatch.setattr(host, '_engine_for', lambda device: eng)
+    monkeypatch.setattr(host, '_stream_for', lambda device: 0)
+    monkeypatch.setattr(host, '_model_device', lambda: torch.device('cpu'))
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize('case', [c for c in rf.CASES if c[0] in SUBSET], ids=lambda c: c[0])
+def test_reference_mrr_floor(emu_device, case):
+    rf.check_case(case, use_cuda=False)
