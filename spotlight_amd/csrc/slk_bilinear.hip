@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     float loss_acc = 0.0f;
 
     for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
-        const bool nt_keys = (a.nt & 8) != 0;
+        const bool nt_keys = (SLK_NT_OF(a) & 8) != 0;
         const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
         if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
         const uint32_t user = key & a.umask;
@@ -81,14 +81,14 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         if (BLOOM)
             u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         else
-            u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (a.nt & 1) != 0) : slk_vzero<VEC>();
+            u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
         // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
         // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
         // fetching early there only lengthens register lifetimes)
         constexpr bool EARLY_STATE = EXPL && !BLOOM && UPD == SLK_UPD_ADAGRAD;
         slk_vec<VEC> su = slk_vzero<VEC>();
-        if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (a.nt & 1) != 0);
+        if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
         float sbu = 0.0f;
         if (EARLY_STATE) sbu = a.S1[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
             if (EARLY_STATE)
-                slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (a.nt & 1) != 0);
+                slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (SLK_NT_OF(a) & 1) != 0);
             else
-                slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
+                slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
         }
         if (EARLY_STATE) {
             if (lane == 0 && gbu != 0.0f) {  // gbu == 0 is an exact no-op for Adagrad (slk_apply_bias)

@@ -221,6 +221,14 @@ __device__ __forceinline__ void slk_vstore<1>(float *p, const slk_vec<1> &x) {
     *p = x.v[0];
 }
 
+// The cache-policy bits a kernel acts on: the ctx option ("nt", a kernel argument), or a build-time constant
+// (-DSLK_NT_FIXED=3) that removes the policy branches around every row access.
+#ifdef SLK_NT_FIXED
+#define SLK_NT_OF(a) (SLK_NT_FIXED)
+#else
+#define SLK_NT_OF(a) ((a).nt)
+#endif
+
 // Non-temporal (streaming) variants for rows that a pass touches exactly once: they should not
 // displace the re-read data (item rows, records) from L2 / Infinity Cache.  hipcc only; the test
 // harness's host build uses the plain accesses.

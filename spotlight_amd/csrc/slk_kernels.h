@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
     const int d0 = lane * VEC;
     const bool on = d0 < D;
     const bool rows_on = on && PART != SLK_PART_BIAS;
-    const bool nt_rows = (a.nt & 2) != 0, nt_keys = (a.nt & 8) != 0;
+    const bool nt_rows = (SLK_NT_OF(a) & 2) != 0, nt_keys = (SLK_NT_OF(a) & 8) != 0;
     const uint32_t ibegin = a.ibegin, iend = a.iend;
 
     if (blockIdx.x == 0 && a.mb_loss_out) {

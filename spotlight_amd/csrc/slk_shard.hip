@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
-        slk_vec<VEC> u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (a.nt & 1) != 0) : slk_vzero<VEC>();
+        slk_vec<VEC> u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
         const float bu = a.P[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         do {
             const size_t sp_ = (size_t)a.vslot[2 * (size_t)q] * a.RSV, sn_ = (size_t)a.vslot[2 * (size_t)q + 1] * a.RSV;
             // exchange buffers are read / written exactly once: streaming hints (ctx option "nt" bit 0)
-            const bool nt = (a.nt & 1) != 0;
+            const bool nt = (SLK_NT_OF(a) & 1) != 0;
             const slk_vec<VEC> vi = on ? slk_vload_if_nt<VEC>(a.vrows + sp_ + d0, nt) : slk_vzero<VEC>();
             const slk_vec<VEC> vj = on ? slk_vload_if_nt<VEC>(a.vrows + sn_ + d0, nt) : slk_vzero<VEC>();
             const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.vrows[sp_ + D];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
             }
             ++q;
         } while (q < a.end && a.ukey[q] == key);
-        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (a.nt & 1) != 0);
+        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
         if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
     }
     const double tot = slk_block_sum_256((double)loss_acc, red);
