@@ -13,7 +13,7 @@ from spotlight_amd.factorization._components import _predict_process_ids
 from spotlight_amd.factorization.representations import BilinearNet
 from spotlight_amd.helpers import _repr_model
 from spotlight_amd.layers import BloomEmbedding, ScaledEmbedding, ZeroEmbedding
-from spotlight_amd.torch_utils import set_seed, shuffle
+from spotlight_amd.torch_utils import set_seed
 
 _ENGINES = {}
 

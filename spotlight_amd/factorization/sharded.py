@@ -213,7 +213,6 @@ from spotlight_amd.factorization import implicit as _host  # noqa: E402
 from spotlight_amd.factorization._components import _predict_process_ids  # noqa: E402
 from spotlight_amd.factorization.implicit import ImplicitFactorizationModel  # noqa: E402
 from spotlight_amd.factorization.representations import BilinearNet  # noqa: E402
-from spotlight_amd.torch_utils import shuffle  # noqa: E402
 
 _FULL_INIT_LIMIT_BYTES = 8 << 30
 

@@ -20,7 +20,7 @@ from spotlight_amd.helpers import _repr_model
 from spotlight_amd.layers import BloomEmbedding
 from spotlight_amd.losses import adaptive_hinge_loss, bpr_loss, hinge_loss, pointwise_loss
 from spotlight_amd.sequence.representations import PADDING_IDX, CNNNet, LSTMNet, MixtureLSTMNet, PoolNet
-from spotlight_amd.torch_utils import set_seed, shuffle
+from spotlight_amd.torch_utils import set_seed
 
 _LOSS_FUNCTIONS = {'pointwise': pointwise_loss, 'bpr': bpr_loss, 'hinge': hinge_loss,
                    'adaptive_hinge': adaptive_hinge_loss}

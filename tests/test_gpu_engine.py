@@ -1,7 +1,6 @@
 """Parity tests proper: the real gfx950 library (csrc/libspotlight_hip.so) on cuda:0 through
 its C ABI, against the CPU oracle, numpy and the golden vectors recorded from the live
 reference.  Run with `python -m pytest tests -m gpu` on an MI355X."""
-import numpy as np
 import pytest
 
 import engine_checks as ec

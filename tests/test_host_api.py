@@ -16,7 +16,6 @@ from spotlight_amd.cross_validation import random_train_test_split, shuffle_inte
 from spotlight_amd.datasets.synthetic import generate_sequential
 from spotlight_amd.factorization import implicit as host
 from spotlight_amd.factorization.implicit import ImplicitFactorizationModel
-from spotlight_amd.interactions import Interactions
 from spotlight_amd.layers import BloomEmbedding
 from spotlight_amd.sequence.implicit import ImplicitSequenceModel
 from spotlight_amd.sequence.representations import PoolNet
