@@ -353,6 +353,7 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
         if (wd > (double)(total_words - w)) wd = (double)(total_words - w);
         if (wd >= 4294967295.0) return slk_fail(ctx, SLK_EINVAL, "slk_shuffle_perm: window too large");
         fy_args a;
+        memset(&a, 0, sizeof(a));
         a.raw = raw;
         a.w0 = w;
         a.W = (uint32_t)wd;
