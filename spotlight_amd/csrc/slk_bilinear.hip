@@ -127,8 +127,9 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
                 gbu += gp + gn;
                 if (lane == 0) {
-                    rec[D] = gp;
-                    rec[D + 1] = gn;
+                    float *gq = a.gsn + 2 * (size_t)(q - a.begin);
+                    gq[0] = gp;
+                    gq[1] = gn;
                     loss_acc += l;
                 }
             } else if (EXPL) {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 float l, g;
                 slk_explicit_loss(a.loss_kind, sc, e_rating, a.inv_b, a.end - a.begin, l, g);
                 if (lane == 0) {
-                    rec[D] = g;
+                    a.gsn[q - a.begin] = g;
                     loss_acc += l;
                 }
                 if (g != 0.0f) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
                 for (int s = 0; s < a.NP; ++s) {
                     const float g = a.gk[kb + s];
-                    if (lane == 0) rec[D + s] = g;
+                    if (lane == 0) a.gsn[(size_t)(q - a.begin) * a.NP + s] = g;
                     if (g != 0.0f) {
                         const uint32_t it = a.uit[qb + s];
                         slk_vec<VEC> v;
@@ -740,15 +741,16 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         }
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
     }
-    const int RS = D + ((NP + 3) / 4) * 4;  // record = user row + NP dL/dscore, 16-B granular
+    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN };  // ctx->extra slots
+    const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * 4))) return rc;  // dL/dscore per (position, pair)
     const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     if (pre) {
         if ((rc = slk_ensure(ctx, ctx->gk, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
-    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1 };
     if (late) {
         const size_t nl = 2 * (size_t)bsz, nlh = nl * (size_t)(Hi ? Hi : 1);
         if ((rc = slk_ensure(ctx, ctx->extra[BL_LIVE], nl * 4))) return rc;
@@ -919,6 +921,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.sk = (float *)ctx->sk.p;
             a.snap = (float *)ctx->snap.p;
             a.RS = RS;
+            a.gsn = (float *)ctx->extra[BL_GSN].p;
             a.ikey = (const uint32_t *)pb.ikey[1].p;
             a.imask = (uint32_t)((1ull << ibits) - 1);
             a.ipay = (const uint32_t *)pb.ipay[1].p;

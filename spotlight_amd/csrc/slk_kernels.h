@@ -92,6 +92,8 @@ struct slk_pass_args {
     float *sk;               // PRE mode: scores per (interaction, pair)
     float *snap;             // records, see slk_item_mode
     int RS;                  // record stride in floats
+    float *gsn;              // SNAP / SEQ: dL/dscore of the minibatch's pairs, [payload - begin * NP] (kept out of the
+                             // records so that a D = 64 record is exactly two aligned 128-B lines)
     uint32_t ibegin, iend;   // this minibatch's window in the item-sorted occurrence arrays
     const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
     uint32_t imask;
@@ -121,8 +123,8 @@ struct slk_pass_args {
 enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
 
 // How the item pass turns an occurrence payload r into a gradient contribution:
-//   SNAP  r = pos*NP + s; record(pos) = [u_old (D) | g_0..g_{NP-1}];  vec = g_s * u_old, bias g_s
-//   SEQ   r = pos*NP + s; record(pos) = [repr (D) | hist (D) | g_0..g_{NP-1}];
+//   SNAP  r = pos*NP + s; record(pos) = [u_old (D)], g_s = gsn[r - begin*NP];  vec = g_s * u_old, bias g_s
+//   SEQ   r = pos*NP + s; record(pos) = [repr (D) | hist (D)], g_s likewise;
 //         vec = g_s * repr (+ hist when s == 0), bias g_s                       (PoolNet)
 //   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (row-sharded)
 enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2 };
@@ -212,7 +214,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
         const uint32_t s = r - pos * NP;
         const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
         if (MODE == SLK_ITEM_SNAP) {
-            gb = rec[D + s];
+            gb = a.gsn[r - a.begin * NP];
             // several negatives per interaction (adaptive hinge): only the positive and the selected
             // negative carry a gradient, so the row is fetched only when dL/dscore != 0 (a dependent
             // load; with one negative every occurrence is live and both loads are issued at once)
@@ -220,7 +222,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
         } else {
-            gb = rec[2 * D + s];
+            gb = a.gsn[r - a.begin * NP];
             const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];

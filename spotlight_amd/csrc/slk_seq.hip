@@ -22,7 +22,7 @@
 
 #include "slk_kernels.h"
 
-enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1 };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
+enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1, SQ_GSN = 23 };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
 
 struct slk_seq_args {
     const float *E;         // item_embeddings
@@ -33,6 +33,7 @@ struct slk_seq_args {
     uint32_t s_begin, s_end;  // this minibatch's sequences (chunk-local)
     float *rec;             // records of this minibatch: index (s - s_begin) * L + t
     int RS;
+    float *gsn;             // dL/dscore per (record, pair): [record * NP + pair]
     const uint32_t *mcount;  // mask.sum() of this minibatch
     double *loss_partial;
     int loss_kind;
@@ -204,11 +205,13 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                     if (on) slk_vstore<VEC>(rec + d0, rep);
                     if (lane == 0) {
                         loss_acc += (double)(l * mask);
-                        rec[2 * D] = gp;
+                        // 32-bit index off the uniform base: no 64-bit address pair held in VGPRs
+                        const uint32_t gi = (bl * (uint32_t)L + (uint32_t)t) * (uint32_t)a.NP;
+                        a.gsn[gi] = gp;
                         if (!ADAPT) {
-                            rec[2 * D + 1] = gn;
+                            a.gsn[gi + 1] = gn;
                         } else {
-                            for (int j = 0; j < nn; ++j) rec[2 * D + 1 + j] = (j == chosen) ? gn : 0.0f;
+                            for (int j = 0; j < nn; ++j) a.gsn[gi + 1 + j] = (j == chosen) ? gn : 0.0f;
                         }
                     }
                     // advance the running sums, then overwrite the staged row by dL/d(prefix sum)
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
 //     t0 + k, broadcast by __shfl) and all of the chunk's row loads are issued back to back
 //     instead of one dependent (id -> row) pair per loop iteration.
 template <int VEC, int G, bool ADAPT, bool BLOOM, int CMAX>
-__global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(2) void k_seq_pass_reg(slk_seq_args a) {
     constexpr int NG = 256 / G;
     constexpr int DL = G * VEC;
     __shared__ double red[256];
@@ -404,11 +407,13 @@ __global__ __launch_bounds__(256) void k_seq_pass_reg(slk_seq_args a) {
                         if (on) slk_vstore<VEC>(rec + d0, rep);
                         if (lane == 0) {
                             loss_acc += (double)(l * mask);
-                            rec[2 * D] = gp;
+                            // 32-bit index off the uniform base: no 64-bit address pair held in VGPRs
+                            const uint32_t gi = (bl * (uint32_t)L + (uint32_t)t) * (uint32_t)a.NP;
+                            a.gsn[gi] = gp;
                             if (!ADAPT) {
-                                rec[2 * D + 1] = gn;
+                                a.gsn[gi + 1] = gn;
                             } else {
-                                for (int j = 0; j < nn; ++j) rec[2 * D + 1 + j] = (j == chosen) ? gn : 0.0f;
+                                for (int j = 0; j < nn; ++j) a.gsn[gi + 1 + j] = (j == chosen) ? gn : 0.0f;
                             }
                         }
                         // advance the running sums; the row's registers now hold dL/d(prefix sum)
@@ -625,8 +630,9 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIK0 + b], nts_max * NP * Hi * 4))) return rc;
         if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIP0 + b], nts_max * NP * Hi * 4))) return rc;
     }
-    const int RS = 2 * D + ((NP + 3) / 4) * 4;
+    const int RS = 2 * ((D + 3) / 4 * 4);  // record = [representation | history gradient], 16-B granular halves
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * L * RS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SQ_GSN], (size_t)bsz * L * NP * 4))) return rc;  // dL/dscore per (timestep, pair)
     const unsigned max_grid = (unsigned)ctx->num_cus * 8;
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[SQ_MCOUNT], (size_t)mb_per_chunk * 4))) return rc;
@@ -738,6 +744,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             q.s_end = b1;
             q.rec = (float *)ctx->snap.p;
             q.RS = RS;
+            q.gsn = (float *)ctx->extra[SQ_GSN].p;
             q.mcount = mcount + mb;
             q.loss_partial = (double *)ctx->losspart.p;
             q.loss_kind = loss;
@@ -763,6 +770,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             a.end = b1 * (uint32_t)L;
             a.snap = (float *)ctx->snap.p;
             a.RS = RS;
+            a.gsn = (float *)ctx->extra[SQ_GSN].p;
             a.ibegin = a.begin * (uint32_t)NP;
             a.iend = a.end * (uint32_t)NP;
             a.ikey = (const uint32_t *)ctx->ikey[1].p;
