@@ -61,10 +61,11 @@ def test_sharded_whole_chunk_with_slices(world, slices, loss, opt):
     run_world(world, [loss, opt, 8, 'chunk', slices])
 
 
-@pytest.mark.parametrize('world,slices', [(2, 4), (3, 2)])
+@pytest.mark.parametrize('world,slices', [(2, 4), (3, 2), (4, 4), (8, 4), (8, 1)])
 def test_sharded_bench_loop_equal_shares(world, slices):
     """The loop bench.py runs at N > 1: ShardedBilinearTrainer.train over equal per-rank shares of every
-    global minibatch, negatives drawn on each rank's device, several minibatches per chunk."""
+    global minibatch, negatives drawn on each rank's device, several minibatches per chunk; up to the 8 ranks x 4
+    slices of `bench.py --gpus 8`."""
     run_world(world, ['bpr', 'adagrad', 16, 'train', slices])
 
 
