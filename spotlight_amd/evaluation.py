@@ -22,6 +22,12 @@ def _device_ranks(model, keys, num_items, exclude, targets):
     import torch
     from spotlight_amd.factorization import implicit as host
     per_tile = max(1, _SCORE_BYTES // (4 * num_items))
+    # score rows are model._num_items wide: every target / exclude index must address that row
+    for lists in (targets, exclude):
+        for x in lists:
+            x = np.asarray(x)
+            if x.size and (x.min() < 0 or x.max() >= num_items):  # numpy's error on predictions[indices]
+                raise IndexError('index {} is out of bounds for axis 0 with size {}'.format(int(x.max()), num_items))
     out = []
     for lo in range(0, len(keys), per_tile):
         hi = min(lo + per_tile, len(keys))
@@ -43,16 +49,21 @@ def _device_ranks(model, keys, num_items, exclude, targets):
     return out
 
 
+def _has_fast_path(model):
+    return getattr(model, '_batch_scores', None) is not None
+
+
 def mrr_score(model, test, train=None):
     """Mean reciprocal rank of each test user's held-out items among all items, train items pushed
     to the end of the ranking (evaluation.py:9-56).  One score per user with test interactions."""
     test = test.tocsr()
     train = train.tocsr() if train is not None else None
     users = np.array([u for u in range(test.shape[0]) if test.indptr[u + 1] > test.indptr[u]], dtype=np.int64)
-    if hasattr(model, '_batch_scores') and len(users):
+    if _has_fast_path(model) and len(users):
         targets = [test[u].indices for u in users]
         exclude = [train[u].indices if train is not None else np.zeros(0, np.int64) for u in users]
-        ranks = _device_ranks(model, users, test.shape[1], exclude, targets)
+        # the score rows' stride is the MODEL's item count (test may have been built with another num_items)
+        ranks = _device_ranks(model, users, model._num_items, exclude, targets)
         return np.array([(1.0 / r).mean() for r in ranks])
     mrrs = []
     for user_id in users:
@@ -68,7 +79,7 @@ def sequence_mrr_score(model, test, exclude_preceding=False):
     before it (evaluation.py:59-109)."""
     sequences = test.sequences[:, :-1]
     targets = test.sequences[:, -1:]
-    if hasattr(model, '_batch_scores') and len(sequences):
+    if _has_fast_path(model) and len(sequences):
         exclude = [sequences[i] if exclude_preceding else np.zeros(0, np.int64) for i in range(len(sequences))]
         ranks = _device_ranks(model, sequences, model._num_items, exclude, [targets[i] for i in range(len(sequences))])
         return np.array([(1.0 / r).mean() for r in ranks])

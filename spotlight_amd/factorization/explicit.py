@@ -122,5 +122,6 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
             out = torch.sigmoid(out)
         return out.cpu().numpy().flatten()
 
-    def _batch_scores(self, user_ids):
-        raise AttributeError('ranking fast path is defined for the implicit-feedback models')
+    # evaluation.mrr_score's device fast path ranks raw scores; predicted ratings (exp / sigmoid of them)
+    # take the generic predict() route, as in the reference (evaluation.py:9-56)
+    _batch_scores = None

@@ -72,6 +72,14 @@ def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
         engine.gather_rows_i64(d_src.data_ptr(), d_perm.data_ptr(), n, row_len, d_dst.data_ptr(), stream=stream)
 
 
+def _reject_negative_ids(ids):
+    """The reference's torch embedding raises IndexError on a negative id; the kernels address rows with
+    unsigned 32-bit ids, so a negative one must never reach them."""
+    id_min = ids if isinstance(ids, int) else np.asarray(ids).min()
+    if id_min < 0:
+        raise IndexError('index out of range in self')
+
+
 class _OptimizerBinding(object):
     """Maps a torch.optim object onto slk_optim.  The torch optimizer stays the owner of
     hyper-parameters and state tensors (so state_dict / pickle / resuming fit() behave as
@@ -236,11 +244,13 @@ class ImplicitFactorizationModel(object):
         user_id_max = user_ids if isinstance(user_ids, int) else user_ids.max()
         if user_id_max >= self._num_users:
             raise ValueError('Maximum user id greater than number of users in model.')
+        _reject_negative_ids(user_ids)
         if allow_items_none and item_ids is None:
             return
         item_id_max = item_ids if isinstance(item_ids, int) else item_ids.max()
         if item_id_max >= self._num_items:
             raise ValueError('Maximum item id greater than number of items in model.')
+        _reject_negative_ids(item_ids)
 
     def _slk_tables(self):
         return self._net.slk_tables()

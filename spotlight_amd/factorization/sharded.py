@@ -234,6 +234,10 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
     Restrictions of the exchange path: pointwise / bpr / hinge losses, plain (non-bloom) tables.
     """
 
+    # evaluation.mrr_score's one-device fast path scores against whole tables; this model's are local shards
+    # indexed by local rows, so ranking goes through predict() (rows assembled from their owners)
+    _batch_scores = None
+
     def __init__(self, *args, **kwargs):
         self._group = kwargs.pop('group', None)
         super(ShardedImplicitFactorizationModel, self).__init__(*args, **kwargs)

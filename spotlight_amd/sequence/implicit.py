@@ -130,6 +130,7 @@ class ImplicitSequenceModel(object):
             item_id_max = item_ids.max()
         if item_id_max >= self._num_items:
             raise ValueError('Maximum item id greater than number of items in model.')
+        _host._reject_negative_ids(item_ids)
 
     def _slk_tables(self):
         w = self._net.tables()

@@ -53,6 +53,11 @@ def main():
     pu, pi = np.arange(0, 20, dtype=np.int64), (np.arange(0, 20, dtype=np.int64) * 7 + 1) % I
     pred_pairs = model.predict(pu, pi)
     assert model._net.tables()[0].shape[0] == local_rows(U, world, rank)
+    # ranking metrics on the sharded model go through predict() (every rank makes the same calls)
+    from spotlight_amd.evaluation import mrr_score
+    test_inter = Interactions(rs.randint(0, 9, 30).astype(np.int32), rs.randint(0, I, 30).astype(np.int32),
+                              num_users=U, num_items=I)
+    mrr = mrr_score(model, test_inter, train=inter)
 
     # reassemble the tables
     full = []
@@ -91,6 +96,10 @@ def main():
         assert np.abs(pred_all - want_all).max() <= ptol * np.abs(want_all).max()
         assert np.abs(pred_pairs - want_pairs).max() <= ptol * np.abs(want_pairs).max()
         assert pred_all.dtype == np.float32 and pred_all.shape == (I,)
+        want_mrr = mrr_score(ref, test_inter, train=inter)  # the one-device model's fast path
+        # scores agree to ptol, so nearly every rank (hence reciprocal rank) is identical
+        assert mrr.shape == want_mrr.shape and np.isfinite(mrr).all()
+        assert np.mean(np.abs(mrr - want_mrr) > 1e-6) <= (0.25 if opt == 'adagrad' else 0.5), (mrr, want_mrr)
         print('SHARD_MODEL_OK world=%d loss=%s opt=%s' % (world, loss, opt))
     dist.barrier()
     dist.destroy_process_group()

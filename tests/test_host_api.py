@@ -211,3 +211,34 @@ def test_losses_module_matches_the_kernel_formulas():
     assert torch.allclose(L.logistic_loss(y, pred), want, atol=1e-6)
     with pytest.raises(ValueError):
         L.regression_loss(obs.clone().requires_grad_(True), pred)
+
+
+def test_mrr_fast_path_uses_the_models_item_count(emu_device):
+    """A test Interactions built without num_items (fewer columns than the model has items): the score
+    rows are model._num_items wide, and the fast path must index them so."""
+    model = check_factorization_fast_path()
+    rs = np.random.RandomState(8)
+    from spotlight_amd.interactions import Interactions
+    small = Interactions(rs.randint(0, 40, 200).astype(np.int32), rs.randint(0, 50, 200).astype(np.int32))
+    assert small.num_items < model._num_items
+    fast = ev.mrr_score(model, small)
+    slow = ev.mrr_score(OnlyPredict(model), small)
+    assert np.allclose(fast, slow, rtol=1e-12, atol=0)
+    # more items than the model knows: numpy's IndexError on the generic route, the same here
+    big = Interactions(np.array([1, 2], dtype=np.int32), np.array([3, model._num_items + 4], dtype=np.int32))
+    with pytest.raises(IndexError):
+        ev.mrr_score(OnlyPredict(model), big)
+    with pytest.raises(IndexError):
+        ev.mrr_score(model, big)
+
+
+def test_negative_ids_are_rejected_before_any_kernel(emu_device):
+    from spotlight_amd.interactions import Interactions
+    model = check_factorization_fast_path()
+    with pytest.raises(IndexError):
+        model.predict(np.array([-1, 2]), np.array([1, 2]))
+    with pytest.raises(IndexError):
+        model.predict(-3)
+    bad = Interactions(np.array([1, -2], dtype=np.int32), np.array([3, 4], dtype=np.int32), num_users=40, num_items=70)
+    with pytest.raises(IndexError):
+        model.fit(bad)

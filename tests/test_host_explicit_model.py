@@ -78,3 +78,20 @@ def test_errors(emu_device):
     m = ExplicitFactorizationModel(n_iter=1, embedding_dim=8, random_state=np.random.RandomState(1))
     with pytest.raises(TypeError):
         m.fit(inter)  # no ratings
+
+
+def test_mrr_score_on_an_explicit_model_takes_the_predict_route(emu_device):
+    """evaluation.mrr_score(explicit_model, test) works as in the reference: ranking of predict()'s
+    ratings (no device fast path for explicit models)."""
+    model = check_fit_predict_against_fixture('explicit_poisson_adagrad')
+    rs = np.random.RandomState(2)
+    test = Interactions(rs.randint(0, model._num_users, 60).astype(np.int32),
+                        rs.randint(0, model._num_items, 60).astype(np.int32),
+                        num_users=model._num_users, num_items=model._num_items)
+    got = ev.mrr_score(model, test)
+
+    class OnlyPredict(object):
+        def predict(self, *a, **kw):
+            return model.predict(*a, **kw)
+    want = ev.mrr_score(OnlyPredict(), test)
+    assert got.shape == want.shape and np.array_equal(got, want)
