@@ -13,8 +13,9 @@ HBM beforehand.  value = interactions processed by all ranks / max-over-ranks wa
 Extra objects on the JSON line:
   roofline     dominant kernel: algorithmic bytes per launch / mean launch
                duration from hipEvents recorded on the launch stream (slk_profile_*)
-  cpu_baseline oracle/slk_oracle.c (scalar C port of the reference path, 1 thread) timed on
-               the host on a bounded sample of the same workload (rank 0, N=1 only)
+  cpu_baseline Spotlight's own CPU PyTorch path (oracle/_ref, staged by oracle/make_ref.sh) timed on the
+               host cores on a bounded sample of the same workload (rank 0, N=1 only; kind "reference");
+               oracle/slk_oracle.c (scalar C port, 1 thread) as the secondary field `port`
 """
 import argparse
 import json
@@ -85,9 +86,49 @@ def parse():
     ap.add_argument('--side-stream', type=int, default=1, help='1: run the engine on a dedicated HIP stream')
     ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE',
                     help='engine tuning option (slk_ctx_set_option), e.g. item_grid_mult=28')
+    ap.add_argument('--backend', default='hip', choices=['hip', 'emu'],
+                    help="hip: the product (libspotlight_hip.so on MI355X, RCCL).  emu: TEST HARNESS ONLY -- the same host code over "
+                         "tests/emu's CPU build of the kernels and gloo, so that the N > 1 launch path can be exercised on a box "
+                         "without GPUs (tests/test_bench_cli.py); never a measurement")
+    ap.add_argument('--no-probes', action='store_true', help='skip the copy / triad / step-ceiling bandwidth probes')
+    ap.add_argument('--no-sharded-check', action='store_true',
+                    help='N=1: skip the consistency run of the row-sharded path (world 1) against the fused path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
+
+
+def reference_cpu_baseline(args, seconds):
+    """Spotlight's own CPU PyTorch path (the copy staged by oracle/make_ref.sh under oracle/_ref/) timed
+    on this machine's host cores by oracle/ref_cpu_baseline.py, in its own process: same table shapes, loss
+    and minibatch as the GPU workload, protocol of the reference's examples/bloom_embeddings/performance.py:24-38.
+    Returns None when the copy is not staged."""
+    import subprocess
+    script = os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py')
+    if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'spotlight')):
+        return None
+    cmd = [sys.executable, script, '--users', str(args.users), '--items', str(args.items), '--dim', str(args.dim),
+           '--batch', str(args.batch), '--loss', args.loss, '--seconds', str(seconds)]
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60 + 12 * seconds)
+        rec = json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+        return {'error': repr(e)[:300]}
+    if 'sparse_adagrad' not in rec:
+        return {'error': str(rec)[:300]}
+    sa, da = rec['sparse_adagrad'], rec.get('default_dense_adam')
+    out = {'value': sa['interactions_per_s'], 'unit': 'interactions/s', 'cores': rec['threads'], 'kind': 'reference',
+           'cpu_model': rec['cpu_model'],
+           'sample': 'spotlight ImplicitFactorizationModel.fit() on CPU PyTorch %s, sparse=True + Adagrad(lr=1e-2), %s loss, '
+                     '%d users x %d items, dim %d, minibatch %d: warm-up fit + min of 2 timed fits of %d minibatch(es) '
+                     '(%.1f s each), torch.set_num_threads(%d)%s'
+                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], rec['batch'],
+                        sa['minibatches_per_fit'], sa['seconds'], rec['threads'],
+                        '; ' + rec['note'] if rec['note'] else '')}
+    if da:
+        out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s',
+                                               'sample': '%d minibatch(es) per fit, %.1f s' % (da['minibatches_per_fit'], da['seconds'])}
+    return out
 
 
 def cpu_baseline(args, seconds):
@@ -251,8 +292,135 @@ def bench_c3(args):
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: launch the N ranks ourselves (one process
+    per GPU, torch.distributed.run on 127.0.0.1) and pass rank 0's JSON line through.  Fails loudly when the
+    machine does not have N GPUs -- it never degrades to fewer ranks."""
+    import socket
+    import subprocess
+    if args.backend == 'hip':
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d requested but %d HIP device(s) visible; refusing to run fewer ranks\n'
+                             % (args.gpus, have))
+            return 3
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SLK_BENCH_SPAWNED='1')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
+class Backend(object):
+    """Device plumbing of the benchmark: 'hip' = torch-ROCm tensors + RCCL + libspotlight_hip.so (the product);
+    'emu' = CPU tensors + gloo + tests/emu's build of the same kernels (test harness for the launch logic)."""
+
+    def __init__(self, kind, local_rank):
+        self.kind = kind
+        if kind == 'hip':
+            torch.cuda.set_device(local_rank)
+            self.dev = torch.device('cuda', local_rank)
+            self.engine = _native.Engine(local_rank)
+            self.dist_backend = 'nccl'
+            self.name = torch.cuda.get_device_name(local_rank)
+        else:
+            sys.path.insert(0, os.path.join(ROOT, 'tests'))
+            from emu_backend import emu_lib
+            self.dev = torch.device('cpu')
+            self.engine = _native.Engine(0, lib=emu_lib())
+            self.dist_backend = 'gloo'
+            self.name = 'cpu emulator (test harness)'
+        self.side = None
+
+    def init_dist(self, rank, world, local_rank):
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29400')
+        if self.kind == 'hip':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        return dist
+
+    def generator(self, seed):
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(seed)
+        return gen
+
+    def use_side_stream(self):
+        if self.kind == 'hip':
+            self.side = torch.cuda.Stream(self.dev)
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
+            torch.cuda.set_stream(self.side)
+
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream if self.kind == 'hip' else 0
+
+    def sync(self):
+        if self.kind == 'hip':
+            torch.cuda.synchronize(self.dev)
+
+
+def measured_stream_rates(be, stream):
+    """Copy / triad GB/s of this GPU (slk_probe_stream: float4 kernels over 1 GiB buffers) -- the measured figure
+    SURVEY.md 8(d) asks for next to the nominal peak."""
+    n = (1 << 28) if be.kind == 'hip' else (1 << 12)
+    a, b, c = (torch.ones(n, device=be.dev) for _ in range(3))
+    copy_ms = be.engine.probe_stream(0, a.data_ptr(), b.data_ptr(), None, n, iters=10, stream=stream)
+    triad_ms = be.engine.probe_stream(1, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream)
+    del a, b, c
+    return {'copy_GBs': 8.0 * n / copy_ms / 1e6, 'triad_GBs': 12.0 * n / triad_ms / 1e6,
+            'note': 'float4 copy (read + write) / triad (2 reads + write) over 1 GiB buffers, hipEvents, 10 launches'}
+
+
+def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):
+    """N = 1 consistency of the two engines: the same two minibatches, from the same tables and the same RNG
+    state, through the fused path and through the row-sharded exchange path at world 1 (exchange = device copy);
+    per-minibatch losses must agree.  Runs on copies of the tables."""
+    from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
+    import torch.distributed as dist
+    eng = be.engine
+    K = 2
+    state = np.random.RandomState(77).get_state()
+    losses = []
+    times = []
+    for path in ('fused', 'sharded'):
+        t = [x.clone() for x in tables]
+        a1 = [x.clone() for x in s1]
+        a2 = [x.clone() for x in s2] if s2 else None
+        op = _native.make_optim(args.opt, [x.data_ptr() for x in a1], [x.data_ptr() for x in a2] if a2 else None, lr=1e-2)
+        mb = torch.zeros(K, device=be.dev)
+        eng.rng_set_state(state)
+        be.sync()
+        t0 = time.perf_counter()
+        if path == 'fused':
+            tb = _native.make_tables([x.data_ptr() for x in t], t[0].shape[0], t[1].shape[0], args.dim)
+            eng.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), K * B, B, args.loss, 1, mb.data_ptr(), stream=stream)
+        else:
+            tr = ShardedBilinearTrainer(eng, t, op, t[1].shape[0], stream=stream, slices=args.slices or None)
+            tr.train(users[:K * B], items[:K * B], B, loss=args.loss, mb_loss=mb)
+        be.sync()
+        times.append((time.perf_counter() - t0) / K * 1e3)
+        losses.append(mb.cpu().numpy().astype(np.float64))
+        del t, a1, a2
+    rel = float(np.abs(losses[0] - losses[1]).max() / np.abs(losses[0]).max())
+    return {'minibatches': K, 'loss_fused': losses[0].tolist(), 'loss_sharded_world1': losses[1].tolist(),
+            'max_rel_diff': rel, 'consistent': bool(rel <= 1e-5),
+            'ms_per_step_untimed_warm': {'fused': times[0], 'sharded_world1': times[1]}}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n'
+                         % (args.gpus, os.environ['WORLD_SIZE']))
+        sys.exit(3)
     if args.workload == 'c4':
         return bench_c4(args)
     if args.workload == 'c3':
@@ -268,22 +436,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    be = Backend(args.backend, local_rank)
+    want_sharded_check = (world == 1 and not args.sharded and not args.no_sharded_check and args.workload in ('c2', 'c5'))
     if world > 1 or args.sharded:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29400')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+        dist = be.init_dist(rank, world, local_rank)
+    dev = be.dev
     U, I, D, B = args.users, args.items, args.dim, args.batch
     K, W = args.steps, args.warmup
 
-    eng = _native.Engine(local_rank)
+    eng = be.engine
     for kv in args.set:
         name, value = kv.split('=')
         eng.set_option(name, int(value))
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
+    gen = be.generator(1234 + rank)
     # per-GPU shard: U x D users, I x D items (N > 1: the global tables are world times larger,
     # row-sharded cyclically; per-GPU work is fixed = weak scaling)
     tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen),
@@ -301,13 +466,11 @@ def main():
     mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
     # the engine runs on its own HIP stream (ordered against torch's current stream by events)
-    side = torch.cuda.Stream(dev) if args.side_stream else None
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.set_stream(side)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    if args.side_stream:
+        be.use_side_stream()
+    stream = be.stream()
     trainer = None
-    if dist is not None:
+    if world > 1 or args.sharded:
         from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
         trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
         trainer.reserve(B, 8)  # exchange buffers of the timed loop's chunks (8 minibatches) up front
@@ -324,11 +487,13 @@ def main():
         trainer.train(users[lo:hi], items[lo:hi], B, loss=args.loss, mb_loss=mb_loss[first_mb:first_mb + n_mb])
         xgmi_rows[0] += trainer.exchange_rows
 
+    multi = world > 1 or args.sharded
+
     def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
+        be.sync()
+        if multi:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            be.sync()
 
     if trainer is None:
         eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # scratch for the timed call's shape
@@ -339,7 +504,7 @@ def main():
     # timed region: EXACTLY K steps, no instrumentation inside
     t0 = time.perf_counter()
     run(W, K)
-    torch.cuda.synchronize(dev)
+    be.sync()
     elapsed = time.perf_counter() - t0
     barrier()
     # per-kernel durations: K more steps with hipEvents around every launch (slk_profile_*);
@@ -349,17 +514,34 @@ def main():
     eng.profile_enable(True)
     t1 = time.perf_counter()
     run(W + K, K)
-    torch.cuda.synchronize(dev)
+    be.sync()
     elapsed_profiled = time.perf_counter() - t1
     eng.profile_enable(False)
     prof = eng.profile_read()
     xgmi_rows[0] = xg
-    if dist is not None:
+    ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
+    if multi:
         dist.barrier()
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(mb_loss)  # per-rank shares of each global minibatch loss
+        # what the process group itself observed: its size and every rank's device
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, ranks_seen[0])
+        ranks_seen = seen
+        assert dist.get_world_size() == world == args.gpus or args.sharded, (dist.get_world_size(), world, args.gpus)
+    probes = ceiling = shard_check = None
+    if rank == 0 and world == 1 and trainer is None and not args.no_probes:
+        probes = measured_stream_rates(be, stream)
+        um, im, touched = eng.probe_step_ceiling(tb, op, B, iters=10, stream=stream)
+        ceiling = {'user_side_ms': um, 'item_side_ms': im, 'items_touched': touched}
+    if want_sharded_check and rank == 0:
+        try:
+            dist = be.init_dist(0, 1, local_rank)  # after the timed region: a world-1 group for the exchange path
+            shard_check = sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream)
+        except Exception as e:
+            shard_check = {'error': repr(e)[:300]}
 
     losses = mb_loss.cpu().numpy()
     assert np.isfinite(losses).all() and (losses[W:] > 0).all(), losses
@@ -385,6 +567,16 @@ def main():
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
                 'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange')}}
+        if probes:
+            roof['measured'] = probes
+        if ceiling:
+            # the step's algorithmic accesses alone (slk_probe_step_ceiling): what exact grouping + hand-over cost on top
+            tot = ceiling['user_side_ms'] + ceiling['item_side_ms']
+            ceiling.update({'ms_per_step': tot, 'step_frac_of_peak': (ub + ib) * B / (tot * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                            'user_side_frac_of_peak': ub * B / (ceiling['user_side_ms'] * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                            'note': 'algorithmic row accesses only (no sorts, records, ids, biases, duplicate handling) on the '
+                                    'same tables in the same lane layout; the item side touches each distinct item once'})
+            roof['ceiling'] = ceiling
         if trainer is not None:
             rsv = eng.shard_row_floats(D)
             kern_ms = sum(prof[k][1] for k in ('sample', 'prep', 'user_pass', 'item_pass', 'exchange')) / K
@@ -403,7 +595,10 @@ def main():
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-               'data': 'synthetic',
+               'data': 'synthetic' if be.kind == 'hip' else 'synthetic; CPU EMULATOR TEST RUN, not a measurement',
+               'ranks': {'world_size_observed': dist.get_world_size() if multi else 1, 'devices': ranks_seen,
+                         'launched_by': 'bench.py (torch.distributed.run)' if os.environ.get('SLK_BENCH_SPAWNED') else
+                                        ('torchrun' if 'WORLD_SIZE' in os.environ else 'single process')},
                'config': {'workload': '%s: synthetic uniform ids, %d users x %d items, dim %d, %s loss, '
                                       '%s lr=1e-2, minibatch %d%s, on-GPU numpy-exact negatives'
                                       % (args.workload.upper(), U * world, I * world, D, args.loss, args.opt, B * world,
@@ -416,8 +611,19 @@ def main():
                'roofline': roof,
                'ms_per_step_with_kernel_timers': elapsed_profiled / K * 1e3,
                'final_minibatch_loss': float(losses[-1])}
+        if shard_check is not None:
+            out['sharded_world1_consistency'] = shard_check
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+            # the reference itself on this box's host cores; the scalar C port (1 thread) as a secondary field
+            ref = reference_cpu_baseline(args, args.cpu_seconds)
+            port = cpu_baseline(args, 6.0 if ref and 'value' in ref else args.cpu_seconds)
+            if ref and 'value' in ref:
+                out['cpu_baseline'] = ref
+                out['cpu_baseline']['port'] = port
+            else:
+                out['cpu_baseline'] = port
+                if ref:
+                    out['cpu_baseline']['reference_error'] = ref.get('error')
     else:
         out = None
     if dist is not None:

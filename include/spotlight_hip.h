@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 3
+#define SLK_ABI_VERSION 4
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -347,6 +347,24 @@ enum slk_kernel_class {
 int slk_profile_enable(slk_ctx *ctx, int32_t on);
 int slk_profile_read(slk_ctx *ctx, int32_t kernel_class, int64_t *launches, double *total_ms);
 int slk_profile_reset(slk_ctx *ctx);
+
+/* Bandwidth probes of the device (measurement support; SURVEY.md 8(d): "report the measured triad number
+ * next to the nominal peak").  Both synchronise the stream and return average launch durations from
+ * hipEvents recorded on it.
+ *  slk_probe_stream        kind 0: a = b (float4 copy, 8 B moved per float); kind 1: a = b + s*c (triad,
+ *                          12 B per float) over caller-owned device buffers of n_floats (multiple of 4).
+ *  slk_probe_step_ceiling  the BilinearNet training step's ALGORITHMIC row accesses and nothing else (no
+ *                          sorts, no user->item records, no id / key streams, no biases), on the caller's live
+ *                          tables (values are written back unchanged), in the passes' lane layout:
+ *                          user side = per interaction U[u] + state1 read and written, V[pos], V[neg] read
+ *                          (factorization/representations.py:80-91 + the optimizer's row update); item side =
+ *                          per distinct item of 2*batch uniform draws V[i] + state1 read and written.  The sum
+ *                          of the two durations is what an exact fused step could reach if grouping and the
+ *                          hand-over of pre-step user rows were free. */
+int slk_probe_stream(slk_ctx *ctx, int32_t kind, float *d_a, const float *d_b, const float *d_c, int64_t n_floats,
+                     int32_t iters, double *avg_ms, void *stream);
+int slk_probe_step_ceiling(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t batch,
+                           int32_t iters, double *user_ms, double *item_ms, int64_t *items_touched, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 3
+SLK_ABI_VERSION = 4
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -101,6 +101,10 @@ _PROTOTYPES = {
     'slk_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'slk_profile_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'slk_profile_reset': (C.c_int, [C.c_void_p]),
+    'slk_probe_stream': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                   C.POINTER(C.c_double), C.c_void_p]),
+    'slk_probe_step_ceiling': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int32,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))
@@ -324,6 +328,20 @@ class Engine(object):
 
     def profile_reset(self):
         self._check(self._lib.slk_profile_reset(self._ctx))
+
+    def probe_stream(self, kind, d_a, d_b, d_c, n_floats, iters=10, stream=0):
+        """Average ms of one float4 copy (kind 0) / triad (kind 1) launch over n_floats."""
+        ms = C.c_double()
+        self._check(self._lib.slk_probe_stream(self._ctx, int(kind), d_a, d_b, d_c, int(n_floats), int(iters),
+                                               C.byref(ms), stream))
+        return float(ms.value)
+
+    def probe_step_ceiling(self, tables, optim, batch, iters=10, stream=0):
+        """(user-side ms, item-side ms, distinct items touched) of the step's algorithmic accesses only."""
+        um, im, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self._lib.slk_probe_step_ceiling(self._ctx, C.byref(tables), C.byref(optim), int(batch), int(iters),
+                                                     C.byref(um), C.byref(im), C.byref(n), stream))
+        return float(um.value), float(im.value), int(n.value)
 
     def profile_read(self):
         out = {}

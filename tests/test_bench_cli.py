@@ -1,0 +1,78 @@
+"""bench.py's launch logic on a box without GPUs: `--backend emu` runs the same host code (argument handling,
+self-spawn of N ranks through torch.distributed.run, the sharded trainer loop, max-over-ranks timing, the JSON line)
+over gloo and the emulator build of the kernels.  The numbers are meaningless; the structure is what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+SMALL = ['--backend', 'emu', '--users', '3000', '--items', '700', '--dim', '16', '--batch', '256', '--steps', '2',
+         '--warmup', '1', '--no-cpu-baseline']
+
+
+def run_bench(extra, env_extra=None, timeout=900):
+    from emu_backend import emu_lib
+    emu_lib()  # build once, before several ranks race for it
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, BENCH] + SMALL + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                       timeout=timeout)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def test_single_rank_line_has_the_contract_fields():
+    rc, out, err = run_bench(['--gpus', '1'])
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out  # exactly ONE JSON line on stdout
+    rec = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert key in rec, key
+    assert rec['n_gpus'] == 1 and rec['steps'] == 2 and rec['warmup'] == 1 and rec['vs_baseline'] is None
+    roof = rec['roofline']
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'measured', 'ceiling'):
+        assert key in roof, key
+    assert roof['measured']['copy_GBs'] > 0 and roof['ceiling']['ms_per_step'] > 0
+    chk = rec['sharded_world1_consistency']
+    assert chk.get('consistent') is True, chk
+    assert rec['ranks']['world_size_observed'] == 1
+
+
+@pytest.mark.parametrize('n', [2, 4])
+def test_gpus_n_spawns_n_ranks_itself(n):
+    """`python bench.py --gpus N` with no torchrun environment launches the N ranks itself."""
+    rc, out, err = run_bench(['--gpus', str(n)])
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == n and rec['ranks']['world_size_observed'] == n
+    assert sorted(d['rank'] for d in rec['ranks']['devices']) == list(range(n))
+    assert rec['ranks']['launched_by'].startswith('bench.py')
+    assert rec['config']['global_batch'] == 256 * n and rec['scaling'] == 'weak'
+    assert rec['roofline']['xgmi']['rows_per_step_per_gpu'] > 0
+
+
+def test_world_size_mismatch_fails_loudly():
+    rc, out, err = run_bench(['--gpus', '2'], env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert rc != 0 and 'WORLD_SIZE' in err and not out.strip()
+
+
+def test_hip_backend_refuses_more_ranks_than_gpus():
+    """On this GPU-less box the product backend must refuse `--gpus 2` instead of running fewer ranks."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('box has >= 2 GPUs')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '1', '--warmup', '0'], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=300)
+    assert p.returncode != 0 and b'refusing' in p.stderr and not p.stdout.strip()
