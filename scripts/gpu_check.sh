@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the MI355X box via gpurun: parity tests, smoke, bench, rocprofv3 kernel stats.
-# usage: scripts/gpu_check.sh <tag> [stages...]   stages: tests smoke bench prof pmc
+# usage: scripts/gpu_check.sh <tag> [stages...]   stages: tests parity smoke bench prof pmc shard c4
 set -u
 TAG=${1:-r1}; shift || true
 STAGES=${@:-tests smoke bench prof}
@@ -14,6 +14,9 @@ for st in $STAGES; do
     tests)
       timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
       echo "pytest exit $?" >> $OUT/pytest_gpu.log; tail -15 $OUT/pytest_gpu.log ;;
+    parity)
+      timeout 1500 python -m pytest tests/test_gpu_bench_parity.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest_bench_parity.log 2>&1
+      echo "pytest exit $?" >> $OUT/pytest_bench_parity.log; grep -a "parity\|passed\|failed\|Error\|exit" $OUT/pytest_bench_parity.log | tail -25 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
     bench)

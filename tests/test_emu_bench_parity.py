@@ -1,0 +1,46 @@
+"""The bench-size parity checks (tests/bench_parity.py) at toy sizes through the emulator build: keeps the checker
+itself -- compaction, teacher forcing, the conditioned Adagrad bound -- under test on a box without a GPU."""
+import pytest
+import torch
+
+import bench_parity as bp
+from emu_backend import emu_lib
+from spotlight_amd import _native
+
+
+@pytest.fixture(scope='module')
+def emu():
+    eng = _native.Engine(0, lib=emu_lib())
+    yield eng, torch.device('cpu'), 0
+    eng.close()
+
+
+@pytest.mark.parametrize('trained', [False, True])
+def test_bilinear_compacted_minibatch(emu, trained):
+    eng, dev, stream = emu
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, 5000, 900, 16, 700, loss='bpr', trained=trained,
+                                       scale=None if not trained else 0.125, seed=int(trained))
+    assert out['users_touched'] <= 700 and out['items_touched'] <= 1400
+
+
+def test_bilinear_bloom_adaptive_minibatch(emu):
+    eng, dev, stream = emu
+    bp.bilinear_minibatch_parity(eng, dev, stream, 4000, 800, 32, 300, loss='adaptive_hinge', nn=5, bloom_rows=160, n_hash=4,
+                                 trained=True, scale=0.1, seed=3)
+
+
+@pytest.mark.parametrize('pad_frac', [0.0, 0.3])
+def test_poolnet_minibatch(emu, pad_frac):
+    eng, dev, stream = emu
+    bp.poolnet_minibatch_parity(eng, dev, stream, 500, 16, 12, 20, loss='bpr', trained=pad_frac > 0,
+                                scale=None if pad_frac == 0 else 0.125, pad_frac=pad_frac, seed=4)
+
+
+def test_multi_chunk_teacher_forcing(emu):
+    eng, dev, stream = emu
+    eng.set_option('chunk_interactions', 512)  # 2 minibatches of 256 per prep chunk
+    try:
+        out = bp.multi_chunk_parity(eng, dev, stream, 3000, 700, 16, 256, n_full=5, tail=77, check_at=(2, 5))
+    finally:
+        eng.set_option('chunk_interactions', 1 << 23)
+    assert out['minibatches'] == 6 and len(out['checked']) == 2

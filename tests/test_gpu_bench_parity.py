@@ -1,0 +1,71 @@
+"""`-m gpu`: one minibatch of every benchmarked workload AT ITS REAL SIZE against the CPU oracle (tests/bench_parity.py
+explains the compaction and the tolerances), plus a multi-chunk call (more than 8 M interactions)."""
+import pytest
+import torch
+
+import bench_parity as bp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from spotlight_amd import _native
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    eng = _native.Engine(0)  # libspotlight_hip.so or ImportError: no fallback
+    yield eng, dev, torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize()
+    eng.close()
+
+
+@pytest.mark.parametrize('trained', [False, True])
+def test_c2_minibatch_at_bench_size(hip, trained):
+    """BASELINE.json configs[1] = bench.py's default workload: 10M users x 1M items, dim 64, bpr, Adagrad(1e-2),
+    minibatch 2^20.  trained=False is bench.py's exact initial state (N(0, 1/D) rows, zero biases, zero
+    accumulators); trained=True has O(1) scores, non-zero biases and accumulators."""
+    eng, dev, stream = hip
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, loss='bpr', trained=trained,
+                                       scale=None if not trained else 0.5 / 8.0, seed=int(trained))
+    print('C2 parity', out)
+
+
+def test_c3_minibatch_at_bench_size(hip):
+    """configs[2]: 10M x 1M, adaptive hinge n=5, BloomEmbedding item table (compression 0.2 -> 200k rows x 4 hashes),
+    dim 128, minibatch 2^18 (bench.py --workload c3)."""
+    eng, dev, stream = hip
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, 10_000_000, 1_000_000, 128, 1 << 18, loss='adaptive_hinge', nn=5,
+                                       bloom_rows=200_000, n_hash=4, trained=True, scale=0.5 / 128 ** 0.5, seed=3)
+    print('C3 parity', out)
+
+
+@pytest.mark.parametrize('pad_frac', [0.0, 0.2])
+def test_c4_minibatch_at_bench_size(hip, pad_frac):
+    """configs[3]: PoolNet, 4096 sequences x len 200 per minibatch, 1M items, dim 64, bpr (bench.py --workload c4);
+    also SURVEY 8(d)'s 20 %-left-padded variant."""
+    eng, dev, stream = hip
+    out = bp.poolnet_minibatch_parity(eng, dev, stream, 1_000_000, 64, 4096, 200, loss='bpr', trained=pad_frac > 0,
+                                      scale=None if pad_frac == 0 else 0.5 / 8.0, pad_frac=pad_frac, seed=4)
+    print('C4 parity', out)
+
+
+def test_c5_shard_minibatch_at_bench_size(hip):
+    """configs[4], the per-GPU shard bench.py --workload c5 runs: 12.5M users x 125M items (32 GB item table +
+    32 GB accumulators), dim 64, bpr, minibatch 2^20.  Every touched row is compared; the other 120M+ rows must
+    come back bit-identical."""
+    eng, dev, stream = hip
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, 12_500_000, 125_000_000, 64, 1 << 20, loss='bpr', seed=5,
+                                       check_grads=False)
+    print('C5-shard parity', out)
+    torch.cuda.empty_cache()
+
+
+def test_multi_chunk_call_at_bench_size(hip):
+    """10 minibatches of 2^20 (+ a short one) in ONE call: two prep chunks (8 + 3 minibatches).  Negatives and RNG
+    state bit-exact over the whole call; minibatches 8 (first of the second chunk) and 10 (the short tail) against
+    the oracle by teacher forcing."""
+    eng, dev, stream = hip
+    out = bp.multi_chunk_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, n_full=10, tail=300_001,
+                                check_at=(8, 10))
+    print('multi-chunk parity', out)
