@@ -342,7 +342,8 @@ enum slk_kernel_class {
     SLK_K_SCORE = 5,    /* adaptive-hinge score/select; predict    */
     SLK_K_EXCHANGE = 6, /* row-sharded path: owner-side row gather  */
     SLK_K_SEQ_PASS = 7, /* PoolNet sequence pass                    */
-    SLK_K_COUNT = 8
+    SLK_K_EPOCH = 8,    /* persistent epoch kernel: all minibatches of a chunk in one launch */
+    SLK_K_COUNT = 9
 };
 int slk_profile_enable(slk_ctx *ctx, int32_t on);
 int slk_profile_read(slk_ctx *ctx, int32_t kernel_class, int64_t *launches, double *total_ms);

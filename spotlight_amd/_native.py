@@ -20,7 +20,7 @@ LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
               'regression': 4, 'poisson': 5, 'logistic': 6}
 OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
 KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5,
-                  'exchange': 6, 'seq_pass': 7}
+                  'exchange': 6, 'seq_pass': 7, 'epoch': 8}
 
 
 class SlkBloom(C.Structure):

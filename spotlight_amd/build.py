@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['slk_api.hip', 'slk_sort.hip', 'slk_rng.hip', 'slk_mtjump.hip', 'slk_bilinear.hip', 'slk_shard.hip', 'slk_seq.hip', 'slk_eval.hip', 'slk_shuffle.hip', 'slk_seqprep.hip', 'slk_embed.hip', 'slk_probe.hip']
+SOURCES = ['slk_api.hip', 'slk_sort.hip', 'slk_rng.hip', 'slk_mtjump.hip', 'slk_bilinear.hip', 'slk_shard.hip', 'slk_seq.hip', 'slk_eval.hip', 'slk_shuffle.hip', 'slk_seqprep.hip', 'slk_embed.hip', 'slk_probe.hip', 'slk_epoch.hip']
 HEADERS = ['slk_common.h', 'slk_kernels.h', os.path.join('..', '..', 'include', 'spotlight_hip.h')]
 LIB = os.path.join(CSRC, 'libspotlight_hip.so')
 ARCH = 'gfx950'

@@ -759,7 +759,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
-    if (dense) {
+    // minibatches of a few thousand interactions: every minibatch of a chunk inside ONE persistent launch (slk_epoch.hip)
+    const bool epoch_route = !pre && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    if (dense && !epoch_route) {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
                                  (size_t)tables->num_items};
@@ -1068,12 +1070,21 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return SLK_OK;
     };
 
+    auto do_chunk = [&](int64_t c0, slk_prep_bufs &pb) -> int {
+        if (!epoch_route) return do_passes(c0, pb);
+        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, RS, (float *)ctx->snap.p,
+                                     (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, s);
+        mb_global += (nc + bsz - 1) / bsz;
+        return rc;
+    };
+
     if (nsets == 1) {
         // everything in order on the caller's stream
         for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
             if ((rc = do_sample(c0, ctx->pb[0], s))) return rc;
             if ((rc = do_sort(c0, ctx->pb[0], s))) return rc;
-            if ((rc = do_passes(c0, ctx->pb[0]))) return rc;
+            if ((rc = do_chunk(c0, ctx->pb[0]))) return rc;
         }
         ctx->last_stream = s;
         return SLK_OK;
@@ -1100,7 +1111,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (sort_ahead && (rc = do_sort(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
         }
-        if ((rc = do_passes(c0, ctx->pb[set]))) return rc;
+        if ((rc = do_chunk(c0, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }
     ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream

@@ -19,6 +19,16 @@
 #define SLK_WAVES_PER_EU(n)
 #endif
 
+// Wait until every outstanding vector-memory operation of this wave (stores included) has been acknowledged: what a
+// workgroup does before it signals another one that its write-through (sc1) stores may be read (slk_epoch.hip).  Inline
+// asm because the compiler's own wait-count bookkeeping may drop a builtin wait it considers redundant
+// (MI355X_MICROARCH.md, "Compiler hazard").  hipcc only; the test harness's host build has no memory pipeline.
+#if defined(__HIPCC__)
+#define SLK_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SLK_DRAIN_VMEM() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // ctx
 // ---------------------------------------------------------------------------------------
@@ -34,6 +44,8 @@ struct slk_rng_dev {
     int32_t insufficient;     // sticky: a sampling call ran out of generated words
     unsigned long long t_last;  // stream index of the word that produced the last output
     unsigned long long accepted;
+    int32_t epoch_abort;      // sticky: the persistent epoch kernel abandoned a launch (grid barrier time-out)
+    int32_t pad_;
 };
 
 #define SLK_EXTRA_BUFS 48
@@ -69,6 +81,11 @@ struct slk_ctx {
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
+    int opt_epoch_kernel = 0;      // 1: minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip)
+    int64_t opt_epoch_max_batch = 4096;
+    int opt_epoch_max_grid = 128;  // workgroups of the persistent launch (<= one per CU)
+    int64_t opt_epoch_dense_elems = (int64_t)1 << 23;  // dense optimizers: largest model (parameters) the persistent route takes
+    std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
@@ -156,6 +173,11 @@ int slk_sort_reserve(slk_ctx *ctx, size_t n);
 // returned to the host).
 int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32_t *d_heads, uint32_t *d_segid,
                       uint32_t *nseg_out, hipStream_t s);
+// slk_epoch.hip: the persistent route of slk_bilinear_train
+bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss, bool bloom);
+int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
+                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
+                        float *d_mb_loss, hipStream_t s);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
@@ -280,6 +302,56 @@ template <int VEC>
 __device__ __forceinline__ void slk_vstore_if_nt(float *p, const slk_vec<VEC> &x, bool nt) {
     if (nt) slk_vstore_nt<VEC>(p, x);
     else slk_vstore<VEC>(p, x);
+}
+
+// Device-coherent accesses for data that OTHER workgroups of the SAME launch write or read (the persistent epoch
+// kernel, slk_epoch.hip): agent-scope relaxed atomics = `global_load/store ... sc1` on gfx950.  An sc1 store is
+// written through to the fabric; an sc1 load bypasses the CU's L1 (which another CU's stores never refresh).  With
+// both sides sc1 the hand-over needs no release / acquire fence (MI355X_MICROARCH.md, "Valid forms"): only the
+// producer's `s_waitcnt vmcnt(0)` before it signals.  8 bytes per access (the widest atomic): a 16-B lane slice
+// is two of them -- these kernels are latency-bound, not bandwidth-bound.
+__device__ __forceinline__ float slk_ld_coh(const float *p) {
+    const uint32_t b = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+__device__ __forceinline__ void slk_st_coh(float *p, float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VEC>
+__device__ __forceinline__ slk_vec<VEC> slk_vload_coh(const float *p) {
+    slk_vec<VEC> r;
+    if (VEC == 4) {
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) memcpy(&r.v[i], &w[i % 4], 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r.v[i] = slk_ld_coh(p + i);
+    }
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void slk_vstore_coh(float *p, const slk_vec<VEC> &x) {
+    if (VEC == 4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) memcpy(&w[i], &x.v[i % VEC], 4);
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+        __hip_atomic_store(q, (unsigned long long)w[0] | ((unsigned long long)w[1] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, (unsigned long long)w[2] | ((unsigned long long)w[3] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) slk_st_coh(p + i, x.v[i]);
+    }
 }
 
 template <int VEC>

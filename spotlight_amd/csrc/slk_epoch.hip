@@ -1,0 +1,453 @@
+// slk_epoch.hip -- the PERSISTENT EPOCH KERNEL: every minibatch of a prepared chunk inside ONE launch.
+//
+// Replaces the Python minibatch loop of ImplicitFactorizationModel.fit() (spotlight/factorization/implicit.py:223-243)
+// at the reference's own operating points -- batch_size 256 (its default, implicit.py:80) to a few thousand (1024 in
+// its tests, tests/factorization/test_implicit.py:40-57) -- where a minibatch moves a few hundred KB and the
+// per-minibatch launches of slk_bilinear.hip (user pass, item pass, dense sweep) cost more than the work.
+//
+// One cooperative launch (all workgroups resident) runs, for every minibatch of the chunk in order:
+//
+//   USER PHASE   one row group per unique user (head of its run in the (minibatch, user)-sorted list): U[u], V[pos],
+//                V[neg], biases; dot products by __shfl_xor; loss + dL/dscore; records (pre-step user row, dL/dscore
+//                per pair) for the item phase; the optimizer update of U[u] and its bias in place
+//   -- grid barrier --
+//   ITEM PHASE   one row group per unique item (head of its run in the (minibatch, item)-sorted occurrence list): sums
+//                g * u_old over the run in occurrence order, updates V[i] and its bias; one workgroup also reduces the
+//                minibatch's loss partials into loss.item()
+//   -- grid barrier --
+//
+// i.e. the two ownership passes of the launch path (same sorted lists, same summation order, same arithmetic: the
+// trained tables are BIT-IDENTICAL to the per-minibatch launches, which the tests assert), with the launch boundaries
+// replaced by an in-kernel barrier.  The dense optimizers (the reference's default Adam + l2, Adagrad + weight decay:
+// EVERY row is updated every step, torch/optim/adam.py:414-546) need no third phase and no gradient buffer: the owner of
+// a run also sweeps the rows of the gap between the previous run's id and its own with a zero gradient.
+//
+// Inter-workgroup visibility (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1s that other CUs' stores
+// never refresh).  Everything one workgroup writes and another reads within the launch -- table rows, optimizer state,
+// records, loss partials -- is accessed ONLY through slk_*_coh (agent-scope relaxed atomics = sc1 write-through stores /
+// L1-bypassing loads): with both sides sc1 the hand-over needs no cache flush, only the producer's `s_waitcnt vmcnt(0)`
+// before it arrives at the barrier.  The barrier is one monotonic device-scope counter (arrive = relaxed fetch_add,
+// wait = relaxed sc1 polling with s_sleep by ONE lane per workgroup); it is placement-independent and every spin is
+// bounded: on a time-out the high bit of the counter is raised, every workgroup leaves, and the host reports SLK_EIO.
+// The sorted id lists are written by the prep kernels BEFORE the launch and never change: plain (cached) loads.
+#include "slk_kernels.h"
+
+enum { SLK_EUPD_ADAGRAD = 0, SLK_EUPD_SPARSE_ADAM = 1, SLK_EUPD_ADAM_DENSE = 2, SLK_EUPD_ADAGRAD_DENSE = 3 };
+
+#define SLK_EPOCH_ABORT 0x80000000u
+#define SLK_EPOCH_MAX_SPINS (1u << 24)  // x (s_sleep + one fabric round trip): seconds
+
+// per-minibatch optimizer coefficients, formed on the host in double exactly as torch does (bias corrections and
+// lr decay depend on the step count)
+struct slk_step_coef {
+    float c0;  // Adagrad (sparse / dense): clr.  SparseAdam: lr * sqrt(bc2) / bc1.  Adam dense: lr / bc1
+    float c1;  // Adam dense: sqrt(bc2)
+};
+
+struct slk_epoch_args {
+    float *P[4], *S1[4], *S2[4];
+    int D;
+    uint32_t n_users, n_items;
+    uint32_t nc, bsz, n_mb;        // interactions of the chunk, minibatch size, minibatches
+    const uint32_t *ukey, *uit;    // (minibatch << ubits) | user, sorted; [2 * position] = (pos item, neg item)
+    uint32_t umask;
+    const uint32_t *ikey, *ipay;   // (minibatch << ibits) | item, sorted; occurrence -> 2 * position + pair
+    uint32_t imask;
+    float *snap;                   // records: [position - b0][RS] pre-step user rows
+    int RS;
+    float *gsn;                    // [2 * (position - b0) + pair] dL/dscore
+    double *partial;               // [2][gridDim.x] per-workgroup loss sums, double-buffered by minibatch parity
+    float *mb_loss;                // [n_mb] loss.item() of each minibatch
+    const slk_step_coef *coef;     // [n_mb]
+    unsigned *bar;                 // barrier counter, zeroed before the launch
+    int *status;                   // raised on a barrier time-out
+    int loss_kind;
+    float eps, omb1, omb2, beta2, wd;
+};
+
+// ---- the grid barrier -------------------------------------------------------------------------------------------------
+// target = gridDim.x * (number of barriers passed so far + 1).  Returns false when the launch is being abandoned.
+__device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsigned target, int *s_flag) {
+    SLK_DRAIN_VMEM();  // every wave: its write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned seen = __hip_atomic_fetch_add(e.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        unsigned spins = 0;
+        while ((seen & ~SLK_EPOCH_ABORT) < target && !(seen & SLK_EPOCH_ABORT)) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = __hip_atomic_load(e.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > SLK_EPOCH_MAX_SPINS) {  // a workgroup never arrived: give up, tell everyone
+                __hip_atomic_fetch_or(e.bar, SLK_EPOCH_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                seen = SLK_EPOCH_ABORT;
+            }
+        }
+        *s_flag = (seen & SLK_EPOCH_ABORT) ? 0 : 1;
+    }
+    __syncthreads();
+    const bool ok = *s_flag != 0;
+    __syncthreads();  // s_flag may be rewritten by the next barrier
+    return ok;
+}
+
+// ---- row updates: the arithmetic of slk_apply_vec / k_dense_sweep_all, element for element, on coherent accesses -------
+template <int VEC, int UPD>
+__device__ __forceinline__ void slk_epoch_update(const slk_epoch_args &e, const slk_step_coef &c, int t, size_t off,
+                                                 slk_vec<VEC> p, slk_vec<VEC> s1, slk_vec<VEC> s2, const slk_vec<VEC> &g) {
+    if (UPD == SLK_EUPD_ADAGRAD) {  // torch/optim/adagrad.py:360-385
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s1.v[i] += g.v[i] * g.v[i];
+            p.v[i] += -c.c0 * (g.v[i] / (sqrtf(s1.v[i]) + e.eps));
+        }
+        slk_vstore_coh<VEC>(e.S1[t] + off, s1);
+    } else if (UPD == SLK_EUPD_SPARSE_ADAM) {  // torch/optim/_functional.py:61-84
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float mu = (g.v[i] - s1.v[i]) * e.omb1;
+            const float vu = (g.v[i] * g.v[i] - s2.v[i]) * e.omb2;
+            s1.v[i] = mu + s1.v[i];
+            s2.v[i] = vu + s2.v[i];
+            p.v[i] += -c.c0 * (s1.v[i] / (sqrtf(s2.v[i]) + e.eps));
+        }
+        slk_vstore_coh<VEC>(e.S1[t] + off, s1);
+        slk_vstore_coh<VEC>(e.S2[t] + off, s2);
+    } else if (UPD == SLK_EUPD_ADAM_DENSE) {  // torch/optim/adam.py:414-546 (k_dense_sweep_all)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float gv = g.v[i] + e.wd * p.v[i];
+            const float m = s1.v[i] + e.omb1 * (gv - s1.v[i]);
+            const float v = s2.v[i] * e.beta2 + e.omb2 * (gv * gv);
+            s1.v[i] = m;
+            s2.v[i] = v;
+            p.v[i] += -c.c0 * (m / (sqrtf(v) / c.c1 + e.eps));
+        }
+        slk_vstore_coh<VEC>(e.S1[t] + off, s1);
+        slk_vstore_coh<VEC>(e.S2[t] + off, s2);
+    } else {  // torch/optim/adagrad.py:350-385, dense branch with weight decay
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float gv = g.v[i] + e.wd * p.v[i];
+            const float s = s1.v[i] + gv * gv;
+            s1.v[i] = s;
+            p.v[i] += -c.c0 * (gv / (sqrtf(s) + e.eps));
+        }
+        slk_vstore_coh<VEC>(e.S1[t] + off, s1);
+    }
+    slk_vstore_coh<VEC>(e.P[t] + off, p);
+}
+
+template <int UPD>
+__device__ __forceinline__ constexpr bool slk_epoch_has_s2() {
+    return UPD == SLK_EUPD_SPARSE_ADAM || UPD == SLK_EUPD_ADAM_DENSE;
+}
+template <int UPD>
+__device__ __forceinline__ constexpr bool slk_epoch_dense() {
+    return UPD == SLK_EUPD_ADAM_DENSE || UPD == SLK_EUPD_ADAGRAD_DENSE;
+}
+
+// dense optimizers: rows [lo, hi) of embedding table `te` and bias table `tb` received no gradient this step
+template <int VEC, int G, int UPD>
+__device__ __forceinline__ void slk_epoch_sweep_gap(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb,
+                                                    uint32_t lo, uint32_t hi, int D, int d0, bool on, int lane) {
+    const slk_vec<VEC> zero = slk_vzero<VEC>();
+    const slk_vec<1> zero1 = slk_vzero<1>();
+    for (uint32_t r = lo; r < hi; ++r) {
+        if (on) {
+            const size_t off = (size_t)r * D + d0;
+            const slk_vec<VEC> p = slk_vload_coh<VEC>(e.P[te] + off), s1 = slk_vload_coh<VEC>(e.S1[te] + off);
+            const slk_vec<VEC> s2 = slk_epoch_has_s2<UPD>() ? slk_vload_coh<VEC>(e.S2[te] + off) : zero;
+            slk_epoch_update<VEC, UPD>(e, c, te, off, p, s1, s2, zero);
+        }
+        if (lane == 0) {
+            const slk_vec<1> p = slk_vload_coh<1>(e.P[tb] + r), s1 = slk_vload_coh<1>(e.S1[tb] + r);
+            const slk_vec<1> s2 = slk_epoch_has_s2<UPD>() ? slk_vload_coh<1>(e.S2[tb] + r) : zero1;
+            slk_epoch_update<1, UPD>(e, c, tb, r, p, s1, s2, zero1);
+        }
+    }
+}
+
+template <int VEC, int G, int UPD>
+__global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
+    HIP_DYNAMIC_SHARED(double, red)              // [256] block reduction + the barrier's flag behind it
+    int *s_flag = reinterpret_cast<int *>(red + 256);
+    constexpr int GPB = 256 / G;
+    constexpr bool DENSE = slk_epoch_dense<UPD>();
+    constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int D = e.D, d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t gslot = blockIdx.x * GPB + grp, gstride = gridDim.x * GPB;
+    const slk_vec<VEC> zero = slk_vzero<VEC>();
+    const slk_vec<1> zero1 = slk_vzero<1>();
+    unsigned barriers = 0;
+
+    for (uint32_t mb = 0; mb < e.n_mb; ++mb) {
+        const uint32_t b0 = mb * e.bsz, b1 = (e.nc - b0 < e.bsz) ? e.nc : b0 + e.bsz;
+        const float inv_b = 1.0f / (float)(b1 - b0);
+        const slk_step_coef c = e.coef[mb];
+
+        // ------------------------------------------------ USER PHASE
+        float loss_acc = 0.0f;
+        for (uint32_t p = b0 + gslot; p < b1; p += gstride) {
+            // the sorted lists are immutable: key, predecessor and the first pair's items in one (cached) round trip
+            const uint32_t key = e.ukey[p];
+            const bool first = p == b0;
+            const uint32_t prev = first ? 0u : e.ukey[p - 1];
+            uint32_t ip = e.uit[2 * (size_t)p], in = e.uit[2 * (size_t)p + 1];
+            if (!first && prev == key) continue;  // not the head of its user's run
+            const uint32_t user = key & e.umask;
+            const size_t uoff = (size_t)user * D + d0;
+            // every coherent load whose address is known goes out before the first use: one fabric round trip
+            slk_vec<VEC> u = on ? slk_vload_coh<VEC>(e.P[0] + uoff) : zero;
+            const slk_vec<VEC> su1 = on ? slk_vload_coh<VEC>(e.S1[0] + uoff) : zero;
+            const slk_vec<VEC> su2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[0] + uoff) : zero;
+            const float bu = slk_ld_coh(e.P[2] + user);
+            slk_vec<VEC> gu = zero;
+            float gbu = 0.0f;
+            uint32_t q = p;
+            do {
+                if (q != p) {
+                    ip = e.uit[2 * (size_t)q];
+                    in = e.uit[2 * (size_t)q + 1];
+                }
+                const slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
+                const slk_vec<VEC> vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+                const float bi = slk_ld_coh(e.P[3] + ip), bj = slk_ld_coh(e.P[3] + in);
+                if (on) slk_vstore_coh<VEC>(e.snap + (size_t)(q - b0) * e.RS + d0, u);
+                const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
+                const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bj;
+                float l, gp, gn;
+                slk_pair_loss(e.loss_kind, sp, sn, inv_b, l, gp, gn);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
+                gbu += gp + gn;
+                if (lane == 0) {
+                    slk_st_coh(e.gsn + 2 * (size_t)(q - b0), gp);
+                    slk_st_coh(e.gsn + 2 * (size_t)(q - b0) + 1, gn);
+                    loss_acc += l;
+                }
+                ++q;
+            } while (q < b1 && e.ukey[q] == key);
+
+            if (DENSE) {  // rows between the previous run's user and this one (and past the last one): zero gradient
+                slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 0, 2, first ? 0u : (prev & e.umask) + 1u, user, D, d0, on, lane);
+                if (q == b1) slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 0, 2, user + 1u, e.n_users, D, d0, on, lane);
+            }
+            if (on) slk_epoch_update<VEC, UPD>(e, c, 0, uoff, u, su1, su2, gu);
+            if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gbu == 0.0f)) {  // zero gradient: an exact no-op for Adagrad
+                slk_vec<1> bp, bs1, bs2 = zero1, bg;
+                bp.v[0] = bu;
+                bs1 = slk_vload_coh<1>(e.S1[2] + user);
+                if (HAS_S2) bs2 = slk_vload_coh<1>(e.S2[2] + user);
+                bg.v[0] = gbu;
+                slk_epoch_update<1, UPD>(e, c, 2, user, bp, bs1, bs2, bg);
+            }
+        }
+        {
+            const double tot = slk_block_sum_256((double)loss_acc, red);
+            if (threadIdx.x == 0) {
+                unsigned long long bits;
+                memcpy(&bits, &tot, 8);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(e.partial + (size_t)(mb & 1u) * gridDim.x + blockIdx.x),
+                                   bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!slk_epoch_barrier(e, gridDim.x * ++barriers, s_flag)) return;
+
+        // ------------------------------------------------ ITEM PHASE
+        const uint32_t ib0 = 2u * b0, ib1 = 2u * b1;
+        for (uint32_t r = ib0 + gslot; r < ib1; r += gstride) {
+            const uint32_t key = e.ikey[r];
+            const bool first = r == ib0;
+            const uint32_t prev = first ? 0u : e.ikey[r - 1];
+            uint32_t pay = e.ipay[r];
+            if (!first && prev == key) continue;
+            const uint32_t item = key & e.imask;
+            const size_t voff = (size_t)item * D + d0;
+            const slk_vec<VEC> v = on ? slk_vload_coh<VEC>(e.P[1] + voff) : zero;
+            const slk_vec<VEC> sv1 = on ? slk_vload_coh<VEC>(e.S1[1] + voff) : zero;
+            const slk_vec<VEC> sv2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[1] + voff) : zero;
+            const float bi = slk_ld_coh(e.P[3] + item);
+            slk_vec<VEC> gv = zero;
+            float gb = 0.0f;
+            bool any = false;
+            uint32_t k = r;
+            do {
+                if (k != r) pay = e.ipay[k];
+                const uint32_t pos = pay >> 1;
+                const float g = slk_ld_coh(e.gsn + (pay - ib0));
+                const slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0) : zero;
+                if (g != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const float cc = g * uo.v[i];
+                        gv.v[i] += cc;
+                    }
+                    gb += g;
+                    any = true;
+                }
+                ++k;
+            } while (k < ib1 && e.ikey[k] == key);
+
+            if (DENSE) {
+                slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 1, 3, first ? 0u : (prev & e.imask) + 1u, item, D, d0, on, lane);
+                if (k == ib1) slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 1, 3, item + 1u, e.n_items, D, d0, on, lane);
+            }
+            // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
+            // row; the dense optimizers update every row anyway
+            if (UPD == SLK_EUPD_ADAGRAD && !any) continue;
+            if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v, sv1, sv2, gv);
+            if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gb == 0.0f)) {
+                slk_vec<1> bp, bs1, bs2 = zero1, bg;
+                bp.v[0] = bi;
+                bs1 = slk_vload_coh<1>(e.S1[3] + item);
+                if (HAS_S2) bs2 = slk_vload_coh<1>(e.S2[3] + item);
+                bg.v[0] = gb;
+                slk_epoch_update<1, UPD>(e, c, 3, item, bp, bs1, bs2, bg);
+            }
+        }
+        // loss.item() of this minibatch: the partials of the user phase became visible at the barrier
+        if (blockIdx.x == mb % gridDim.x) {
+            double x = 0.0;
+            for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
+                const unsigned long long bits = __hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(e.partial + (size_t)(mb & 1u) * gridDim.x + i), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                double d;
+                memcpy(&d, &bits, 8);
+                x += d;
+            }
+            const double tot = slk_block_sum_256(x, red);
+            if (threadIdx.x == 0) e.mb_loss[mb] = (float)(tot * (double)inv_b);
+        }
+        if (!slk_epoch_barrier(e, gridDim.x * ++barriers, s_flag)) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+typedef void (*slk_epoch_fn)(slk_epoch_args);
+
+template <int VEC, int G>
+static slk_epoch_fn epoch_fn(int upd) {
+    switch (upd) {
+        case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD>;
+        case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM>;
+        case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE>;
+        default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE>;
+    }
+}
+
+// Whether a slk_bilinear_train call takes the persistent route (option "epoch_kernel": 0 never, 1 when eligible).
+bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss,
+                        bool bloom) {
+    if (!ctx->opt_epoch_kernel || bloom) return false;
+    if (loss != SLK_LOSS_POINTWISE && loss != SLK_LOSS_BPR && loss != SLK_LOSS_HINGE) return false;
+    if (bsz > ctx->opt_epoch_max_batch) return false;
+    const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    // the dense optimizers rewrite every row every minibatch: in one launch of at most one workgroup per CU that
+    // is only sensible for tables that are small next to the chip's caches
+    if (dense && (tables->num_users + tables->num_items) * (int64_t)(tables->dim + 1) > ctx->opt_epoch_dense_elems) return false;
+    return true;
+}
+
+// All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one cooperative launch.
+int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
+                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
+                        float *d_mb_loss, hipStream_t s) {
+    int vec, g, rc;
+    if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
+    const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
+    const unsigned gpb = 256u / (unsigned)g;
+    // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU, <= 128
+    unsigned grid = (unsigned)((2 * bsz + gpb - 1) / gpb);
+    const unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+
+    enum { EP_COEF = 40, EP_BAR, EP_PARTIAL };  // ctx->extra slots
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 256))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)2 * grid * 8))) return rc;
+
+    slk_epoch_args e;
+    memset(&e, 0, sizeof(e));
+    int upd;
+    switch (optim->kind) {
+        case SLK_OPT_ADAGRAD: upd = SLK_EUPD_ADAGRAD; break;
+        case SLK_OPT_SPARSE_ADAM: upd = SLK_EUPD_SPARSE_ADAM; break;
+        case SLK_OPT_ADAM_DENSE: upd = SLK_EUPD_ADAM_DENSE; break;
+        default: upd = SLK_EUPD_ADAGRAD_DENSE; break;
+    }
+    // per-step coefficients, in double like torch (slk_set_opt_coeffs / slk_dense_sweeps)
+    ctx->ep_coef.resize(n_mb);
+    for (uint32_t m = 0; m < n_mb; ++m) {
+        const double step = (double)(optim->step + 1 + m);
+        slk_step_coef &c = *reinterpret_cast<slk_step_coef *>(&ctx->ep_coef[m]);
+        c.c0 = c.c1 = 0.0f;
+        if (upd == SLK_EUPD_ADAGRAD || upd == SLK_EUPD_ADAGRAD_DENSE) {
+            c.c0 = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
+        } else {
+            const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);
+            if (upd == SLK_EUPD_SPARSE_ADAM) {
+                c.c0 = (float)(optim->lr * sqrt(bc2) / bc1);
+            } else {
+                c.c0 = (float)(optim->lr / bc1);
+                c.c1 = (float)sqrt(bc2);
+            }
+        }
+    }
+    SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[EP_COEF].p, ctx->ep_coef.data(), (size_t)n_mb * sizeof(slk_step_coef),
+                                hipMemcpyHostToDevice, s));
+    SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 256, s));
+
+    for (int t = 0; t < 4; ++t) {
+        e.P[t] = tables->d_param[t];
+        e.S1[t] = optim->d_state1[t];
+        e.S2[t] = optim->d_state2[t];
+    }
+    e.D = tables->dim;
+    e.n_users = (uint32_t)tables->num_users;
+    e.n_items = (uint32_t)tables->num_items;
+    e.nc = nc;
+    e.bsz = (uint32_t)bsz;
+    e.n_mb = n_mb;
+    e.ukey = (const uint32_t *)pb.ukey[1].p;
+    e.uit = (const uint32_t *)pb.uval[1].p;
+    e.umask = (uint32_t)((1ull << ubits) - 1);
+    e.ikey = (const uint32_t *)pb.ikey[1].p;
+    e.ipay = (const uint32_t *)pb.ipay[1].p;
+    e.imask = (uint32_t)((1ull << ibits) - 1);
+    e.snap = snap;
+    e.RS = RS;
+    e.gsn = gsn;
+    e.partial = (double *)ctx->extra[EP_PARTIAL].p;
+    e.mb_loss = d_mb_loss;
+    e.coef = (const slk_step_coef *)ctx->extra[EP_COEF].p;
+    e.bar = (unsigned *)ctx->extra[EP_BAR].p;
+    e.status = &ctx->d_rng->epoch_abort;
+    e.loss_kind = loss;
+    e.eps = (float)optim->eps;
+    e.omb1 = (float)(1.0 - optim->beta1);
+    e.omb2 = (float)(1.0 - optim->beta2);
+    e.beta2 = (float)optim->beta2;
+    e.wd = (float)optim->weight_decay;
+
+    slk_epoch_fn fn = nullptr;
+#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd)
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
+#undef SLK_PICK_EPOCH
+    slk_prof_begin(ctx, SLK_K_EPOCH, s);
+    void *kargs[1] = {&e};
+    const size_t lds = 256 * sizeof(double) + 16;
+    // cooperative: the launch is refused (not deadlocked) if the grid could not be resident at once
+    hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
+    if (le != hipSuccess)
+        return slk_fail(ctx, SLK_EIO, "cooperative launch of k_bilinear_epoch (%u workgroups) failed: %s", grid,
+                        hipGetErrorString(le));
+    slk_prof_end(ctx, s);
+    optim->step += n_mb;
+    return SLK_OK;
+}

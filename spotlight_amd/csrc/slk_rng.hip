@@ -370,6 +370,9 @@ SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     SLK_HIP(ctx, hipMemcpy(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost));
     if (h.insufficient)
         return slk_fail(ctx, SLK_EIO, "sampler ran out of generated words (rejection tail > 12 sigma)");
+    if (h.epoch_abort)
+        return slk_fail(ctx, SLK_EIO, "persistent epoch kernel abandoned a launch: a workgroup never reached the grid barrier "
+                                      "(set option epoch_kernel=0 for the per-minibatch launches)");
     memcpy(h_key, h.key, sizeof(h.key));
     *pos = h.pos;
     return SLK_OK;

@@ -1,6 +1,6 @@
 // tests/emu/emu_runtime.cpp -- TEST HARNESS ONLY (see tests/emu/hip/hip_runtime.h).
-// Fiber scheduler that executes one HIP block at a time on the calling OS thread, plus
-// host stand-ins for the handful of hip* runtime calls the engine makes.
+// Fiber scheduler that executes one HIP block at a time (plain launches) or a whole cooperative grid at once
+// on the calling OS thread, plus host stand-ins for the handful of hip* runtime calls the engine makes.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -33,15 +33,15 @@ emu_ctx_switch:
 namespace emu {
 
 Fiber *cur = nullptr;
-uint3_ g_blockIdx, g_blockDim, g_gridDim;
+uint3_ g_blockDim, g_gridDim;
 
-static const size_t kStack = 128 * 1024;
+static const size_t kStack = 128 * 1024;      // plain launches: one block at a time
+static const size_t kCoopStack = 64 * 1024;   // cooperative launches: every block of the grid is resident
 static const unsigned kMaxThreads = 1024;
 static char *g_stacks = nullptr;
-static std::vector<Fiber> g_fibers;
+static size_t g_stacks_bytes = 0;
 static void *g_sched_sp = nullptr;
 static const std::function<void()> *g_body = nullptr;
-static std::vector<char> g_dyn;
 
 struct WaveSync {
     unsigned long long slot[2][64];
@@ -49,34 +49,47 @@ struct WaveSync {
     unsigned arrived[7][64];
     unsigned gen[7][64];
 };
-static std::vector<WaveSync> g_waves;
-static unsigned g_alive = 0, g_bar_arrived = 0, g_bar_gen = 0;
 
-void *dyn_shared() { return g_dyn.data(); }
+// per-block state: barrier bookkeeping, wave exchange slots, dynamic LDS, the block's fibers
+struct Block {
+    uint3_ idx;
+    std::vector<Fiber> fibers;
+    std::vector<WaveSync> waves;
+    std::vector<char> dyn;
+    unsigned alive = 0, bar_arrived = 0, bar_gen = 0;
+};
+static std::vector<Block> g_blocks;
+
+static inline Block &blk() { return *static_cast<Block *>(cur->blk); }
+uint3_ block_idx() { return blk().idx; }
+void *dyn_shared() { return blk().dyn.data(); }
 
 static void yield_to_scheduler() { emu_ctx_switch(&cur->sp, g_sched_sp); }
+void yield() { yield_to_scheduler(); }
 
 static void fiber_entry() {
     (*g_body)();
+    Block &b = blk();
     cur->done = true;
-    --g_alive;
+    --b.alive;
     // a finished thread no longer participates in barriers (hardware: terminated waves)
-    if (g_alive && g_bar_arrived == g_alive) {
-        g_bar_arrived = 0;
-        ++g_bar_gen;
+    if (b.alive && b.bar_arrived == b.alive) {
+        b.bar_arrived = 0;
+        ++b.bar_gen;
     }
     yield_to_scheduler();
     std::abort();  // never resumed
 }
 
 void syncthreads() {
-    unsigned my = g_bar_gen;
-    if (++g_bar_arrived == g_alive) {
-        g_bar_arrived = 0;
-        ++g_bar_gen;
+    Block &b = blk();
+    unsigned my = b.bar_gen;
+    if (++b.bar_arrived == b.alive) {
+        b.bar_arrived = 0;
+        ++b.bar_gen;
         return;
     }
-    while (g_bar_gen == my) yield_to_scheduler();
+    while (b.bar_gen == my) yield_to_scheduler();
 }
 
 static int ilog2(int w) {
@@ -88,7 +101,7 @@ static int ilog2(int w) {
 unsigned long long shfl_exchange(unsigned long long v, int src, int width) {
     if (width <= 1) return v;
     const unsigned lane = cur->linear & 63u;
-    WaveSync &w = g_waves[cur->linear >> 6];
+    WaveSync &w = blk().waves[cur->linear >> 6];
     const int lw = ilog2(width), seg = (int)lane / width;
     const unsigned my = w.gen[lw][seg];
     w.slot[my & 1][lane] = v;
@@ -101,52 +114,107 @@ unsigned long long shfl_exchange(unsigned long long v, int src, int width) {
     return w.slot[my & 1][src];
 }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+static void init_block(Block &b, uint3_ idx, dim3 block, unsigned nthreads, size_t shmem, char *stacks, size_t stack_bytes) {
+    b.idx = idx;
+    b.fibers.resize(nthreads);
+    b.waves.assign((nthreads + 63) / 64, WaveSync());
+    std::memset(b.waves.data(), 0, b.waves.size() * sizeof(WaveSync));
+    b.dyn.assign(shmem + 64, 0);
+    b.alive = nthreads;
+    b.bar_arrived = 0;
+    b.bar_gen = 0;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber &f = b.fibers[t];
+        f.linear = t;
+        f.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        f.done = false;
+        f.blk = &b;
+        uintptr_t top = reinterpret_cast<uintptr_t>(stacks + stack_bytes * (t + 1));
+        top &= ~uintptr_t(15);
+        void **sp = reinterpret_cast<void **>(top);
+        *--sp = nullptr;                                  // fake return address
+        *--sp = reinterpret_cast<void *>(&fiber_entry);   // popped by ret
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;      // rbp rbx r12-r15
+        f.sp = sp;
+    }
+}
+
+static void ensure_stacks(size_t bytes) {
+    if (bytes <= g_stacks_bytes) return;
+    std::free(g_stacks);
+    g_stacks = static_cast<char *>(std::malloc(bytes));
+    g_stacks_bytes = bytes;
+}
+
+static unsigned check_block(dim3 block) {
     const unsigned nthreads = block.x * block.y * block.z;
     if (nthreads == 0 || nthreads > kMaxThreads || (nthreads & 63u)) {
         std::fprintf(stderr, "emu: unsupported block size %u\n", nthreads);
         std::abort();
     }
-    if (!g_stacks) g_stacks = static_cast<char *>(std::malloc(kStack * kMaxThreads));
-    g_fibers.resize(nthreads);
-    g_waves.resize((nthreads + 63) / 64);
-    g_dyn.assign(shmem + 64, 0);
+    return nthreads;
+}
+
+// run every fiber of blocks [first, first + count) round-robin until all are done
+static void run_blocks(size_t first, size_t count) {
+    unsigned long long spins = 0;
+    for (;;) {
+        unsigned alive = 0;
+        for (size_t k = first; k < first + count; ++k) {
+            Block &b = g_blocks[k];
+            for (Fiber &f : b.fibers) {
+                if (f.done) continue;
+                cur = &f;
+                emu_ctx_switch(&g_sched_sp, cur->sp);
+            }
+            alive += b.alive;
+        }
+        if (!alive) break;
+        if (++spins > 2000000000ull) {
+            std::fprintf(stderr, "emu: grid appears deadlocked\n");
+            std::abort();
+        }
+    }
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+    const unsigned nthreads = check_block(block);
+    ensure_stacks(kStack * kMaxThreads);
     g_body = &body;
     g_blockDim = {block.x, block.y, block.z};
     g_gridDim = {grid.x, grid.y, grid.z};
+    g_blocks.resize(1);
+    // one block at a time: `static` stand-ins for __shared__ variables belong to the running block
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
-                g_blockIdx = {bx, by, bz};
-                std::memset(g_waves.data(), 0, g_waves.size() * sizeof(WaveSync));
-                g_alive = nthreads;
-                g_bar_arrived = 0;
-                for (unsigned t = 0; t < nthreads; ++t) {
-                    Fiber &f = g_fibers[t];
-                    f.linear = t;
-                    f.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-                    f.done = false;
-                    uintptr_t top = reinterpret_cast<uintptr_t>(g_stacks + kStack * (t + 1));
-                    top &= ~uintptr_t(15);
-                    void **sp = reinterpret_cast<void **>(top);
-                    *--sp = nullptr;                                  // fake return address
-                    *--sp = reinterpret_cast<void *>(&fiber_entry);   // popped by ret
-                    for (int r = 0; r < 6; ++r) *--sp = nullptr;      // rbp rbx r12-r15
-                    f.sp = sp;
-                }
-                unsigned long long spins = 0;
-                while (g_alive) {
-                    for (unsigned t = 0; t < nthreads; ++t) {
-                        if (g_fibers[t].done) continue;
-                        cur = &g_fibers[t];
-                        emu_ctx_switch(&g_sched_sp, cur->sp);
-                    }
-                    if (++spins > 2000000000ull) {
-                        std::fprintf(stderr, "emu: block (%u,%u,%u) appears deadlocked\n", bx, by, bz);
-                        std::abort();
-                    }
-                }
+                init_block(g_blocks[0], uint3_{bx, by, bz}, block, nthreads, shmem, g_stacks, kStack);
+                run_blocks(0, 1);
             }
+    cur = nullptr;
+}
+
+// hipLaunchCooperativeKernel: every block of the grid is resident at once (blocks may wait for each other through
+// global memory; __builtin_amdgcn_s_sleep yields).  Such kernels must keep their LDS in the dynamic region
+// (HIP_DYNAMIC_SHARED): the `static` stand-in for __shared__ variables would be shared by all blocks.
+void launch_coop(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+    const unsigned nthreads = check_block(block);
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    if (nblocks == 0 || nblocks > 64) {
+        std::fprintf(stderr, "emu: cooperative grid of %zu blocks unsupported\n", nblocks);
+        std::abort();
+    }
+    ensure_stacks(kCoopStack * nthreads * nblocks);
+    g_body = &body;
+    g_blockDim = {block.x, block.y, block.z};
+    g_gridDim = {grid.x, grid.y, grid.z};
+    g_blocks.resize(nblocks);
+    size_t k = 0;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx, ++k)
+                init_block(g_blocks[k], uint3_{bx, by, bz}, block, nthreads, shmem, g_stacks + kCoopStack * nthreads * k, kCoopStack);
+    run_blocks(0, nblocks);
     cur = nullptr;
 }
 

@@ -65,17 +65,21 @@ struct Fiber {
     uint3_ tid;
     unsigned linear;
     bool done;
+    void *blk;  // the fiber's block (emu_runtime.cpp)
 };
 extern Fiber *cur;
-extern uint3_ g_blockIdx, g_blockDim, g_gridDim;
+extern uint3_ g_blockDim, g_gridDim;
+uint3_ block_idx();
 void *dyn_shared();
+void yield();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+void launch_coop(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 void syncthreads();
 unsigned long long shfl_exchange(unsigned long long v, int src_lane_in_wave, int width);
 }  // namespace emu
 
 #define threadIdx (::emu::cur->tid)
-#define blockIdx (::emu::g_blockIdx)
+#define blockIdx (::emu::block_idx())
 #define blockDim (::emu::g_blockDim)
 #define gridDim (::emu::g_gridDim)
 #define warpSize 64
@@ -86,7 +90,28 @@ static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 
     emu::launch(grid, block, shmem, [=]() { kernel(static_cast<KArgs>(args)...); });
 }
 
+// cooperative launch: all blocks resident, arguments passed as an array of pointers (one kernel parameter here)
+template <class A>
+static inline hipError_t hipLaunchCooperativeKernel(void (*kernel)(A), dim3 grid, dim3 block, void **args, size_t shmem,
+                                                    hipStream_t) {
+    const A a = *static_cast<const A *>(args[0]);
+    emu::launch_coop(grid, block, shmem, [=]() { kernel(a); });
+    return hipSuccess;
+}
+
 static inline void __syncthreads() { emu::syncthreads(); }
+// agent-scope relaxed atomics (gfx950: sc1 accesses that bypass the CU's L1): fibers never pre-empt and there are no
+// caches here, so plain accesses; a sleeping wave lets the other fibers (= other workgroups) run
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+template <class T, class V>
+static inline T emu_fetch_add(T *p, V v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class V>
+static inline T emu_fetch_or(T *p, V v) { T o = *p; *p = (T)(o | (T)v); return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
+#define __hip_atomic_fetch_or(p, v, order, scope) emu_fetch_or((p), (v))
+static inline void __builtin_amdgcn_s_sleep(int) { emu::yield(); }
 static inline int __lane_id() { return (int)(emu::cur->linear & 63u); }
 
 template <class T>
