@@ -74,7 +74,8 @@ def parse():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--batch', type=int, default=1 << 20)
     ap.add_argument('--loss', default='bpr')
-    ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam'])
+    ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam', 'adam_dense'],
+                    help='adam_dense = the reference default: Adam(lr=1e-2, weight_decay=1e-6) over every row every step')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
                     help='c2: BilinearNet BPR step (the headline metric); c3: adaptive hinge n=5 over a BloomEmbedding '
                          'item table, dim 128; c4: PoolNet sequence step; c5: the per-GPU shard of the 1B-item x '
@@ -370,11 +371,14 @@ def measured_stream_rates(be, stream):
     SURVEY.md 8(d) asks for next to the nominal peak."""
     n = (1 << 28) if be.kind == 'hip' else (1 << 12)
     a, b, c = (torch.ones(n, device=be.dev) for _ in range(3))
-    copy_ms = be.engine.probe_stream(0, a.data_ptr(), b.data_ptr(), None, n, iters=10, stream=stream)
-    triad_ms = be.engine.probe_stream(1, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream)
+    ms = {k: be.engine.probe_stream(k, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream) for k in range(6)}
     del a, b, c
-    return {'copy_GBs': 8.0 * n / copy_ms / 1e6, 'triad_GBs': 12.0 * n / triad_ms / 1e6,
-            'note': 'float4 copy (read + write) / triad (2 reads + write) over 1 GiB buffers, hipEvents, 10 launches'}
+    gbs = {'copy_plain': 8.0 * n / ms[0] / 1e6, 'triad_plain': 12.0 * n / ms[1] / 1e6, 'copy_nt_x4': 8.0 * n / ms[2] / 1e6,
+           'triad_nt_x4': 12.0 * n / ms[3] / 1e6, 'read_only': 4.0 * n / ms[4] / 1e6, 'write_only': 4.0 * n / ms[5] / 1e6}
+    return {'copy_GBs': max(gbs['copy_plain'], gbs['copy_nt_x4']), 'triad_GBs': max(gbs['triad_plain'], gbs['triad_nt_x4']),
+            'variants_GBs': gbs,
+            'note': 'slk_probe_stream over 1 GiB buffers, hipEvents, 10 launches each: float4 copy / triad, plain grid-stride and '
+                    'non-temporal with 4 accesses in flight per lane; read-only and write-only streams'}
 
 
 def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):
@@ -392,7 +396,8 @@ def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):
         t = [x.clone() for x in tables]
         a1 = [x.clone() for x in s1]
         a2 = [x.clone() for x in s2] if s2 else None
-        op = _native.make_optim(args.opt, [x.data_ptr() for x in a1], [x.data_ptr() for x in a2] if a2 else None, lr=1e-2)
+        op = _native.make_optim(args.opt, [x.data_ptr() for x in a1], [x.data_ptr() for x in a2] if a2 else None, lr=1e-2,
+                                weight_decay=1e-6 if args.opt == 'adam_dense' else 0.0)
         mb = torch.zeros(K, device=be.dev)
         eng.rng_set_state(state)
         be.sync()
@@ -455,10 +460,10 @@ def main():
               torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen),
               torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
     s1 = [torch.zeros_like(t) for t in tables]
-    s2 = [torch.zeros_like(t) for t in tables] if args.opt == 'sparse_adam' else None
+    s2 = [torch.zeros_like(t) for t in tables] if args.opt != 'adagrad' else None
     tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
     op = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None,
-                            lr=1e-2)
+                            lr=1e-2, weight_decay=1e-6 if args.opt == 'adam_dense' else 0.0)
     n_total = (W + 2 * K) * B  # W warmup + K timed + K profiled
     I_global = I * world
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
@@ -549,7 +554,7 @@ def main():
 
     if rank == 0:
         value = world * K * B / elapsed
-        s_words = 1 if args.opt == 'adagrad' else 2
+        s_words = 1 if args.opt == 'adagrad' else 2  # (adam_dense: the per-row figure; its full-table sweep is extra)
         ub, ib = algorithmic_bytes(D, s_words)
         kern = {}
         for name, per_int in (('user_pass', ub), ('item_pass', ib)):
@@ -566,7 +571,10 @@ def main():
                 'kernels': kern,
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
-                'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange')}}
+                'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange', 'dense_sweep', 'epoch')}}
+        if prof['epoch'][0]:
+            roof['persistent_epoch_kernel'] = {'launches': prof['epoch'][0], 'us_per_minibatch': prof['epoch'][1] / K * 1e3,
+                                               'note': 'every minibatch of a chunk inside one cooperative launch (slk_epoch.hip)'}
         if probes:
             roof['measured'] = probes
         if ceiling:

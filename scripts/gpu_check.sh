@@ -17,6 +17,11 @@ for st in $STAGES; do
     parity)
       timeout 1500 python -m pytest tests/test_gpu_bench_parity.py -m gpu -q -s -p no:cacheprovider > $OUT/pytest_bench_parity.log 2>&1
       echo "pytest exit $?" >> $OUT/pytest_bench_parity.log; grep -a "parity\|passed\|failed\|Error\|exit" $OUT/pytest_bench_parity.log | tail -25 ;;
+    epoch)
+      timeout 900 python -m pytest tests/test_gpu_engine.py -m gpu -q -k epoch -p no:cacheprovider > $OUT/pytest_epoch.log 2>&1
+      echo "pytest exit $?" >> $OUT/pytest_epoch.log; tail -25 $OUT/pytest_epoch.log ;;
+    small)
+      bash $ROOT/scripts/sweep_small_batch.sh $TAG ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
     bench)

@@ -159,6 +159,10 @@ class Engine(object):
             raise SlkError(rc, (self._lib.slk_last_error(None) or b'').decode())
         self._ctx = ctx
         self.device_id = int(device_id)
+        # A/B measurements: SPOTLIGHT_HIP_OPTIONS="name=value,..." applies slk_ctx_set_option to every new ctx
+        for kv in filter(None, os.environ.get('SPOTLIGHT_HIP_OPTIONS', '').split(',')):
+            name, value = kv.split('=')
+            self.set_option(name.strip(), int(value))
 
     def close(self):
         if getattr(self, '_ctx', None):

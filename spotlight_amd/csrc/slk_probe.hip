@@ -28,6 +28,34 @@ __global__ __launch_bounds__(256) void k_probe_triad(float4 *__restrict__ a, con
     }
 }
 
+// streaming variants: 4 independent 16-B accesses per lane per iteration, non-temporal (nothing is re-read)
+// kind 2: copy, 3: triad, 4: read only (the sum is kept live through a never-taken store), 5: write only
+template <int KIND>
+__global__ __launch_bounds__(256) void k_probe_stream4(float *__restrict__ a, const float *__restrict__ b,
+                                                       const float *__restrict__ c, float s, size_t n4) {
+    const size_t tile = (size_t)gridDim.x * 256;
+    slk_vec<4> acc = slk_vzero<4>();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * tile) {
+        slk_vec<4> x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t j = i + k * tile;
+            x[k] = y[k] = acc;
+            if (KIND != 5 && j < n4) x[k] = slk_vload_nt<4>(b + 4 * j);
+            if (KIND == 3 && j < n4) y[k] = slk_vload_nt<4>(c + 4 * j);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t j = i + k * tile;
+            if (j >= n4) continue;
+            if (KIND == 3) slk_vaxpy<4>(x[k], s, y[k]);
+            if (KIND == 4) slk_vaxpy<4>(acc, 1.0f, x[k]);
+            if (KIND != 4) slk_vstore_nt<4>(a + 4 * j, x[k]);
+        }
+    }
+    if (KIND == 4 && acc.v[0] + acc.v[1] + acc.v[2] + acc.v[3] == 12345.678f) slk_vstore<4>(a, acc);
+}
+
 __device__ __forceinline__ uint32_t slk_mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -126,18 +154,28 @@ static int probe_time(slk_ctx *ctx, int iters, hipStream_t s, double *avg_ms, F 
 SLK_EXPORT int slk_probe_stream(slk_ctx *ctx, int32_t kind, float *d_a, const float *d_b, const float *d_c,
                                 int64_t n_floats, int32_t iters, double *avg_ms, void *stream) {
     if (!ctx) return SLK_EINVAL;
-    if (!d_a || !d_b || (kind == 1 && !d_c) || n_floats < 4 || (n_floats & 3) || iters < 1 || !avg_ms || kind < 0 || kind > 1)
+    if (!d_a || !d_b || ((kind == 1 || kind == 3) && !d_c) || n_floats < 4 || (n_floats & 3) || iters < 1 || !avg_ms || kind < 0 ||
+        kind > 5)
         return slk_fail(ctx, SLK_EINVAL, "slk_probe_stream: bad arguments");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     const size_t n4 = (size_t)n_floats / 4;
     const unsigned grid = (unsigned)ctx->num_cus * 8u;
+    const unsigned grid4 = (unsigned)ctx->num_cus * 16u;
     return probe_time(ctx, iters, s, avg_ms, [&]() {
-        if (kind == 0)
-            hipLaunchKernelGGL(k_probe_copy, dim3(grid), dim3(256), 0, s, (float4 *)d_a, (const float4 *)d_b, n4);
-        else
-            hipLaunchKernelGGL(k_probe_triad, dim3(grid), dim3(256), 0, s, (float4 *)d_a, (const float4 *)d_b,
-                               (const float4 *)d_c, 0.5f, n4);
+        float *a4 = d_a;
+        const float *b4 = d_b, *c4 = d_c;
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(k_probe_copy, dim3(grid), dim3(256), 0, s, (float4 *)d_a, (const float4 *)d_b, n4); break;
+            case 1:
+                hipLaunchKernelGGL(k_probe_triad, dim3(grid), dim3(256), 0, s, (float4 *)d_a, (const float4 *)d_b,
+                                   (const float4 *)d_c, 0.5f, n4);
+                break;
+            case 2: hipLaunchKernelGGL(k_probe_stream4<2>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+            case 3: hipLaunchKernelGGL(k_probe_stream4<3>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+            case 4: hipLaunchKernelGGL(k_probe_stream4<4>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+            default: hipLaunchKernelGGL(k_probe_stream4<5>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+        }
     });
 }
 

@@ -247,7 +247,9 @@ hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     std::memset(p, 0, sizeof(*p));
-    p->multiProcessorCount = 2;  // keeps emulated grids tiny
+    // keeps emulated grids tiny; SLK_EMU_CUS widens them (cooperative grids of several workgroups)
+    const char *cus = std::getenv("SLK_EMU_CUS");
+    p->multiProcessorCount = cus ? std::atoi(cus) : 2;
     std::snprintf(p->name, sizeof(p->name), "emu");
     std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
     p->totalGlobalMem = size_t(1) << 34;

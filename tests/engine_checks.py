@@ -816,3 +816,63 @@ def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=
         assert np.array_equal(runs[0][0][t], runs[1][0][t]), ('param', t)
         assert np.array_equal(runs[0][1][t], runs[1][1][t]), ('state', t)
     assert np.allclose(runs[0][2], runs[1][2], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
+# ---------------------------------------------------------------------------------------
+def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, B=256, seed=31, chunk=None, epochs=2,
+                                        max_grid=None):
+    """The persistent route (option epoch_kernel = 1: every minibatch of a chunk in one cooperative launch) performs the
+    launch path's arithmetic in the launch path's order: losses to fp32 summation-order noise, negatives, RNG state and
+    EVERY table / optimizer-state tensor bit for bit -- including the dense optimizers, whose full-table sweep the
+    persistent route folds into the gaps between the owned rows."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    results = []
+    for route in (0, 1):
+        eng.set_option('epoch_kernel', route)
+        if chunk:
+            eng.set_option('chunk_interactions', chunk)
+        if max_grid:
+            eng.set_option('epoch_max_grid', max_grid)
+        try:
+            dev = be.model(params, opt=opt, **hp)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            losses = []
+            neg_out = be.alloc(np.full(N, -1, dtype=np.int64))
+            eng.profile_reset()
+            eng.profile_enable(True)
+            for _ in range(epochs):
+                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
+                                   be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+                losses.append(be.get(mb_loss).copy())
+            eng.profile_enable(False)
+            prof = eng.profile_read()
+            # the route under test really ran: the persistent kernel or the two passes, never both
+            if route:
+                assert prof['epoch'][0] >= epochs and prof['user_pass'][0] == 0, prof
+            else:
+                assert prof['epoch'][0] == 0 and prof['user_pass'][0] == epochs * n_mb, prof
+            st = eng.rng_get_state()
+            assert dev.optim.step == epochs * n_mb
+            results.append((np.concatenate(losses), [be.get(neg_out), st[1], np.array(st[2])] +
+                            [be.get(x) for x in dev.p + dev.s1 + dev.s2]))
+        finally:
+            eng.set_option('epoch_kernel', 0)
+            eng.set_option('chunk_interactions', 1 << 23)
+            eng.set_option('epoch_max_grid', 128)
+    (la, ta), (lb, tb) = results
+    assert np.abs(la - lb).max() <= 2e-6 * np.abs(la).max(), (la, lb)
+    for k, (a, b) in enumerate(zip(ta, tb)):
+        assert np.array_equal(a, b), ('tensor %d differs between the persistent kernel and the launch path' % k,
+                                      float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))

@@ -1,0 +1,50 @@
+"""The persistent epoch kernel (csrc/slk_epoch.hip) through the emulator build: the cooperative grid runs as
+concurrently scheduled fiber blocks (tests/emu), so the grid barrier, the phase structure, the gap sweeps of the dense
+optimizers and the bit-identity with the per-minibatch launches are exercised without a GPU.  (What the emulator
+cannot show -- cross-XCD visibility of the sc1 accesses -- is what the same checks assert under `-m gpu`.)"""
+import pytest
+
+import engine_checks as ec
+from emu_backend import EmuBackend
+
+
+@pytest.fixture(scope='module')
+def be():
+    b = EmuBackend()
+    yield b
+    b.close()
+
+
+@pytest.mark.parametrize('loss', ['pointwise', 'bpr', 'hinge'])
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
+    ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 8)
+
+
+@pytest.mark.parametrize('D,B', [(32, 100), (64, 70), (20, 64), (3, 64)])
+def test_epoch_kernel_other_layouts(be, D, B):
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', D, U=23, I=31, N=3 * B + 7, B=B)
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adam_dense', D, U=23, I=31, N=3 * B + 7, B=B, epochs=1)
+
+
+def test_epoch_kernel_heavy_duplicates_tiny_tables_and_one_workgroup(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 8, U=1, I=2, N=130, B=64)
+    ec.check_epoch_kernel_is_bit_identical(be, 'hinge', 'adam_dense', 8, U=3, I=1, N=100, B=100)
+    ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 8, U=40, I=30, N=300, B=64, max_grid=1)
+
+
+def test_epoch_kernel_several_chunks(be):
+    """chunks of 2 minibatches: the launch is repeated per chunk, the step count and RNG stream carry over"""
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'sparse_adam', 16, N=1500, B=128, chunk=256)
+    ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'adagrad_dense', 16, N=1500, B=128, chunk=256)
+
+
+def test_epoch_kernel_wider_cooperative_grid(monkeypatch):
+    """A context that believes in 12 CUs: grids of up to 12 concurrently resident workgroups and strided positions."""
+    monkeypatch.setenv('SLK_EMU_CUS', '12')
+    b = EmuBackend()
+    try:
+        ec.check_epoch_kernel_is_bit_identical(b, 'bpr', 'adagrad', 32, U=500, I=300, N=1300, B=512, epochs=1)
+        ec.check_epoch_kernel_is_bit_identical(b, 'pointwise', 'adam_dense', 16, U=90, I=70, N=700, B=200, epochs=1, max_grid=5)
+    finally:
+        b.close()

@@ -232,3 +232,27 @@ def test_minibatch_of_one_interaction(be):
     last minibatch of one interaction."""
     ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 16, U=9, I=7, N=5, B=1, epochs=1)
     ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, U=9, I=7, N=65, B=64, epochs=1)
+
+
+# ---- persistent epoch kernel (csrc/slk_epoch.hip): one cooperative launch per chunk of minibatches ----
+@pytest.mark.parametrize('loss', ['pointwise', 'bpr', 'hinge'])
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
+    """C1 shape (MovieLens-100K: 943 x 1682, dim 32, minibatch 1024, the reference's test kwargs,
+    tests/factorization/test_implicit.py:40-57): 64 workgroups across all 8 XCDs hand rows and records to each other
+    through sc1 accesses only -- a stale read anywhere would break the bit-identity with the launch path."""
+    ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 32, U=943, I=1682, N=20000, B=1024, epochs=2)
+
+
+@pytest.mark.parametrize('D,U,I,B,N', [(64, 100000, 50000, 4096, 40000), (64, 3000, 1000, 256, 9000), (128, 5000, 700, 2048, 10000),
+                                       (20, 300, 200, 512, 3000), (32, 5, 3, 1024, 5000)])
+def test_epoch_kernel_sizes_and_layouts(be, D, U, I, B, N):
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', D, U=U, I=I, N=N, B=B, epochs=2)
+    ec.check_epoch_kernel_is_bit_identical(be, 'hinge', 'sparse_adam', D, U=U, I=I, N=N, B=B, epochs=1)
+    if (U + I) * D < 2_000_000:
+        ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'adam_dense', D, U=U, I=I, N=N, B=B, epochs=1)
+
+
+def test_epoch_kernel_many_minibatches_and_chunks(be):
+    """400 minibatches in 4 launches (chunks of 100): thousands of grid barriers back to back"""
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=102400, B=256, epochs=1, chunk=25600)
