@@ -95,7 +95,7 @@ def parse():
     ap.add_argument('--no-sharded-check', action='store_true',
                     help='N=1: skip the consistency run of the row-sharded path (world 1) against the fused path')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-seconds', type=float, default=30.0)
     return ap.parse_args()
 
 
@@ -118,16 +118,18 @@ def reference_cpu_baseline(args, seconds):
     if 'sparse_adagrad' not in rec:
         return {'error': str(rec)[:300]}
     sa, da = rec['sparse_adagrad'], rec.get('default_dense_adam')
-    out = {'value': sa['interactions_per_s'], 'unit': 'interactions/s', 'cores': rec['threads'], 'kind': 'reference',
-           'cpu_model': rec['cpu_model'],
+    out = {'value': sa['interactions_per_s'], 'unit': 'interactions/s', 'cores': sa['threads'], 'kind': 'reference',
+           'cpu_model': rec['cpu_model'], 'host_cores': rec['host_cores'],
+           'interactions_per_s_by_threads': sa['interactions_per_s_by_threads'],
            'sample': 'spotlight ImplicitFactorizationModel.fit() on CPU PyTorch %s, sparse=True + Adagrad(lr=1e-2), %s loss, '
-                     '%d users x %d items, dim %d, minibatch %d: warm-up fit + min of 2 timed fits of %d minibatch(es) '
-                     '(%.1f s each), torch.set_num_threads(%d)%s'
-                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], rec['batch'],
-                        sa['minibatches_per_fit'], sa['seconds'], rec['threads'],
+                     '%d users x %d items, dim %d, minibatch %d (bounded sample; the GPU workload uses %d): warm-up fit + min '
+                     'of 2 timed fits of %d minibatch(es) (%.1f s each); torch.set_num_threads: every host core (%d) and 16 were '
+                     'probed, the faster (%d) was timed%s'
+                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], rec['batch'], rec['gpu_workload_batch'],
+                        sa['minibatches_per_fit'], sa['seconds'], rec['host_cores'], sa['threads'],
                         '; ' + rec['note'] if rec['note'] else '')}
     if da:
-        out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s',
+        out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s', 'cores': da['threads'],
                                                'sample': '%d minibatch(es) per fit, %.1f s' % (da['minibatches_per_fit'], da['seconds'])}
     return out
 

@@ -7,17 +7,19 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-run() {  # name users items dim opt batch steps
-  for route in 0 1; do
+run() {  # name users items dim opt batch steps [routes] [extra --set for the persistent route]
+  for route in ${8:-0 1}; do
+    EXTRA=""
+    [ $route = 1 ] && [ -n "${9:-}" ] && EXTRA="--set $9"
     timeout 300 python bench.py --users $2 --items $3 --dim $4 --opt $5 --batch $6 --steps $7 --warmup 50 --no-cpu-baseline \
-        --no-probes --no-sharded-check --set epoch_kernel=$route 2> $OUT/err.txt | python -c "
+        --no-probes --no-sharded-check --set epoch_kernel=$route $EXTRA 2> $OUT/err.txt | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read())
 except Exception as e:
     print('$1 B=$6 $5 route=$route FAILED', e); sys.exit(0)
 r=d['roofline']; k=r['kernels']; o=r['other_ms_per_step']
-print(json.dumps({'shape':'$1','users':$2,'items':$3,'dim':$4,'opt':'$5','batch':$6,'steps':d['steps'],'epoch_kernel':$route,
+print(json.dumps({'shape':'$1','users':$2,'items':$3,'dim':$4,'opt':'$5','batch':$6,'steps':d['steps'],'epoch_kernel':$route,'extra':'$EXTRA',
   'us_per_minibatch':d['ms_per_step']*1e3,'M_interactions_per_s':d['value']/1e6,
   'kernel_us_per_minibatch':{'user_pass':k['user_pass']['avg_ms']*1e3 if k['user_pass']['launches'] else 0.0,
     'item_pass':k['item_pass']['avg_ms']*1e3 if k['item_pass']['launches'] else 0.0,'dense_sweep':o['dense_sweep']*1e3,
@@ -29,6 +31,10 @@ run c1 943 1682 32 adam_dense 1024 2000
 run c1 943 1682 32 adagrad 256 4000
 run c1 943 1682 32 adam_dense 256 4000
 run c1 943 1682 32 adagrad 4096 1000
+run c1 943 1682 32 adagrad 4096 1000 1 epoch_max_grid=256
+run c1 943 1682 32 adagrad 4096 1000 1 epoch_max_grid=64
+run c1 943 1682 32 adagrad 1024 2000 1 epoch_max_grid=32
+run c1 943 1682 32 adagrad 1024 2000 1 epoch_max_grid=16
 run mid 1000000 100000 64 adagrad 1024 2000
 run mid 1000000 100000 64 adagrad 4096 1000
 run mid 1000000 100000 64 sparse_adam 1024 2000

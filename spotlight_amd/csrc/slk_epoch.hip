@@ -12,8 +12,7 @@
 //                per pair) for the item phase; the optimizer update of U[u] and its bias in place
 //   -- grid barrier --
 //   ITEM PHASE   one row group per unique item (head of its run in the (minibatch, item)-sorted occurrence list): sums
-//                g * u_old over the run in occurrence order, updates V[i] and its bias; one workgroup also reduces the
-//                minibatch's loss partials into loss.item()
+//                g * u_old over the run in occurrence order, updates V[i] and its bias
 //   -- grid barrier --
 //
 // i.e. the two ownership passes of the launch path (same sorted lists, same summation order, same arithmetic: the
@@ -56,7 +55,7 @@ struct slk_epoch_args {
     float *snap;                   // records: [position - b0][RS] pre-step user rows
     int RS;
     float *gsn;                    // [2 * (position - b0) + pair] dL/dscore
-    double *partial;               // [2][gridDim.x] per-workgroup loss sums, double-buffered by minibatch parity
+    double *partial;               // [n_mb][gridDim.x] per-workgroup loss sums
     float *mb_loss;                // [n_mb] loss.item() of each minibatch
     const slk_step_coef *coef;     // [n_mb]
     unsigned *bar;                 // barrier counter, zeroed before the launch
@@ -67,10 +66,18 @@ struct slk_epoch_args {
 
 // ---- the grid barrier -------------------------------------------------------------------------------------------------
 // target = gridDim.x * (number of barriers passed so far + 1).  Returns false when the launch is being abandoned.
-__device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsigned target, int *s_flag) {
+// `partial` (optional): a value thread 0 publishes on its way in (the workgroup's loss sum; read barriers later).
+__device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsigned target, int *s_flag, const double *s_wave_sums,
+                                                  double *partial_out) {
     SLK_DRAIN_VMEM();  // every wave: its write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (partial_out) {
+            const double tot = ((s_wave_sums[0] + s_wave_sums[1]) + s_wave_sums[2]) + s_wave_sums[3];
+            unsigned long long bits;
+            memcpy(&bits, &tot, 8);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(partial_out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned seen = __hip_atomic_fetch_add(e.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         unsigned spins = 0;
         while ((seen & ~SLK_EPOCH_ABORT) < target && !(seen & SLK_EPOCH_ABORT)) {
@@ -85,9 +92,7 @@ __device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsig
         *s_flag = (seen & SLK_EPOCH_ABORT) ? 0 : 1;
     }
     __syncthreads();
-    const bool ok = *s_flag != 0;
-    __syncthreads();  // s_flag may be rewritten by the next barrier
-    return ok;
+    return *s_flag != 0;  // the caller alternates between two flag words, so no third barrier is needed
 }
 
 // ---- row updates: the arithmetic of slk_apply_vec / k_dense_sweep_all, element for element, on coherent accesses -------
@@ -146,31 +151,65 @@ __device__ __forceinline__ constexpr bool slk_epoch_dense() {
     return UPD == SLK_EUPD_ADAM_DENSE || UPD == SLK_EUPD_ADAGRAD_DENSE;
 }
 
-// dense optimizers: rows [lo, hi) of embedding table `te` and bias table `tb` received no gradient this step
-template <int VEC, int G, int UPD>
-__device__ __forceinline__ void slk_epoch_sweep_gap(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb,
-                                                    uint32_t lo, uint32_t hi, int D, int d0, bool on, int lane) {
-    const slk_vec<VEC> zero = slk_vzero<VEC>();
-    const slk_vec<1> zero1 = slk_vzero<1>();
-    for (uint32_t r = lo; r < hi; ++r) {
-        if (on) {
-            const size_t off = (size_t)r * D + d0;
-            const slk_vec<VEC> p = slk_vload_coh<VEC>(e.P[te] + off), s1 = slk_vload_coh<VEC>(e.S1[te] + off);
-            const slk_vec<VEC> s2 = slk_epoch_has_s2<UPD>() ? slk_vload_coh<VEC>(e.S2[te] + off) : zero;
-            slk_epoch_update<VEC, UPD>(e, c, te, off, p, s1, s2, zero);
+// Dense optimizers: rows [lo, hi) of embedding table `te` and bias table `tb` received no gradient this step.  The kernel
+// is latency-bound, so the rows go SLK_GAP_BATCH at a time: all loads of a batch are in flight together (one fabric
+// round trip per batch instead of one per row).
+#define SLK_GAP_BATCH 4
+template <int VEC, int UPD>
+struct slk_gap_rows {
+    slk_vec<VEC> p[SLK_GAP_BATCH], s1[SLK_GAP_BATCH], s2[SLK_GAP_BATCH];
+    slk_vec<1> bp[SLK_GAP_BATCH], bs1[SLK_GAP_BATCH], bs2[SLK_GAP_BATCH];
+    uint32_t lo, n;
+
+    __device__ __forceinline__ void load(const slk_epoch_args &e, int te, int tb, uint32_t lo_, uint32_t hi, int D, int d0, bool on,
+                                         int lane) {
+        lo = lo_;
+        n = hi > lo_ ? (hi - lo_ < (uint32_t)SLK_GAP_BATCH ? hi - lo_ : (uint32_t)SLK_GAP_BATCH) : 0u;
+#pragma unroll
+        for (int k = 0; k < SLK_GAP_BATCH; ++k) {
+            p[k] = s1[k] = s2[k] = slk_vzero<VEC>();
+            bp[k] = bs1[k] = bs2[k] = slk_vzero<1>();
+            if ((uint32_t)k >= n) continue;
+            const uint32_t r = lo + (uint32_t)k;
+            if (on) {
+                const size_t off = (size_t)r * D + d0;
+                p[k] = slk_vload_coh<VEC>(e.P[te] + off);
+                s1[k] = slk_vload_coh<VEC>(e.S1[te] + off);
+                if (slk_epoch_has_s2<UPD>()) s2[k] = slk_vload_coh<VEC>(e.S2[te] + off);
+            }
+            if (lane == 0) {
+                bp[k] = slk_vload_coh<1>(e.P[tb] + r);
+                bs1[k] = slk_vload_coh<1>(e.S1[tb] + r);
+                if (slk_epoch_has_s2<UPD>()) bs2[k] = slk_vload_coh<1>(e.S2[tb] + r);
+            }
         }
-        if (lane == 0) {
-            const slk_vec<1> p = slk_vload_coh<1>(e.P[tb] + r), s1 = slk_vload_coh<1>(e.S1[tb] + r);
-            const slk_vec<1> s2 = slk_epoch_has_s2<UPD>() ? slk_vload_coh<1>(e.S2[tb] + r) : zero1;
-            slk_epoch_update<1, UPD>(e, c, tb, r, p, s1, s2, zero1);
+    }
+    __device__ __forceinline__ void apply(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb, int D, int d0, bool on,
+                                          int lane) const {
+#pragma unroll
+        for (int k = 0; k < SLK_GAP_BATCH; ++k) {
+            if ((uint32_t)k >= n) continue;
+            const uint32_t r = lo + (uint32_t)k;
+            if (on) slk_epoch_update<VEC, UPD>(e, c, te, (size_t)r * D + d0, p[k], s1[k], s2[k], slk_vzero<VEC>());
+            if (lane == 0) slk_epoch_update<1, UPD>(e, c, tb, r, bp[k], bs1[k], bs2[k], slk_vzero<1>());
         }
+    }
+};
+
+template <int VEC, int UPD>
+__device__ __forceinline__ void slk_epoch_sweep_rows(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb, uint32_t lo,
+                                                     uint32_t hi, int D, int d0, bool on, int lane) {
+    for (uint32_t r = lo; r < hi; r += SLK_GAP_BATCH) {
+        slk_gap_rows<VEC, UPD> gb;
+        gb.load(e, te, tb, r, hi, D, d0, on, lane);
+        gb.apply(e, c, te, tb, D, d0, on, lane);
     }
 }
 
 template <int VEC, int G, int UPD>
 __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
-    HIP_DYNAMIC_SHARED(double, red)              // [256] block reduction + the barrier's flag behind it
-    int *s_flag = reinterpret_cast<int *>(red + 256);
+    HIP_DYNAMIC_SHARED(double, s_wave_sums)      // [4] per-wave loss sums + the barrier's two flag words behind them
+    int *s_flags = reinterpret_cast<int *>(s_wave_sums + 4);
     constexpr int GPB = 256 / G;
     constexpr bool DENSE = slk_epoch_dense<UPD>();
     constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
@@ -182,6 +221,16 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
     const slk_vec<1> zero1 = slk_vzero<1>();
     unsigned barriers = 0;
 
+    // The sorted id lists are immutable: what a row group needs of them for its FIRST position of the next phase is
+    // fetched before the barrier it is about to wait at, off the critical path.
+    uint32_t nx_key = 0, nx_prev = 0, nx_a = 0, nx_b = 0;
+    if (gslot < (e.nc < e.bsz ? e.nc : e.bsz)) {
+        nx_key = e.ukey[gslot];
+        nx_prev = gslot ? e.ukey[gslot - 1] : 0u;
+        nx_a = e.uit[2 * (size_t)gslot];
+        nx_b = e.uit[2 * (size_t)gslot + 1];
+    }
+
     for (uint32_t mb = 0; mb < e.n_mb; ++mb) {
         const uint32_t b0 = mb * e.bsz, b1 = (e.nc - b0 < e.bsz) ? e.nc : b0 + e.bsz;
         const float inv_b = 1.0f / (float)(b1 - b0);
@@ -190,30 +239,36 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
         // ------------------------------------------------ USER PHASE
         float loss_acc = 0.0f;
         for (uint32_t p = b0 + gslot; p < b1; p += gstride) {
-            // the sorted lists are immutable: key, predecessor and the first pair's items in one (cached) round trip
-            const uint32_t key = e.ukey[p];
             const bool first = p == b0;
-            const uint32_t prev = first ? 0u : e.ukey[p - 1];
-            uint32_t ip = e.uit[2 * (size_t)p], in = e.uit[2 * (size_t)p + 1];
+            const bool pre = p == b0 + gslot;  // this position's list entries were prefetched
+            const uint32_t key = pre ? nx_key : e.ukey[p];
+            const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ukey[p - 1]);
+            uint32_t ip = pre ? nx_a : e.uit[2 * (size_t)p], in = pre ? nx_b : e.uit[2 * (size_t)p + 1];
             if (!first && prev == key) continue;  // not the head of its user's run
             const uint32_t user = key & e.umask;
             const size_t uoff = (size_t)user * D + d0;
-            // every coherent load whose address is known goes out before the first use: one fabric round trip
+            // every coherent load whose address is known goes out before the first use: ONE fabric round trip
             slk_vec<VEC> u = on ? slk_vload_coh<VEC>(e.P[0] + uoff) : zero;
             const slk_vec<VEC> su1 = on ? slk_vload_coh<VEC>(e.S1[0] + uoff) : zero;
             const slk_vec<VEC> su2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[0] + uoff) : zero;
             const float bu = slk_ld_coh(e.P[2] + user);
+            slk_vec<1> bus1 = zero1, bus2 = zero1;
+            if (lane == 0) {
+                bus1 = slk_vload_coh<1>(e.S1[2] + user);
+                if (HAS_S2) bus2 = slk_vload_coh<1>(e.S2[2] + user);
+            }
+            slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
+            slk_vec<VEC> vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+            float bi = slk_ld_coh(e.P[3] + ip), bj = slk_ld_coh(e.P[3] + in);
+            // dense optimizers: the rows between the previous run's user and this one receive a zero gradient
+            slk_gap_rows<VEC, UPD> gap;
+            const uint32_t gap_lo = first ? 0u : (prev & e.umask) + 1u;
+            if (DENSE) gap.load(e, 0, 2, gap_lo, user, D, d0, on, lane);
+
             slk_vec<VEC> gu = zero;
             float gbu = 0.0f;
             uint32_t q = p;
-            do {
-                if (q != p) {
-                    ip = e.uit[2 * (size_t)q];
-                    in = e.uit[2 * (size_t)q + 1];
-                }
-                const slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
-                const slk_vec<VEC> vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
-                const float bi = slk_ld_coh(e.P[3] + ip), bj = slk_ld_coh(e.P[3] + in);
+            for (;;) {
                 if (on) slk_vstore_coh<VEC>(e.snap + (size_t)(q - b0) * e.RS + d0, u);
                 const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
                 const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bj;
@@ -228,40 +283,53 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
                     loss_acc += l;
                 }
                 ++q;
-            } while (q < b1 && e.ukey[q] == key);
-
-            if (DENSE) {  // rows between the previous run's user and this one (and past the last one): zero gradient
-                slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 0, 2, first ? 0u : (prev & e.umask) + 1u, user, D, d0, on, lane);
-                if (q == b1) slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 0, 2, user + 1u, e.n_users, D, d0, on, lane);
+                if (!(q < b1 && e.ukey[q] == key)) break;
+                ip = e.uit[2 * (size_t)q];  // further occurrences of the same user in this minibatch
+                in = e.uit[2 * (size_t)q + 1];
+                vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
+                vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+                bi = slk_ld_coh(e.P[3] + ip);
+                bj = slk_ld_coh(e.P[3] + in);
             }
+
             if (on) slk_epoch_update<VEC, UPD>(e, c, 0, uoff, u, su1, su2, gu);
             if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gbu == 0.0f)) {  // zero gradient: an exact no-op for Adagrad
-                slk_vec<1> bp, bs1, bs2 = zero1, bg;
+                slk_vec<1> bp, bg;
                 bp.v[0] = bu;
-                bs1 = slk_vload_coh<1>(e.S1[2] + user);
-                if (HAS_S2) bs2 = slk_vload_coh<1>(e.S2[2] + user);
                 bg.v[0] = gbu;
-                slk_epoch_update<1, UPD>(e, c, 2, user, bp, bs1, bs2, bg);
+                slk_epoch_update<1, UPD>(e, c, 2, user, bp, bus1, bus2, bg);
+            }
+            if (DENSE) {
+                gap.apply(e, c, 0, 2, D, d0, on, lane);
+                slk_epoch_sweep_rows<VEC, UPD>(e, c, 0, 2, gap_lo + SLK_GAP_BATCH, user, D, d0, on, lane);
+                if (q == b1) slk_epoch_sweep_rows<VEC, UPD>(e, c, 0, 2, user + 1u, e.n_users, D, d0, on, lane);
             }
         }
-        {
-            const double tot = slk_block_sum_256((double)loss_acc, red);
-            if (threadIdx.x == 0) {
-                unsigned long long bits;
-                memcpy(&bits, &tot, 8);
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(e.partial + (size_t)(mb & 1u) * gridDim.x + blockIdx.x),
-                                   bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        // this row group's first position of the item phase
+        const uint32_t ib0 = 2u * b0, ib1 = 2u * b1;
+        if (ib0 + gslot < ib1) {
+            nx_key = e.ikey[ib0 + gslot];
+            nx_prev = gslot ? e.ikey[ib0 + gslot - 1] : 0u;
+            nx_a = e.ipay[ib0 + gslot];
         }
-        if (!slk_epoch_barrier(e, gridDim.x * ++barriers, s_flag)) return;
+        {   // the workgroup's loss sum: waves by shuffle, the four wave sums by thread 0 on its way into the barrier
+            double x = (double)loss_acc;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+            if ((threadIdx.x & 63) == 0) s_wave_sums[threadIdx.x >> 6] = x;
+        }
+        if (!slk_epoch_barrier(e, gridDim.x * (barriers + 1), s_flags + (barriers & 1u), s_wave_sums,
+                               e.partial + (size_t)mb * gridDim.x + blockIdx.x))
+            return;
+        ++barriers;
 
         // ------------------------------------------------ ITEM PHASE
-        const uint32_t ib0 = 2u * b0, ib1 = 2u * b1;
         for (uint32_t r = ib0 + gslot; r < ib1; r += gstride) {
-            const uint32_t key = e.ikey[r];
             const bool first = r == ib0;
-            const uint32_t prev = first ? 0u : e.ikey[r - 1];
-            uint32_t pay = e.ipay[r];
+            const bool pre = r == ib0 + gslot;
+            const uint32_t key = pre ? nx_key : e.ikey[r];
+            const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ikey[r - 1]);
+            uint32_t pay = pre ? nx_a : e.ipay[r];
             if (!first && prev == key) continue;
             const uint32_t item = key & e.imask;
             const size_t voff = (size_t)item * D + d0;
@@ -269,15 +337,22 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
             const slk_vec<VEC> sv1 = on ? slk_vload_coh<VEC>(e.S1[1] + voff) : zero;
             const slk_vec<VEC> sv2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[1] + voff) : zero;
             const float bi = slk_ld_coh(e.P[3] + item);
+            slk_vec<1> bis1 = zero1, bis2 = zero1;
+            if (lane == 0) {
+                bis1 = slk_vload_coh<1>(e.S1[3] + item);
+                if (HAS_S2) bis2 = slk_vload_coh<1>(e.S2[3] + item);
+            }
+            float g = slk_ld_coh(e.gsn + (pay - ib0));
+            slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((pay >> 1) - b0) * e.RS + d0) : zero;
+            slk_gap_rows<VEC, UPD> gap;
+            const uint32_t gap_lo = first ? 0u : (prev & e.imask) + 1u;
+            if (DENSE) gap.load(e, 1, 3, gap_lo, item, D, d0, on, lane);
+
             slk_vec<VEC> gv = zero;
             float gb = 0.0f;
             bool any = false;
             uint32_t k = r;
-            do {
-                if (k != r) pay = e.ipay[k];
-                const uint32_t pos = pay >> 1;
-                const float g = slk_ld_coh(e.gsn + (pay - ib0));
-                const slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0) : zero;
+            for (;;) {
                 if (g != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
@@ -288,40 +363,56 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
                     any = true;
                 }
                 ++k;
-            } while (k < ib1 && e.ikey[k] == key);
-
-            if (DENSE) {
-                slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 1, 3, first ? 0u : (prev & e.imask) + 1u, item, D, d0, on, lane);
-                if (k == ib1) slk_epoch_sweep_gap<VEC, G, UPD>(e, c, 1, 3, item + 1u, e.n_items, D, d0, on, lane);
+                if (!(k < ib1 && e.ikey[k] == key)) break;
+                pay = e.ipay[k];
+                g = slk_ld_coh(e.gsn + (pay - ib0));
+                uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((pay >> 1) - b0) * e.RS + d0) : zero;
             }
+
             // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
             // row; the dense optimizers update every row anyway
-            if (UPD == SLK_EUPD_ADAGRAD && !any) continue;
-            if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v, sv1, sv2, gv);
-            if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gb == 0.0f)) {
-                slk_vec<1> bp, bs1, bs2 = zero1, bg;
-                bp.v[0] = bi;
-                bs1 = slk_vload_coh<1>(e.S1[3] + item);
-                if (HAS_S2) bs2 = slk_vload_coh<1>(e.S2[3] + item);
-                bg.v[0] = gb;
-                slk_epoch_update<1, UPD>(e, c, 3, item, bp, bs1, bs2, bg);
+            if (!(UPD == SLK_EUPD_ADAGRAD && !any)) {
+                if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v, sv1, sv2, gv);
+                if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gb == 0.0f)) {
+                    slk_vec<1> bp, bg;
+                    bp.v[0] = bi;
+                    bg.v[0] = gb;
+                    slk_epoch_update<1, UPD>(e, c, 3, item, bp, bis1, bis2, bg);
+                }
+            }
+            if (DENSE) {
+                gap.apply(e, c, 1, 3, D, d0, on, lane);
+                slk_epoch_sweep_rows<VEC, UPD>(e, c, 1, 3, gap_lo + SLK_GAP_BATCH, item, D, d0, on, lane);
+                if (k == ib1) slk_epoch_sweep_rows<VEC, UPD>(e, c, 1, 3, item + 1u, e.n_items, D, d0, on, lane);
             }
         }
-        // loss.item() of this minibatch: the partials of the user phase became visible at the barrier
-        if (blockIdx.x == mb % gridDim.x) {
-            double x = 0.0;
-            for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) {
-                const unsigned long long bits = __hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>(e.partial + (size_t)(mb & 1u) * gridDim.x + i), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                double d;
-                memcpy(&d, &bits, 8);
-                x += d;
-            }
-            const double tot = slk_block_sum_256(x, red);
-            if (threadIdx.x == 0) e.mb_loss[mb] = (float)(tot * (double)inv_b);
+        // this row group's first position of the next minibatch's user phase
+        if (mb + 1 < e.n_mb && b1 + gslot < e.nc && gslot < e.bsz) {
+            nx_key = e.ukey[b1 + gslot];
+            nx_prev = gslot ? e.ukey[b1 + gslot - 1] : 0u;
+            nx_a = e.uit[2 * (size_t)(b1 + gslot)];
+            nx_b = e.uit[2 * (size_t)(b1 + gslot) + 1];
         }
-        if (!slk_epoch_barrier(e, gridDim.x * ++barriers, s_flag)) return;
+        if (!slk_epoch_barrier(e, gridDim.x * (barriers + 1), s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
+        ++barriers;
+    }
+
+    // loss.item() of every minibatch (implicit.py:240): the workgroups' partial sums, published on the way into each
+    // user-phase barrier, are all visible now; one wave per minibatch adds them up
+    for (uint32_t mb = blockIdx.x * 4 + (threadIdx.x >> 6); mb < e.n_mb; mb += gridDim.x * 4) {
+        const uint32_t b0 = mb * e.bsz, b1 = (e.nc - b0 < e.bsz) ? e.nc : b0 + e.bsz;
+        double x = 0.0;
+        for (unsigned i = threadIdx.x & 63u; i < gridDim.x; i += 64) {
+            const unsigned long long bits = __hip_atomic_load(
+                reinterpret_cast<const unsigned long long *>(e.partial + (size_t)mb * gridDim.x + i), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            double d;
+            memcpy(&d, &bits, 8);
+            x += d;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+        if ((threadIdx.x & 63) == 0) e.mb_loss[mb] = (float)(x * (double)(1.0f / (float)(b1 - b0)));
     }
 }
 
@@ -370,7 +461,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     enum { EP_COEF = 40, EP_BAR, EP_PARTIAL };  // ctx->extra slots
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 256))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)2 * grid * 8))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * grid * 8))) return rc;
 
     slk_epoch_args e;
     memset(&e, 0, sizeof(e));
@@ -441,7 +532,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
 #undef SLK_PICK_EPOCH
     slk_prof_begin(ctx, SLK_K_EPOCH, s);
     void *kargs[1] = {&e};
-    const size_t lds = 256 * sizeof(double) + 16;
+    const size_t lds = 4 * sizeof(double) + 16;
     // cooperative: the launch is refused (not deadlocked) if the grid could not be resident at once
     hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
     if (le != hipSuccess)
