@@ -94,6 +94,7 @@ def parse():
     ap.add_argument('--no-probes', action='store_true', help='skip the copy / triad / step-ceiling bandwidth probes')
     ap.add_argument('--no-sharded-check', action='store_true',
                     help='N=1: skip the consistency run of the row-sharded path (world 1) against the fused path')
+    ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=30.0)
     return ap.parse_args()
@@ -551,7 +552,7 @@ def main():
             shard_check = {'error': repr(e)[:300]}
 
     losses = mb_loss.cpu().numpy()
-    assert np.isfinite(losses).all() and (losses[W:] > 0).all(), losses
+    assert args.no_loss_check or (np.isfinite(losses).all() and (losses[W:] > 0).all()), losses
     losses = losses[:W + K]
 
     if rank == 0:

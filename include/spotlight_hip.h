@@ -368,6 +368,14 @@ int slk_probe_stream(slk_ctx *ctx, int32_t kind, float *d_a, const float *d_b, c
                      int32_t iters, double *avg_ms, void *stream);
 int slk_probe_step_ceiling(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t batch,
                            int32_t iters, double *user_ms, double *item_ms, int64_t *items_touched, void *stream);
+/*  slk_probe_random_rows   the random-row regime of a table far larger than the caches (the 1B-item configuration):
+ *                          n_access row groups each read (rmw = 0) or read and write back (rmw = 1) one embedding row
+ *                          and its optimizer-state row in d_buf (2 * rows * dim floats); layout 0 = two separate
+ *                          tables [rows][dim] + [rows][dim] (torch's parameter / state tensors), layout 1 = interleaved
+ *                          [rows][2 * dim] records; order 0 = ascending rows (what an ownership pass over sorted ids
+ *                          sees), order 1 = uniformly random rows (what the user pass's item lookups see). */
+int slk_probe_random_rows(slk_ctx *ctx, float *d_buf, int64_t rows, int32_t dim, int32_t layout, int32_t order,
+                          int32_t rmw, int64_t n_access, int32_t iters, double *avg_ms, void *stream);
 
 #ifdef __cplusplus
 }

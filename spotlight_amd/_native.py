@@ -103,6 +103,8 @@ _PROTOTYPES = {
     'slk_profile_reset': (C.c_int, [C.c_void_p]),
     'slk_probe_stream': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                    C.POINTER(C.c_double), C.c_void_p]),
+    'slk_probe_random_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                        C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     'slk_probe_step_ceiling': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int32,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),
 }
@@ -338,6 +340,13 @@ class Engine(object):
         ms = C.c_double()
         self._check(self._lib.slk_probe_stream(self._ctx, int(kind), d_a, d_b, d_c, int(n_floats), int(iters),
                                                C.byref(ms), stream))
+        return float(ms.value)
+
+    def probe_random_rows(self, d_buf, rows, dim, layout, order, rmw, n_access, iters=10, stream=0):
+        """Average ms of n_access row (+ state row) reads / read-modify-writes; see include/spotlight_hip.h."""
+        ms = C.c_double()
+        self._check(self._lib.slk_probe_random_rows(self._ctx, d_buf, int(rows), int(dim), int(layout), int(order), int(rmw),
+                                                    int(n_access), int(iters), C.byref(ms), stream))
         return float(ms.value)
 
     def probe_step_ceiling(self, tables, optim, batch, iters=10, stream=0):

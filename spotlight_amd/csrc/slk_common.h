@@ -83,6 +83,8 @@ struct slk_ctx {
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     int opt_epoch_kernel = 0;      // 1: minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip)
     int64_t opt_epoch_max_batch = 4096;
+    int opt_epoch_barrier = 0;     // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters)
+    int opt_epoch_debug = 0;       // measurement only: 1 skip the phases' work, 2 do not wait at barriers, 4 no store drain
     int opt_epoch_max_grid = 128;  // workgroups of the persistent launch (<= one per CU)
     int64_t opt_epoch_dense_elems = (int64_t)1 << 23;  // dense optimizers: largest model (parameters) the persistent route takes
     std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)

@@ -33,7 +33,7 @@
 
 enum { SLK_EUPD_ADAGRAD = 0, SLK_EUPD_SPARSE_ADAM = 1, SLK_EUPD_ADAM_DENSE = 2, SLK_EUPD_ADAGRAD_DENSE = 3 };
 
-#define SLK_EPOCH_ABORT 0x80000000u
+#define SLK_EPOCH_ABORT 0xffffffffu
 #define SLK_EPOCH_MAX_SPINS (1u << 24)  // x (s_sleep + one fabric round trip): seconds
 
 // per-minibatch optimizer coefficients, formed on the host in double exactly as torch does (bias corrections and
@@ -62,14 +62,21 @@ struct slk_epoch_args {
     int *status;                   // raised on a barrier time-out
     int loss_kind;
     float eps, omb1, omb2, beta2, wd;
+    int bar_kind;                  // 0: one arrival counter, 1: 8 sub-counters + a top counter
+    int debug;                     // measurement only (option "epoch_debug"): 1 skip the phases' work, 2 do not wait at barriers, 4 no drain
 };
 
 // ---- the grid barrier -------------------------------------------------------------------------------------------------
-// target = gridDim.x * (number of barriers passed so far + 1).  Returns false when the launch is being abandoned.
-// `partial` (optional): a value thread 0 publishes on its way in (the workgroup's loss sum; read barriers later).
-__device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsigned target, int *s_flag, const double *s_wave_sums,
+// `epoch` = number of barriers passed so far + 1 (monotonic within the launch; all words are zeroed before it).
+// Arrivals are counted by device-scope fetch_adds; the LAST arriver publishes the epoch in a separate word that all
+// others poll (relaxed sc1 loads + s_sleep, ONE lane per workgroup), so the pollers do not queue behind the arrivals at
+// the counter's memory channel.  bar_kind 1 adds a level: workgroups first meet on one of 8 sub-counters (blockIdx % 8 --
+// a grouping, not a placement assumption) and only the last of each group touches the top counter.
+// Returns false when the launch is being abandoned (a spin ran out: the flag word is raised to ~0 for everyone).
+// `partial_out` (optional): a value thread 0 publishes on its way in (the workgroup's loss sum; read barriers later).
+__device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsigned epoch, int *s_flag, const double *s_wave_sums,
                                                   double *partial_out) {
-    SLK_DRAIN_VMEM();  // every wave: its write-through stores have been acknowledged
+    if (!(e.debug & 4)) SLK_DRAIN_VMEM();  // every wave: its write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0) {
         if (partial_out) {
@@ -78,18 +85,34 @@ __device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsig
             memcpy(&bits, &tot, 8);
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(partial_out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        unsigned seen = __hip_atomic_fetch_add(e.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        unsigned spins = 0;
-        while ((seen & ~SLK_EPOCH_ABORT) < target && !(seen & SLK_EPOCH_ABORT)) {
-            __builtin_amdgcn_s_sleep(1);
-            seen = __hip_atomic_load(e.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > SLK_EPOCH_MAX_SPINS) {  // a workgroup never arrived: give up, tell everyone
-                __hip_atomic_fetch_or(e.bar, SLK_EPOCH_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(e.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                seen = SLK_EPOCH_ABORT;
+        unsigned *flag = e.bar + 32;  // its own 128-B line
+        bool last;
+        if (e.bar_kind == 1) {
+            const unsigned sub = blockIdx.x & 7u;
+            const unsigned members = (gridDim.x - sub + 7u) / 8u;
+            const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+            last = __hip_atomic_fetch_add(e.bar + 64 + 32 * sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == members * epoch;
+            if (last) last = __hip_atomic_fetch_add(e.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == groups * epoch;
+        } else {
+            last = __hip_atomic_fetch_add(e.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x * epoch;
+        }
+        unsigned seen = epoch;
+        if (last) {
+            __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!(e.debug & 2)) {
+            unsigned spins = 0;
+            seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (seen < epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > SLK_EPOCH_MAX_SPINS) {  // a workgroup never arrived: give up, tell everyone
+                    __hip_atomic_store(flag, SLK_EPOCH_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(e.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seen = SLK_EPOCH_ABORT;
+                }
             }
         }
-        *s_flag = (seen & SLK_EPOCH_ABORT) ? 0 : 1;
+        *s_flag = seen == SLK_EPOCH_ABORT ? 0 : 1;
     }
     __syncthreads();
     return *s_flag != 0;  // the caller alternates between two flag words, so no third barrier is needed
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
 
         // ------------------------------------------------ USER PHASE
         float loss_acc = 0.0f;
-        for (uint32_t p = b0 + gslot; p < b1; p += gstride) {
+        for (uint32_t p = b0 + gslot; p < b1 && !(e.debug & 1); p += gstride) {
             const bool first = p == b0;
             const bool pre = p == b0 + gslot;  // this position's list entries were prefetched
             const uint32_t key = pre ? nx_key : e.ukey[p];
@@ -318,13 +341,13 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
             for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
             if ((threadIdx.x & 63) == 0) s_wave_sums[threadIdx.x >> 6] = x;
         }
-        if (!slk_epoch_barrier(e, gridDim.x * (barriers + 1), s_flags + (barriers & 1u), s_wave_sums,
+        if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums,
                                e.partial + (size_t)mb * gridDim.x + blockIdx.x))
             return;
         ++barriers;
 
         // ------------------------------------------------ ITEM PHASE
-        for (uint32_t r = ib0 + gslot; r < ib1; r += gstride) {
+        for (uint32_t r = ib0 + gslot; r < ib1 && !(e.debug & 1); r += gstride) {
             const bool first = r == ib0;
             const bool pre = r == ib0 + gslot;
             const uint32_t key = pre ? nx_key : e.ikey[r];
@@ -393,7 +416,7 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
             nx_a = e.uit[2 * (size_t)(b1 + gslot)];
             nx_b = e.uit[2 * (size_t)(b1 + gslot) + 1];
         }
-        if (!slk_epoch_barrier(e, gridDim.x * (barriers + 1), s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
+        if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
         ++barriers;
     }
 
@@ -460,7 +483,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
 
     enum { EP_COEF = 40, EP_BAR, EP_PARTIAL };  // ctx->extra slots
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 256))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 2048))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * grid * 8))) return rc;
 
     slk_epoch_args e;
@@ -492,7 +515,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     }
     SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[EP_COEF].p, ctx->ep_coef.data(), (size_t)n_mb * sizeof(slk_step_coef),
                                 hipMemcpyHostToDevice, s));
-    SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 256, s));
+    SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 2048, s));
 
     for (int t = 0; t < 4; ++t) {
         e.P[t] = tables->d_param[t];
@@ -525,6 +548,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.omb2 = (float)(1.0 - optim->beta2);
     e.beta2 = (float)optim->beta2;
     e.wd = (float)optim->weight_decay;
+    e.bar_kind = ctx->opt_epoch_barrier;
+    e.debug = ctx->opt_epoch_debug;
 
     slk_epoch_fn fn = nullptr;
 #define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd)

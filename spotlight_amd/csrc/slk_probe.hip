@@ -130,6 +130,51 @@ __global__ __launch_bounds__(256) void k_probe_item_side(slk_probe_args a) {
     }
 }
 
+// Random-row regime (the item table of the 1B-item configuration: 125M rows per GPU, every touched row in its own DRAM
+// page): row + optimizer-state read-modify-write with the two kept in SEPARATE tables (the layout torch's parameter /
+// state tensors have) or INTERLEAVED as [row | state] records of 2 * D floats (one location per update instead of two).
+struct slk_rows_args {
+    float *buf;
+    uint64_t rows;
+    uint64_t n_access;
+    uint64_t stride;  // ascending order: row(k) = k * stride + mix(k) % stride
+    int D, layout, order, rmw, nt;
+    uint32_t salt;
+};
+
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void k_probe_random_rows(slk_rows_args a) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
+    const int D = a.D, d0 = lane * VEC;
+    const bool on = d0 < D;
+    const bool nt = a.nt != 0;
+    float acc = 0.0f;
+    for (uint64_t k = (uint64_t)blockIdx.x * GPB + grp; k < a.n_access; k += (uint64_t)gridDim.x * GPB) {
+        const uint32_t h = slk_mix32((uint32_t)k ^ a.salt), h2 = slk_mix32(h + 0x9e3779b9u);
+        uint64_t row = a.order == 0 ? k * a.stride + h % a.stride : (((uint64_t)h << 32) | h2) % a.rows;
+        if (row >= a.rows) row = a.rows - 1;
+        if (!on) continue;
+        float *pp = a.layout ? a.buf + row * 2 * D + d0 : a.buf + row * D + d0;
+        float *ps = a.layout ? pp + D : a.buf + (a.rows + row) * D + d0;
+        slk_vec<VEC> p = slk_vload_if_nt<VEC>(pp, nt);
+        slk_vec<VEC> s = slk_vload_if_nt<VEC>(ps, nt);
+        const float z = slk_group_sum<G>(slk_vdot<VEC>(p, s)) * 0.0f;
+        if (a.rmw) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                p.v[i] += z;
+                s.v[i] += z;
+            }
+            slk_vstore_if_nt<VEC>(ps, s, nt);
+            slk_vstore_if_nt<VEC>(pp, p, nt);
+        } else {
+            acc += z;
+        }
+    }
+    if (!a.rmw && acc == 12345.678f) a.buf[0] = acc;
+}
+
 // average duration of `iters` back-to-back launches of fn(i) on stream s (one untimed launch first)
 template <typename F>
 static int probe_time(slk_ctx *ctx, int iters, hipStream_t s, double *avg_ms, F launch) {
@@ -223,4 +268,33 @@ SLK_EXPORT int slk_probe_step_ceiling(slk_ctx *ctx, const slk_tables *tables, co
     });
 #undef SLK_PROBE_U
 #undef SLK_PROBE_I
+}
+
+SLK_EXPORT int slk_probe_random_rows(slk_ctx *ctx, float *d_buf, int64_t rows, int32_t dim, int32_t layout, int32_t order,
+                                     int32_t rmw, int64_t n_access, int32_t iters, double *avg_ms, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g;
+    if (!d_buf || rows < 1 || n_access < 1 || iters < 1 || !avg_ms || !slk_pick_layout(dim, &vec, &g))
+        return slk_fail(ctx, SLK_EINVAL, "slk_probe_random_rows: bad arguments");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    slk_rows_args a;
+    memset(&a, 0, sizeof(a));
+    a.buf = d_buf;
+    a.rows = (uint64_t)rows;
+    a.n_access = (uint64_t)n_access;
+    a.stride = (uint64_t)(rows / n_access) ? (uint64_t)(rows / n_access) : 1;
+    a.D = dim;
+    a.layout = layout;
+    a.order = order;
+    a.rmw = rmw;
+    a.nt = (ctx->opt_nt & 2) != 0;
+    const unsigned grid = slk_grid_for(ctx, (size_t)n_access, 256u / (unsigned)g, ctx->opt_item_grid_mult);
+    unsigned salt = 7;
+#define SLK_PROBE_R(V_, G_) hipLaunchKernelGGL((k_probe_random_rows<V_, G_>), dim3(grid), dim3(256), 0, s, a)
+    return probe_time(ctx, iters, s, avg_ms, [&]() {
+        a.salt = salt++ * 0x9e3779b9u;
+        SLK_FOR_LAYOUT(vec, g, SLK_PROBE_R);
+    });
+#undef SLK_PROBE_R
 }

@@ -46,5 +46,8 @@ def test_epoch_kernel_wider_cooperative_grid(monkeypatch):
     try:
         ec.check_epoch_kernel_is_bit_identical(b, 'bpr', 'adagrad', 32, U=500, I=300, N=1300, B=512, epochs=1)
         ec.check_epoch_kernel_is_bit_identical(b, 'pointwise', 'adam_dense', 16, U=90, I=70, N=700, B=200, epochs=1, max_grid=5)
+        # two-level barrier: 12 workgroups in 8 groups of 1-2, and 5 workgroups (fewer than groups)
+        ec.check_epoch_kernel_is_bit_identical(b, 'bpr', 'sparse_adam', 32, U=500, I=300, N=1300, B=512, epochs=1, barrier=1)
+        ec.check_epoch_kernel_is_bit_identical(b, 'hinge', 'adagrad', 16, U=90, I=70, N=700, B=200, epochs=1, max_grid=5, barrier=1)
     finally:
         b.close()
