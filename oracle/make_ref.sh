@@ -18,6 +18,11 @@ fi
 rm -rf "$HERE/_ref"
 mkdir -p "$HERE/_ref"
 cp -r "$SRC/spotlight" "$HERE/_ref/spotlight"
+# the reference's own test modules that need no dataset download (synthetic data only): run UNMODIFIED against this
+# package through its `spotlight` import aliases by tests/test_gpu_reference_tests.py
+mkdir -p "$HERE/_ref/tests/sequence"
+cp "$SRC/tests/test_layers.py" "$HERE/_ref/tests/test_layers.py"
+cp "$SRC/tests/sequence/test_sequence_implicit.py" "$HERE/_ref/tests/sequence/test_sequence_implicit.py"
 find "$HERE/_ref" -name __pycache__ -type d -prune -exec rm -rf {} +
 # provenance of the staged copy (checked by tests/test_oracle.py when /root/reference is present)
 ( cd "$SRC/spotlight" && find . -name '*.py' | LC_ALL=C sort | xargs sha256sum ) > "$HERE/_ref/MANIFEST.sha256"

@@ -760,13 +760,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     // minibatches of a few thousand interactions: every minibatch of a chunk inside ONE persistent launch (slk_epoch.hip)
-    const bool epoch_route = !pre && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
-    if (dense && !epoch_route) {
+    bool epoch_route = !pre && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    auto ensure_dense_buffers = [&]() -> int {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
                                  (size_t)tables->num_items};
-        if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
-    }
+        return slk_ensure_dgrad(ctx, elems, 15u, s);
+    };
+    if (dense && !epoch_route && (rc = ensure_dense_buffers())) return rc;
 
     if (reserve_only) {
         if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
@@ -1075,6 +1076,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
         int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, RS, (float *)ctx->snap.p,
                                      (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, s);
+        if (rc == SLK_EAGAIN_EPOCH) {  // cooperative launch refused: nothing ran; per-minibatch launches from here on
+            epoch_route = false;
+            if (dense && (rc = ensure_dense_buffers())) return rc;
+            return do_passes(c0, pb);
+        }
         mb_global += (nc + bsz - 1) / bsz;
         return rc;
     };

@@ -9,6 +9,7 @@
 
 #include "../../include/spotlight_hip.h"
 
+#define SLK_EAGAIN_EPOCH 1  // internal: the persistent route declined a chunk, take the launch path
 #define SLK_EXPORT extern "C" __attribute__((visibility("default")))
 
 // Occupancy target of a kernel in waves per SIMD (caps its VGPR budget at 512 / n).  hipcc only;
@@ -81,12 +82,16 @@ struct slk_ctx {
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
-    int opt_epoch_kernel = 0;      // 1: minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip)
-    int64_t opt_epoch_max_batch = 4096;
+    // minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip).  Defaults from the
+    // same-box A/Bs in profiles/r02_c_small_batch.jsonl: the persistent route wins at 256 (13 vs 21 us per minibatch) and
+    // 1024 (19 vs 24), loses at 4096 (42 vs 30) and -- its gap sweeps are serial per row group -- with the dense optimizers
+    int opt_epoch_kernel = 1;
+    int64_t opt_epoch_max_batch = 1024;
+    bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
     int opt_epoch_barrier = 0;     // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters)
     int opt_epoch_debug = 0;       // measurement only: 1 skip the phases' work, 2 do not wait at barriers, 4 no store drain
     int opt_epoch_max_grid = 128;  // workgroups of the persistent launch (<= one per CU)
-    int64_t opt_epoch_dense_elems = (int64_t)1 << 23;  // dense optimizers: largest model (parameters) the persistent route takes
+    int64_t opt_epoch_dense_elems = 0;  // dense optimizers: largest model (parameters) the persistent route takes (0: never)
     std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)

@@ -457,7 +457,7 @@ static slk_epoch_fn epoch_fn(int upd) {
 // Whether a slk_bilinear_train call takes the persistent route (option "epoch_kernel": 0 never, 1 when eligible).
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss,
                         bool bloom) {
-    if (!ctx->opt_epoch_kernel || bloom) return false;
+    if (!ctx->opt_epoch_kernel || ctx->epoch_refused || bloom) return false;
     if (loss != SLK_LOSS_POINTWISE && loss != SLK_LOSS_BPR && loss != SLK_LOSS_HINGE) return false;
     if (bsz > ctx->opt_epoch_max_batch) return false;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
@@ -560,10 +560,15 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     const size_t lds = 4 * sizeof(double) + 16;
     // cooperative: the launch is refused (not deadlocked) if the grid could not be resident at once
     hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
-    if (le != hipSuccess)
-        return slk_fail(ctx, SLK_EIO, "cooperative launch of k_bilinear_epoch (%u workgroups) failed: %s", grid,
-                        hipGetErrorString(le));
     slk_prof_end(ctx, s);
+    if (le != hipSuccess) {
+        // the grid cannot be resident at once (device shared with other work, cooperative launches unsupported): nothing
+        // has run -- the caller takes the per-minibatch launches for this chunk and stops asking
+        (void)hipGetLastError();
+        slk_fail(ctx, SLK_EIO, "cooperative launch of k_bilinear_epoch (%u workgroups) refused: %s", grid, hipGetErrorString(le));
+        ctx->epoch_refused = true;
+        return SLK_EAGAIN_EPOCH;
+    }
     optim->step += n_mb;
     return SLK_OK;
 }

@@ -839,6 +839,8 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
     results = []
     for route in (0, 1):
         eng.set_option('epoch_kernel', route)
+        eng.set_option('epoch_max_batch', 1 << 20)      # the persistent route for every size / optimizer under test,
+        eng.set_option('epoch_dense_elems', 1 << 40)     # not only where it is the default
         if chunk:
             eng.set_option('chunk_interactions', chunk)
         if max_grid:
@@ -869,7 +871,9 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
             results.append((np.concatenate(losses), [be.get(neg_out), st[1], np.array(st[2])] +
                             [be.get(x) for x in dev.p + dev.s1 + dev.s2]))
         finally:
-            eng.set_option('epoch_kernel', 0)
+            eng.set_option('epoch_kernel', 1)
+            eng.set_option('epoch_max_batch', 1024)
+            eng.set_option('epoch_dense_elems', 0)
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('epoch_max_grid', 128)
             eng.set_option('epoch_barrier', 0)
