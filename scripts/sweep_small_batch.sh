@@ -26,18 +26,15 @@ print(json.dumps({'shape':'$1','users':$2,'items':$3,'dim':$4,'opt':'$5','batch'
     'epoch':o['epoch']*1e3,'sample':o['sample']*1e3,'prep':o['prep']*1e3},'loss':d['final_minibatch_loss']}))" | tee -a $OUT/small_batch.jsonl
   done
 }
-run c1 943 1682 32 adagrad 1024 2000
-run c1 943 1682 32 adam_dense 1024 2000
 run c1 943 1682 32 adagrad 256 4000
-run c1 943 1682 32 adam_dense 256 4000
-run c1 943 1682 32 adagrad 4096 1000
-run c1 943 1682 32 adagrad 4096 1000 1 epoch_max_grid=256
-run c1 943 1682 32 adagrad 4096 1000 1 epoch_max_grid=64
-run c1 943 1682 32 adagrad 1024 2000 1 epoch_max_grid=32
-run c1 943 1682 32 adagrad 1024 2000 1 epoch_max_grid=16
+run c1 943 1682 32 adagrad 1024 2000
+run c1 943 1682 32 adagrad 2048 1000 "0 1" epoch_max_batch=8192
+run c1 943 1682 32 adagrad 4096 1000 "0 1" epoch_max_batch=8192
+run c1 943 1682 32 adam_dense 1024 2000 "0 1" epoch_dense_elems=100000000
+run c1 943 1682 32 adam_dense 256 4000 "0 1" epoch_dense_elems=100000000
 run mid 1000000 100000 64 adagrad 1024 2000
-run mid 1000000 100000 64 adagrad 4096 1000
+run mid 1000000 100000 64 adagrad 4096 1000 "0 1" epoch_max_batch=8192
 run mid 1000000 100000 64 sparse_adam 1024 2000
 run c2 10000000 1000000 64 adagrad 1024 2000
-run c2 10000000 1000000 64 adagrad 4096 1000
+run c2 10000000 1000000 64 adagrad 256 4000
 cat $OUT/err.txt | tail -5

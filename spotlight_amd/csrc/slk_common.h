@@ -88,9 +88,9 @@ struct slk_ctx {
     int opt_epoch_kernel = 1;
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
-    int opt_epoch_barrier = 0;     // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters)
+    int opt_epoch_barrier = -1;    // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters), -1 by grid size
     int opt_epoch_debug = 0;       // measurement only: 1 skip the phases' work, 2 do not wait at barriers, 4 no store drain
-    int opt_epoch_max_grid = 128;  // workgroups of the persistent launch (<= one per CU)
+    int opt_epoch_max_grid = 256;  // workgroups (one wavefront each) of the persistent launch, <= one per CU
     int64_t opt_epoch_dense_elems = 0;  // dense optimizers: largest model (parameters) the persistent route takes (0: never)
     std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal

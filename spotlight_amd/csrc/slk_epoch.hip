@@ -31,6 +31,12 @@
 // The sorted id lists are written by the prep kernels BEFORE the launch and never change: plain (cached) loads.
 #include "slk_kernels.h"
 
+// One wavefront per workgroup, at most one workgroup per CU: a CU retires its vector-memory instructions one line at a
+// time (scripts/micro/coherent_latency.hip: ~5 cycles per loaded line, ~14 per stored line, the same for plain and sc1
+// accesses), so the four waves of a 256-thread workgroup queue behind each other exactly where this kernel spends its time;
+// spread over 4x as many CUs the same work measured 18.8 -> see profiles/ us per minibatch at C1 shape, minibatch 1024.
+#define SLK_EPOCH_TB 64
+
 enum { SLK_EUPD_ADAGRAD = 0, SLK_EUPD_SPARSE_ADAM = 1, SLK_EUPD_ADAM_DENSE = 2, SLK_EUPD_ADAGRAD_DENSE = 3 };
 
 #define SLK_EPOCH_ABORT 0xffffffffu
@@ -230,10 +236,12 @@ __device__ __forceinline__ void slk_epoch_sweep_rows(const slk_epoch_args &e, co
 }
 
 template <int VEC, int G, int UPD>
-__global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
-    HIP_DYNAMIC_SHARED(double, s_wave_sums)      // [4] per-wave loss sums + the barrier's two flag words behind them
+__global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args e) {
+    HIP_DYNAMIC_SHARED(double, s_wave_sums)      // [4] per-wave loss sums (unused slots stay 0) + the barrier's two flag words
     int *s_flags = reinterpret_cast<int *>(s_wave_sums + 4);
-    constexpr int GPB = 256 / G;
+    if (threadIdx.x < 4) s_wave_sums[threadIdx.x] = 0.0;
+    constexpr int TB = SLK_EPOCH_TB, NW = TB / 64;
+    constexpr int GPB = TB / G;
     constexpr bool DENSE = slk_epoch_dense<UPD>();
     constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(256) void k_bilinear_epoch(slk_epoch_args e) {
 
     // loss.item() of every minibatch (implicit.py:240): the workgroups' partial sums, published on the way into each
     // user-phase barrier, are all visible now; one wave per minibatch adds them up
-    for (uint32_t mb = blockIdx.x * 4 + (threadIdx.x >> 6); mb < e.n_mb; mb += gridDim.x * 4) {
+    for (uint32_t mb = blockIdx.x * NW + (threadIdx.x >> 6); mb < e.n_mb; mb += gridDim.x * NW) {
         const uint32_t b0 = mb * e.bsz, b1 = (e.nc - b0 < e.bsz) ? e.nc : b0 + e.bsz;
         double x = 0.0;
         for (unsigned i = threadIdx.x & 63u; i < gridDim.x; i += 64) {
@@ -474,8 +482,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
     const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
-    const unsigned gpb = 256u / (unsigned)g;
-    // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU, <= 128
+    const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
+    // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU
     unsigned grid = (unsigned)((2 * bsz + gpb - 1) / gpb);
     const unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
     if (grid > cap) grid = cap;
@@ -548,7 +556,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.omb2 = (float)(1.0 - optim->beta2);
     e.beta2 = (float)optim->beta2;
     e.wd = (float)optim->weight_decay;
-    e.bar_kind = ctx->opt_epoch_barrier;
+    // two levels pay above ~128 arrivals (profiles/r02_d_epoch_kernel_anatomy.jsonl: 256 workgroups 9.3 -> 6.0 us per pair)
+    e.bar_kind = ctx->opt_epoch_barrier >= 0 ? ctx->opt_epoch_barrier : (grid > 128 ? 1 : 0);
     e.debug = ctx->opt_epoch_debug;
 
     slk_epoch_fn fn = nullptr;
@@ -559,7 +568,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     void *kargs[1] = {&e};
     const size_t lds = 4 * sizeof(double) + 16;
     // cooperative: the launch is refused (not deadlocked) if the grid could not be resident at once
-    hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), kargs, lds, s);
+    hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(SLK_EPOCH_TB), kargs, lds, s);
     slk_prof_end(ctx, s);
     if (le != hipSuccess) {
         // the grid cannot be resident at once (device shared with other work, cooperative launches unsupported): nothing

@@ -822,7 +822,7 @@ def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------
 def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, B=256, seed=31, chunk=None, epochs=2,
-                                        max_grid=None, barrier=0):
+                                        max_grid=None, barrier=-1):
     """The persistent route (option epoch_kernel = 1: every minibatch of a chunk in one cooperative launch) performs the
     launch path's arithmetic in the launch path's order: losses to fp32 summation-order noise, negatives, RNG state and
     EVERY table / optimizer-state tensor bit for bit -- including the dense optimizers, whose full-table sweep the
@@ -875,8 +875,8 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
             eng.set_option('epoch_max_batch', 1024)
             eng.set_option('epoch_dense_elems', 0)
             eng.set_option('chunk_interactions', 1 << 23)
-            eng.set_option('epoch_max_grid', 128)
-            eng.set_option('epoch_barrier', 0)
+            eng.set_option('epoch_max_grid', 256)
+            eng.set_option('epoch_barrier', -1)
     (la, ta), (lb, tb) = results
     assert np.abs(la - lb).max() <= 2e-6 * np.abs(la).max(), (la, lb)
     for k, (a, b) in enumerate(zip(ta, tb)):
