@@ -235,3 +235,54 @@ def replay_explicit_with_oracle(case, rec):
     errs['predict_pairs'] = rel_inf(po.explicit_predict(rec['predict_users'], rec['predict_items'], loss=loss),
                                     rec['predict_pairs'])
     return errs, fr
+
+
+def conditioned_trajectory_bounds(case, rec, rel_delta=1e-5):
+    """How far a recorded multi-step run may legitimately be from an implementation whose SUMMED GRADIENTS agree with the
+    reference's to `rel_delta` (north star: "fp32 loss/grad within 1e-5 rel"): the recorded run is replayed through the
+    oracle one minibatch at a time and, per element, the first-order effect of a gradient perturbation of
+    delta = rel_delta * ||g||inf (per embedding table; the two bias tables against their joint norm; touched rows only)
+    on that step's update is accumulated over the steps:
+
+        Adagrad (sparse or dense, +wd)    lr * delta / (sqrt(sum_pre + g^2) + eps)
+        Adam / SparseAdam                 (lr / bc1) * delta / (sqrt(v_new / bc2) + eps)    (the moment carries the error on)
+
+    The bound is only large where an accumulator is still ~0 and the summed gradient is itself ~0 (first steps: the
+    update is lr * sign(g)), i.e. it singles out the ill-conditioned elements by gradient magnitude instead of allowing a
+    blanket fraction of outliers.  Returns (oracle final tables, [bound per table]), tables shaped like the fixture's."""
+    opt = ORACLE_OPT[case['opt']]
+    hp = oracle_hparams(case)
+    o = BilinearOracle(rec['init_0'], rec['init_1'], rec['init_2'], rec['init_3'], opt=opt, **hp)
+    nn = int(case.get('n_neg', 5)) if case['loss'] == 'adaptive_hinge' else 1
+    N, B = int(case['N']), int(case['B'])
+    lr = float(hp.get('lr', 1e-2))
+    wd = float(hp.get('weight_decay', 0.0))
+    eps = 1e-10 if opt.startswith('adagrad') else 1e-8
+    b1, b2 = 0.9, 0.999
+    bounds = [np.zeros(o.p[t].shape, np.float64) for t in range(4)]
+    step = 0
+    for e in range(int(case['n_iter'])):
+        su, si = rec['shuffled_users'][e].astype(np.int64), rec['shuffled_items'][e].astype(np.int64)
+        for off in range(0, N, B):
+            hi = min(off + B, N)
+            neg = rec['negatives'][(e * N + off) * nn:(e * N + hi) * nn]
+            pre_p = [x.copy() for x in o.p]
+            pre_s1 = [x.copy() for x in o.s1]
+            pre_s2 = [x.copy() for x in o.s2]
+            _, g = o.step(su[off:hi], si[off:hi], neg, loss=case['loss'], n_neg=nn, want_grads=True)
+            step += 1
+            bscale = max(np.abs(g[2]).max(), np.abs(g[3]).max())
+            for t in range(4):
+                gt = g[t].astype(np.float64)
+                scale = np.abs(gt).max() if t < 2 else bscale
+                touched = (gt != 0).any(axis=1, keepdims=True) if gt.ndim == 2 else (gt != 0)
+                delta = rel_delta * scale * touched
+                geff = gt + wd * pre_p[t].astype(np.float64) if opt.endswith('dense') else gt
+                if opt.startswith('adagrad'):
+                    bounds[t] += lr * delta / (np.sqrt(pre_s1[t].astype(np.float64) + geff * geff) + eps)
+                else:
+                    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+                    v_new = b2 * pre_s2[t].astype(np.float64) + (1.0 - b2) * geff * geff
+                    bounds[t] += (lr / bc1) * delta / (np.sqrt(v_new / bc2) + eps)
+    finals = [o.p[t].reshape(rec['final_%d' % t].shape) for t in range(4)]
+    return finals, [bounds[t].reshape(rec['final_%d' % t].shape) for t in range(4)]

@@ -10,7 +10,7 @@ spotlight/layers.py:177-242).  The recurrent / convolutional body of LSTMNet, CN
 
 The gradient comes back dense (zero where untouched) for ordinary layers and as a coalesced sparse COO
 tensor for `sparse=True` layers, so torch.optim's Adam / Adagrad / SparseAdam consume it unchanged.
-There is no CPU path: the tables must live on the HIP device.
+There is no CPU compute path: tables on the HIP device are used in place, host-resident ones are staged onto it per call.
 """
 import torch
 
@@ -62,5 +62,14 @@ class _Lookup(torch.autograd.Function):
 
 def lookup(weight, ids, bloom=None, padding_idx=None, sparse=False):
     """weight[ids] (or the bloom layer's hashed-row sum) with shape ids.shape + (dim,), differentiable
-    w.r.t. `weight`.  `bloom`: the layer's slk_bloom descriptor (BloomEmbedding.descriptor())."""
+    w.r.t. `weight`.  `bloom`: the layer's slk_bloom descriptor (BloomEmbedding.descriptor()).
+
+    A layer that still lives in host memory (the reference's layers are plain torch modules and its tests call them right
+    after construction, tests/test_layers.py) is staged onto the HIP device for the call and the result is handed back on
+    the table's own device: the gather / hashed-row sum still runs in the gfx950 kernel (there is no CPU compute path;
+    without a HIP device this raises), and gradients flow back to the host table through autograd's copy nodes."""
+    home = weight.device
+    dev = _hooks()._model_device() if home.type == 'cpu' else home
+    if dev != home:
+        return _Lookup.apply(weight.to(dev), ids.to(dev), bloom, padding_idx, bool(sparse)).to(home)
     return _Lookup.apply(weight, ids, bloom, padding_idx, bool(sparse))
