@@ -143,7 +143,7 @@ def check_single_step_gradients(be, loss, D, U=50, I=40, B=128, nn=3, seed=11):
         assert np.array_equal(be.get(dev.p[t]).ravel(), np.asarray(params[t], np.float32).ravel())
 
 
-def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5):
+def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, bias_tables=(2, 3)):
     """Per element: how far ONE optimizer step may move a parameter / its state when the summed gradient is perturbed by
     delta = rel_delta * ||g||inf (per embedding table, the bias tables against their joint norm; touched rows only) --
     the north star's gradient tolerance carried through the update formulas:
@@ -154,11 +154,11 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5):
     lr, wd = float(hp.get('lr', 1e-2)), float(hp.get('weight_decay', 0.0))
     b1, b2 = hp.get('betas', (0.9, 0.999))
     eps = hp.get('eps') or (1e-10 if opt.startswith('adagrad') else 1e-8)
-    bscale = max(np.abs(g[2]).max(), np.abs(g[3]).max())
+    bscale = max(np.abs(g[t]).max() for t in bias_tables)
     out = []
-    for t in range(4):
+    for t in range(len(g)):
         gt = np.asarray(g[t], np.float64)
-        scale = np.abs(gt).max() if t < 2 else bscale
+        scale = bscale if t in bias_tables else np.abs(gt).max()
         touched = (gt != 0).any(axis=1, keepdims=True) if gt.ndim == 2 else (gt != 0)
         delta = np.broadcast_to(rel_delta * scale * touched, gt.shape)
         geff = gt + wd * np.asarray(pre_p[t], np.float64).reshape(gt.shape) if opt.endswith('dense') else gt
@@ -172,6 +172,24 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5):
             ds1, ds2 = (1.0 - b1) * delta, 2.0 * (1.0 - b2) * np.abs(geff) * delta
         out.append((dp, ds1, ds2))
     return out
+
+
+def assert_step_within_bounds(be, dev, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, bias_tables=(2, 3), what=''):
+    """After ONE engine step and ONE oracle step from the same tables / state: every element of every parameter and
+    optimizer-state tensor within 1e-5 * ||.||inf + step_update_bounds (no quota)."""
+    bounds = step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, bias_tables=bias_tables)
+    adam = opt in ('sparse_adam', 'adam_dense')
+    for t in range(len(g)):
+        dp, ds1, ds2 = bounds[t]
+        for got, want, bound, nm in ((dev.p[t], ora.p[t], dp, 'param'), (dev.s1[t], ora.s1[t], ds1, 'state1'),
+                                     (dev.s2[t], ora.s2[t], ds2, 'state2')):
+            if nm == 'state2' and not adam:
+                continue
+            w64 = np.asarray(want, np.float64)
+            d = np.abs(be.get(got).astype(np.float64).reshape(w64.shape) - w64)
+            tol = 1e-5 * max(np.abs(w64).max(), 1e-30) + bound.reshape(w64.shape)
+            assert not (d > tol).any(), ('%s step %d table %d %s: %d elements beyond the conditioned bound'
+                                         % (what, step, t, nm, int((d > tol).sum())), float(d.max()))
 
 
 def check_replays_reference_fixture(be, golden_dir, name):
@@ -274,19 +292,7 @@ def check_replays_reference_fixture(be, golden_dir, name):
                                be.ptr(mb_loss), d_neg_in=be.ptr(d_neg), stream=be.stream)
             assert dev2.optim.step == step
             assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (e, off)
-            bounds = step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step)
-            adam = opt in ('sparse_adam', 'adam_dense')
-            for t in range(4):
-                dp, ds1, ds2 = bounds[t]
-                for got, want, bound, what in ((dev2.p[t], ora.p[t], dp, 'param'), (dev2.s1[t], ora.s1[t], ds1, 'state1'),
-                                               (dev2.s2[t], ora.s2[t], ds2, 'state2')):
-                    if what == 'state2' and not adam:
-                        continue
-                    w64 = np.asarray(want, np.float64)
-                    d = np.abs(be.get(got).astype(np.float64).reshape(w64.shape) - w64)
-                    tol = 1e-5 * max(np.abs(w64).max(), 1e-30) + bound.reshape(w64.shape)
-                    assert not (d > tol).any(), ('step %d table %d %s: %d elements beyond the conditioned bound'
-                                                 % (step, t, what, int((d > tol).sum())), float(d.max()))
+            assert_step_within_bounds(be, dev2, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp)
     # chunking is value-neutral: the per-minibatch calls end where the per-epoch calls did, bit for bit
     for t in range(4):
         assert np.array_equal(be.get(dev2.p[t]), open_tables[t]), ('closed-loop run differs from the open-loop one', t)
@@ -432,10 +438,36 @@ def check_seq_replays_reference_fixture(be, golden_dir, name):
     assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
     st = eng.rng_get_state()
     assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
-    for t in range(2):
+    for t in range(2):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
         bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
         assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+    open_tables = [be.get(dev.p[t]).copy() for t in range(2)]
+    # ---- closed loop (see check_replays_reference_fixture): every minibatch from the engine's own tables, one oracle step
+    from oracle.oracle import PoolNetOracle
+    opt, hp = ORACLE_OPT[str(case['opt'])], _oracle_hparams(case)
+    dev2 = be.seq_model([rec['init_0'], rec['init_1']], opt=opt, item_bloom=desc, **hp)
+    step = 0
+    for e in range(int(case['n_iter'])):
+        sh = rec['shuffled'][e].astype(np.int64)
+        base = e * N * L * nn
+        for off in range(0, N, B):
+            hi = min(off + B, N)
+            neg = rec['negatives'][base + off * L * nn:base + hi * L * nn].astype(np.int64)
+            pre_p = [be.get(x).copy() for x in dev2.p]
+            pre_s1 = [be.get(x).copy() for x in dev2.s1]
+            pre_s2 = [be.get(x).copy() for x in dev2.s2]
+            ora = PoolNetOracle(pre_p[0], pre_p[1], opt=opt, state1=pre_s1, state2=pre_s2, step=step, item_bloom=desc, **hp)
+            want_loss, g = ora.step(sh[off:hi], neg, loss=str(case['loss']), n_neg=nn, want_grads=True)
+            step += 1
+            d_seqs, d_neg = be.alloc(sh[off:hi]), be.alloc(neg)
+            mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+            eng.poolnet_train(dev2.tables, dev2.optim, 0, be.ptr(d_seqs), hi - off, L, B, str(case['loss']), nn, be.ptr(mb_loss),
+                              d_neg_in=be.ptr(d_neg), stream=be.stream)
+            assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (e, off)
+            assert_step_within_bounds(be, dev2, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, bias_tables=(1,), what='seq')
+    for t in range(2):
+        assert np.array_equal(be.get(dev2.p[t]), open_tables[t]), ('closed-loop run differs from the open-loop one', t)
     # predictions on the reference's final tables
     fin = be.seq_model([rec['final_0'], rec['final_1']], item_bloom=desc)
     out = be.alloc(np.empty(int(case['I']), dtype=np.float32))
@@ -571,10 +603,40 @@ def check_bloom_replays_reference_fixture(be, golden_dir, name):
     losses = np.concatenate(losses)
     assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
     assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
-    for t in range(4):
+    for t in range(4):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
         bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
         assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+    open_tables = [be.get(dev.p[t]).copy() for t in range(4)]
+    # ---- closed loop (see check_replays_reference_fixture)
+    from oracle.oracle import BloomBilinearOracle
+    opt, hp = ORACLE_OPT[str(case['opt'])], _oracle_hparams(case)
+    dev2 = be.model([rec['init_%d' % t] for t in range(4)], opt=opt, user_bloom=mk(case['user_bloom']),
+                    item_bloom=mk(case['item_bloom']), **hp)
+    step = 0
+    for e in range(int(case['n_iter'])):
+        su, si = rec['shuffled_users'][e].astype(np.int64), rec['shuffled_items'][e].astype(np.int64)
+        for off in range(0, N, B):
+            hi = min(off + B, N)
+            neg = rec['negatives'][(e * N + off) * nn:(e * N + hi) * nn].astype(np.int64)
+            pre_p = [be.get(x).copy() for x in dev2.p]
+            pre_s1 = [be.get(x).copy() for x in dev2.s1]
+            pre_s2 = [be.get(x).copy() for x in dev2.s2]
+            ora = BloomBilinearOracle(*pre_p, user_bloom=mk(case['user_bloom']), item_bloom=mk(case['item_bloom']), opt=opt,
+                                      step=step, **hp)
+            for t in range(4):
+                ora.s1[t][...] = pre_s1[t].reshape(ora.s1[t].shape)
+                ora.s2[t][...] = pre_s2[t].reshape(ora.s2[t].shape)
+            want_loss, g = ora.step(su[off:hi], si[off:hi], neg, loss=str(case['loss']), n_neg=nn, want_grads=True)
+            step += 1
+            d_su, d_si, d_neg = be.alloc(su[off:hi]), be.alloc(si[off:hi]), be.alloc(neg)
+            mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+            eng.bilinear_train(dev2.tables, dev2.optim, be.ptr(d_su), be.ptr(d_si), hi - off, B, str(case['loss']), nn,
+                               be.ptr(mb_loss), d_neg_in=be.ptr(d_neg), stream=be.stream)
+            assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (e, off)
+            assert_step_within_bounds(be, dev2, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, what='bloom')
+    for t in range(4):
+        assert np.array_equal(be.get(dev2.p[t]), open_tables[t]), ('closed-loop run differs from the open-loop one', t)
 
 
 BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_default', 'bloom_both_bpr_adagrad',
@@ -746,10 +808,34 @@ def check_explicit_replays_reference_fixture(be, golden_dir, name):
     losses = np.concatenate(losses)
     assert abs(losses[0] - rec['losses'][0]) / abs(rec['losses'][0]) < 1e-5
     assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
-    for t in range(4):
+    for t in range(4):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
         bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
         assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+    open_tables = [be.get(dev.p[t]).copy() for t in range(4)]
+    # ---- closed loop (see check_replays_reference_fixture)
+    opt, hp = ORACLE_OPT[str(case['opt'])], _oracle_hparams(case)
+    dev2 = be.model([rec['init_%d' % t] for t in range(4)], opt=opt, **hp)
+    step = 0
+    for e in range(int(case['n_iter'])):
+        su, si = rec['shuffled_users'][e].astype(np.int64), rec['shuffled_items'][e].astype(np.int64)
+        sr = rec['shuffled_ratings'][e].astype(np.float32)
+        for off in range(0, N, B):
+            hi = min(off + B, N)
+            pre_p = [be.get(x).copy() for x in dev2.p]
+            pre_s1 = [be.get(x).copy() for x in dev2.s1]
+            pre_s2 = [be.get(x).copy() for x in dev2.s2]
+            ora = BilinearOracle(*pre_p, opt=opt, sparse_grads=True, state1=pre_s1, state2=pre_s2, step=step, **hp)
+            want_loss, g = ora.explicit_step(su[off:hi], si[off:hi], sr[off:hi], loss=loss, want_grads=True)
+            step += 1
+            d_u, d_i, d_r = be.alloc(su[off:hi]), be.alloc(si[off:hi]), be.alloc(sr[off:hi])
+            mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+            eng.bilinear_train_explicit(dev2.tables, dev2.optim, be.ptr(d_u), be.ptr(d_i), be.ptr(d_r), hi - off, B, loss,
+                                        be.ptr(mb_loss), stream=be.stream)
+            assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (e, off)
+            assert_step_within_bounds(be, dev2, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, what='explicit')
+    for t in range(4):
+        assert np.array_equal(be.get(dev2.p[t]), open_tables[t]), ('closed-loop run differs from the open-loop one', t)
 
 
 def check_high_row_ids(be, U=(1 << 25) + 3, I=(1 << 21) + 1, D=4, N=4000, B=1024, seed=2):
