@@ -22,19 +22,32 @@ rs = np.random.RandomState(42)
 inter = Interactions(rs.randint(0, 943, 100000).astype(np.int32), rs.randint(0, 1682, 100000).astype(np.int32),
                      num_users=943, num_items=1682)
 train, test = random_train_test_split(inter, random_state=np.random.RandomState(42))
-mk = lambda: ImplicitFactorizationModel(loss='bpr', embedding_dim=32, batch_size=1024, n_iter=10, learning_rate=1e-2,
-                                        l2=1e-6, use_cuda=True, random_state=np.random.RandomState(42))
-mk().fit(train)  # warm-up: library load, scratch
-torch.cuda.synchronize()
-model = mk()
-t0 = time.perf_counter()
-model.fit(train)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-t1 = time.perf_counter()
-mrr = mrr_score(model, test, train=train).mean()
-t2 = time.perf_counter()
-print(json.dumps({'workload': 'C1 shape: 943 x 1682, 80000 train interactions, dim 32, bpr, default Adam + l2, batch 1024, '
-                              '10 epochs', 'fit_s': dt, 'interactions_per_s': len(train) * 10 / dt,
-                  'us_per_minibatch': dt / (10 * ((len(train) + 1023) // 1024)) * 1e6, 'mrr_eval_s': t2 - t1,
-                  'mrr_on_uniform_synthetic_data': float(mrr)}))
+from spotlight_amd.factorization import implicit as host  # noqa: E402
+
+out = {'workload': 'C1 shape: 943 x 1682, 80000 train interactions, dim 32, bpr, batch 1024, 10 epochs (the reference\'s '
+                   'tests/factorization/test_implicit.py:40-57 kwargs)', 'runs': []}
+for name, kw in (('default Adam + l2 (dense: every row every step; per-minibatch launches)', dict(l2=1e-6)),
+                 ('optimizer_func=Adagrad (row-sparse; persistent epoch kernel)',
+                  dict(optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2)))):
+    for pipelined in (True, False):
+        host._PIPELINE_MAX_DRAWS = (1 << 22) if pipelined else 0
+        mk = lambda: ImplicitFactorizationModel(loss='bpr', embedding_dim=32, batch_size=1024, n_iter=10, learning_rate=1e-2,
+                                                use_cuda=True, random_state=np.random.RandomState(42), **kw)
+        mk().fit(train)  # warm-up: library load, scratch
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            model = mk()
+            t0 = time.perf_counter()
+            model.fit(train)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        t1 = time.perf_counter()
+        mrr = mrr_score(model, test, train=train).mean()
+        t2 = time.perf_counter()
+        out['runs'].append({'optimizer': name, 'next_epoch_prepared_while_training': pipelined, 'fit_s': best,
+                            'interactions_per_s': len(train) * 10 / best,
+                            'us_per_minibatch_end_to_end': best / (10 * ((len(train) + 1023) // 1024)) * 1e6,
+                            'mrr_eval_s': t2 - t1, 'mrr_on_uniform_synthetic_data': float(mrr)})
+print(json.dumps(out))

@@ -198,6 +198,11 @@ class Engine(object):
         self._check(self._lib.slk_rng_get_state(self._ctx, key.ctypes.data, C.byref(pos)))
         return ('MT19937', key, int(pos.value), 0, 0.0)
 
+    def check(self):
+        """Synchronises the ctx's last stream and raises if a kernel reported a failure through the ctx (the sticky flags
+        slk_rng_get_state reports: sampler ran dry, persistent epoch kernel abandoned a launch)."""
+        self.rng_get_state()
+
     def sample_items(self, num_items, count, d_out, stream=0):
         self._check(self._lib.slk_sample_items(self._ctx, int(num_items), int(count), d_out, stream))
 

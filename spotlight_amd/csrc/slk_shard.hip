@@ -118,14 +118,15 @@ __global__ __launch_bounds__(256) void k_shard_slots(const uint32_t *uit, const 
     }
 }
 
-// owner side: one block per received segment (source, unit): ids move from [source][unit] order
+// owner side: blockIdx.x = received segment (source, unit), blockIdx.y strides inside it (a single-rank run has two
+// segments of a million ids each: one block per segment took 3.5 ms, profiles/r02_a_kernel_stats.md): ids move from [source][unit] order
 // to [unit][source] order, with the item-pass key (minibatch, row) and payload (slot inside the
 // minibatch's record buffer).  segtab[seg] = {from, to, len, minibatch, first slot of the minibatch}
 __global__ __launch_bounds__(256) void k_shard_regroup(const int32_t *recv_ids, const uint32_t *segtab, unsigned ibits,
                                                        int32_t *rid, uint32_t *ikey, uint32_t *ipay) {
     const uint32_t *sg = segtab + 5 * (size_t)blockIdx.x;
     const uint32_t from = sg[0], to = sg[1], len = sg[2], mb = sg[3], mb_first = sg[4];
-    for (uint32_t i = threadIdx.x; i < len; i += 256) {
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < len; i += gridDim.y * 256) {
         const int32_t id = recv_ids[from + i];
         rid[to + i] = id;
         ikey[to + i] = (mb << ibits) | (uint32_t)id;
@@ -406,7 +407,13 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
             }
         slk_prof_begin(ctx, SLK_K_PREP, s);
         SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_SEGTAB].p, tab, (size_t)nseg * 5 * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_shard_regroup, dim3((unsigned)nseg), dim3(256), 0, s, d_recv_ids,
+        // enough blocks per segment to fill the chip whatever the segment count is
+        unsigned per_seg = (unsigned)((8 * ctx->num_cus + nseg - 1) / nseg);
+        const unsigned seg_blocks = (unsigned)((nr / nseg + 255) / 256) + 1u;
+        if (per_seg > seg_blocks) per_seg = seg_blocks;
+        if (per_seg < 1u) per_seg = 1u;
+        if (per_seg > 65535u) per_seg = 65535u;
+        hipLaunchKernelGGL(k_shard_regroup, dim3((unsigned)nseg, per_seg), dim3(256), 0, s, d_recv_ids,
                            (const uint32_t *)ctx->extra[SH_SEGTAB].p, ibits, (int32_t *)ctx->extra[SH_RID].p,
                            (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_shard_regroup");

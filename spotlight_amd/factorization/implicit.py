@@ -16,6 +16,7 @@ from spotlight_amd.layers import BloomEmbedding, ScaledEmbedding, ZeroEmbedding
 from spotlight_amd.torch_utils import set_seed
 
 _ENGINES = {}
+_PIPELINE_MAX_DRAWS = 1 << 22  # fit(): epochs of at most this many negative draws prepare the next epoch while training
 
 
 def _engine_for(device):
@@ -29,6 +30,23 @@ def _engine_for(device):
 def _stream_for(device):
     """Raw hipStream_t of torch's current stream on `device`."""
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_PREP = {}
+
+
+def _prep_lane_for(device):
+    """(engine, raw stream) on which the NEXT epoch's shuffle and negatives are prepared while the current epoch trains
+    (fit() of small datasets, see ImplicitFactorizationModel.fit): a second slk_ctx with its own scratch and a side HIP
+    stream.  Under the GPU-less test harness (one synchronous emulator engine) it is the training engine itself."""
+    engine = _engine_for(device)
+    if _native._LIB is None or engine._lib is not _native._LIB:
+        return engine, _stream_for(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index not in _PREP:
+        _PREP[index] = (_native.Engine(index), torch.cuda.Stream(device))
+    prep_engine, side = _PREP[index]
+    return prep_engine, side.cuda_stream
 
 
 def _model_device():
@@ -280,6 +298,9 @@ class ImplicitFactorizationModel(object):
         # (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
         d_users0 = ids_to_device(user_ids, device)
         d_items0 = ids_to_device(item_ids, device)
+        nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
+        if self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS:
+            return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose)
         d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         for epoch_num in range(self._n_iter):
@@ -302,6 +323,51 @@ class ImplicitFactorizationModel(object):
                 print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
             if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):
+        """The epoch loop for datasets of the reference's own scale (MovieLens-100K: 80 000 interactions per epoch): there an
+        epoch trains in about a millisecond and the numpy-exact device shuffle -- a chain of small launches and read-backs --
+        costs as much again.  The RandomState stream is consumed in the reference's order (shuffle of epoch e, negatives of
+        epoch e, shuffle of epoch e + 1, ...), but nothing in training touches it, so epoch e + 1's shuffle and negatives are
+        drawn on a second slk_ctx / HIP stream while epoch e trains from its own (already drawn) negatives.  Same ids, same
+        negatives, same RandomState afterwards, bit-identical tables; only the wall time changes."""
+        prep, prep_stream = _prep_lane_for(device)
+        torch.cuda.current_stream(device).synchronize() if device.type == 'cuda' else None  # the id upload is complete
+        bufs = [(torch.empty_like(d_users0), torch.empty_like(d_items0),
+                 torch.empty(n * nn, dtype=torch.int64, device=device)) for _ in range(2)]
+        d_perm = torch.empty(n, dtype=torch.int64, device=device)
+
+        def prepare(slot):
+            # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as numpy would consume it
+            prep.rng_set_state(self._random_state.get_state())
+            d_users, d_items, d_neg = bufs[slot]
+            device_epoch_shuffle(prep, self._random_state, n, d_perm, [(d_users0, d_users, 1), (d_items0, d_items, 1)],
+                                 prep_stream)
+            # one randint per minibatch == one contiguous draw over the epoch (sampling.py:34)
+            prep.sample_items(self._num_items, n * nn, d_neg.data_ptr(), stream=prep_stream)
+            self._random_state.set_state(prep.rng_get_state())  # synchronises the prep stream
+
+        prepare(0)
+        for epoch_num in range(self._n_iter):
+            d_users, d_items, d_neg = bufs[epoch_num % 2]
+            ostruct = binding.as_struct()
+            engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n, self._batch_size, self._loss,
+                                  self._num_negative_samples, mb_loss.data_ptr(), d_neg_in=d_neg.data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            state_after_epoch = self._random_state.get_state()
+            if epoch_num + 1 < self._n_iter:
+                prepare((epoch_num + 1) % 2)  # overlaps the training kernels of this epoch
+
+            epoch_loss = float(mb_loss.double().mean().item())  # also waits for this epoch's kernels
+            engine.check()  # errors the training kernels can only report through the ctx (e.g. an abandoned launch)
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                # the reference stops here having consumed the stream up to this epoch's negatives only
+                self._random_state.set_state(state_after_epoch)
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
     def predict(self, user_ids, item_ids=None):

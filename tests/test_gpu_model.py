@@ -266,3 +266,9 @@ def test_lookup_matches_torch_embedding_on_gpu(dim, sparse):
     scale = exact.abs().max()
     assert float((g.double() - exact).abs().max() / scale) < 1e-5
     assert float((w_ref.grad.double() - exact).abs().max() / scale) < 1e-4
+
+
+def test_pipelined_fit_is_value_neutral_on_gpu():
+    """Epoch e + 1's shuffle and negatives drawn on a second ctx / HIP stream while epoch e trains: same tables, bit for bit."""
+    from test_host_model import check_pipelined_fit_is_value_neutral
+    check_pipelined_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())

@@ -233,3 +233,35 @@ def test_bloom_layer_api(emu_device):
         BloomEmbedding(10, 4, num_hash_functions=25)
     with pytest.raises(NotImplementedError):
         BloomEmbedding(10, 4, bag=True)
+
+
+def check_pipelined_fit_is_value_neutral(use_cuda=False, to_numpy=lambda w: w.detach().numpy()):
+    """fit() of a small dataset prepares epoch e + 1's shuffle and negatives while epoch e trains
+    (ImplicitFactorizationModel._fit_pipelined); the serial loop it replaces must give the same tables, losses and
+    RandomState, bit for bit."""
+    rs = np.random.RandomState(12)
+    inter = Interactions(rs.randint(0, 90, 2000).astype(np.int32), rs.randint(0, 60, 2000).astype(np.int32),
+                         num_users=90, num_items=60)
+    results = []
+    for limit in (host._PIPELINE_MAX_DRAWS, 0):
+        old = host._PIPELINE_MAX_DRAWS
+        host._PIPELINE_MAX_DRAWS = limit
+        try:
+            for loss, kw in (('bpr', dict(optimizer_func=_adagrad)), ('adaptive_hinge', dict(num_negative_samples=3)),
+                             ('pointwise', dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=0.01)))):
+                model = ImplicitFactorizationModel(loss=loss, embedding_dim=16, n_iter=3, batch_size=256, use_cuda=use_cuda,
+                                                   random_state=np.random.RandomState(7), **kw)
+                model.fit(inter)
+                model.fit(inter)  # resume: optimizer steps and the RandomState carry over
+                st = model._random_state.get_state()
+                results.append([to_numpy(w).copy() for w in model._net.tables()] + [st[1].copy(), np.array(st[2])])
+        finally:
+            host._PIPELINE_MAX_DRAWS = old
+    half = len(results) // 2
+    for a, b in zip(results[:half], results[half:]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_pipelined_fit_is_value_neutral(emu_device):
+    check_pipelined_fit_is_value_neutral()
