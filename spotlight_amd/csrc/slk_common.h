@@ -30,6 +30,16 @@
 #define SLK_DRAIN_VMEM() ((void)0)
 #endif
 
+// Marks the next plain kernel launch as one whose workgroups wait for each other inside the kernel (grid barrier): all of
+// them must be resident at once.  On the GPU that is a property of the launch geometry (at most one wavefront-sized
+// workgroup per CU, slk_epoch.hip) and the marker is empty; the test harness, which otherwise executes one block at a
+// time, runs the marked grid's blocks concurrently.
+#if defined(__HIPCC__)
+#define SLK_RESIDENT_GRID_LAUNCH() ((void)0)
+#else
+#define SLK_RESIDENT_GRID_LAUNCH() ::emu::next_launch_resident()
+#endif
+
 // ---------------------------------------------------------------------------------------
 // ctx
 // ---------------------------------------------------------------------------------------
@@ -89,6 +99,8 @@ struct slk_ctx {
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
     int opt_epoch_barrier = -1;    // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters), -1 by grid size
+    int opt_epoch_cooperative = 0; // 1: hipLaunchCooperativeKernel (launch-time residency check; it also keeps kernels of OTHER streams
+                                   // from running beside it, measured: profiles/r02_h_c1_fit_timeline_adagrad.json), 0: plain launch
     int opt_epoch_debug = 0;       // measurement only: 1 skip the phases' work, 2 do not wait at barriers, 4 no store drain
     int opt_epoch_max_grid = 256;  // workgroups (one wavefront each) of the persistent launch, <= one per CU
     int64_t opt_epoch_dense_elems = 0;  // dense optimizers: largest model (parameters) the persistent route takes (0: never)

@@ -567,8 +567,18 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     slk_prof_begin(ctx, SLK_K_EPOCH, s);
     void *kargs[1] = {&e};
     const size_t lds = 4 * sizeof(double) + 16;
-    // cooperative: the launch is refused (not deadlocked) if the grid could not be resident at once
-    hipError_t le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(SLK_EPOCH_TB), kargs, lds, s);
+    // The grid (<= one wavefront-sized workgroup per CU) is resident as a whole on any device that is not saturated by other
+    // work for seconds, which is what the barrier's bounded spins tolerate.  A plain launch lets kernels of other streams
+    // (the next epoch's shuffle and negatives, implicit.py's pipelined fit) run beside it; the cooperative form adds a
+    // launch-time residency check but serialises the device.
+    hipError_t le = hipSuccess;
+    if (ctx->opt_epoch_cooperative) {
+        le = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(SLK_EPOCH_TB), kargs, lds, s);
+    } else {
+        SLK_RESIDENT_GRID_LAUNCH();
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(SLK_EPOCH_TB), lds, s, e);
+        le = hipGetLastError();
+    }
     slk_prof_end(ctx, s);
     if (le != hipSuccess) {
         // the grid cannot be resident at once (device shared with other work, cooperative launches unsupported): nothing

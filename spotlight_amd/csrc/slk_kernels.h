@@ -124,8 +124,8 @@ enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
 
 // How the item pass turns an occurrence payload r into a gradient contribution:
 //   SNAP  r = pos*NP + s; record(pos) = [u_old (D)], g_s = gsn[r - begin*NP];  vec = g_s * u_old, bias g_s
-//   SEQ   r = pos*NP + s; record(pos) = [repr (D) | g_0 * repr + hist (D)], g_s likewise;
-//         vec = second half when s == 0, g_s * repr otherwise; bias g_s          (PoolNet)
+//   SEQ   r = pos*NP + s; record(pos) = [repr (D) | hist (D)], g_s likewise;
+//         vec = g_s * repr (+ hist when s == 0), bias g_s                       (PoolNet)
 //   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (row-sharded)
 enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2 };
 
@@ -222,12 +222,15 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
         } else {
-            // PoolNet: the sequence's own item (s == 0) takes the pre-combined row gp * representation + history
-            // gradient the sequence pass left in the record's second half; a sampled candidate g * representation
             gb = a.gsn[r - a.begin * NP];
-            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + (s == 0 ? D : 0) + d0) : slk_vzero<VEC>();
+            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) c.v[i] = s == 0 ? u.v[i] : gb * u.v[i];
+            for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
+            if (s == 0 && on) {
+                const slk_vec<VEC> h = slk_vload<VEC>(rec + D + d0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c.v[i] += h.v[i];
+            }
         }
     }
 }

@@ -13,7 +13,7 @@
 //        sums are stitched with a block-level scan (forward: prefix sum + non-zero count ->
 //        representation -> scores -> loss -> dL/dscore; backward: suffix sum of
 //        dL/d(prefix sum)).  Per timestep it writes one record
-//             [ representation (D) | gp * representation + history gradient (D) ]   (+ dL/dscore in a side array)
+//             [ representation (D) | history gradient (D) | dL/dscore of the 1+n pairs ]
 //        -- everything the item rows' owners need.
 //   ITEM PASS (slk_kernels.h, SEQ mode)  occurrences (timestep, pair) sorted by item; one
 //        owner group per unique item sums  g * representation (+ history gradient for the
@@ -202,15 +202,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                     gp = gp * w;
                     gn = gn * w;
                     float *rec = recs + (size_t)t * a.RS;
-                    if (on) {
-                        // record = [ representation | gp * representation (+ history gradient, added in (C)) ]: the owner of
-                        // the sequence's own item then reads ONE row per occurrence instead of two
-                        slk_vec<VEC> cp;
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) cp.v[i] = gp * rep.v[i];
-                        slk_vstore<VEC>(rec + d0, rep);
-                        slk_vstore<VEC>(rec + D + d0, cp);
-                    }
+                    if (on) slk_vstore<VEC>(rec + d0, rep);
                     if (lane == 0) {
                         loss_acc += (double)(l * mask);
                         // 32-bit index off the uniform base: no 64-bit address pair held in VGPRs
@@ -254,13 +246,7 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                 for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
             }
             for (int t = t1 - 1; t >= t0; --t) {
-                if (on) {  // gp * representation (this thread's own store of (B2)) + history gradient
-                    float *hp = recs + (size_t)t * a.RS + D + d0;
-                    slk_vec<VEC> cp = slk_vload<VEC>(hp);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) cp.v[i] += suf.v[i];
-                    slk_vstore<VEC>(hp, cp);
-                }
+                if (on) slk_vstore<VEC>(recs + (size_t)t * a.RS + D + d0, suf);
                 const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
@@ -418,14 +404,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(2) void k_seq_pass_reg(slk_se
                         gp = gp * w;
                         gn = gn * w;
                         float *rec = recs + (size_t)t * a.RS;
-                        if (on) {
-                            // record = [ representation | gp * representation (+ history gradient, added in (C)) ]
-                            slk_vec<VEC> cp;
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) cp.v[i] = gp * rep.v[i];
-                            slk_vstore<VEC>(rec + d0, rep);
-                            slk_vstore<VEC>(rec + D + d0, cp);
-                        }
+                        if (on) slk_vstore<VEC>(rec + d0, rep);
                         if (lane == 0) {
                             loss_acc += (double)(l * mask);
                             // 32-bit index off the uniform base: no 64-bit address pair held in VGPRs
@@ -472,13 +451,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(2) void k_seq_pass_reg(slk_se
 #pragma unroll
             for (int k = CMAX - 1; k >= 0; --k) {
                 if (k < cnt) {
-                    if (on) {  // gp * representation (this thread's own store of (B2)) + history gradient
-                        float *hp = recs + (size_t)(t0 + k) * a.RS + D + d0;
-                        slk_vec<VEC> cp = slk_vload<VEC>(hp);
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) cp.v[i] += suf.v[i];
-                        slk_vstore<VEC>(hp, cp);
-                    }
+                    if (on) slk_vstore<VEC>(recs + (size_t)(t0 + k) * a.RS + D + d0, suf);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) suf.v[i] += e[k].v[i];
                 }

@@ -67,6 +67,14 @@ void *dyn_shared() { return blk().dyn.data(); }
 static void yield_to_scheduler() { emu_ctx_switch(&cur->sp, g_sched_sp); }
 void yield() { yield_to_scheduler(); }
 
+static bool g_resident_next = false;
+void next_launch_resident() { g_resident_next = true; }
+bool take_resident_flag() {
+    const bool f = g_resident_next;
+    g_resident_next = false;
+    return f;
+}
+
 static void fiber_entry() {
     (*g_body)();
     Block &b = blk();

@@ -74,6 +74,8 @@ void *dyn_shared();
 void yield();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 void launch_coop(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+void next_launch_resident();   // SLK_RESIDENT_GRID_LAUNCH(): the next plain launch runs all of its blocks concurrently
+bool take_resident_flag();
 void syncthreads();
 unsigned long long shfl_exchange(unsigned long long v, int src_lane_in_wave, int width);
 }  // namespace emu
@@ -87,7 +89,10 @@ unsigned long long shfl_exchange(unsigned long long v, int src_lane_in_wave, int
 template <class... KArgs, class... Args>
 static inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem,
                                       hipStream_t, Args... args) {
-    emu::launch(grid, block, shmem, [=]() { kernel(static_cast<KArgs>(args)...); });
+    if (emu::take_resident_flag())
+        emu::launch_coop(grid, block, shmem, [=]() { kernel(static_cast<KArgs>(args)...); });
+    else
+        emu::launch(grid, block, shmem, [=]() { kernel(static_cast<KArgs>(args)...); });
 }
 
 // cooperative launch: all blocks resident, arguments passed as an array of pointers (one kernel parameter here)

@@ -1013,7 +1013,7 @@ def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------
 def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, B=256, seed=31, chunk=None, epochs=2,
-                                        max_grid=None, barrier=-1):
+                                        max_grid=None, barrier=-1, cooperative=0):
     """The persistent route (option epoch_kernel = 1: every minibatch of a chunk in one cooperative launch) performs the
     launch path's arithmetic in the launch path's order: losses to fp32 summation-order noise, negatives, RNG state and
     EVERY table / optimizer-state tensor bit for bit -- including the dense optimizers, whose full-table sweep the
@@ -1037,6 +1037,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         if max_grid:
             eng.set_option('epoch_max_grid', max_grid)
         eng.set_option('epoch_barrier', barrier)
+        eng.set_option('epoch_cooperative', cooperative)
         try:
             dev = be.model(params, opt=opt, **hp)
             eng.rng_set_state(state)
@@ -1068,6 +1069,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('epoch_max_grid', 256)
             eng.set_option('epoch_barrier', -1)
+            eng.set_option('epoch_cooperative', 0)
     (la, ta), (lb, tb) = results
     assert np.abs(la - lb).max() <= 2e-6 * np.abs(la).max(), (la, lb)
     for k, (a, b) in enumerate(zip(ta, tb)):

@@ -33,6 +33,10 @@ def test_epoch_kernel_heavy_duplicates_tiny_tables_and_one_workgroup(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 8, U=40, I=30, N=300, B=64, max_grid=1)
 
 
+def test_epoch_kernel_cooperative_launch_form(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 16, cooperative=1, epochs=1)
+
+
 def test_epoch_kernel_several_chunks(be):
     """chunks of 2 minibatches: the launch is repeated per chunk, the step count and RNG stream carry over"""
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'sparse_adam', 16, N=1500, B=128, chunk=256)

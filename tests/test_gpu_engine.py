@@ -253,6 +253,10 @@ def test_epoch_kernel_sizes_and_layouts(be, D, U, I, B, N):
         ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'adam_dense', D, U=U, I=I, N=N, B=B, epochs=1)
 
 
+def test_epoch_kernel_cooperative_launch_form(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2, cooperative=1)
+
+
 def test_epoch_kernel_two_level_barrier(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2, barrier=1)
     ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 64, U=3000, I=1000, N=9000, B=256, epochs=1, barrier=1)
