@@ -79,6 +79,14 @@ int slk_prep_stream_init(slk_ctx *ctx) {
     return SLK_OK;
 }
 
+hipStream_t slk_copy_stream(slk_ctx *ctx) {
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->copy_stream = nullptr;  // the null stream still gives correct results
+    }
+    return ctx->copy_stream;
+}
+
 SLK_EXPORT int slk_abi_version(void) { return SLK_ABI_VERSION; }
 
 SLK_EXPORT int slk_ctx_create(slk_ctx **out, int device_id) {
@@ -138,6 +146,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
     if (ctx->d_jump) (void)hipFree(ctx->d_jump);
     delete ctx;

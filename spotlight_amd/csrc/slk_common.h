@@ -109,6 +109,7 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // small state copies (slk_rng_{set,get}_state): never the null stream
     hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)
     // row-sharded path (slk_shard.hip): geometry of the chunk staged by slk_shard_chunk_begin/commit
@@ -143,6 +144,8 @@ void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s);
 void slk_prof_end(slk_ctx *ctx, hipStream_t s);
 int slk_prof_drain(slk_ctx *ctx);
 int slk_prep_stream_init(slk_ctx *ctx);
+// the ctx's own non-blocking stream for small host <-> device copies that must not touch the null stream
+hipStream_t slk_copy_stream(slk_ctx *ctx);
 
 #define SLK_HIP(ctx, call)                                                                   \
     do {                                                                                     \

@@ -358,7 +358,11 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
     memset(&h, 0, sizeof(h));
     memcpy(h.key, h_key, sizeof(h.key));
     h.pos = pos;
-    SLK_HIP(ctx, hipMemcpy(ctx->d_rng, &h, sizeof(h), hipMemcpyHostToDevice));
+    // stream-ordered, not a null-stream hipMemcpy: that one would wait for (and hold up) the work of every other stream of
+    // the process -- e.g. the training kernels another ctx has in flight while this one prepares the next epoch
+    hipStream_t cs = slk_copy_stream(ctx);
+    SLK_HIP(ctx, hipMemcpyAsync(ctx->d_rng, &h, sizeof(h), hipMemcpyHostToDevice, cs));
+    SLK_HIP(ctx, hipStreamSynchronize(cs));
     return SLK_OK;
 }
 
@@ -367,7 +371,9 @@ SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->last_stream) SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     slk_rng_dev h;
-    SLK_HIP(ctx, hipMemcpy(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost));
+    hipStream_t cs = slk_copy_stream(ctx);
+    SLK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost, cs));
+    SLK_HIP(ctx, hipStreamSynchronize(cs));
     if (h.insufficient)
         return slk_fail(ctx, SLK_EIO, "sampler ran out of generated words (rejection tail > 12 sigma)");
     if (h.epoch_abort)

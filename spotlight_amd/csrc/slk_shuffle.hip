@@ -321,8 +321,8 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     }
     need_words += 12.0 * sqrt(2.0 * (double)N) + 4096.0;
     int32_t pos0 = 0;
+    SLK_HIP(ctx, hipMemcpyAsync(&pos0, &ctx->d_rng->pos, sizeof(pos0), hipMemcpyDeviceToHost, s));
     SLK_HIP(ctx, hipStreamSynchronize(s));
-    SLK_HIP(ctx, hipMemcpy(&pos0, &ctx->d_rng->pos, sizeof(pos0), hipMemcpyDeviceToHost));
     const unsigned long long nblocks = 1ull + (unsigned long long)((need_words + (double)pos0) / SLK_MT_N) + 1ull;
     const unsigned long long total_words = nblocks * SLK_MT_N;
     if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
