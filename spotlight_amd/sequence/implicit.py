@@ -172,6 +172,10 @@ class ImplicitSequenceModel(object):
         d_prev = _host.ids_to_device(sequences, device)
         d_sequences = torch.empty_like(d_prev)
         d_perm = torch.empty(n_seq, dtype=torch.int64, device=device)
+        nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
+        if self._n_iter > 1 and n_seq * seq_len * nn <= _host._PIPELINE_MAX_DRAWS:
+            return self._fit_pipelined(binding, engine, device, stream, tables, d_prev, d_sequences, d_perm, n_seq, seq_len, nn,
+                                       mb_loss, verbose)
         for epoch_num in range(self._n_iter):
             engine.rng_set_state(self._random_state.get_state())
             _host.device_epoch_shuffle(engine, self._random_state, n_seq, d_perm, [(d_prev, d_sequences, seq_len)],
@@ -190,6 +194,44 @@ class ImplicitSequenceModel(object):
                 print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
             if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def _fit_pipelined(self, binding, engine, device, stream, tables, d_prev, d_sequences, d_perm, n_seq, seq_len, nn, mb_loss,
+                       verbose):
+        """Small datasets (see ImplicitFactorizationModel._fit_pipelined): epoch e + 1's shuffle (composed with epoch e's, as
+        the reference's rebinding of `sequences` does) and negatives are drawn on a second slk_ctx / HIP stream while epoch e
+        trains from its own, already drawn negatives.  Same sequences, negatives, RandomState and tables, bit for bit."""
+        prep, prep_stream = _host._prep_lane_for(device)
+        torch.cuda.current_stream(device).synchronize() if device.type == 'cuda' else None  # the upload is complete
+        negs = [torch.empty(n_seq * seq_len * nn, dtype=torch.int64, device=device) for _ in range(2)]
+
+        def prepare(src, dst, d_neg):
+            prep.rng_set_state(self._random_state.get_state())
+            _host.device_epoch_shuffle(prep, self._random_state, n_seq, d_perm, [(src, dst, seq_len)], prep_stream)
+            prep.sample_items(self._num_items, n_seq * seq_len * nn, d_neg.data_ptr(), stream=prep_stream)
+            self._random_state.set_state(prep.rng_get_state())  # synchronises the prep stream
+
+        prepare(d_prev, d_sequences, negs[0])
+        for epoch_num in range(self._n_iter):
+            ostruct = binding.as_struct()
+            engine.poolnet_train(tables, ostruct, self._padding_idx(), d_sequences.data_ptr(), n_seq, seq_len,
+                                 self._batch_size, self._loss, self._num_negative_samples, mb_loss.data_ptr(),
+                                 d_neg_in=negs[epoch_num % 2].data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            state_after_epoch = self._random_state.get_state()
+            if epoch_num + 1 < self._n_iter:
+                # this epoch's (shuffled) sequences are the source of the next permutation; its previous source is free
+                prepare(d_sequences, d_prev, negs[(epoch_num + 1) % 2])
+            d_prev, d_sequences = d_sequences, d_prev
+
+            epoch_loss = float(mb_loss.double().mean().item())  # also waits for this epoch's kernels
+            engine.check()
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                self._random_state.set_state(state_after_epoch)
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
     def _fit_autograd(self, sequences, verbose):

@@ -272,3 +272,8 @@ def test_pipelined_fit_is_value_neutral_on_gpu():
     """Epoch e + 1's shuffle and negatives drawn on a second ctx / HIP stream while epoch e trains: same tables, bit for bit."""
     from test_host_model import check_pipelined_fit_is_value_neutral
     check_pipelined_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
+
+
+def test_pipelined_seq_fit_is_value_neutral_on_gpu():
+    from test_host_seq_model import check_pipelined_seq_fit_is_value_neutral
+    check_pipelined_seq_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
