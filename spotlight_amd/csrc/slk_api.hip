@@ -176,8 +176,6 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_max_grid = (int)value;
     } else if (!strcmp(name, "epoch_barrier") && value >= -1 && value <= 1) {
         ctx->opt_epoch_barrier = (int)value;
-    } else if (!strcmp(name, "fused_shuffle") && (value == 0 || value == 1)) {
-        ctx->opt_fused_shuffle = (int)value;
     } else if (!strcmp(name, "epoch_cooperative") && (value == 0 || value == 1)) {
         ctx->opt_epoch_cooperative = (int)value;
     } else if (!strcmp(name, "epoch_debug") && value >= 0 && value <= 7) {

@@ -128,7 +128,6 @@ struct slk_ctx {
     int64_t em_occ = -1, em_rows = 0, em_segments = -1;
     int em_dim = 0;
 
-    int opt_fused_shuffle = 1;      // slk_shuffle_perm, n <= 2^17: all draws in one single-workgroup launch (0: range-by-range sweeps)
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
 
     // profiling

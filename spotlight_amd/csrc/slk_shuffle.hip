@@ -216,171 +216,6 @@ __global__ __launch_bounds__(64) void k_fy_tail(const uint32_t *raw, unsigned lo
     if (lane == 0) *consumed = result;
 }
 
-// ---------------------------------------------------------------------------------------
-// Small n (<= FY_FUSED_MAX_N: MovieLens-100K's 80 000 training interactions, the reference's own scale): ALL of the draws in
-// ONE launch of ONE workgroup.  The range-by-range fixpoint above costs ~90 small launches and ~25 host read-backs at
-// n = 80 000 -- 1.7 ms, as long as the epoch it shuffles takes to train.  Here the same iteration (A_new = exclusive prefix
-// of the decisions taken with A_old, from the same expected curve, to the same unique fixpoint) runs as a loop over
-// __syncthreads(): every thread owns a contiguous chunk of the window, a sweep is two passes over the chunk around one
-// block scan, the ranges follow each other inside the kernel (each starts where the previous one stopped consuming words),
-// the last FY_FUSED_TAIL draws are walked in order, and the RNG state is left exactly as numpy leaves it -- no host
-// involvement at all.  An exhausted word supply raises the ctx's sticky `insufficient` flag (reported by slk_rng_get_state).
-// ---------------------------------------------------------------------------------------
-#define FY_FUSED_THREADS 1024
-#define FY_FUSED_MAX_N (1u << 17)
-#define FY_FUSED_TAIL 256
-
-__device__ __forceinline__ uint32_t fy_block_exclusive_scan_1024(uint32_t c, uint32_t *s_wave, uint32_t *total) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
-    }
-    __syncthreads();  // s_wave of the previous call no longer in use
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int k = 0; k < FY_FUSED_THREADS / 64; ++k) {
-        const uint32_t x = s_wave[k];
-        if (k < wave) before += x;
-        all += x;
-    }
-    *total = all;
-    return before + incl - c;
-}
-
-__global__ __launch_bounds__(FY_FUSED_THREADS) void k_fy_draws_fused(const uint32_t *raw, unsigned long long total_words,
-                                                                       uint32_t N, uint32_t *A0, uint32_t *A1, uint32_t *J,
-                                                                       slk_rng_dev *st) {
-    __shared__ uint32_t s_wave[FY_FUSED_THREADS / 64];
-    __shared__ uint32_t s_flag;
-    __shared__ uint32_t s_tail[FY_FUSED_THREADS];
-    const int t = threadIdx.x;
-    unsigned long long w = (unsigned long long)st->pos;  // next unconsumed word (word 0 = first word of the key block)
-    uint32_t g = 0, hi = N - 1;
-    bool failed = false;
-    while (hi >= FY_FUSED_TAIL && !failed) {
-        uint32_t mask = hi;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        uint32_t lo = (mask >> 1) + 1;
-        if (lo < FY_FUSED_TAIL) lo = FY_FUSED_TAIL;
-        const uint32_t need = hi - lo + 1;
-        double wd = ((double)mask + 1.0) * log(((double)hi + 1.0) / (double)lo) + 12.0 * sqrt(2.0 * (double)need) + 64.0;
-        if (wd > (double)(total_words - w)) wd = (double)(total_words - w);
-        fy_args a;
-        a.raw = raw;
-        a.w0 = w;
-        a.W = (uint32_t)wd;
-        a.mask = mask;
-        a.hi = hi;
-        a.need = need;
-        const uint32_t per = (a.W + FY_FUSED_THREADS - 1) / FY_FUSED_THREADS;
-        const uint32_t b0 = (uint32_t)t * per < a.W ? (uint32_t)t * per : a.W, b1 = b0 + per < a.W ? b0 + per : a.W;
-        for (uint32_t i = b0; i < b1; ++i) {  // the expected curve (k_fy_init)
-            const double x = ((double)hi + 1.0) * (1.0 - exp(-(double)i / ((double)mask + 1.0)));
-            A0[i] = x >= (double)need ? need : (uint32_t)x;
-        }
-        __syncthreads();
-        int cur = 0, sweeps = 0;
-        for (;;) {
-            a.A_old = cur ? A1 : A0;
-            a.A_new = cur ? A0 : A1;
-            uint32_t c = 0, v;
-            for (uint32_t i = b0; i < b1; ++i) c += fy_decide(a, i, &v) ? 1u : 0u;
-            uint32_t total;
-            uint32_t run = fy_block_exclusive_scan_1024(c, s_wave, &total);
-            bool diff = false;
-            for (uint32_t i = b0; i < b1; ++i) {
-                const bool ok = fy_decide(a, i, &v);
-                diff |= a.A_old[i] != run;
-                a.A_new[i] = run;
-                run += ok ? 1u : 0u;
-            }
-            if (t == 0) s_flag = 0;
-            __syncthreads();
-            if (diff) s_flag = 1;
-            __syncthreads();  // also: this sweep's A_new is visible to the whole workgroup
-            cur ^= 1;
-            ++sweeps;
-            const bool changed = s_flag != 0;
-            __syncthreads();  // s_flag is rewritten next sweep
-            if (!changed) break;
-            if (sweeps > 4000) {
-                failed = true;
-                break;
-            }
-        }
-        // the converged decisions: J[g + A(t)] = v_t for the accepted words; consumed = index of the last one + 1
-        a.A_old = cur ? A1 : A0;
-        if (t == 0) s_flag = 0;
-        __syncthreads();
-        for (uint32_t i = b0; i < b1; ++i) {
-            uint32_t v;
-            if (fy_decide(a, i, &v)) {
-                const uint32_t acc = a.A_old[i];
-                J[g + acc] = v;
-                if (acc == need - 1) s_flag = i + 1;
-            }
-        }
-        __syncthreads();
-        const uint32_t consumed = s_flag;
-        __syncthreads();
-        if (consumed == 0) failed = true;  // the window ran out of generated words before the range was complete
-        w += consumed;
-        g += need;
-        hi = lo - 1;
-    }
-    // the last draws (i = hi .. 1) in order: FY_FUSED_THREADS words tempered at once into LDS, walked by thread 0 (k_fy_tail)
-    while (hi >= 1 && !failed) {
-        if (w >= total_words) {
-            failed = true;
-            break;
-        }
-        __syncthreads();
-        const unsigned long long idx = w + (unsigned long long)t;
-        s_tail[t] = idx < total_words ? fy_temper(raw[idx]) : 0u;
-        if (t == 0) s_flag = 0;
-        __syncthreads();
-        const int avail = (total_words - w < (unsigned long long)FY_FUSED_THREADS) ? (int)(total_words - w) : FY_FUSED_THREADS;
-        if (t == 0) {
-            int l = 0;
-            uint32_t i = hi, gg = g;
-            for (; l < avail && i >= 1; ++l) {
-                uint32_t mask = i;
-                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-                const uint32_t v = s_tail[l] & mask;
-                if (v <= i) {
-                    J[gg] = v;
-                    ++gg;
-                    --i;
-                }
-            }
-            s_wave[0] = i;
-            s_wave[1] = gg;
-            s_wave[2] = (uint32_t)l;
-        }
-        __syncthreads();
-        hi = s_wave[0];
-        g = s_wave[1];
-        w += s_wave[2];
-        __syncthreads();
-    }
-    if (failed) {
-        if (t == 0) st->insufficient = 1;
-        return;
-    }
-    // numpy's state after the last consumed word w - 1: its key block and the offset behind it (k_fy_rng_finalize)
-    const unsigned long long t_last = w - 1, blk = t_last / SLK_MT_N;
-    __syncthreads();
-    uint32_t keep = 0;
-    if (t < SLK_MT_N) keep = raw[blk * SLK_MT_N + t];
-    __syncthreads();  // every thread has read st->pos (at entry) and its word before the state is overwritten
-    if (t < SLK_MT_N) st->key[t] = keep;
-    if (t == 0) st->pos = (int32_t)(t_last % SLK_MT_N) + 1;
-}
-
 // step g (i = n-1-g) writes position j: key = j, value = i; self-swaps get the sentinel key n
 __global__ __launch_bounds__(256) void k_fy_keys(const uint32_t *J, uint32_t n, uint32_t *key, uint32_t *val) {
     for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g + 1 < n; g += gridDim.x * 256) {
@@ -485,25 +320,6 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
         hi = lo - 1;
     }
     need_words += 12.0 * sqrt(2.0 * (double)N) + 4096.0;
-    uint32_t *J = nullptr;
-    if (N <= FY_FUSED_MAX_N && ctx->opt_fused_shuffle) {
-        // ---- (1) the draws, small n: one launch, no read-backs (k_fy_draws_fused); the stream position is read in-kernel,
-        // so the word supply is sized for the latest possible start (pos = 624)
-        const unsigned long long nblocks = 1ull + (unsigned long long)((need_words + (double)SLK_MT_N) / SLK_MT_N) + 1ull;
-        const unsigned long long total_words = nblocks * SLK_MT_N;
-        if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
-        // a range's window is its expected word count plus a 12-sigma + 64 word margin: for the short ranges near the tail
-        // the margin dominates, so the two window-sized arrays get 2n + 4096 words rather than n
-        for (int b = 0; b < 5; ++b)
-            if ((rc = slk_ensure(ctx, ctx->extra[FY_B0 + b], ((size_t)N * (b == 1 || b == 2 ? 2 : 1) + 4096) * 4))) return rc;
-        if ((rc = slk_mt_generate_blocks(ctx, nblocks, s))) return rc;
-        J = (uint32_t *)ctx->extra[FY_B0].p;
-        hipLaunchKernelGGL(k_fy_draws_fused, dim3(1), dim3(FY_FUSED_THREADS), 0, s, (const uint32_t *)ctx->raw.p, total_words, N,
-                           (uint32_t *)ctx->extra[FY_B1].p, (uint32_t *)ctx->extra[FY_B2].p, J, ctx->d_rng);
-        SLK_LAUNCH_CHECK(ctx, "k_fy_draws_fused");
-        ctx->fy_sweeps = -1;
-        slk_prof_end(ctx, s);
-    } else {
     int32_t pos0 = 0;
     SLK_HIP(ctx, hipMemcpyAsync(&pos0, &ctx->d_rng->pos, sizeof(pos0), hipMemcpyDeviceToHost, s));
     SLK_HIP(ctx, hipStreamSynchronize(s));
@@ -516,7 +332,7 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     if ((rc = slk_ensure(ctx, ctx->extra[FY_SMALL], nb_max * 8 + 64))) return rc;
     if ((rc = slk_mt_generate_blocks(ctx, nblocks, s))) return rc;
     const uint32_t *raw = (const uint32_t *)ctx->raw.p;
-    J = (uint32_t *)ctx->extra[FY_B0].p;
+    uint32_t *J = (uint32_t *)ctx->extra[FY_B0].p;
     uint32_t *Abuf[2] = {(uint32_t *)ctx->extra[FY_B1].p, (uint32_t *)ctx->extra[FY_B2].p};
     uint32_t *cnt = (uint32_t *)ctx->extra[FY_SMALL].p, *off = cnt + nb_max;
     int *d_flag = (int *)(off + nb_max);
@@ -596,8 +412,6 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     hipLaunchKernelGGL(k_fy_rng_finalize, dim3(1), dim3(256), 0, s, ctx->d_rng, raw, w - 1);
     SLK_LAUNCH_CHECK(ctx, "k_fy_rng_finalize");
     slk_prof_end(ctx, s);
-
-    }
 
     // ---- (2) the swaps
     slk_prof_begin(ctx, SLK_K_PREP, s);

@@ -113,23 +113,12 @@ def test_pipelined_chunks_match_single_chunk(be):
         eng.set_option('no_such_option', 1)
 
 
-@pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 255, 256, 257, 258, 511, 512, 623, 4095, 4096, 4097, 8192, 12345, 65535, 65536,
-                               65537, 65538, 70001, 80000, 131071, 131072, 131073])
+@pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 623, 4095, 4096, 4097, 8192, 12345, 65535, 65536, 65537, 65538, 70001,
+                               131073])
 def test_device_shuffle_is_numpy_exact(be, n):
     """slk_shuffle_perm: sizes around the in-order tail (4096), the power-of-two range edges and the
     MT19937 block size; RandomState continuity checked through the next randint."""
     ec.check_shuffle_matches_numpy(be, n, seed=n + 1, burn=n % 5, rows=3 if n in (10, 4097) else 0)
-
-
-@pytest.mark.parametrize('n', [300, 4097, 70001])
-def test_device_shuffle_range_by_range_route_at_small_n(be, n):
-    """n <= 2^17 takes the single-launch route by default; the range-by-range sweeps (the route of large n) stay covered at
-    sizes the emulator can afford."""
-    be.engine.set_option('fused_shuffle', 0)
-    try:
-        ec.check_shuffle_matches_numpy(be, n, seed=n + 7, burn=3)
-    finally:
-        be.engine.set_option('fused_shuffle', 1)
 
 
 def test_minibatch_of_one_interaction(be):
