@@ -113,7 +113,7 @@ def test_pipelined_chunks_match_single_chunk(be):
         eng.set_option('no_such_option', 1)
 
 
-@pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 623, 4095, 4096, 4097, 8192, 12345, 65535, 65536, 65537, 65538, 70001,
+@pytest.mark.parametrize('n', [0, 1, 2, 3, 10, 623, 4095, 4096, 4097, 8192, 12345, 65535, 65536, 65537, 65538, 70001, 80000,
                                131073])
 def test_device_shuffle_is_numpy_exact(be, n):
     """slk_shuffle_perm: sizes around the in-order tail (4096), the power-of-two range edges and the
