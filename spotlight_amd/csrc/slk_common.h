@@ -94,7 +94,7 @@ struct slk_ctx {
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     // minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip).  Defaults from the
     // same-box A/Bs in profiles/r02_c_small_batch.jsonl: the persistent route wins at 256 (13 vs 21 us per minibatch) and
-    // 1024 (19 vs 24), loses at 4096 (42 vs 30) and -- its gap sweeps are serial per row group -- with the dense optimizers
+    // 1024 (17 vs 24), loses at 4096 (57 vs 30)
     int opt_epoch_kernel = 1;
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
@@ -103,7 +103,9 @@ struct slk_ctx {
                                    // from running beside it, measured: profiles/r02_h_c1_fit_timeline_adagrad.json), 0: plain launch
     int opt_epoch_debug = 0;       // measurement only: 1 skip the phases' work, 2 do not wait at barriers, 4 no store drain
     int opt_epoch_max_grid = 256;  // workgroups (one wavefront each) of the persistent launch, <= one per CU
-    int64_t opt_epoch_dense_elems = 0;  // dense optimizers: largest model (parameters) the persistent route takes (0: never)
+    int64_t opt_epoch_dense_elems = (int64_t)1 << 18;  // dense optimizers: largest model (parameters) the persistent route takes:
+                                   // every row group sweeps rows / row-groups rows per phase, so only models of the reference's own
+                                   // scale (MovieLens-100K at dim 32: 87 K parameters)
     std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)

@@ -18,8 +18,8 @@
 // i.e. the two ownership passes of the launch path (same sorted lists, same summation order, same arithmetic: the
 // trained tables are BIT-IDENTICAL to the per-minibatch launches, which the tests assert), with the launch boundaries
 // replaced by an in-kernel barrier.  The dense optimizers (the reference's default Adam + l2, Adagrad + weight decay:
-// EVERY row is updated every step, torch/optim/adam.py:414-546) need no third phase and no gradient buffer: the owner of
-// a run also sweeps the rows of the gap between the previous run's id and its own with a zero gradient.
+// EVERY row is updated every step, torch/optim/adam.py:414-546) need no third phase and no gradient buffer: the rows a
+// minibatch touches are stamped one phase ahead and every row group sweeps a share of the unstamped ones (see below).
 //
 // Inter-workgroup visibility (MI355X: 8 XCDs with private, mutually non-coherent L2s; per-CU L1s that other CUs' stores
 // never refresh).  Everything one workgroup writes and another reads within the launch -- table rows, optimizer state,
@@ -64,6 +64,7 @@ struct slk_epoch_args {
     double *partial;               // [n_mb][gridDim.x] per-workgroup loss sums
     float *mb_loss;                // [n_mb] loss.item() of each minibatch
     const slk_step_coef *coef;     // [n_mb]
+    uint32_t *touch_u, *touch_i;   // dense optimizers: touch[row] = (last minibatch that looks the row up) + 1; zeroed before the launch
     unsigned *bar;                 // barrier counter, zeroed before the launch
     int *status;                   // raised on a barrier time-out
     int loss_kind;
@@ -180,58 +181,36 @@ __device__ __forceinline__ constexpr bool slk_epoch_dense() {
     return UPD == SLK_EUPD_ADAM_DENSE || UPD == SLK_EUPD_ADAGRAD_DENSE;
 }
 
-// Dense optimizers: rows [lo, hi) of embedding table `te` and bias table `tb` received no gradient this step.  The kernel
-// is latency-bound, so the rows go SLK_GAP_BATCH at a time: all loads of a batch are in flight together (one fabric
-// round trip per batch instead of one per row).
-#define SLK_GAP_BATCH 4
+// Dense optimizers (the reference's default Adam + l2, Adagrad + weight decay): EVERY row is updated every step, the rows a
+// minibatch does not touch with a zero gradient (torch/optim/adam.py:414-546; k_dense_sweep_all on the launch path).  Which rows
+// a minibatch touches depends on ids only, so the phase BEFORE a table's turn stamps them (touch[row] = minibatch + 1: the
+// users of minibatch m + 1 during item phase m, the items of minibatch m during user phase m) and during the table's own phase
+// every row group sweeps a strided share of ALL rows, skipping the stamped ones -- their owners update them with the summed
+// gradient.  Balanced (rows / row groups iterations per phase), no gradient buffer, no third phase; the arithmetic is
+// k_dense_sweep_all's element for element.
 template <int VEC, int UPD>
-struct slk_gap_rows {
-    slk_vec<VEC> p[SLK_GAP_BATCH], s1[SLK_GAP_BATCH], s2[SLK_GAP_BATCH];
-    slk_vec<1> bp[SLK_GAP_BATCH], bs1[SLK_GAP_BATCH], bs2[SLK_GAP_BATCH];
-    uint32_t lo, n;
-
-    __device__ __forceinline__ void load(const slk_epoch_args &e, int te, int tb, uint32_t lo_, uint32_t hi, int D, int d0, bool on,
-                                         int lane) {
-        lo = lo_;
-        n = hi > lo_ ? (hi - lo_ < (uint32_t)SLK_GAP_BATCH ? hi - lo_ : (uint32_t)SLK_GAP_BATCH) : 0u;
-#pragma unroll
-        for (int k = 0; k < SLK_GAP_BATCH; ++k) {
-            p[k] = s1[k] = s2[k] = slk_vzero<VEC>();
-            bp[k] = bs1[k] = bs2[k] = slk_vzero<1>();
-            if ((uint32_t)k >= n) continue;
-            const uint32_t r = lo + (uint32_t)k;
-            if (on) {
-                const size_t off = (size_t)r * D + d0;
-                p[k] = slk_vload_coh<VEC>(e.P[te] + off);
-                s1[k] = slk_vload_coh<VEC>(e.S1[te] + off);
-                if (slk_epoch_has_s2<UPD>()) s2[k] = slk_vload_coh<VEC>(e.S2[te] + off);
-            }
-            if (lane == 0) {
-                bp[k] = slk_vload_coh<1>(e.P[tb] + r);
-                bs1[k] = slk_vload_coh<1>(e.S1[tb] + r);
-                if (slk_epoch_has_s2<UPD>()) bs2[k] = slk_vload_coh<1>(e.S2[tb] + r);
-            }
+__device__ __forceinline__ void slk_epoch_sweep_untouched(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb,
+                                                          const uint32_t *touch, uint32_t want, uint32_t n_rows, uint32_t gslot,
+                                                          uint32_t gstride, int D, int d0, bool on, int lane) {
+    for (uint32_t r = gslot; r < n_rows; r += gstride) {
+        // stamp, row, state and (lane 0) the bias triple in one round trip
+        const uint32_t stamp = __hip_atomic_load(touch + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slk_vec<VEC> p = slk_vzero<VEC>(), s1 = p, s2 = p;
+        slk_vec<1> bp = slk_vzero<1>(), bs1 = bp, bs2 = bp;
+        if (on) {
+            const size_t off = (size_t)r * D + d0;
+            p = slk_vload_coh<VEC>(e.P[te] + off);
+            s1 = slk_vload_coh<VEC>(e.S1[te] + off);
+            if (slk_epoch_has_s2<UPD>()) s2 = slk_vload_coh<VEC>(e.S2[te] + off);
         }
-    }
-    __device__ __forceinline__ void apply(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb, int D, int d0, bool on,
-                                          int lane) const {
-#pragma unroll
-        for (int k = 0; k < SLK_GAP_BATCH; ++k) {
-            if ((uint32_t)k >= n) continue;
-            const uint32_t r = lo + (uint32_t)k;
-            if (on) slk_epoch_update<VEC, UPD>(e, c, te, (size_t)r * D + d0, p[k], s1[k], s2[k], slk_vzero<VEC>());
-            if (lane == 0) slk_epoch_update<1, UPD>(e, c, tb, r, bp[k], bs1[k], bs2[k], slk_vzero<1>());
+        if (lane == 0) {
+            bp = slk_vload_coh<1>(e.P[tb] + r);
+            bs1 = slk_vload_coh<1>(e.S1[tb] + r);
+            if (slk_epoch_has_s2<UPD>()) bs2 = slk_vload_coh<1>(e.S2[tb] + r);
         }
-    }
-};
-
-template <int VEC, int UPD>
-__device__ __forceinline__ void slk_epoch_sweep_rows(const slk_epoch_args &e, const slk_step_coef &c, int te, int tb, uint32_t lo,
-                                                     uint32_t hi, int D, int d0, bool on, int lane) {
-    for (uint32_t r = lo; r < hi; r += SLK_GAP_BATCH) {
-        slk_gap_rows<VEC, UPD> gb;
-        gb.load(e, te, tb, r, hi, D, d0, on, lane);
-        gb.apply(e, c, te, tb, D, d0, on, lane);
+        if (stamp == want) continue;  // touched: its owner applies the summed gradient
+        if (on) slk_epoch_update<VEC, UPD>(e, c, te, (size_t)r * D + d0, p, s1, s2, slk_vzero<VEC>());
+        if (lane == 0) slk_epoch_update<1, UPD>(e, c, tb, r, bp, bs1, bs2, slk_vzero<1>());
     }
 }
 
@@ -260,6 +239,15 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         nx_prev = gslot ? e.ukey[gslot - 1] : 0u;
         nx_a = e.uit[2 * (size_t)gslot];
         nx_b = e.uit[2 * (size_t)gslot + 1];
+    }
+
+    if (DENSE) {  // prologue: the users of minibatch 0
+        const uint32_t nb1 = e.nc < e.bsz ? e.nc : e.bsz;
+        if (lane == 0)
+            for (uint32_t p = gslot; p < nb1; p += gstride)
+                __hip_atomic_store(e.touch_u + (e.ukey[p] & e.umask), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
+        ++barriers;
     }
 
     for (uint32_t mb = 0; mb < e.n_mb; ++mb) {
@@ -291,11 +279,6 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
             slk_vec<VEC> vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
             float bi = slk_ld_coh(e.P[3] + ip), bj = slk_ld_coh(e.P[3] + in);
-            // dense optimizers: the rows between the previous run's user and this one receive a zero gradient
-            slk_gap_rows<VEC, UPD> gap;
-            const uint32_t gap_lo = first ? 0u : (prev & e.umask) + 1u;
-            if (DENSE) gap.load(e, 0, 2, gap_lo, user, D, d0, on, lane);
-
             slk_vec<VEC> gu = zero;
             float gbu = 0.0f;
             uint32_t q = p;
@@ -330,14 +313,17 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 bg.v[0] = gbu;
                 slk_epoch_update<1, UPD>(e, c, 2, user, bp, bus1, bus2, bg);
             }
-            if (DENSE) {
-                gap.apply(e, c, 0, 2, D, d0, on, lane);
-                slk_epoch_sweep_rows<VEC, UPD>(e, c, 0, 2, gap_lo + SLK_GAP_BATCH, user, D, d0, on, lane);
-                if (q == b1) slk_epoch_sweep_rows<VEC, UPD>(e, c, 0, 2, user + 1u, e.n_users, D, d0, on, lane);
-            }
         }
         // this row group's first position of the item phase
         const uint32_t ib0 = 2u * b0, ib1 = 2u * b1;
+        if (DENSE) {
+            // user rows this minibatch does not touch (stamped during the previous item phase / the prologue), and the stamps
+            // of the items it does touch, for the item phase behind the barrier
+            slk_epoch_sweep_untouched<VEC, UPD>(e, c, 0, 2, e.touch_u, mb + 1u, e.n_users, gslot, gstride, D, d0, on, lane);
+            if (lane == 0)
+                for (uint32_t r = ib0 + gslot; r < ib1; r += gstride)
+                    __hip_atomic_store(e.touch_i + (e.ikey[r] & e.imask), mb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (ib0 + gslot < ib1) {
             nx_key = e.ikey[ib0 + gslot];
             nx_prev = gslot ? e.ikey[ib0 + gslot - 1] : 0u;
@@ -375,10 +361,6 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             }
             float g = slk_ld_coh(e.gsn + (pay - ib0));
             slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((pay >> 1) - b0) * e.RS + d0) : zero;
-            slk_gap_rows<VEC, UPD> gap;
-            const uint32_t gap_lo = first ? 0u : (prev & e.imask) + 1u;
-            if (DENSE) gap.load(e, 1, 3, gap_lo, item, D, d0, on, lane);
-
             slk_vec<VEC> gv = zero;
             float gb = 0.0f;
             bool any = false;
@@ -411,10 +393,13 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                     slk_epoch_update<1, UPD>(e, c, 3, item, bp, bis1, bis2, bg);
                 }
             }
-            if (DENSE) {
-                gap.apply(e, c, 1, 3, D, d0, on, lane);
-                slk_epoch_sweep_rows<VEC, UPD>(e, c, 1, 3, gap_lo + SLK_GAP_BATCH, item, D, d0, on, lane);
-                if (k == ib1) slk_epoch_sweep_rows<VEC, UPD>(e, c, 1, 3, item + 1u, e.n_items, D, d0, on, lane);
+        }
+        if (DENSE) {
+            slk_epoch_sweep_untouched<VEC, UPD>(e, c, 1, 3, e.touch_i, mb + 1u, e.n_items, gslot, gstride, D, d0, on, lane);
+            if (lane == 0 && mb + 1 < e.n_mb) {
+                const uint32_t nb1 = (e.nc - b1 < e.bsz) ? e.nc : b1 + e.bsz;
+                for (uint32_t p = b1 + gslot; p < nb1; p += gstride)
+                    __hip_atomic_store(e.touch_u + (e.ukey[p] & e.umask), mb + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // this row group's first position of the next minibatch's user phase
@@ -489,7 +474,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
 
-    enum { EP_COEF = 40, EP_BAR, EP_PARTIAL };  // ctx->extra slots
+    enum { EP_COEF = 40, EP_BAR, EP_PARTIAL, EP_TOUCH };  // ctx->extra slots
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 2048))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * grid * 8))) return rc;
@@ -524,6 +509,12 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[EP_COEF].p, ctx->ep_coef.data(), (size_t)n_mb * sizeof(slk_step_coef),
                                 hipMemcpyHostToDevice, s));
     SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 2048, s));
+    const bool dense_opt = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    if (dense_opt) {
+        const size_t rows = (size_t)tables->num_users + (size_t)tables->num_items;
+        if ((rc = slk_ensure(ctx, ctx->extra[EP_TOUCH], rows * 4))) return rc;
+        SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_TOUCH].p, 0, rows * 4, s));
+    }
 
     for (int t = 0; t < 4; ++t) {
         e.P[t] = tables->d_param[t];
@@ -548,6 +539,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.partial = (double *)ctx->extra[EP_PARTIAL].p;
     e.mb_loss = d_mb_loss;
     e.coef = (const slk_step_coef *)ctx->extra[EP_COEF].p;
+    e.touch_u = dense_opt ? (uint32_t *)ctx->extra[EP_TOUCH].p : nullptr;
+    e.touch_i = dense_opt ? e.touch_u + tables->num_users : nullptr;
     e.bar = (unsigned *)ctx->extra[EP_BAR].p;
     e.status = &ctx->d_rng->epoch_abort;
     e.loss_kind = loss;

@@ -1065,7 +1065,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         finally:
             eng.set_option('epoch_kernel', 1)
             eng.set_option('epoch_max_batch', 1024)
-            eng.set_option('epoch_dense_elems', 0)
+            eng.set_option('epoch_dense_elems', 1 << 18)
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('epoch_max_grid', 256)
             eng.set_option('epoch_barrier', -1)
