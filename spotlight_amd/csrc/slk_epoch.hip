@@ -470,6 +470,12 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
     // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU
     unsigned grid = (unsigned)((2 * bsz + gpb - 1) / gpb);
+    if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
+        // the dense optimizers also sweep every row of the larger table once per phase: one row per row group if the chip allows
+        const int64_t rows = tables->num_users > tables->num_items ? tables->num_users : tables->num_items;
+        const unsigned by_rows = (unsigned)((rows + gpb - 1) / gpb);
+        if (by_rows > grid) grid = by_rows;
+    }
     const unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
