@@ -353,7 +353,9 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
     if (!ctx || !h_key) return SLK_EINVAL;
     if (pos < 0 || pos > SLK_MT_N) return slk_fail(ctx, SLK_EINVAL, "slk_rng_set_state: pos %d outside [0, 624]", pos);
     SLK_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->last_stream) SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    // the stream the ctx's kernels were last enqueued on -- which may be the null stream (torch's default): a null handle is
+    // a stream to wait for, not "no stream" (the state copy below no longer synchronises with it implicitly)
+    SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     slk_rng_dev h;
     memset(&h, 0, sizeof(h));
     memcpy(h.key, h_key, sizeof(h.key));
@@ -369,7 +371,9 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
 SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     if (!ctx || !h_key || !pos) return SLK_EINVAL;
     SLK_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->last_stream) SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    // the stream the ctx's kernels were last enqueued on -- which may be the null stream (torch's default): a null handle is
+    // a stream to wait for, not "no stream" (the state copy below no longer synchronises with it implicitly)
+    SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     slk_rng_dev h;
     hipStream_t cs = slk_copy_stream(ctx);
     SLK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost, cs));
