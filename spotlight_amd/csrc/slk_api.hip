@@ -164,10 +164,6 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_user_grid_mult = (int)value;
-    } else if (!strcmp(name, "item_direct") && (value == 0 || value == 1)) {
-        ctx->opt_item_direct = (int)value;
-    } else if (!strcmp(name, "item_direct_grid_mult") && value >= 1 && value <= 4096) {
-        ctx->opt_item_direct_grid_mult = (int)value;
     } else if (!strcmp(name, "seq_variant") && (value == 0 || value == 1)) {
         ctx->opt_seq_variant = (int)value;
     } else if (!strcmp(name, "explicit_fused") && (value == 0 || value == 1)) {

@@ -205,86 +205,6 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// ITEM PASS, direct variant (ctx option "item_direct"): one row group per position of the item-sorted occurrence list; the
-// head of a run walks it (records in occurrence order, same sums as k_item_pass), everybody else leaves.  No LDS tiles, no
-// head compaction: when (nearly) every occurrence is its own run -- the row-sharded 1B-item configuration, 125M rows per
-// GPU -- the tile machinery of k_item_pass is pure overhead.  1-negative losses, plain tables (SNAP records).
-// ---------------------------------------------------------------------------------------
-template <int VEC, int G, int UPD>
-__global__ __launch_bounds__(256) void k_item_pass_direct(slk_pass_args a) {
-    __shared__ double red[256];
-    constexpr int GPB = 256 / G;
-    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
-    const int D = a.D, d0 = lane * VEC;
-    const bool on = d0 < D;
-    const bool nt_rows = (SLK_NT_OF(a) & 2) != 0;
-    const uint32_t ibegin = a.ibegin, iend = a.iend;
-    if (blockIdx.x == 0 && a.mb_loss_out) {
-        double x = 0.0;
-        for (int i = threadIdx.x; i < a.n_loss_partial; i += 256) x += a.loss_partial[i];
-        const double tot = slk_block_sum_256(x, red);
-        if (threadIdx.x == 0) *a.mb_loss_out = (float)(tot * (double)a.inv_b);
-    }
-    for (uint32_t r = ibegin + blockIdx.x * GPB + grp; r < iend; r += gridDim.x * GPB) {
-        const uint32_t key = a.ikey[r];
-        const uint32_t prev = r > ibegin ? a.ikey[r - 1] : ~key;
-        uint32_t pay = a.ipay[r];
-        if (prev == key) continue;  // not the head of its run
-        const uint32_t item = key & a.imask;
-        const size_t voff = (size_t)item * D + d0;
-        // the run's first record, the row and its state: independent loads, one round trip
-        float g = a.gsn[pay - a.begin * 2u];
-        slk_vec<VEC> uo = on ? slk_vload<VEC>(a.snap + (size_t)((pay >> 1) - a.begin) * a.RS + d0) : slk_vzero<VEC>();
-        slk_vec<VEC> p = slk_vzero<VEC>(), sv = slk_vzero<VEC>();
-        float pb = 0.0f, sb = 0.0f;
-        if (UPD != SLK_UPD_GRAD_ONLY) {
-            if (on) {
-                p = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-                sv = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
-            }
-            pb = a.P[3][item];
-            sb = a.S1[3][item];
-        }
-        slk_vec<VEC> gv = slk_vzero<VEC>();
-        float gb = 0.0f;
-        bool any = false;
-        uint32_t k = r;
-        for (;;) {
-            if (g != 0.0f) {
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float cc = g * uo.v[i];
-                    gv.v[i] += cc;
-                }
-                gb += g;
-                any = true;
-            }
-            ++k;
-            if (!(k < iend && a.ikey[k] == key)) break;
-            pay = a.ipay[k];
-            g = a.gsn[pay - a.begin * 2u];
-            uo = on ? slk_vload<VEC>(a.snap + (size_t)((pay >> 1) - a.begin) * a.RS + d0) : slk_vzero<VEC>();
-        }
-        if (UPD != SLK_UPD_SPARSE_ADAM && !any) continue;
-        if (on) slk_apply_vec_pre<VEC, UPD>(a, 1, voff, p, sv, gv, nullptr, nt_rows);
-        if (lane == 0 && !(UPD == SLK_UPD_ADAGRAD && gb == 0.0f)) {
-            slk_vec<1> bpv, bsv, gbv;
-            bpv.v[0] = pb;
-            bsv.v[0] = sb;
-            gbv.v[0] = gb;
-            slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
-        }
-    }
-}
-
-template <int VEC, int G>
-static slk_pass_fn item_pass_direct_fn(int upd) {
-    if (upd == SLK_UPD_ADAGRAD) return k_item_pass_direct<VEC, G, SLK_UPD_ADAGRAD>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass_direct<VEC, G, SLK_UPD_SPARSE_ADAM>;
-    return k_item_pass_direct<VEC, G, SLK_UPD_GRAD_ONLY>;
-}
-
-// ---------------------------------------------------------------------------------------
 // adaptive hinge: scores for every (interaction, pair), then the per-column selection of
 // _get_multiple_negative_predictions' view(n, B) layout (factorization/implicit.py:266-275)
 // ---------------------------------------------------------------------------------------
@@ -858,13 +778,12 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     const int upd = slk_upd_for(optim->kind);
     pass_fn upass = nullptr, ipass = nullptr, spass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr,
-            rpass_rows = nullptr, ipass_direct = nullptr;
+            rpass_rows = nullptr;
     const int umode = (expl && ctx->opt_explicit_fused) ? 2 : (pre ? 1 : 0);
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
         upass = user_pass_fn<V_, G_>(upd, umode, bloom);                                  \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
-        if (ctx->opt_item_direct && !pre && !bloom) ipass_direct = item_pass_direct_fn<V_, G_>(upd); \
         spass = k_score_pass<V_, G_>;                                                     \
         if (bloom) {                                                                      \
             ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_ROWS>(upd);     \
@@ -1084,11 +1003,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             slk_prof_end(ctx, s);
 
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-            if (ipass_direct) {
-                hipLaunchKernelGGL(ipass_direct, dim3(slk_grid_for(ctx, (size_t)bm * NP, gpb, ctx->opt_item_direct_grid_mult)),
-                                   dim3(256), 0, s, a);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass_direct");
-            } else if (!Hi) {
+            if (!Hi) {
                 hipLaunchKernelGGL(ipass, dim3(igrid), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_item_pass");
             } else {

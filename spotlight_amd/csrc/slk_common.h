@@ -90,8 +90,6 @@ struct slk_ctx {
     int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
-    int opt_item_direct = 0;       // 1: k_item_pass_direct (one row group per occurrence, no LDS tiles) for the 1-negative losses
-    int opt_item_direct_grid_mult = 8;
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     // minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip).  Defaults from the

@@ -1076,40 +1076,3 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         assert np.array_equal(a, b), ('tensor %d differs between the persistent kernel and the launch path' % k,
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
 
-
-def check_option_is_bit_neutral(be, option, values, loss='bpr', opt='adagrad', D=16, U=300, I=170, N=2500, B=700, seed=41, epochs=2,
-                                extra=()):
-    """A tuning option that selects another kernel for the same arithmetic (e.g. "item_direct"): losses, negatives, RNG state
-    and every table / state tensor bit for bit equal for all `values`.  `extra`: (name, value) options held fixed."""
-    eng = be.engine
-    rs = np.random.RandomState(seed)
-    users = rs.randint(0, U, N).astype(np.int64)
-    items = rs.randint(0, I, N).astype(np.int64)
-    sc = min(0.3, 1.0 / np.sqrt(D))
-    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
-    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
-    state = np.random.RandomState(seed + 1).get_state()
-    n_mb = (N + B - 1) // B
-    results = []
-    for v in values:
-        eng.set_option(option, v)
-        for name, val in extra:
-            eng.set_option(name, val)
-        try:
-            dev = be.model(params, opt=opt, **hp)
-            eng.rng_set_state(state)
-            d_users, d_items = be.alloc(users), be.alloc(items)
-            losses = []
-            for _ in range(epochs):
-                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
-                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1, be.ptr(mb_loss),
-                                   stream=be.stream)
-                losses.append(be.get(mb_loss).copy())
-            st = eng.rng_get_state()
-            results.append([np.concatenate(losses), st[1], np.array(st[2])] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
-        finally:
-            eng.set_option(option, values[0])
-    for other in results[1:]:
-        for k, (a, b) in enumerate(zip(results[0], other)):
-            assert np.array_equal(a, b), ('tensor %d differs between %s = %r and %r' % (k, option, values[0], values[1]),
-                                          float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))

@@ -179,9 +179,3 @@ def test_device_to_sequence_argument_errors(be):
     with pytest.raises(_native.SlkError):  # no plan pending
         eng.to_sequence_fill(be.ptr(d), be.ptr(d), stream=be.stream)
 
-
-@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('hinge', 'sparse_adam'), ('pointwise', 'adam_dense')])
-def test_direct_item_pass_is_bit_neutral(be, loss, opt):
-    """k_item_pass_direct (option item_direct = 1) against the tiled k_item_pass; minibatches above the persistent route's size."""
-    ec.check_option_is_bit_neutral(be, 'item_direct', (0, 1), loss=loss, opt=opt, B=1100, N=3000)
-    ec.check_option_is_bit_neutral(be, 'item_direct', (0, 1), loss=loss, opt=opt, D=64, U=7, I=3, B=1100, N=2300)

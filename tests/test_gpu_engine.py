@@ -266,8 +266,3 @@ def test_epoch_kernel_many_minibatches_and_chunks(be):
     """400 minibatches in 4 launches (chunks of 100): thousands of grid barriers back to back"""
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=102400, B=256, epochs=1, chunk=25600)
 
-
-@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('hinge', 'sparse_adam'), ('pointwise', 'adam_dense')])
-def test_direct_item_pass_is_bit_neutral(be, loss, opt):
-    ec.check_option_is_bit_neutral(be, 'item_direct', (0, 1), loss=loss, opt=opt, D=64, U=30000, I=9000, B=8192, N=50000)
-    ec.check_option_is_bit_neutral(be, 'item_direct', (0, 1), loss=loss, opt=opt, D=32, U=50, I=20, B=2048, N=9000)
