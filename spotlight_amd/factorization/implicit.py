@@ -16,7 +16,10 @@ from spotlight_amd.layers import BloomEmbedding, ScaledEmbedding, ZeroEmbedding
 from spotlight_amd.torch_utils import set_seed
 
 _ENGINES = {}
-_PIPELINE_MAX_DRAWS = 1 << 22  # fit(): epochs of at most this many negative draws prepare the next epoch while training
+# fit(): epochs of at most this many negative draws prepare the next epoch while training.  Larger epochs do not gain:
+# at 10^8 interactions the two lanes time-slice the chip (train 71 ms + prepare 38 ms alone, 100 ms together:
+# profiles/r02_m_fit_pipelined_at_1e8_no_gain.json)
+_PIPELINE_MAX_DRAWS = 1 << 22
 
 
 def _engine_for(device):
