@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 4
+#define SLK_ABI_VERSION 5
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -283,28 +283,37 @@ int slk_rank_targets(slk_ctx *ctx, float *d_scores, int64_t n_rows, int64_t num_
  *        a2a: counts (M*S per peer); the ONE host synchronisation of the chunk; a2a: ids
  *   slk_shard_chunk_commit    both count matrices (host) + the received ids ([source][unit])
  * Per unit t (no host synchronisation: every split size is known from the matrices):
- *   slk_shard_gather       owner: d_rows_out[j] = row record of unit t's j-th request
- *                          ([source] order)
- *        a2a: row records back to the requesters
+ *   slk_shard_gather       owner: the rows of unit t's requests into d_rows_out ([source] segments)
+ *        a2a: rows back to the requesters
  *   slk_shard_user_pass    forward/loss/backward/user update (factorization/implicit.py:229-243
- *                          restricted to this rank's users of unit t); d_grad_out[slot] =
- *                          gradient record, same slot order as the rows received
- *        a2a: gradient records to the owners
+ *                          restricted to this rank's users of unit t); the gradient of a lookup goes
+ *                          to the slot of d_grad_out its row came in at in d_rows_in
+ *        a2a: gradients to the owners
  * Per minibatch:
- *   slk_shard_item_pass    owner: per unique item row, sum of the records received for the S
- *                          units of the minibatch ([slice][source] order), then ONE optimizer
- *                          update (duplicates summed before the update, as autograd does);
- *                          advances optim->step.
+ *   slk_shard_item_pass    owner: per unique item row, sum of the gradients received for the S
+ *                          units of the minibatch (d_grad_in: the units' regions one after the other),
+ *                          then ONE optimizer update (duplicates summed before the update, as autograd
+ *                          does); advances optim->step.
  *
- * A record is slk_shard_row_floats(dim) floats: [row or gradient (dim) | bias or bias gradient
- * | pad to 16 B].  pointwise/bpr/hinge only (one negative per interaction). */
+ * Exchange buffers (rows and gradients alike) are arrays of SLOTS in blocks of SLK_SHARD_BLOCK = 64:
+ * a block is 64 rows of `dim` floats followed by the 64 scalars (bias / bias gradient) of those rows, so
+ * a row of a dim-64 table is one aligned 256-B line on both sides of the wire.  Inside a unit's buffer
+ * every peer's segment starts on a block boundary: a peer that exchanges c lookups of the unit owns
+ * ceil(c / 64) * 64 slots = slk_shard_buffer_floats(dim, c) floats -- the split sizes of the all-to-all,
+ * in [peer] order; the slots past c are never read.  pointwise/bpr/hinge only (one negative per
+ * interaction). */
+#define SLK_SHARD_BLOCK 64
 typedef struct slk_shard {
     int32_t world, rank;
     int64_t num_items_global; /* negatives are drawn in [0, num_items_global) (sampling.py:34) */
     int64_t global_batch;     /* unused since ABI 3 (passed per minibatch to slk_shard_user_pass) */
 } slk_shard;
 
-int slk_shard_row_floats(int32_t dim);
+/* floats of a buffer segment that holds `slots` lookups (rounded up to whole blocks) */
+int64_t slk_shard_buffer_floats(int32_t dim, int64_t slots);
+/* Optional: allocates the scratch of chunks of up to n local interactions whose owner side receives up to n_recv
+ * lookups now, so that a loop whose first chunk is its largest does not allocate (and synchronise the device) inside it. */
+int slk_shard_reserve(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh, int64_t n, int64_t n_recv);
 /* d_users_local: LOCAL user rows (user / world) of this rank's n interactions of the chunk;
  * d_items: GLOBAL item ids; h_mb_off[M + 1] (host): minibatch boundaries inside [0, n];
  * negatives: sampled from the ctx RNG over the global item range (one contiguous draw for the

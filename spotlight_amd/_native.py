@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 4
+SLK_ABI_VERSION = 5
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -86,7 +86,8 @@ _PROTOTYPES = {
                                      C.c_void_p]),
     'slk_rank_targets': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    'slk_shard_row_floats': (C.c_int, [C.c_int32]),
+    'slk_shard_buffer_floats': (C.c_int64, [C.c_int32, C.c_int64]),
+    'slk_shard_reserve': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_int64, C.c_int64]),
     'slk_shard_chunk_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
                                         C.c_int64, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -301,8 +302,11 @@ class Engine(object):
                                                d_rank_out, stream))
 
     # -- row-sharded training phases (include/spotlight_hip.h: slk_shard_*) --------------
-    def shard_row_floats(self, dim):
-        return int(self._lib.slk_shard_row_floats(int(dim)))
+    def shard_buffer_floats(self, dim, slots):
+        return int(self._lib.slk_shard_buffer_floats(int(dim), int(slots)))
+
+    def shard_reserve(self, tables, shard, n, n_recv):
+        self._check(self._lib.slk_shard_reserve(self._ctx, C.byref(tables), C.byref(shard), int(n), int(n_recv)))
 
     def shard_chunk_begin(self, tables, shard, d_users_local, d_items, n, mb_off, n_slices, d_send_ids,
                           d_send_counts, d_neg_in=None, d_neg_out=None, stream=0):

@@ -120,6 +120,7 @@ struct slk_ctx {
     int sh_M = 0, sh_S = 0, sh_world = 0;
     unsigned sh_ubits = 0;
     std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
+    std::vector<int64_t> sh_sslots, sh_rslots;  // per unit: slots of its requester-side buffers / first slot of its owner-side region
     std::vector<uint64_t> sh_host, sh_host2;     // host staging for small H2D tables (begin / commit)
 
     // Interactions.to_sequence plan (slk_seqprep.hip): rows pending a slk_to_sequence_fill (-1: none)

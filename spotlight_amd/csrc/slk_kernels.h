@@ -108,11 +108,10 @@ struct slk_pass_args {
     float *mb_loss_out;      // this minibatch's loss.item()
     int loss_kind;
     float inv_b;             // 1 / (minibatch size)   [sequences: 1 / mask.sum()]
-    // row-sharded path: item rows arrive in / gradient rows leave through exchange buffers
-    const float *vrows;      // [slot * RSV]: item row (D floats) + bias at [D]
-    float *grows;            // [slot * RSV]: g * u_old (D floats) + g at [D]
+    // row-sharded path: item rows arrive in / gradient rows leave through exchange buffers (slot layout: slk_blk_row)
+    const float *vrows;      // slot -> item row (D floats) + bias
+    float *grows;            // slot -> g * u_old (D floats) + g
     const uint32_t *vslot;   // [pos*NP + s] -> slot
-    int RSV;
     // optimizer coefficients, rounded from double on the host exactly as torch does
     float c_lr;    // Adagrad: clr.  SparseAdam: step_size.
     float c_eps;
@@ -126,8 +125,22 @@ enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
 //   SNAP  r = pos*NP + s; record(pos) = [u_old (D)], g_s = gsn[r - begin*NP];  vec = g_s * u_old, bias g_s
 //   SEQ   r = pos*NP + s; record(pos) = [repr (D) | hist (D)], g_s likewise;
 //         vec = g_s * repr (+ hist when s == 0), bias g_s                       (PoolNet)
-//   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (row-sharded)
-enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2 };
+//   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (user-bloom rows)
+//   BLK   r = slot of an exchange buffer (slk_blk_row / slk_blk_scalar): vec, bias grad  (row-sharded)
+enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2, SLK_ITEM_BLK = 3 };
+
+// Exchange buffers of the row-sharded path (slk_shard.hip): slots come in blocks of 64, a block is 64 rows of D floats
+// followed by the 64 scalars (bias / bias gradient) of those rows.  Every row of a D = 64 table is then one aligned
+// 256-B line on both sides of the wire and the scalars of 64 consecutive slots share one line (a [row | scalar]
+// record of 260 B straddles three lines and makes every store a partial one); a block is 64 * (D + 1) floats, so a
+// peer's segment is contiguous -- one all-to-all moves rows and scalars -- as long as segments start on block
+// boundaries (the per-peer slot counts are rounded up to 64).
+__device__ __forceinline__ size_t slk_blk_row(uint32_t slot, int D) {
+    return (size_t)(slot >> 6) * (size_t)(SLK_SHARD_BLOCK * (D + 1)) + (size_t)(slot & 63u) * (size_t)D;
+}
+__device__ __forceinline__ size_t slk_blk_scalar(uint32_t slot, int D) {
+    return (size_t)(slot >> 6) * (size_t)(SLK_SHARD_BLOCK * (D + 1)) + (size_t)SLK_SHARD_BLOCK * (size_t)D + (slot & 63u);
+}
 
 // Row update for the elements one lane owns.  GRAD_ONLY stores the summed gradient into the
 // dense gradient buffer (aliased on S1) for the full-table sweep.
@@ -208,6 +221,9 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
         const float *rec = a.snap + (size_t)(r - a.begin) * a.RS;
         gb = rec[D];
         c = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+    } else if (MODE == SLK_ITEM_BLK) {
+        gb = a.snap[slk_blk_scalar(r, D)];
+        c = on ? slk_vload<VEC>(a.snap + slk_blk_row(r, D) + d0) : slk_vzero<VEC>();
     } else {
         const uint32_t NP = (uint32_t)a.NP;
         const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);

@@ -13,7 +13,9 @@
 //   slk_shard_chunk_begin   negatives; sort the chunk's local interactions by (unit, user), a
 //                           unit being one of the S user-slices of one minibatch; bucket the 2n
 //                           item lookups by (owner, unit) -> send_ids (owner-local rows),
-//                           send_counts[owner][unit]
+//                           send_counts[owner][unit]; every lookup gets a SLOT of its unit's
+//                           exchange buffers (slk_blk_row in slk_kernels.h: blocks of 64 rows + their
+//                           64 scalars; a peer's slots start on a block boundary)
 //        [a2a: counts; ONE host sync; a2a: ids to the owners]
 //   slk_shard_chunk_commit  both count matrices come back from the host; owner side: received
 //                           ids regrouped by (unit, source) and sorted by (minibatch, row)
@@ -41,11 +43,11 @@
 
 // scratch slots in ctx->extra
 enum { SH_OKEY0 = 0, SH_OKEY1, SH_OVAL0, SH_OVAL1, SH_VSLOT, SH_HIST, SH_SEGSTART, SH_UNITBASE, SH_MBOFF, SH_RID,
-       SH_SEGTAB };
+       SH_SEGTAB, SH_GSLOT };
 
-static inline int shard_rsv(int D) { return ((D + 1 + 3) / 4) * 4; }
+static inline int64_t pad_slots(int64_t lookups) { return (lookups + SLK_SHARD_BLOCK - 1) / SLK_SHARD_BLOCK * SLK_SHARD_BLOCK; }
 
-SLK_EXPORT int slk_shard_row_floats(int32_t dim) { return shard_rsv(dim); }
+SLK_EXPORT int64_t slk_shard_buffer_floats(int32_t dim, int64_t slots) { return pad_slots(slots) * (int64_t)(dim + 1); }
 
 // key = (unit << ubits) | user with unit = minibatch * S + user % S; value = (neg << 32) | pos so
 // the sorted values are the item pairs.  mb_off[0..M]: minibatch boundaries in the chunk.
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256) void k_shard_owner_keys(const uint32_t *uit, c
 }
 
 // one block: seg_start = exclusive scan of the (owner, unit) counts in sorted order;
-// unit_base[o][t] = lookups of unit t owned by ranks < o (slot offset inside unit t's buffers)
+// unit_base[o][t] = first slot of owner o inside unit t's buffers: the slots of the owners before it, each owner's
+// count rounded up to whole blocks
 __global__ __launch_bounds__(256) void k_shard_scan(const unsigned long long *hist, uint32_t world, uint32_t T,
                                                     uint32_t *seg_start, uint32_t *unit_base, int64_t *counts_out) {
     const uint32_t bins = world * T;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void k_shard_scan(const unsigned long long *hi
         uint32_t run = 0;
         for (uint32_t o = 0; o < world; ++o) {
             unit_base[o * T + t] = run;
-            run += (uint32_t)hist[o * T + t];
+            run += ((uint32_t)hist[o * T + t] + (SLK_SHARD_BLOCK - 1u)) & ~(SLK_SHARD_BLOCK - 1u);
         }
     }
     for (uint32_t b = threadIdx.x; b < bins; b += 256) counts_out[b] = (int64_t)hist[b];
@@ -121,23 +124,25 @@ __global__ __launch_bounds__(256) void k_shard_slots(const uint32_t *uit, const 
 // owner side: blockIdx.x = received segment (source, unit), blockIdx.y strides inside it (a single-rank run has two
 // segments of a million ids each: one block per segment took 3.5 ms, profiles/r02_a_kernel_stats.md): ids move from [source][unit] order
 // to [unit][source] order, with the item-pass key (minibatch, row) and payload (slot inside the
-// minibatch's record buffer).  segtab[seg] = {from, to, len, minibatch, first slot of the minibatch}
+// minibatch's record buffer).  segtab[seg] = {from, to, len, minibatch, first slot of the segment in its unit's
+// buffers, first slot of the segment in its minibatch's gradient buffer}
 __global__ __launch_bounds__(256) void k_shard_regroup(const int32_t *recv_ids, const uint32_t *segtab, unsigned ibits,
-                                                       int32_t *rid, uint32_t *ikey, uint32_t *ipay) {
-    const uint32_t *sg = segtab + 5 * (size_t)blockIdx.x;
-    const uint32_t from = sg[0], to = sg[1], len = sg[2], mb = sg[3], mb_first = sg[4];
+                                                       int32_t *rid, uint32_t *gslot, uint32_t *ikey, uint32_t *ipay) {
+    const uint32_t *sg = segtab + 6 * (size_t)blockIdx.x;
+    const uint32_t from = sg[0], to = sg[1], len = sg[2], mb = sg[3], unit_slot = sg[4], mb_slot = sg[5];
     for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < len; i += gridDim.y * 256) {
         const int32_t id = recv_ids[from + i];
         rid[to + i] = id;
+        gslot[to + i] = unit_slot + i;
         ikey[to + i] = (mb << ibits) | (uint32_t)id;
-        ipay[to + i] = to + i - mb_first;
+        ipay[to + i] = mb_slot + i;
     }
 }
 
-// owner side: record(j) = [V[id_j] (D) | bias[id_j] | pad]
+// owner side: slot(j) of the unit's row buffer = V[id_j] (D), bias[id_j]
 template <int VEC, int G>
-__global__ __launch_bounds__(256) void k_shard_gather(const float *V, const float *bi, int D, int RSV,
-                                                      const int32_t *ids, int64_t n, float *out) {
+__global__ __launch_bounds__(256) void k_shard_gather(const float *V, const float *bi, int D, const int32_t *ids,
+                                                      const uint32_t *gslot, int64_t n, float *out) {
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
@@ -145,9 +150,9 @@ __global__ __launch_bounds__(256) void k_shard_gather(const float *V, const floa
     const bool on = d0 < D;
     for (int64_t j = (int64_t)blockIdx.x * GPB + grp; j < n; j += (int64_t)gridDim.x * GPB) {
         const int64_t i = (int64_t)ids[j];
-        float *rec = out + (size_t)j * RSV;
-        if (on) slk_vstore<VEC>(rec + d0, slk_vload<VEC>(V + (size_t)i * D + d0));
-        if (lane == 0) rec[D] = bi[i];
+        const uint32_t slot = gslot[j];
+        if (on) slk_vstore<VEC>(out + slk_blk_row(slot, D) + d0, slk_vload<VEC>(V + (size_t)i * D + d0));
+        if (lane == 0) out[slk_blk_scalar(slot, D)] = bi[i];
     }
 }
 
@@ -175,13 +180,15 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         float gbu = 0.0f;
         uint32_t q = p;
         do {
-            const size_t sp_ = (size_t)a.vslot[2 * (size_t)q] * a.RSV, sn_ = (size_t)a.vslot[2 * (size_t)q + 1] * a.RSV;
+            const uint32_t slp = a.vslot[2 * (size_t)q], sln = a.vslot[2 * (size_t)q + 1];
+            const size_t sp_ = slk_blk_row(slp, D), sn_ = slk_blk_row(sln, D);
+            const size_t bp_ = slk_blk_scalar(slp, D), bn_ = slk_blk_scalar(sln, D);
             // exchange buffers are read / written exactly once: streaming hints (ctx option "nt" bit 0)
             const bool nt = (SLK_NT_OF(a) & 1) != 0;
             const slk_vec<VEC> vi = on ? slk_vload_if_nt<VEC>(a.vrows + sp_ + d0, nt) : slk_vzero<VEC>();
             const slk_vec<VEC> vj = on ? slk_vload_if_nt<VEC>(a.vrows + sn_ + d0, nt) : slk_vzero<VEC>();
-            const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.vrows[sp_ + D];
-            const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.vrows[sn_ + D];
+            const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.vrows[bp_];
+            const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.vrows[bn_];
             float l, gp, gn;
             slk_pair_loss(a.loss_kind, sp, sn, a.inv_b, l, gp, gn);
             slk_vec<VEC> cp, cn;
@@ -197,8 +204,8 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
                 slk_vstore_if_nt<VEC>(a.grows + sn_ + d0, cn, nt);
             }
             if (lane == 0) {
-                a.grows[sp_ + D] = gp;
-                a.grows[sn_ + D] = gn;
+                a.grows[bp_] = gp;
+                a.grows[bn_] = gn;
                 loss_acc += l;
             }
             ++q;
@@ -242,6 +249,41 @@ static int check_chunk(slk_ctx *ctx, const slk_shard *sh, int32_t M, int32_t S) 
         return slk_fail(ctx, SLK_EINVAL, "shard chunk: minibatches %d x slices %d x world %d must be in [1, %d]", M, S,
                         sh->world, SLK_SHARD_MAX_BINS);
     return SLK_OK;
+}
+
+// Scratch of chunks of up to n local interactions whose owner side receives up to n_recv lookups, allocated now: a
+// timed loop that starts with a larger chunk than its warm-up would otherwise pay hipFree + hipMalloc (device-wide
+// synchronisations) inside its first chunk.
+SLK_EXPORT int slk_shard_reserve(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh, int64_t n, int64_t n_recv) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_shard(ctx, sh))) return rc;
+    if (n < 0 || n >= ((int64_t)1 << 30) || n_recv < 0 || n_recv >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_reserve: n %lld / n_recv %lld out of range", (long long)n, (long long)n_recv);
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n, nl = 2 * nn, nr = (size_t)n_recv;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_HIST], (size_t)SLK_SHARD_MAX_BINS * 8))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGSTART], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_UNITBASE], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_MBOFF], (size_t)(SLK_SHARD_MAX_BINS + 1) * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGTAB], (size_t)SLK_SHARD_MAX_BINS * 6 * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->neg32, nn * 4))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if ((rc = slk_ensure(ctx, ctx->ukey[b], nn * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->uval[b], nn * 8))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_OKEY0 + b], nl * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_OVAL0 + b], nl * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->ikey[b], nr * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->ipay[b], nr * 4))) return rc;
+    }
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_VSLOT], nl * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_RID], nr * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[SH_GSLOT], nr * 4))) return rc;
+    const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
+    if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
+    if ((rc = slk_sample_reserve(ctx, sh->num_items_global, n))) return rc;
+    return slk_sort_reserve(ctx, nl > nr ? nl : nr);
 }
 
 SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
@@ -354,24 +396,33 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
     if (ctx->sh_M < 1 || ctx->sh_world != sh->world) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: no chunk begun for this world size");
     if (!h_send_counts || !h_recv_counts) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: NULL count matrix");
     const int M = ctx->sh_M, S = ctx->sh_S, W = ctx->sh_world, T = M * S;
-    // ---- unit windows: user-sorted positions (requester) and received-lookup positions (owner)
+    // ---- unit windows: user-sorted positions (requester) and received-lookup positions (owner); slots of the unit's
+    //      exchange buffers on either side (per-peer counts rounded up to whole blocks)
     ctx->sh_ustart.assign((size_t)T + 1, 0);
     ctx->sh_rstart.assign((size_t)T + 1, 0);
+    ctx->sh_sslots.assign((size_t)T, 0);
+    ctx->sh_rslots.assign((size_t)T + 1, 0);  // exclusive prefix over the units: first slot of unit t's received region
     for (int t = 0; t < T; ++t) {
-        int64_t sent = 0, recv = 0;
+        int64_t sent = 0, recv = 0, sslots = 0, rslots = 0;
         for (int r = 0; r < W; ++r) {
             if (h_send_counts[(size_t)r * T + t] < 0 || h_recv_counts[(size_t)r * T + t] < 0)
                 return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: negative count");
             sent += h_send_counts[(size_t)r * T + t];
             recv += h_recv_counts[(size_t)r * T + t];
+            sslots += pad_slots(h_send_counts[(size_t)r * T + t]);
+            rslots += pad_slots(h_recv_counts[(size_t)r * T + t]);
         }
         if (sent & 1) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: unit %d sends an odd number of lookups", t);
         ctx->sh_ustart[t + 1] = ctx->sh_ustart[t] + sent / 2;
         ctx->sh_rstart[t + 1] = ctx->sh_rstart[t] + recv;
+        ctx->sh_sslots[t] = sslots;
+        ctx->sh_rslots[t + 1] = ctx->sh_rslots[t] + rslots;
     }
     if (ctx->sh_ustart[T] != ctx->sh_n)
         return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: send counts cover %lld interactions, chunk has %lld",
                         (long long)ctx->sh_ustart[T], (long long)ctx->sh_n);
+    if (ctx->sh_rslots[T] >= ((int64_t)1 << 32))
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: %lld received slots >= 2^32", (long long)ctx->sh_rslots[T]);
     const int64_t nr = ctx->sh_rstart[T];
     if (nr >= ((int64_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: %lld received lookups >= 2^31", (long long)nr);
     if (nr > 0 && !d_recv_ids) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: d_recv_ids is NULL");
@@ -387,26 +438,31 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
             if ((rc = slk_ensure(ctx, ctx->ipay[b], (size_t)nr * 4))) return rc;
         }
         if ((rc = slk_ensure(ctx, ctx->extra[SH_RID], (size_t)nr * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_GSLOT], (size_t)nr * 4))) return rc;
         const int nseg = W * T;
-        if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGTAB], (size_t)nseg * 5 * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGTAB], (size_t)nseg * 6 * 4))) return rc;
         // received buffer order: [source][unit]; regrouped order: [unit][source]
-        ctx->sh_host2.resize(((size_t)nseg * 5 + 1) / 2 + 1);
+        ctx->sh_host2.resize(((size_t)nseg * 6 + 1) / 2 + 1);
         uint32_t *tab = (uint32_t *)ctx->sh_host2.data();
         int64_t from = 0;
         for (int r = 0; r < W; ++r)
             for (int t = 0; t < T; ++t) {
-                int64_t to = ctx->sh_rstart[t];
-                for (int r2 = 0; r2 < r; ++r2) to += h_recv_counts[(size_t)r2 * T + t];
-                uint32_t *sg = tab + 5 * ((size_t)r * T + t);
+                int64_t to = ctx->sh_rstart[t], unit_slot = 0;
+                for (int r2 = 0; r2 < r; ++r2) {
+                    to += h_recv_counts[(size_t)r2 * T + t];
+                    unit_slot += pad_slots(h_recv_counts[(size_t)r2 * T + t]);
+                }
+                uint32_t *sg = tab + 6 * ((size_t)r * T + t);
                 sg[0] = (uint32_t)from;
                 sg[1] = (uint32_t)to;
                 sg[2] = (uint32_t)h_recv_counts[(size_t)r * T + t];
                 sg[3] = (uint32_t)(t / S);
-                sg[4] = (uint32_t)ctx->sh_rstart[(size_t)(t / S) * S];
+                sg[4] = (uint32_t)unit_slot;
+                sg[5] = (uint32_t)(ctx->sh_rslots[t] - ctx->sh_rslots[(size_t)(t / S) * S] + unit_slot);
                 from += h_recv_counts[(size_t)r * T + t];
             }
         slk_prof_begin(ctx, SLK_K_PREP, s);
-        SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_SEGTAB].p, tab, (size_t)nseg * 5 * 4, hipMemcpyHostToDevice, s));
+        SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_SEGTAB].p, tab, (size_t)nseg * 6 * 4, hipMemcpyHostToDevice, s));
         // enough blocks per segment to fill the chip whatever the segment count is
         unsigned per_seg = (unsigned)((8 * ctx->num_cus + nseg - 1) / nseg);
         const unsigned seg_blocks = (unsigned)((nr / nseg + 255) / 256) + 1u;
@@ -415,7 +471,7 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
         if (per_seg > 65535u) per_seg = 65535u;
         hipLaunchKernelGGL(k_shard_regroup, dim3((unsigned)nseg, per_seg), dim3(256), 0, s, d_recv_ids,
                            (const uint32_t *)ctx->extra[SH_SEGTAB].p, ibits, (int32_t *)ctx->extra[SH_RID].p,
-                           (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+                           (uint32_t *)ctx->extra[SH_GSLOT].p, (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_shard_regroup");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
                                          (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, (size_t)nr,
@@ -451,7 +507,7 @@ SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, int32_t u
 #define SLK_GATHER(V_, G_)                                                                                  \
     hipLaunchKernelGGL((k_shard_gather<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n_ids, 256 / G_)), dim3(256), 0, s, \
                        (const float *)local->d_param[1], (const float *)local->d_param[3], (int)local->dim,  \
-                       shard_rsv(local->dim), d_ids, n_ids, d_rows_out)
+                       d_ids, (const uint32_t *)ctx->extra[SH_GSLOT].p + r0, n_ids, d_rows_out)
     SLK_FOR_LAYOUT(vec, g, SLK_GATHER);
 #undef SLK_GATHER
     SLK_LAUNCH_CHECK(ctx, "k_shard_gather");
@@ -517,7 +573,6 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     a.vslot = (const uint32_t *)ctx->extra[SH_VSLOT].p;
     a.vrows = d_rows_in;
     a.grows = d_grad_out;
-    a.RSV = shard_rsv(local->dim);
     a.loss_partial = (double *)ctx->losspart.p;
     a.loss_kind = loss;
     a.inv_b = 1.0f / (float)global_batch;
@@ -566,8 +621,7 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
         slk_pass_args a;
         memset(&a, 0, sizeof(a));
         fill_tables(a, ctx, local, optim, dense);
-        a.snap = const_cast<float *>(d_grad_in);  // records indexed by the slot inside this minibatch
-        a.RS = shard_rsv(local->dim);
+        a.snap = const_cast<float *>(d_grad_in);  // slots inside this minibatch's gradient buffer
         a.begin = 0;
         a.ibegin = (uint32_t)r0;
         a.iend = (uint32_t)(r0 + nr);
@@ -577,13 +631,13 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
         a.mb_loss_out = nullptr;
         slk_pass_fn ipass = nullptr;
         const int upd = slk_upd_for(optim->kind);
-#define SLK_PICK(V_, G_) ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_ROW>(upd)
+#define SLK_PICK(V_, G_) ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_BLK>(upd)
         SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
         const unsigned gpb = 256u / (unsigned)g;
         slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
         hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)nr, 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
-        SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW>");
+        SLK_LAUNCH_CHECK(ctx, "k_item_pass<BLK>");
         slk_prof_end(ctx, s);
     }
     if (dense && (rc = slk_dense_sweeps(ctx, local->d_param, optim, 15u, s))) return rc;

@@ -69,7 +69,7 @@ class ShardedBilinearTrainer(object):
         self.device = w[0].device
         self._tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0], self.dim)
         self._shard = _native.make_shard(self.world, self.rank, self.num_items_global)
-        self.rsv = engine.shard_row_floats(self.dim)
+        self.slot_floats = self.dim + 1  # an exchange slot: a row (dim floats) + its scalar, in blocks of 64 slots
         self._bufs = {}
         self.exchange_rows = 0
         self.last_exchange_rows = 0
@@ -84,16 +84,20 @@ class ShardedBilinearTrainer(object):
             raise ValueError('row-sharded chunk: %d slices x world %d do not fit the engine limits' % (s, w))
         return m
 
-    def _buf(self, name, rows, cols, dtype):
-        """Persistent exchange buffer, grown geometrically (views of the first `rows` rows)."""
-        need = max(int(rows), 1)
+    def _buf(self, name, count, dtype):
+        """Persistent 1-D exchange buffer, grown geometrically (a view of its first `count` elements)."""
+        need = max(int(count), 1)
         b = self._bufs.get(name)
         if b is None or b.shape[0] < need:
-            cap = need + need // 4
-            shape = (cap, cols) if cols else (cap,)
-            b = torch.empty(shape, dtype=dtype, device=self.device)
+            b = torch.empty(need + need // 4, dtype=dtype, device=self.device)
             self._bufs[name] = b
-        return b[:int(rows)]
+        return b[:int(count)]
+
+    @staticmethod
+    def _slots(lookups):
+        """Slots a peer's segment of `lookups` lookups takes in an exchange buffer (whole blocks of
+        SLK_SHARD_BLOCK = 64, include/spotlight_hip.h)."""
+        return (int(lookups) + 63) // 64 * 64
 
     def reserve(self, batch_local, minibatches):
         """Pre-allocates the exchange buffers of chunks of `minibatches` x `batch_local` local interactions
@@ -101,14 +105,16 @@ class ShardedBilinearTrainer(object):
         n = int(batch_local) * int(minibatches)
         per_unit = 2 * int(batch_local) // self.slices + 1
         slack = lambda x: x + x // 4 + 1024
-        self._buf('send_ids', 2 * n, 0, torch.int32)
-        self._buf('recv_ids', slack(2 * n), 0, torch.int32)
-        self._buf('send_counts', self.world * minibatches * self.slices, 0, torch.int64)
-        self._buf('recv_counts', self.world * minibatches * self.slices, 0, torch.int64)
-        self._buf('grad_recv', slack(2 * int(batch_local)), self.rsv, torch.float32)
+        padded = lambda x: (slack(x) + 64 * self.world) * self.slot_floats  # every peer's segment ends on a block boundary
+        self.engine.shard_reserve(self._tables, self._shard, n, slack(2 * n))
+        self._buf('send_ids', 2 * n, torch.int32)
+        self._buf('recv_ids', slack(2 * n), torch.int32)
+        self._buf('send_counts', self.world * minibatches * self.slices, torch.int64)
+        self._buf('recv_counts', self.world * minibatches * self.slices, torch.int64)
+        self._buf('grad_recv', padded(2 * int(batch_local)) + 64 * self.world * self.slices * self.slot_floats, torch.float32)
         for k in range(self.slices):
             for name in ('rows_send%d', 'rows_recv%d', 'grad_send%d'):
-                self._buf(name % k, slack(per_unit), self.rsv, torch.float32)
+                self._buf(name % k, padded(per_unit), torch.float32)
 
     def run_chunk(self, users_local, items, mb_off, global_batches, loss='bpr', neg_in=None, neg_out=None):
         """A chunk of M = len(mb_off) - 1 consecutive global minibatches.  `users_local` / `items`:
@@ -122,48 +128,49 @@ class ShardedBilinearTrainer(object):
         t_n = m_n * s_n
         n = int(mb_off[-1])
         assert int(users_local.numel()) == n and int(mb_off[0]) == 0
-        send_ids = self._buf('send_ids', 2 * n, 0, torch.int32)
-        send_counts = self._buf('send_counts', w * t_n, 0, torch.int64)
+        send_ids = self._buf('send_ids', 2 * n, torch.int32)
+        send_counts = self._buf('send_counts', w * t_n, torch.int64)
         eng.shard_chunk_begin(self._tables, self._shard, users_local.data_ptr() if n else None,
                               items.data_ptr() if n else None, n, mb_off, s_n, send_ids.data_ptr(),
                               send_counts.data_ptr(),
                               d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
                               d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None, stream=st)
         # counts [owner][unit] -> [source][unit]; the chunk's only host synchronisation
-        recv_counts = self._buf('recv_counts', w * t_n, 0, torch.int64)
+        recv_counts = self._buf('recv_counts', w * t_n, torch.int64)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         sc, rc = send_counts.tolist(), recv_counts.tolist()
         sc_peer = [sum(sc[r * t_n:(r + 1) * t_n]) for r in range(w)]
         rc_peer = [sum(rc[r * t_n:(r + 1) * t_n]) for r in range(w)]
-        recv_ids = self._buf('recv_ids', sum(rc_peer), 0, torch.int32)
+        recv_ids = self._buf('recv_ids', sum(rc_peer), torch.int32)
         dist.all_to_all_single(recv_ids, send_ids, rc_peer, sc_peer, group=self.group)
         eng.shard_chunk_commit(self._tables, self._shard, sc, rc, recv_ids.data_ptr(), stream=st)
-        sc_unit = [[sc[r * t_n + t] for r in range(w)] for t in range(t_n)]
-        rc_unit = [[rc[r * t_n + t] for r in range(w)] for t in range(t_n)]
-        n_send = [sum(x) for x in sc_unit]  # = 2 * interactions of the unit
-        n_recv = [sum(x) for x in rc_unit]
-        self.last_exchange_rows = sum(n_send) - sc_peer[self.rank]  # lookups that crossed xGMI
+        # split sizes of unit t's row / gradient exchanges, in floats: every peer's segment is whole blocks of slots
+        f = self.slot_floats
+        sc_unit = [[self._slots(sc[r * t_n + t]) * f for r in range(w)] for t in range(t_n)]
+        rc_unit = [[self._slots(rc[r * t_n + t]) * f for r in range(w)] for t in range(t_n)]
+        n_send = [sum(x) for x in sc_unit]  # floats of the unit's requester-side buffers
+        n_recv = [sum(x) for x in rc_unit]  # floats of its owner-side buffers
+        self.last_exchange_rows = 2 * n - sc_peer[self.rank]  # lookups that crossed xGMI
         self.exchange_rows += self.last_exchange_rows
         loss_out = torch.zeros(m_n, dtype=torch.float32, device=self.device)
-        rsv = self.rsv
         for m in range(m_n):
             units = range(m * s_n, (m + 1) * s_n)
-            # owners: row records of every slice's requests; rows travel back (async)
+            # owners: the rows of every slice's requests; rows travel back (async)
             rows_recv, h_rows = [], []
             for k, t in enumerate(units):
-                rows_send = self._buf('rows_send%d' % k, n_recv[t], rsv, torch.float32)
+                rows_send = self._buf('rows_send%d' % k, n_recv[t], torch.float32)
                 eng.shard_gather(self._tables, t, rows_send.data_ptr(), stream=st)
-                rr = self._buf('rows_recv%d' % k, n_send[t], rsv, torch.float32)
+                rr = self._buf('rows_recv%d' % k, n_send[t], torch.float32)
                 rows_recv.append(rr)
                 h_rows.append(dist.all_to_all_single(rr, rows_send, sc_unit[t], rc_unit[t], group=self.group,
                                                      async_op=True))
-            # requesters: forward / loss / backward / user update per slice; gradient records
-            # travel to the owners (async) while the next slice computes
-            grad_recv = self._buf('grad_recv', sum(n_recv[t] for t in units), rsv, torch.float32)
+            # requesters: forward / loss / backward / user update per slice; gradients travel to
+            # the owners (async) while the next slice computes
+            grad_recv = self._buf('grad_recv', sum(n_recv[t] for t in units), torch.float32)
             h_grad, off = [], 0
             for k, t in enumerate(units):
                 h_rows[k].wait()
-                grad_send = self._buf('grad_send%d' % k, n_send[t], rsv, torch.float32)
+                grad_send = self._buf('grad_send%d' % k, n_send[t], torch.float32)
                 eng.shard_user_pass(self._tables, self.optim, self._shard, t, global_batches[m], loss,
                                     rows_recv[k].data_ptr(), grad_send.data_ptr(), loss_out[m:].data_ptr(),
                                     accumulate=k > 0, stream=st)
@@ -172,7 +179,7 @@ class ShardedBilinearTrainer(object):
                 off += n_recv[t]
             for h in h_grad:
                 h.wait()
-            # owners: per unique row, sum of the minibatch's records, ONE optimizer update
+            # owners: per unique row, sum of the minibatch's gradients, ONE optimizer update
             eng.shard_item_pass(self._tables, self.optim, m, grad_recv.data_ptr(), stream=st)
         return loss_out
 
