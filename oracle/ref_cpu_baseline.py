@@ -99,25 +99,29 @@ def main():
         share_end = time.perf_counter() + max(4.0, (deadline - time.perf_counter()) / (len(variants) - vi))
         kw = (dict(sparse=True, optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2))
               if name == 'sparse_adagrad' else dict())
-        torch.set_num_threads(all_threads)
+        few = min(all_threads, 16)
+        torch.set_num_threads(few)
         model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=D, n_iter=1, batch_size=Bc,
                                            random_state=np.random.RandomState(1), **kw)
         t_warm = timed_fit(model, inter(Bc))  # warm-up epoch: table initialisation, allocator, thread pool
         # the protocol's thread count is every host core; torch's sparse CPU ops do not scale to hundreds of threads, so a
-        # moderate count is probed too and the better one is used for the timed fits (both rates are reported)
-        probe = {}
-        for th in sorted({all_threads, min(all_threads, 16)}, reverse=True):
-            torch.set_num_threads(th)
-            probe[th] = timed_fit(model, inter(Bc))
-        best = min(probe, key=probe.get)
+        # moderate count is probed too and the better one is used for the timed fits (both rates are reported).  The
+        # every-core probe runs an eighth of a minibatch: at 256 threads a whole one takes the leg's entire budget.
+        rate = {few: Bc / timed_fit(model, inter(Bc))}
+        if all_threads != few:
+            torch.set_num_threads(all_threads)
+            n_probe = max(Bc // 8, 1)
+            timed_fit(model, inter(n_probe))  # the larger thread pool's first use
+            rate[all_threads] = n_probe / timed_fit(model, inter(n_probe))
+        best = max(rate, key=rate.get)
         torch.set_num_threads(best)
-        per_mb = probe[best]
+        per_mb = Bc / rate[best]
         k = int(max(1, min(n_max // Bc, (share_end - time.perf_counter()) / 2.0 / max(per_mb, 1e-6))))
         data = inter(k * Bc)
         timings = [timed_fit(model, data) for _ in range(2)]
         out[name] = {'interactions_per_fit': k * Bc, 'minibatches_per_fit': k, 'seconds': min(timings), 'timings': timings,
                      'warmup_seconds': t_warm, 'threads': best, 'interactions_per_s': k * Bc / min(timings),
-                     'interactions_per_s_by_threads': {str(th): Bc / t for th, t in probe.items()}}
+                     'interactions_per_s_by_threads': {str(th): r for th, r in rate.items()}}
         del model
     out['threads'] = out[variants[0]]['threads'] if variants else all_threads
     print(json.dumps(out))
