@@ -29,26 +29,6 @@
 
 #include "slk_kernels.h"
 
-// loss of ONE predicted score against the observed rating and dL/dscore (losses.py:169-244), formed in fp32
-// operation by operation as autograd forms them; bm = minibatch size, inv_b = 1 / bm.
-__device__ __forceinline__ void slk_explicit_loss(int loss_kind, float sc, float r, float inv_b, uint32_t bm, float &l,
-                                                  float &g) {
-    if (loss_kind == SLK_LOSS_REGRESSION) {  // ((r - p) ** 2).mean()
-        const float diff = r - sc;
-        l = diff * diff;
-        g = -(inv_b * (2.0f * diff));
-    } else if (loss_kind == SLK_LOSS_POISSON) {  // p = exp(score); (p - r * log(p)).mean()
-        const float p = expf(sc);
-        l = p - r * logf(p);
-        g = (inv_b + ((-inv_b) * r) / p) * p;
-    } else {  // binary_cross_entropy_with_logits(score, clamp(r, 0, 1)), mean reduction
-        const float t = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
-        const float mx = -sc > 0.0f ? -sc : 0.0f;
-        l = (1.0f - t) * sc + (mx + logf(expf(-mx) + expf(-sc - mx)));
-        g = (slk_sigmoid(sc) - t) / (float)bm;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // USER PASS
 // ---------------------------------------------------------------------------------------
@@ -760,7 +740,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     // minibatches of a few thousand interactions: every minibatch of a chunk inside ONE persistent launch (slk_epoch.hip)
-    bool epoch_route = !pre && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    bool epoch_route = (!pre || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
     auto ensure_dense_buffers = [&]() -> int {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
@@ -1075,7 +1055,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (!epoch_route) return do_passes(c0, pb);
         const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
         int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, RS, (float *)ctx->snap.p,
-                                     (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, s);
+                                     (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, expl ? d_ratings + c0 : nullptr, s);
         if (rc == SLK_EAGAIN_EPOCH) {  // cooperative launch refused: nothing ran; per-minibatch launches from here on
             epoch_route = false;
             if (dense && (rc = ensure_dense_buffers())) return rc;

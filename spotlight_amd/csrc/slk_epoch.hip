@@ -9,7 +9,9 @@
 //
 //   USER PHASE   one row group per unique user (head of its run in the (minibatch, user)-sorted list): U[u], V[pos],
 //                V[neg], biases; dot products by __shfl_xor; loss + dL/dscore; records (pre-step user row, dL/dscore
-//                per pair) for the item phase; the optimizer update of U[u] and its bias in place
+//                per pair) for the item phase; the optimizer update of U[u] and its bias in place.  Explicit feedback
+//                (ExplicitFactorizationModel.fit, spotlight/factorization/explicit.py:213-236, batch_size 256 by default):
+//                ONE pair per interaction, the loss formed against the observed rating
 //   -- grid barrier --
 //   ITEM PHASE   one row group per unique item (head of its run in the (minibatch, item)-sorted occurrence list): sums
 //                g * u_old over the run in occurrence order, updates V[i] and its bias
@@ -55,12 +57,14 @@ struct slk_epoch_args {
     uint32_t n_users, n_items;
     uint32_t nc, bsz, n_mb;        // interactions of the chunk, minibatch size, minibatches
     const uint32_t *ukey, *uit;    // (minibatch << ubits) | user, sorted; [2 * position] = (pos item, neg item)
+    const uint32_t *uk;            // explicit feedback: uit[position] = item, uk[position] = the interaction's index in
+    const float *ratings;          //   ratings[] (chunk-local)
     uint32_t umask;
-    const uint32_t *ikey, *ipay;   // (minibatch << ibits) | item, sorted; occurrence -> 2 * position + pair
+    const uint32_t *ikey, *ipay;   // (minibatch << ibits) | item, sorted; occurrence -> 2 * position + pair (explicit: position)
     uint32_t imask;
     float *snap;                   // records: [position - b0][RS] pre-step user rows
     int RS;
-    float *gsn;                    // [2 * (position - b0) + pair] dL/dscore
+    float *gsn;                    // [2 * (position - b0) + pair] dL/dscore (explicit: [position - b0])
     double *partial;               // [n_mb][gridDim.x] per-workgroup loss sums
     float *mb_loss;                // [n_mb] loss.item() of each minibatch
     const slk_step_coef *coef;     // [n_mb]
@@ -214,8 +218,9 @@ __device__ __forceinline__ void slk_epoch_sweep_untouched(const slk_epoch_args &
     }
 }
 
-template <int VEC, int G, int UPD>
+template <int VEC, int G, int UPD, bool EXPL>
 __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args e) {
+    constexpr uint32_t NP = EXPL ? 1u : 2u;  // score pairs (= item occurrences) per interaction
     HIP_DYNAMIC_SHARED(double, s_wave_sums)      // [4] per-wave loss sums (unused slots stay 0) + the barrier's two flag words
     int *s_flags = reinterpret_cast<int *>(s_wave_sums + 4);
     if (threadIdx.x < 4) s_wave_sums[threadIdx.x] = 0.0;
@@ -237,8 +242,8 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
     if (gslot < (e.nc < e.bsz ? e.nc : e.bsz)) {
         nx_key = e.ukey[gslot];
         nx_prev = gslot ? e.ukey[gslot - 1] : 0u;
-        nx_a = e.uit[2 * (size_t)gslot];
-        nx_b = e.uit[2 * (size_t)gslot + 1];
+        nx_a = e.uit[NP * (size_t)gslot];
+        nx_b = EXPL ? e.uk[gslot] : e.uit[2 * (size_t)gslot + 1];
     }
 
     if (DENSE) {  // prologue: the users of minibatch 0
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             const bool pre = p == b0 + gslot;  // this position's list entries were prefetched
             const uint32_t key = pre ? nx_key : e.ukey[p];
             const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ukey[p - 1]);
-            uint32_t ip = pre ? nx_a : e.uit[2 * (size_t)p], in = pre ? nx_b : e.uit[2 * (size_t)p + 1];
+            // pair: (positive item, negative item).  explicit: (item, index of the interaction's rating)
+            uint32_t ip = pre ? nx_a : e.uit[NP * (size_t)p], in = pre ? nx_b : (EXPL ? e.uk[p] : e.uit[2 * (size_t)p + 1]);
             if (!first && prev == key) continue;  // not the head of its user's run
             const uint32_t user = key & e.umask;
             const size_t uoff = (size_t)user * D + d0;
@@ -277,33 +283,52 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (HAS_S2) bus2 = slk_vload_coh<1>(e.S2[2] + user);
             }
             slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
-            slk_vec<VEC> vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
-            float bi = slk_ld_coh(e.P[3] + ip), bj = slk_ld_coh(e.P[3] + in);
+            slk_vec<VEC> vj = (on && !EXPL) ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+            float bi = slk_ld_coh(e.P[3] + ip), bj = EXPL ? 0.0f : slk_ld_coh(e.P[3] + in);
+            float rating = EXPL ? e.ratings[in] : 0.0f;  // an input of the call: plain load
             slk_vec<VEC> gu = zero;
             float gbu = 0.0f;
             uint32_t q = p;
             for (;;) {
                 if (on) slk_vstore_coh<VEC>(e.snap + (size_t)(q - b0) * e.RS + d0, u);
-                const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
-                const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bj;
-                float l, gp, gn;
-                slk_pair_loss(e.loss_kind, sp, sn, inv_b, l, gp, gn);
+                if (EXPL) {
+                    const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
+                    float l, g;
+                    slk_explicit_loss(e.loss_kind, sc, rating, inv_b, b1 - b0, l, g);
+                    if (lane == 0) {
+                        slk_st_coh(e.gsn + (size_t)(q - b0), g);
+                        loss_acc += l;
+                    }
+                    if (g != 0.0f) {
+                        slk_vaxpy<VEC>(gu, g, vi);
+                        gbu += g;
+                    }
+                } else {
+                    const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
+                    const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bj;
+                    float l, gp, gn;
+                    slk_pair_loss(e.loss_kind, sp, sn, inv_b, l, gp, gn);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
-                gbu += gp + gn;
-                if (lane == 0) {
-                    slk_st_coh(e.gsn + 2 * (size_t)(q - b0), gp);
-                    slk_st_coh(e.gsn + 2 * (size_t)(q - b0) + 1, gn);
-                    loss_acc += l;
+                    for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
+                    gbu += gp + gn;
+                    if (lane == 0) {
+                        slk_st_coh(e.gsn + 2 * (size_t)(q - b0), gp);
+                        slk_st_coh(e.gsn + 2 * (size_t)(q - b0) + 1, gn);
+                        loss_acc += l;
+                    }
                 }
                 ++q;
                 if (!(q < b1 && e.ukey[q] == key)) break;
-                ip = e.uit[2 * (size_t)q];  // further occurrences of the same user in this minibatch
-                in = e.uit[2 * (size_t)q + 1];
+                ip = e.uit[NP * (size_t)q];  // further occurrences of the same user in this minibatch
                 vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
-                vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
                 bi = slk_ld_coh(e.P[3] + ip);
-                bj = slk_ld_coh(e.P[3] + in);
+                if (EXPL) {
+                    rating = e.ratings[e.uk[q]];
+                } else {
+                    in = e.uit[2 * (size_t)q + 1];
+                    vj = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+                    bj = slk_ld_coh(e.P[3] + in);
+                }
             }
 
             if (on) slk_epoch_update<VEC, UPD>(e, c, 0, uoff, u, su1, su2, gu);
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             }
         }
         // this row group's first position of the item phase
-        const uint32_t ib0 = 2u * b0, ib1 = 2u * b1;
+        const uint32_t ib0 = NP * b0, ib1 = NP * b1;
         if (DENSE) {
             // user rows this minibatch does not touch (stamped during the previous item phase / the prologue), and the stamps
             // of the items it does touch, for the item phase behind the barrier
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (HAS_S2) bis2 = slk_vload_coh<1>(e.S2[3] + item);
             }
             float g = slk_ld_coh(e.gsn + (pay - ib0));
-            slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((pay >> 1) - b0) * e.RS + d0) : zero;
+            slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
             slk_vec<VEC> gv = zero;
             float gb = 0.0f;
             bool any = false;
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (!(k < ib1 && e.ikey[k] == key)) break;
                 pay = e.ipay[k];
                 g = slk_ld_coh(e.gsn + (pay - ib0));
-                uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((pay >> 1) - b0) * e.RS + d0) : zero;
+                uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
             }
 
             // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
@@ -406,8 +431,8 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         if (mb + 1 < e.n_mb && b1 + gslot < e.nc && gslot < e.bsz) {
             nx_key = e.ukey[b1 + gslot];
             nx_prev = gslot ? e.ukey[b1 + gslot - 1] : 0u;
-            nx_a = e.uit[2 * (size_t)(b1 + gslot)];
-            nx_b = e.uit[2 * (size_t)(b1 + gslot) + 1];
+            nx_a = e.uit[NP * (size_t)(b1 + gslot)];
+            nx_b = EXPL ? e.uk[b1 + gslot] : e.uit[2 * (size_t)(b1 + gslot) + 1];
         }
         if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
         ++barriers;
@@ -437,21 +462,26 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*slk_epoch_fn)(slk_epoch_args);
 
-template <int VEC, int G>
-static slk_epoch_fn epoch_fn(int upd) {
+template <int VEC, int G, bool EXPL>
+static slk_epoch_fn epoch_fn_of(int upd) {
     switch (upd) {
-        case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD>;
-        case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM>;
-        case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE>;
-        default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE>;
+        case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD, EXPL>;
+        case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM, EXPL>;
+        case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE, EXPL>;
+        default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE, EXPL>;
     }
+}
+template <int VEC, int G>
+static slk_epoch_fn epoch_fn(int upd, bool expl) {
+    return expl ? epoch_fn_of<VEC, G, true>(upd) : epoch_fn_of<VEC, G, false>(upd);
 }
 
 // Whether a slk_bilinear_train call takes the persistent route (option "epoch_kernel": 0 never, 1 when eligible).
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss,
                         bool bloom) {
     if (!ctx->opt_epoch_kernel || ctx->epoch_refused || bloom) return false;
-    if (loss != SLK_LOSS_POINTWISE && loss != SLK_LOSS_BPR && loss != SLK_LOSS_HINGE) return false;
+    // one-negative pair losses and the explicit-feedback losses (adaptive hinge needs its score / select passes first)
+    if (loss == SLK_LOSS_ADAPTIVE_HINGE) return false;
     if (bsz > ctx->opt_epoch_max_batch) return false;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     // the dense optimizers rewrite every row every minibatch: in one launch of at most one workgroup per CU that
@@ -463,13 +493,15 @@ bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_
 // All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one cooperative launch.
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
                         int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
-                        float *d_mb_loss, hipStream_t s) {
+                        float *d_mb_loss, const float *d_ratings, hipStream_t s) {
+    const bool expl = loss >= SLK_LOSS_REGRESSION;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+    const unsigned np = expl ? 1u : 2u;
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
     const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
     const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
     // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU
-    unsigned grid = (unsigned)((2 * bsz + gpb - 1) / gpb);
+    unsigned grid = (unsigned)((np * bsz + gpb - 1) / gpb);
     if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
         // the dense optimizers also sweep every row of the larger table once per phase: one row per row group if the chip allows
         const int64_t rows = tables->num_users > tables->num_items ? tables->num_users : tables->num_items;
@@ -534,7 +566,9 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.bsz = (uint32_t)bsz;
     e.n_mb = n_mb;
     e.ukey = (const uint32_t *)pb.ukey[1].p;
-    e.uit = (const uint32_t *)pb.uval[1].p;
+    e.uit = expl ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
+    e.uk = expl ? (const uint32_t *)pb.uval[1].p : nullptr;
+    e.ratings = d_ratings;
     e.umask = (uint32_t)((1ull << ubits) - 1);
     e.ikey = (const uint32_t *)pb.ikey[1].p;
     e.ipay = (const uint32_t *)pb.ipay[1].p;
@@ -560,7 +594,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.debug = ctx->opt_epoch_debug;
 
     slk_epoch_fn fn = nullptr;
-#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd)
+#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd, expl)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
 #undef SLK_PICK_EPOCH
     slk_prof_begin(ctx, SLK_K_EPOCH, s);

@@ -210,6 +210,26 @@ __device__ __forceinline__ void slk_pair_loss(int loss_kind, float sp, float sn,
     }
 }
 
+// loss of ONE predicted score against the observed rating and dL/dscore (losses.py:169-244), formed in fp32
+// operation by operation as autograd forms them; bm = minibatch size, inv_b = 1 / bm.
+__device__ __forceinline__ void slk_explicit_loss(int loss_kind, float sc, float r, float inv_b, uint32_t bm, float &l,
+                                                  float &g) {
+    if (loss_kind == SLK_LOSS_REGRESSION) {  // ((r - p) ** 2).mean()
+        const float diff = r - sc;
+        l = diff * diff;
+        g = -(inv_b * (2.0f * diff));
+    } else if (loss_kind == SLK_LOSS_POISSON) {  // p = exp(score); (p - r * log(p)).mean()
+        const float p = expf(sc);
+        l = p - r * logf(p);
+        g = (inv_b + ((-inv_b) * r) / p) * p;
+    } else {  // binary_cross_entropy_with_logits(score, clamp(r, 0, 1)), mean reduction
+        const float t = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+        const float mx = -sc > 0.0f ? -sc : 0.0f;
+        l = (1.0f - t) * sc + (mx + logf(expf(-mx) + expf(-sc - mx)));
+        g = (slk_sigmoid(sc) - t) / (float)bm;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // ITEM PASS
 // ---------------------------------------------------------------------------------------

@@ -77,6 +77,9 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
         d_users0 = _host.ids_to_device(user_ids, device)
         d_items0 = _host.ids_to_device(item_ids, device)
         d_ratings0 = torch.from_numpy(ratings).to(device).view(torch.int32).to(torch.int64)
+        if self._n_iter > 1 and n <= _host._PIPELINE_MAX_DRAWS:
+            return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, d_ratings0, n, mb_loss,
+                                       verbose)
         d_users, d_items, d_rbits = (torch.empty_like(d_users0), torch.empty_like(d_items0),
                                      torch.empty_like(d_ratings0))
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
@@ -99,6 +102,51 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
                 print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
             if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
+    def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, d_ratings0, n, mb_loss, verbose):
+        """The epoch loop for datasets of the reference's own scale (its README example fits MovieLens-100K with batch_size
+        256): training draws nothing from the RandomState, so epoch e + 1's shuffle is computed on a second slk_ctx / HIP
+        stream while epoch e trains (see ImplicitFactorizationModel._fit_pipelined).  Same permutations, same RandomState
+        afterwards, bit-identical tables."""
+        prep, prep_stream = _host._prep_lane_for(device)
+        torch.cuda.current_stream(device).synchronize() if device.type == 'cuda' else None  # the uploads are complete
+        bufs = [(torch.empty_like(d_users0), torch.empty_like(d_items0), torch.empty_like(d_ratings0),
+                 torch.empty(n, dtype=torch.float32, device=device)) for _ in range(2)]
+        d_perm = torch.empty(n, dtype=torch.int64, device=device)
+        side = torch.cuda.ExternalStream(prep_stream, device=device) if device.type == 'cuda' else None
+
+        def prepare(slot):
+            prep.rng_set_state(self._random_state.get_state())
+            d_users, d_items, d_rbits, d_ratings = bufs[slot]
+            _host.device_epoch_shuffle(prep, self._random_state, n, d_perm,
+                                       [(d_users0, d_users, 1), (d_items0, d_items, 1), (d_ratings0, d_rbits, 1)], prep_stream)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    d_ratings.copy_(d_rbits.to(torch.int32).view(torch.float32))
+            else:
+                d_ratings.copy_(d_rbits.to(torch.int32).view(torch.float32))
+            self._random_state.set_state(prep.rng_get_state())  # synchronises the prep stream (the conversion included)
+
+        prepare(0)
+        for epoch_num in range(self._n_iter):
+            d_users, d_items, _, d_ratings = bufs[epoch_num % 2]
+            ostruct = binding.as_struct()
+            engine.bilinear_train_explicit(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), d_ratings.data_ptr(), n,
+                                           self._batch_size, self._loss, mb_loss.data_ptr(), stream=stream)
+            binding.store_steps(ostruct.step)
+            state_after_epoch = self._random_state.get_state()
+            if epoch_num + 1 < self._n_iter:
+                prepare((epoch_num + 1) % 2)  # overlaps the training kernels of this epoch
+
+            epoch_loss = float(mb_loss.double().mean().item())  # also waits for this epoch's kernels
+            engine.check()
+
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                self._random_state.set_state(state_after_epoch)
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
     def predict(self, user_ids, item_ids=None):

@@ -44,7 +44,9 @@ static void *g_sched_sp = nullptr;
 static const std::function<void()> *g_body = nullptr;
 
 struct WaveSync {
-    unsigned long long slot[2][64];
+    // exchange slots per log2 width: a lane that has left a narrow exchange may enter a wider one (a different call site)
+    // before its partner has read the narrow one's value
+    unsigned long long slot[7][2][64];
     // one (arrived, generation) pair per (log2 width, segment)
     unsigned arrived[7][64];
     unsigned gen[7][64];
@@ -112,14 +114,14 @@ unsigned long long shfl_exchange(unsigned long long v, int src, int width) {
     WaveSync &w = blk().waves[cur->linear >> 6];
     const int lw = ilog2(width), seg = (int)lane / width;
     const unsigned my = w.gen[lw][seg];
-    w.slot[my & 1][lane] = v;
+    w.slot[lw][my & 1][lane] = v;
     if (++w.arrived[lw][seg] == (unsigned)width) {
         w.arrived[lw][seg] = 0;
         ++w.gen[lw][seg];
     } else {
         while (w.gen[lw][seg] == my) yield_to_scheduler();
     }
-    return w.slot[my & 1][src];
+    return w.slot[lw][my & 1][src];
 }
 
 static void init_block(Block &b, uint3_ idx, dim3 block, unsigned nthreads, size_t shmem, char *stacks, size_t stack_bytes) {

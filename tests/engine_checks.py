@@ -1027,6 +1027,10 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
     hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
     state = np.random.RandomState(seed + 1).get_state()
     n_mb = (N + B - 1) // B
+    # explicit feedback (ExplicitFactorizationModel.fit, factorization/explicit.py:213-236): one pair per interaction,
+    # the loss against a rating, no negatives
+    explicit = loss in ('regression', 'poisson', 'logistic')
+    ratings = _ratings_for(rs, loss, N) if explicit else None
     results = []
     for route in (0, 1):
         eng.set_option('epoch_kernel', route)
@@ -1042,14 +1046,19 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
             dev = be.model(params, opt=opt, **hp)
             eng.rng_set_state(state)
             d_users, d_items = be.alloc(users), be.alloc(items)
+            d_ratings = be.alloc(ratings) if explicit else None
             losses = []
             neg_out = be.alloc(np.full(N, -1, dtype=np.int64))
             eng.profile_reset()
             eng.profile_enable(True)
             for _ in range(epochs):
                 mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
-                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
-                                   be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
+                if explicit:
+                    eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), N,
+                                                B, loss, be.ptr(mb_loss), stream=be.stream)
+                else:
+                    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
+                                       be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
                 losses.append(be.get(mb_loss).copy())
             eng.profile_enable(False)
             prof = eng.profile_read()

@@ -21,6 +21,20 @@ def test_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
     ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 8)
 
 
+@pytest.mark.parametrize('loss', ['regression', 'poisson', 'logistic'])
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_explicit_feedback_bit_identical_to_launch_path(be, loss, opt):
+    """ExplicitFactorizationModel's minibatch loop (factorization/explicit.py:213-236) inside the persistent launch"""
+    ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 8)
+
+
+def test_epoch_kernel_explicit_feedback_layouts_duplicates_chunks(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'regression', 'adagrad', 32, U=23, I=31, N=307, B=100)
+    ec.check_epoch_kernel_is_bit_identical(be, 'logistic', 'adam_dense', 3, U=23, I=31, N=199, B=64, epochs=1)
+    ec.check_epoch_kernel_is_bit_identical(be, 'poisson', 'sparse_adam', 8, U=1, I=2, N=130, B=64)
+    ec.check_epoch_kernel_is_bit_identical(be, 'regression', 'adagrad_dense', 16, N=1500, B=128, chunk=256)
+
+
 @pytest.mark.parametrize('D,B', [(32, 100), (64, 70), (20, 64), (3, 64)])
 def test_epoch_kernel_other_layouts(be, D, B):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', D, U=23, I=31, N=3 * B + 7, B=B)

@@ -257,6 +257,13 @@ def test_epoch_kernel_cooperative_launch_form(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2, cooperative=1)
 
 
+@pytest.mark.parametrize('loss', ['regression', 'poisson', 'logistic'])
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_explicit_feedback_bit_identical_to_launch_path(be, loss, opt):
+    """ExplicitFactorizationModel's loop at the reference's MovieLens-100K shape and default batch size (explicit.py:71)"""
+    ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 32, U=943, I=1682, N=20000, B=256, epochs=2)
+
+
 def test_epoch_kernel_two_level_barrier(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2, barrier=1)
     ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 64, U=3000, I=1000, N=9000, B=256, epochs=1, barrier=1)

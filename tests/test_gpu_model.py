@@ -277,3 +277,8 @@ def test_pipelined_fit_is_value_neutral_on_gpu():
 def test_pipelined_seq_fit_is_value_neutral_on_gpu():
     from test_host_seq_model import check_pipelined_seq_fit_is_value_neutral
     check_pipelined_seq_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
+
+
+def test_pipelined_explicit_fit_is_value_neutral_on_gpu():
+    from test_host_explicit_model import check_pipelined_explicit_fit_is_value_neutral
+    check_pipelined_explicit_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())

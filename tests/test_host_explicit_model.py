@@ -71,6 +71,37 @@ def test_fit_predict_match_reference_run(emu_device, name):
     check_fit_predict_against_fixture(name)
 
 
+def check_pipelined_explicit_fit_is_value_neutral(use_cuda=False, to_numpy=lambda w: w.detach().numpy()):
+    """fit() of a small dataset shuffles epoch e + 1 while epoch e trains (ExplicitFactorizationModel._fit_pipelined); the
+    serial loop it replaces must give the same tables and RandomState, bit for bit."""
+    rs = np.random.RandomState(12)
+    inter = Interactions(rs.randint(0, 90, 2000).astype(np.int32), rs.randint(0, 60, 2000).astype(np.int32),
+                         ratings=rs.randint(1, 6, 2000).astype(np.float32), num_users=90, num_items=60)
+    results = []
+    for limit in (host._PIPELINE_MAX_DRAWS, 0):
+        old = host._PIPELINE_MAX_DRAWS
+        host._PIPELINE_MAX_DRAWS = limit
+        try:
+            for loss, kw in (('regression', dict(optimizer_func=_adagrad)), ('poisson', dict()),
+                             ('logistic', dict(sparse=True, optimizer_func=_sparse_adam))):
+                model = ExplicitFactorizationModel(loss=loss, embedding_dim=16, n_iter=3, batch_size=256, use_cuda=use_cuda,
+                                                   random_state=np.random.RandomState(7), **kw)
+                model.fit(inter)
+                model.fit(inter)  # resume: optimizer steps and the RandomState carry over
+                st = model._random_state.get_state()
+                results.append([to_numpy(w).copy() for w in model._net.tables()] + [st[1].copy(), np.array(st[2])])
+        finally:
+            host._PIPELINE_MAX_DRAWS = old
+    half = len(results) // 2
+    for a, b in zip(results[:half], results[half:]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_pipelined_explicit_fit_is_value_neutral(emu_device):
+    check_pipelined_explicit_fit_is_value_neutral()
+
+
 def test_errors(emu_device):
     with pytest.raises(AssertionError):
         ExplicitFactorizationModel(loss='bpr')
