@@ -40,22 +40,9 @@ int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, co
 
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s) {
-#if defined(SLK_USER_SORT_BITS) && defined(__HIPCC__)
-    // experiment: a wider radix for the (minibatch, user) sort -- 27 key bits in 3 onesweep iterations of 9 bits
-    // instead of 4 of 8 (build with -DSLK_USER_SORT_BITS=9; A/B in profiles/README.md)
-    if (n == 0) return SLK_OK;
-    using onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 6>, rocprim::kernel_config<1024, 6>,
-                                                         SLK_USER_SORT_BITS, rocprim::block_radix_rank_algorithm::match>;
-    using config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, onesweep>;
-    size_t tmp = 0;
-    SLK_HIP(ctx, rocprim::radix_sort_pairs<config>(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
-    int rc = slk_ensure(ctx, ctx->sort_tmp, tmp);
-    if (rc) return rc;
-    SLK_HIP(ctx, rocprim::radix_sort_pairs<config>(ctx->sort_tmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, s));
-    return SLK_OK;
-#else
+    // (a 9-bit onesweep configuration -- 27 key bits in 3 iterations instead of 4 -- was measured and not kept:
+    // profiles/README.md, round 1)
     return sort_impl<uint64_t>(ctx, kin, kout, vin, vout, n, end_bit, s);
-#endif
 }
 
 // Sizes the temporary storage for pair sorts of up to n elements (both value widths).
