@@ -12,8 +12,8 @@ the machine bench.py runs on, on the same table shapes / loss / minibatch as the
                                   of the GPU step (row-sparse gradients, row-sparse update)
               default_dense_adam  the reference's defaults (dense gradients, Adam over every table row
                                   every minibatch; factorization/implicit.py:144-148)
-  sample      bounded: the number of interactions per fit() is chosen from the warm-up's rate so that the
-              whole leg takes about --seconds
+  sample      bounded: the number of interactions per fit() is chosen from the probed rate so that the timed
+              fits take about --seconds in all (model construction, warm-up and thread probes come on top)
 
 Prints one JSON object.  Runs in its own process (bench.py spawns it) so that its 2 x (tables + optimizer
 state + gradients) of host memory and its thread pool are gone before anything else happens.
@@ -93,10 +93,8 @@ def main():
            'gpu_workload_batch': B, 'loss': args.loss, 'note': note.strip(), 'torch': torch.__version__,
            'protocol': 'warm-up fit() + min of 2 timed fit()s (reference examples/bloom_embeddings/performance.py:24-38)'}
     variants = [v for v in args.variants.split(',') if v]
-    deadline = time.perf_counter() + args.seconds  # for the timed parts; model construction / warm-up come on top
     all_threads = args.threads or os.cpu_count()
     for vi, name in enumerate(variants):
-        share_end = time.perf_counter() + max(4.0, (deadline - time.perf_counter()) / (len(variants) - vi))
         kw = (dict(sparse=True, optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2))
               if name == 'sparse_adagrad' else dict())
         few = min(all_threads, 16)
@@ -116,7 +114,8 @@ def main():
         best = max(rate, key=rate.get)
         torch.set_num_threads(best)
         per_mb = Bc / rate[best]
-        k = int(max(1, min(n_max // Bc, (share_end - time.perf_counter()) / 2.0 / max(per_mb, 1e-6))))
+        # --seconds is the budget of the TIMED fits (two per variant); model construction, warm-up and probes come on top
+        k = int(max(1, min(n_max // Bc, args.seconds / len(variants) / 2.0 / max(per_mb, 1e-6))))
         data = inter(k * Bc)
         timings = [timed_fit(model, data) for _ in range(2)]
         out[name] = {'interactions_per_fit': k * Bc, 'minibatches_per_fit': k, 'seconds': min(timings), 'timings': timings,
