@@ -7,12 +7,12 @@ timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; python -c "
 import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']; print('C2', d['value']/1e9, 'G/s', d['ms_per_step'], 'frac', r['frac'], 'step', r['step_frac_of_peak'], r['measured']['variants_GBs'], r['ceiling']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline'].get('interactions_per_s_by_threads'))"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check > $OUT/prof_bench.json 2> $OUT/prof.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit > $OUT/prof_bench.json 2> $OUT/prof.err)
 db=$(find $OUT/prof -name "*.db" | head -1)
-[ -n "$db" ] && python scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -12 $OUT/kernel_stats.md
+[ -n "$db" ] && python scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -12 $OUT/kernel_stats.md
 for w in c3 c4 c5; do timeout 600 python bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check > $OUT/bench_$w.json 2>/dev/null; python -c "
 import json; d=json.load(open('$OUT/bench_$w.json')); r=d['roofline']; print('$w', d['value']/1e9, d['unit'], d['ms_per_step'], r.get('step_frac_of_peak'))"; done
 for B in 256 1024 65536 1048576; do S=$((4194304 / B)); [ $S -lt 16 ] && S=16; [ $S -gt 2000 ] && S=2000
-python bench.py --batch $B --steps $S --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check 2>/dev/null | tee $OUT/bench_batch_$B.json | python -c "
+python bench.py --batch $B --steps $S --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_batch_$B.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('C2 tables batch $B: %.1f M interactions/s, %.1f us per minibatch' % (d['value']/1e6, d['ms_per_step']*1e3))"; done
 bash scripts/pmc_run.sh ${1:-r02_final}_pmc --no-probes --no-sharded-check > $GRAFT_REPO_ROOT/gpurun_out/${1:-r02_final}/pmc.log 2>&1; tail -5 $GRAFT_REPO_ROOT/gpurun_out/${1:-r02_final}/pmc.log

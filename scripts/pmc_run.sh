@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" -d $OUT/$name -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "${BARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
+  timeout 600 rocprofv3 --pmc "$@" -d $OUT/$name -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fit "${BARGS[@]}" > $OUT/$name.json 2> $OUT/$name.err
   echo "pmc $name exit $?"
 }
 BARGS=("$@")
@@ -24,6 +24,6 @@ if [ -n "${PMC_TLB:-}" ]; then
   run utcl1 TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum
   run tcpreq TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 fi
-python $ROOT/scripts/summarize_pmc.py $OUT $OUT/pmc_summary "rocprofv3 --pmc passes over python bench.py --steps 4 --warmup 1 ${BARGS[*]} ($TAG)" > /dev/null
+python $ROOT/scripts/summarize_pmc.py $OUT $OUT/pmc_summary "rocprofv3 --pmc passes over python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-fit ${BARGS[*]} ($TAG)" > /dev/null
 for g in fetch write sq tcc utcl1 tcpreq; do rm -rf $OUT/$g; done
 ls $OUT; cat $OUT/pmc_summary.md | head -60
