@@ -125,6 +125,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "item_grid_mult"      item pass: workgroups per CU (default 64)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond) */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
+/* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
+ * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once). */
+int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
 
 /* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference
  * draws shuffles and negatives from (torch_utils.py:46-47, sampling.py:34).  h_key is

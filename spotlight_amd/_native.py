@@ -52,6 +52,7 @@ _PROTOTYPES = {
     'slk_ctx_destroy': (None, [C.c_void_p]),
     'slk_last_error': (C.c_char_p, [C.c_void_p]),
     'slk_ctx_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     'slk_sample_items': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -181,6 +182,12 @@ class Engine(object):
     def set_option(self, name, value):
         """include/spotlight_hip.h: slk_ctx_set_option (tuning knobs; results do not change)."""
         self._check(self._lib.slk_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_stat(self, name):
+        """include/spotlight_hip.h: slk_ctx_get_stat (diagnostics of the last calls)."""
+        v = C.c_int64(0)
+        self._check(self._lib.slk_ctx_get_stat(self._ctx, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def _check(self, rc):
         if rc != SLK_OK:

@@ -182,12 +182,23 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_debug = (int)value;
     } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
         ctx->opt_epoch_dense_elems = value;
+    } else if (!strcmp(name, "shuffle_band") && value >= 0 && value <= 1024) {
+        ctx->opt_shuffle_band = (int)value;
     } else if (!strcmp(name, "nt") && value >= 0 && value <= 15) {
         ctx->opt_nt = (int)value;
     } else {
         return slk_fail(ctx, SLK_EINVAL, "slk_ctx_set_option: unknown option or bad value: %s = %lld", name,
                         (long long)value);
     }
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return SLK_EINVAL;
+    if (!strcmp(name, "shuffle_sweeps")) *value = ctx->fy_sweeps;
+    else if (!strcmp(name, "shuffle_fallbacks")) *value = ctx->fy_fallbacks;
+    else if (!strcmp(name, "epoch_refused")) *value = ctx->epoch_refused ? 1 : 0;
+    else return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_stat: unknown statistic %s", name);
     return SLK_OK;
 }
 

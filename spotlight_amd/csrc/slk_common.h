@@ -132,6 +132,8 @@ struct slk_ctx {
     int em_dim = 0;
 
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
+    int fy_fallbacks = 0;           //   ranges of the last call that left the band and were redone with the full sweeps
+    int opt_shuffle_band = 1;       // slk_shuffle_perm: 1 banded draws (default), 0 full sweeps, > 1 band / value (test hook: forces fall-backs)
 
     // profiling
     bool prof_on = false;

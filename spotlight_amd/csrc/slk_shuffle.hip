@@ -15,6 +15,15 @@
 //      advances every sweep (no cycles), and because shifting A by delta flips only ~0.7 delta
 //      decisions the error contracts geometrically -- ~20 sweeps of an 8-byte-per-word scan
 //      instead of 1e8 dependent steps.  The last 4095 draws are taken in order by one lane.
+//      Round 2 (default): the sweeps run over a BAND only.  A(t) stays within a few standard deviations of the curve
+//      x(t) above (a sum of t Bernoulli decisions: sigma <= sqrt(t)/2), so a word whose threshold hi - v_t lies
+//      outside [x(t) - D(t), x(t) + D(t)], D(t) = 4 sqrt(t) + 16 (8 sigma), is accepted or rejected whatever the exact
+//      count is -- all but ~3 * 2^(k/2) words of a range with mask 2^k - 1.  One pass classifies and counts, the
+//      uncertain words (threshold and the number of certain accepts before them) are compacted into a list that ONE
+//      workgroup resolves (every thread walks its chunk of the list exactly from a starting count; the fixpoint is over
+//      the 1024 starting counts only), and a last pass emits the draws and CHECKS |A(t) - x(t)| <= D(t) for every word it
+//      used: if the band was ever left (it is not, short of an 8-sigma walk) the range is redone with the full sweeps.
+//      Three passes over the words instead of ~20: 10^8 ids 30.7 -> see profiles/README.md.
 //  (2) THE SWAPS.  Step i makes x[i] final and moves the value that sat at i into j_i.  Hence, with
 //      T_p = the steps i' > p with j_i' = p in time order:  X[p] (the value at p when step p
 //      runs) = X[last of T_p] or p if none -- a forest of pointers to larger indices, resolved by
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(256) void k_fy_count(fy_args a, uint32_t *cnt) {
     if (threadIdx.x == 0) cnt[blockIdx.x] = s[0];
 }
 
-// exclusive scan of cnt[nb] -> off[nb]
+// exclusive scan of cnt[nb] -> off[nb]; off[nb] = the total
 __global__ __launch_bounds__(256) void k_fy_scan(const uint32_t *cnt, uint32_t *off, int nb) {
     __shared__ uint32_t s[256];
     __shared__ uint32_t carry;
@@ -106,6 +115,7 @@ __global__ __launch_bounds__(256) void k_fy_scan(const uint32_t *cnt, uint32_t *
         if (t == 255) carry += s[255];
         __syncthreads();
     }
+    if (t == 0) off[nb] = carry;
 }
 
 // A_new = exclusive prefix sum of the decisions taken with A_old; *changed |= (A_new != A_old).
@@ -153,6 +163,204 @@ __global__ __launch_bounds__(256) void k_fy_apply(fy_args a, const uint32_t *off
         __syncthreads();
     }
     if (t == 0) cnt_next[blockIdx.x] = s[0];
+}
+
+// ---- the banded form of (1) -----------------------------------------------------------------------------------------
+// Classification of the 8 consecutive words one thread owns (t0 .. t0 + 7).  x advances by its own derivative per word
+// ((hi + 1 - x) / (mask + 1): the curve's ODE; eight Euler steps of 1e-8 relative size), D is taken at the thread's last
+// word.  Every kernel below calls this with the same arguments, so they agree on every word.
+//   cls: 1 = accepted for every count in the band, 0 = rejected for every count in the band, 2 = uncertain
+struct fy_cls8 {
+    int thr[8];        // accepted iff A(t) <= thr (v_t <= hi - A(t))
+    uint32_t v[8];
+    unsigned char cls[8];
+    double x[8];       // the curve at the word
+    double D;
+};
+
+__device__ __forceinline__ void fy_classify8(const fy_args &a, uint32_t t0, int band_div, fy_cls8 &c) {
+    const double M = (double)a.mask + 1.0, H = (double)a.hi + 1.0;
+    double x = H * (1.0 - exp(-(double)t0 / M));
+    c.D = (4.0 * sqrt((double)t0 + 8.0) + 16.0) / (double)band_div;  // band_div > 1: a test hook that provokes the fall-back
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t t = t0 + (uint32_t)j;
+        c.x[j] = x;
+        c.cls[j] = 0;
+        c.thr[j] = -1;
+        c.v[j] = 0u;
+        if (t < a.W) {
+            const uint32_t v = fy_temper(a.raw[a.w0 + t]) & a.mask;
+            const int thr = (int)a.hi - (int)v;  // both < 2^31
+            c.v[j] = v;
+            c.thr[j] = thr;
+            if ((double)thr >= x + c.D + 1.0) c.cls[j] = 1;
+            else if ((double)thr < x - c.D - 1.0) c.cls[j] = 0;
+            else c.cls[j] = 2;
+        }
+        x += (H - x) / M;
+    }
+}
+
+// pass 1: per tile, the number of certain accepts and of uncertain words
+__global__ __launch_bounds__(256) void k_fyb_count(fy_args a, int band_div, uint32_t *cnt_cert, uint32_t *cnt_unc) {
+    __shared__ unsigned s[256], u[256];
+    fy_cls8 c;
+    fy_classify8(a, blockIdx.x * FY_TILE + threadIdx.x * 8, band_div, c);
+    unsigned nc = 0, nu = 0;
+    for (int j = 0; j < 8; ++j) {
+        nc += c.cls[j] == 1 ? 1u : 0u;
+        nu += c.cls[j] == 2 ? 1u : 0u;
+    }
+    s[threadIdx.x] = nc;
+    u[threadIdx.x] = nu;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            s[threadIdx.x] += s[threadIdx.x + off];
+            u[threadIdx.x] += u[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt_cert[blockIdx.x] = s[0];
+        cnt_unc[blockIdx.x] = u[0];
+    }
+}
+
+// exclusive prefix of two per-thread counts over the 256 threads of a block (returns this thread's two prefixes)
+__device__ __forceinline__ void fy_block_excl2(unsigned a_in, unsigned b_in, unsigned *sa, unsigned *sb, unsigned &a_out,
+                                               unsigned &b_out) {
+    const int t = threadIdx.x;
+    sa[t] = a_in;
+    sb[t] = b_in;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned xa = (t >= d) ? sa[t - d] : 0u, xb = (t >= d) ? sb[t - d] : 0u;
+        __syncthreads();
+        sa[t] += xa;
+        sb[t] += xb;
+        __syncthreads();
+    }
+    a_out = sa[t] - a_in;
+    b_out = sb[t] - b_in;
+}
+
+// pass 2: the uncertain words, in stream order: their threshold and the number of certain accepts before them
+__global__ __launch_bounds__(256) void k_fyb_collect(fy_args a, int band_div, const uint32_t *off_cert, const uint32_t *off_unc,
+                                                     int *u_thr, uint32_t *u_cert) {
+    __shared__ unsigned sa[256], sb[256];
+    fy_cls8 c;
+    fy_classify8(a, blockIdx.x * FY_TILE + threadIdx.x * 8, band_div, c);
+    unsigned nc = 0, nu = 0;
+    for (int j = 0; j < 8; ++j) {
+        nc += c.cls[j] == 1 ? 1u : 0u;
+        nu += c.cls[j] == 2 ? 1u : 0u;
+    }
+    unsigned pc, pu;
+    fy_block_excl2(nc, nu, sa, sb, pc, pu);
+    if (nu == 0) return;
+    uint32_t cert = off_cert[blockIdx.x] + pc, k = off_unc[blockIdx.x] + pu;
+    for (int j = 0; j < 8; ++j) {
+        if (c.cls[j] == 2) {
+            u_thr[k] = c.thr[j];
+            u_cert[k] = cert;
+            ++k;
+        }
+        cert += c.cls[j] == 1 ? 1u : 0u;
+    }
+}
+
+// The uncertain words' decisions, by ONE workgroup: word k is accepted iff u_cert[k] + (accepted uncertain words before k)
+// <= u_thr[k].  Thread i owns the list chunk [i * len, (i + 1) * len) and walks it exactly from a starting count; the
+// starting counts are iterated (each round: walk, block-scan the chunks' accept counts) until none changes -- chunk 0 is
+// right after the first round, and a wrong start perturbs few decisions, so a handful of rounds do.  u_acc[k] = accepted
+// uncertain words before k (u_acc[L] = all of them).
+__global__ __launch_bounds__(1024) void k_fyb_resolve(const uint32_t *off_unc, int nb, const int *u_thr, const uint32_t *u_cert,
+                                                      uint32_t *u_acc, int *status) {
+    __shared__ uint32_t start[1024], cnt[1024];
+    __shared__ int changed;
+    const uint32_t L = off_unc[nb];
+    const int t = threadIdx.x;
+    const uint32_t len = (L + 1023u) / 1024u;
+    const uint32_t k0 = (uint32_t)t * len < L ? (uint32_t)t * len : L, k1 = k0 + len < L ? k0 + len : L;
+    start[t] = 0;
+    __syncthreads();
+    for (int round = 0; round <= 1024; ++round) {
+        uint32_t acc = start[t];
+        for (uint32_t k = k0; k < k1; ++k) acc += ((int)(u_cert[k] + acc) <= u_thr[k]) ? 1u : 0u;
+        cnt[t] = acc - start[t];
+        if (t == 0) changed = 0;
+        __syncthreads();
+        // exclusive scan of the chunk counts -> the next starting counts
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t x = (t >= d) ? cnt[t - d] : 0u;
+            __syncthreads();
+            cnt[t] += x;
+            __syncthreads();
+        }
+        const uint32_t ns = t ? cnt[t - 1] : 0u;
+        if (ns != start[t]) changed = 1;
+        __syncthreads();
+        start[t] = ns;
+        const int ch = changed;
+        __syncthreads();
+        if (!ch) break;
+        if (round == 1024 && t == 0) *status = 1;  // cannot happen: chunk i is final after round i
+    }
+    uint32_t acc = start[t];
+    for (uint32_t k = k0; k < k1; ++k) {
+        u_acc[k] = acc;
+        acc += ((int)(u_cert[k] + acc) <= u_thr[k]) ? 1u : 0u;
+    }
+    if (k1 == L && (k0 < L || t == 0)) u_acc[L] = acc;  // the owner of the last element (thread 0 if the list is empty)
+}
+
+// pass 3: every word's decision is known -> J[g0 + A(t)] = v_t for the accepted words with A(t) < need; *consumed = words
+// used by the range; *status |= 2 if a word the range used lay outside the band the classification assumed
+__global__ __launch_bounds__(256) void k_fyb_emit(fy_args a, int band_div, const uint32_t *off_cert, const uint32_t *off_unc,
+                                                  const int *u_thr, const uint32_t *u_cert, const uint32_t *u_acc, uint32_t *J,
+                                                  uint32_t g0, uint32_t *consumed, int *status) {
+    __shared__ unsigned sa[256], sb[256];
+    fy_cls8 c;
+    fy_classify8(a, blockIdx.x * FY_TILE + threadIdx.x * 8, band_div, c);
+    unsigned nu = 0;
+    for (int j = 0; j < 8; ++j) nu += c.cls[j] == 2 ? 1u : 0u;
+    // this thread's uncertain words are list entries ku .. ku + nu - 1; their decisions from the resolved counts
+    unsigned dummy, pu;
+    fy_block_excl2(0u, nu, sa, sb, dummy, pu);
+    const uint32_t ku0 = off_unc[blockIdx.x] + pu;
+    bool acc[8];
+    unsigned na = 0;
+    {
+        uint32_t ku = ku0;
+        for (int j = 0; j < 8; ++j) {
+            if (c.cls[j] == 2) {
+                acc[j] = (int)(u_cert[ku] + u_acc[ku]) <= u_thr[ku];
+                ++ku;
+            } else {
+                acc[j] = c.cls[j] == 1;
+            }
+            na += acc[j] ? 1u : 0u;
+        }
+    }
+    unsigned pa;
+    fy_block_excl2(na, 0u, sa, sb, pa, dummy);
+    // accepts before this tile = certain ones + uncertain ones accepted
+    uint32_t A = off_cert[blockIdx.x] + u_acc[off_unc[blockIdx.x]] + pa;
+    bool viol = false;
+    const uint32_t t0 = blockIdx.x * FY_TILE + threadIdx.x * 8;
+    for (int j = 0; j < 8; ++j) {
+        if (t0 + j < a.W && A < a.need) {
+            const double dev = (double)A - c.x[j];
+            viol |= dev > c.D || dev < -c.D;
+            if (acc[j]) {
+                J[g0 + A] = c.v[j];
+                if (A == a.need - 1) *consumed = t0 + j + 1;
+            }
+        }
+        A += acc[j] ? 1u : 0u;
+    }
+    if (viol) atomicOr(status, 2);
 }
 
 // the converged decisions: J[g0 + A(t)] = v_t for the accepted words; *consumed = words used by the range
@@ -329,13 +537,14 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     for (int b = 0; b < 5; ++b)
         if ((rc = slk_ensure(ctx, ctx->extra[FY_B0 + b], (size_t)N * 4 + 64))) return rc;
     const size_t nb_max = ((size_t)N * 2 + FY_TILE - 1) / FY_TILE + 2;
-    if ((rc = slk_ensure(ctx, ctx->extra[FY_SMALL], nb_max * 8 + 64))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->extra[FY_SMALL], nb_max * 16 + 128))) return rc;  // 2 x (counts, offsets + total), flags
     if ((rc = slk_mt_generate_blocks(ctx, nblocks, s))) return rc;
     const uint32_t *raw = (const uint32_t *)ctx->raw.p;
     uint32_t *J = (uint32_t *)ctx->extra[FY_B0].p;
     uint32_t *Abuf[2] = {(uint32_t *)ctx->extra[FY_B1].p, (uint32_t *)ctx->extra[FY_B2].p};
+    // small area: cnt[nb_max] | off[nb_max + 1] (+ pad) | cnt_unc[nb_max] | off_unc[nb_max + 1] | status, consumed
     uint32_t *cnt = (uint32_t *)ctx->extra[FY_SMALL].p, *off = cnt + nb_max;
-    int *d_flag = (int *)(off + nb_max);
+    int *d_flag = (int *)(off + nb_max + 4 + nb_max + nb_max + 4);
     uint32_t *d_consumed = (uint32_t *)(d_flag + 1);
 
     // ---- (1) the draws, range by range (constant mask), largest i first
@@ -343,6 +552,7 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     uint32_t g = 0;                                   // draws emitted so far (draw g <-> i = N-1-g)
     uint32_t hi = N - 1;
     int total_sweeps = 0;
+    ctx->fy_fallbacks = 0;
     while (hi >= FY_TAIL) {
         uint32_t mask = hi;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
@@ -361,37 +571,68 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
         a.hi = hi;
         a.need = need;
         const unsigned nb = (a.W + FY_TILE - 1) / FY_TILE;
-        int cur = 0;
-        hipLaunchKernelGGL(k_fy_init, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, Abuf[0], a.W, need, hi, mask);
-        SLK_LAUNCH_CHECK(ctx, "k_fy_init");
-        const int check_every = a.W > (1u << 20) ? 1 : 3;
-        int sweeps = 0, flag = 1;
-        a.A_old = Abuf[0];
-        hipLaunchKernelGGL(k_fy_count, dim3(nb), dim3(256), 0, s, a, cnt);  // later counts come from k_fy_apply
-        SLK_LAUNCH_CHECK(ctx, "k_fy_count");
-        while (flag) {
-            for (int k = 0; k < check_every; ++k) {
-                a.A_old = Abuf[cur];
-                a.A_new = Abuf[cur ^ 1];
-                if (k == check_every - 1) SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
-                hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb);
-                hipLaunchKernelGGL(k_fy_apply, dim3(nb), dim3(256), 0, s, a, (const uint32_t *)off, cnt, d_flag);
-                SLK_LAUNCH_CHECK(ctx, "k_fy_apply");
-                cur ^= 1;
-                ++sweeps;
-            }
-            SLK_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-            SLK_HIP(ctx, hipStreamSynchronize(s));
-            if (sweeps > 2000) return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: acceptance fixpoint did not converge");
-        }
-        total_sweeps += sweeps;
-        a.A_old = Abuf[cur];
         uint32_t consumed = 0;
-        SLK_HIP(ctx, hipMemsetAsync(d_consumed, 0, 4, s));
-        hipLaunchKernelGGL(k_fy_emit, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, a, J, g, d_consumed);
-        SLK_LAUNCH_CHECK(ctx, "k_fy_emit");
-        SLK_HIP(ctx, hipMemcpyAsync(&consumed, d_consumed, 4, hipMemcpyDeviceToHost, s));
-        SLK_HIP(ctx, hipStreamSynchronize(s));
+        bool done = false;
+        if (ctx->opt_shuffle_band) {
+            // ---- banded: classify + count, compact the uncertain words, resolve them, emit + verify (one host round trip)
+            const int band_div = ctx->opt_shuffle_band;
+            uint32_t *cnt_unc = off + nb_max + 4, *off_unc = cnt_unc + nb_max;  // second counter / offset pair
+            int *u_thr = (int *)Abuf[0];
+            uint32_t *u_cert = Abuf[1], *u_acc = (uint32_t *)ctx->extra[FY_B3].p;
+            SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, 8, s));  // status + consumed
+            hipLaunchKernelGGL(k_fyb_count, dim3(nb), dim3(256), 0, s, a, band_div, cnt, cnt_unc);
+            SLK_LAUNCH_CHECK(ctx, "k_fyb_count");
+            hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb);
+            hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt_unc, off_unc, (int)nb);
+            hipLaunchKernelGGL(k_fyb_collect, dim3(nb), dim3(256), 0, s, a, band_div, (const uint32_t *)off,
+                               (const uint32_t *)off_unc, u_thr, u_cert);
+            SLK_LAUNCH_CHECK(ctx, "k_fyb_collect");
+            hipLaunchKernelGGL(k_fyb_resolve, dim3(1), dim3(1024), 0, s, (const uint32_t *)off_unc, (int)nb, (const int *)u_thr,
+                               (const uint32_t *)u_cert, u_acc, d_flag);
+            SLK_LAUNCH_CHECK(ctx, "k_fyb_resolve");
+            hipLaunchKernelGGL(k_fyb_emit, dim3(nb), dim3(256), 0, s, a, band_div, (const uint32_t *)off,
+                               (const uint32_t *)off_unc, (const int *)u_thr, (const uint32_t *)u_cert, (const uint32_t *)u_acc, J,
+                               g, d_consumed, d_flag);
+            SLK_LAUNCH_CHECK(ctx, "k_fyb_emit");
+            int h2[2] = {0, 0};
+            SLK_HIP(ctx, hipMemcpyAsync(h2, d_flag, 8, hipMemcpyDeviceToHost, s));
+            SLK_HIP(ctx, hipStreamSynchronize(s));
+            consumed = (uint32_t)h2[1];
+            done = h2[0] == 0 && consumed != 0;  // otherwise: the band was left (or the window ran out) -- full sweeps decide
+            if (!done) ++ctx->fy_fallbacks;
+        }
+        if (!done) {
+            int cur = 0;
+            hipLaunchKernelGGL(k_fy_init, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, Abuf[0], a.W, need, hi, mask);
+            SLK_LAUNCH_CHECK(ctx, "k_fy_init");
+            const int check_every = a.W > (1u << 20) ? 1 : 3;
+            int sweeps = 0, flag = 1;
+            a.A_old = Abuf[0];
+            hipLaunchKernelGGL(k_fy_count, dim3(nb), dim3(256), 0, s, a, cnt);  // later counts come from k_fy_apply
+            SLK_LAUNCH_CHECK(ctx, "k_fy_count");
+            while (flag) {
+                for (int k = 0; k < check_every; ++k) {
+                    a.A_old = Abuf[cur];
+                    a.A_new = Abuf[cur ^ 1];
+                    if (k == check_every - 1) SLK_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), s));
+                    hipLaunchKernelGGL(k_fy_scan, dim3(1), dim3(256), 0, s, (const uint32_t *)cnt, off, (int)nb);
+                    hipLaunchKernelGGL(k_fy_apply, dim3(nb), dim3(256), 0, s, a, (const uint32_t *)off, cnt, d_flag);
+                    SLK_LAUNCH_CHECK(ctx, "k_fy_apply");
+                    cur ^= 1;
+                    ++sweeps;
+                }
+                SLK_HIP(ctx, hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+                SLK_HIP(ctx, hipStreamSynchronize(s));
+                if (sweeps > 2000) return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: acceptance fixpoint did not converge");
+            }
+            total_sweeps += sweeps;
+            a.A_old = Abuf[cur];
+            SLK_HIP(ctx, hipMemsetAsync(d_consumed, 0, 4, s));
+            hipLaunchKernelGGL(k_fy_emit, dim3(fy_grid(ctx, a.W)), dim3(256), 0, s, a, J, g, d_consumed);
+            SLK_LAUNCH_CHECK(ctx, "k_fy_emit");
+            SLK_HIP(ctx, hipMemcpyAsync(&consumed, d_consumed, 4, hipMemcpyDeviceToHost, s));
+            SLK_HIP(ctx, hipStreamSynchronize(s));
+        }
         if (consumed == 0)
             return slk_fail(ctx, SLK_EIO, "slk_shuffle_perm: ran out of generated words (rejection tail > 12 sigma)");
         w += consumed;

@@ -688,9 +688,27 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
 # ---------------------------------------------------------------------------------------
 # epoch shuffle on the device (slk_shuffle_perm)
 # ---------------------------------------------------------------------------------------
-def check_shuffle_matches_numpy(be, n, seed, burn=7, rows=0):
+def check_shuffle_matches_numpy(be, n, seed, burn=7, rows=0, band=1):
     """d_perm == numpy's RandomState.shuffle(arange(n)) bit for bit, same RandomState afterwards
-    (torch_utils.py:35-52); `rows` > 0 also checks slk_gather_rows_i64 on an [n, rows] array."""
+    (torch_utils.py:35-52); `rows` > 0 also checks slk_gather_rows_i64 on an [n, rows] array.
+    band: 1 = the banded draws (default; no range may fall back to the full sweeps), 0 = the full sweeps only,
+    > 1 = a band that many times too narrow, so that ranges DO leave it and are redone (the fall-back path)."""
+    eng = be.engine
+    eng.set_option('shuffle_band', band)
+    try:
+        _check_shuffle_matches_numpy(be, n, seed, burn, rows)
+        if n > 4096:
+            if band == 1:
+                assert eng.get_stat('shuffle_fallbacks') == 0 and eng.get_stat('shuffle_sweeps') == 0
+            elif band == 0:
+                assert eng.get_stat('shuffle_sweeps') > 0 and eng.get_stat('shuffle_fallbacks') == 0
+            elif band >= 8:
+                assert eng.get_stat('shuffle_fallbacks') > 0 and eng.get_stat('shuffle_sweeps') > 0
+    finally:
+        eng.set_option('shuffle_band', 1)
+
+
+def _check_shuffle_matches_numpy(be, n, seed, burn, rows):
     eng = be.engine
     rs = np.random.RandomState(seed)
     if burn:

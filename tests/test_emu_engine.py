@@ -121,6 +121,13 @@ def test_device_shuffle_is_numpy_exact(be, n):
     ec.check_shuffle_matches_numpy(be, n, seed=n + 1, burn=n % 5, rows=3 if n in (10, 4097) else 0)
 
 
+@pytest.mark.parametrize('n,band', [(4097, 0), (70001, 0), (131073, 0), (5000, 64), (70001, 8), (131073, 32), (65537, 1024)])
+def test_device_shuffle_full_sweeps_and_band_fallback(be, n, band):
+    """band 0: the full fixpoint sweeps alone; band > 1: a band that many times too narrow -- ranges leave it, the emit pass
+    notices, and the full sweeps redo them: same permutation either way."""
+    ec.check_shuffle_matches_numpy(be, n, seed=n + 11, burn=n % 3, band=band)
+
+
 def test_minibatch_of_one_interaction(be):
     """batch_size 1 (the reference crashes there: squeeze() collapses [1, D]) and a
     last minibatch of one interaction."""

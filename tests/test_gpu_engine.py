@@ -182,6 +182,11 @@ def test_device_shuffle_is_numpy_exact(be, n):
     ec.check_shuffle_matches_numpy(be, n, seed=n % 1000 + 3, burn=n % 7, rows=2 if n == 5000 else 0)
 
 
+@pytest.mark.parametrize('n,band', [(1000003, 0), (1000003, 16), ((1 << 24) + 1, 4), (30000000, 0)])
+def test_device_shuffle_full_sweeps_and_band_fallback(be, n, band):
+    ec.check_shuffle_matches_numpy(be, n, seed=n % 1000 + 5, burn=n % 7, band=band)
+
+
 # ---- Interactions.to_sequence on the device (slk_seqprep.hip) ----
 @pytest.mark.parametrize('case', [
     (1, 5, 9, 'int32', 4, None, None), (200, 11, 50, 'int32', 5, 3, 2), (300, 40, 50, 'float', 4, None, 1),
