@@ -38,8 +38,7 @@
 
 #define SLK_MT_N 624
 #define FY_TILE 2048       // words per workgroup in the scan kernels (256 threads x 8)
-#define FY_TAIL 4096       // draws for i < FY_TAIL are taken in order by one lane (k_fy_tail): serial code costs
-                           // ~100 ns per word on this machine, so the tail is kept short (65536 measured +8 ms)
+#define FY_TAIL 4096       // draws for i < FY_TAIL are taken by one wavefront (k_fy_tail)
 
 enum { FY_B0 = 26, FY_B1, FY_B2, FY_B3, FY_B4, FY_SMALL, FY_SORT };  // ctx->extra slots (32 in all)
 
@@ -375,53 +374,85 @@ __global__ __launch_bounds__(256) void k_fy_emit(fy_args a, uint32_t *J, uint32_
     }
 }
 
-// the last draws (i = i_start .. 1) by ONE wavefront: 256 words are tempered at once into LDS, then lane 0
-// walks them in order (is word l <= the current i under its mask?): numpy's rk_interval loop without a
-// dependent global load per word.
+// the last draws (i = i_start .. 1) by ONE wavefront, range by range (constant mask).  A block of 512 raw words at a time:
+// every lane walks ITS 8 consecutive words exactly (numpy's rk_interval loop: accept v <= i, then --i) from a starting
+// count; the starting counts are the wave-wide exclusive prefix of the lanes' accept counts, iterated until no lane's
+// changes -- lane l is right after round l + 1 at the latest, usually after a few.  (A single lane walking the ~5900
+// words in order took 0.67 ms: two thirds of the whole shuffle of a MovieLens-100K-sized epoch.)
+#define FY_TAIL_C 8
 __global__ __launch_bounds__(64) void k_fy_tail(const uint32_t *raw, unsigned long long w0,
                                                 unsigned long long total_words, uint32_t i_start, uint32_t *J,
                                                 uint32_t g0, uint32_t *consumed) {
-    __shared__ uint32_t sv[256];
     const int lane = threadIdx.x;
-    unsigned long long w = w0;
+    unsigned long long w = w0;  // next unconsumed word
     uint32_t i = i_start, g = g0;
-    uint32_t result = 0xffffffffu;  // words consumed; ~0u = ran out of generated words
-    while (i >= 1) {
-        if (w >= total_words) break;
-        // 256 words per round: tempered by the 64 lanes, parked in LDS, then walked in order from
-        // LDS (plain loads the compiler can batch ahead of the dependent decision chain)
-        __syncthreads();
+    bool starved = false;
+    while (i >= 1 && !starved) {
+        uint32_t mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t lo = (mask >> 1) + 1, hi = i;
+        const uint32_t need = hi - lo + 1;  // the draws for i = hi, hi - 1, ..., lo
+        uint32_t a0 = 0;                    // accepted so far in this range
+        while (a0 < need) {
+            if (w >= total_words) {
+                starved = true;
+                break;
+            }
+            uint32_t v[FY_TAIL_C];
+            bool valid[FY_TAIL_C];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long idx = w + (unsigned long long)(r * 64 + lane);
-            sv[r * 64 + lane] = idx < total_words ? fy_temper(raw[idx]) : 0u;
-        }
-        __syncthreads();
-        const int avail = (total_words - w < 256ull) ? (int)(total_words - w) : 256;
-        int l = 0;
-        if (lane == 0) {
-            for (; l < avail && i >= 1; ++l) {
-                uint32_t mask = i;
-                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-                const uint32_t v = sv[l] & mask;
-                if (v <= i) {
-                    J[g] = v;
-                    ++g;
-                    --i;
+            for (int j = 0; j < FY_TAIL_C; ++j) {
+                const unsigned long long idx = w + (unsigned long long)(lane * FY_TAIL_C + j);
+                valid[j] = idx < total_words;
+                v[j] = valid[j] ? (fy_temper(raw[idx]) & mask) : 0u;
+            }
+            uint32_t s = a0;
+            for (int round = 0; round < 66; ++round) {
+                uint32_t acc = s;
+#pragma unroll
+                for (int j = 0; j < FY_TAIL_C; ++j) acc += (valid[j] && acc < need && v[j] <= hi - acc) ? 1u : 0u;
+                const uint32_t cnt = acc - s;
+                uint32_t inc = cnt;  // inclusive prefix over the lanes
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(inc, (unsigned)d, 64);
+                    if (lane >= d) inc += t;
+                }
+                const uint32_t ns = a0 + inc - cnt;
+                uint32_t ch = ns != s ? 1u : 0u;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) ch |= __shfl_xor(ch, m, 64);
+                s = ns;
+                if (!ch) break;
+            }
+            uint32_t acc = s, last_pos = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < FY_TAIL_C; ++j) {
+                if (valid[j] && acc < need && v[j] <= hi - acc) {
+                    J[g + acc] = v[j];
+                    if (acc == need - 1) last_pos = (uint32_t)(lane * FY_TAIL_C + j);
+                    ++acc;
                 }
             }
+            const uint32_t tot = __shfl(acc, 63, 64);  // a0 + the block's accepts
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint32_t o = __shfl_xor(last_pos, m, 64);
+                last_pos = o < last_pos ? o : last_pos;
+            }
+            if (tot >= need) {  // the range ends inside this block: the next one starts at the following word
+                w += (unsigned long long)last_pos + 1ull;
+                a0 = need;
+            } else {
+                a0 = tot;
+                w += 64ull * FY_TAIL_C;
+            }
         }
-        // lane 0's progress to the whole wave
-        i = __shfl(i, 0, 64);
-        g = __shfl(g, 0, 64);
-        l = __shfl(l, 0, 64);
-        if (i == 0) {
-            result = (uint32_t)(w + (unsigned long long)l - w0);
-            break;
-        }
-        w += 256;
+        if (starved) break;
+        g += need;
+        i = lo - 1;
     }
-    if (lane == 0) *consumed = result;
+    if (lane == 0) *consumed = starved ? 0xffffffffu : (uint32_t)(w - w0);
 }
 
 // step g (i = n-1-g) writes position j: key = j, value = i; self-swaps get the sentinel key n
