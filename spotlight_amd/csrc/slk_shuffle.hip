@@ -525,6 +525,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const T *src, const int64_t
     }
 }
 
+// row_len == 1 (the id and rating arrays of fit()): no index arithmetic -- the 64-bit division per element of the general
+// kernel above cost more than the gather's memory traffic
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_elems(const T *src, const int64_t *perm, int64_t n, T *dst) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) dst[e] = src[perm[e]];
+}
+
 static inline unsigned fy_grid(const slk_ctx *ctx, size_t n) {
     size_t b = (n + 255) / 256, cap = (size_t)ctx->num_cus * 16;
     if (b > cap) b = cap;
@@ -719,8 +726,11 @@ SLK_EXPORT int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
-    hipLaunchKernelGGL((k_gather_rows<int64_t>), dim3(fy_grid(ctx, (size_t)(n * row_len))), dim3(256), 0, s, d_src, d_perm,
-                       n, row_len, d_dst);
+    if (row_len == 1)
+        hipLaunchKernelGGL((k_gather_elems<int64_t>), dim3(fy_grid(ctx, (size_t)n)), dim3(256), 0, s, d_src, d_perm, n, d_dst);
+    else
+        hipLaunchKernelGGL((k_gather_rows<int64_t>), dim3(fy_grid(ctx, (size_t)(n * row_len))), dim3(256), 0, s, d_src, d_perm,
+                           n, row_len, d_dst);
     SLK_LAUNCH_CHECK(ctx, "k_gather_rows");
     return SLK_OK;
 }
