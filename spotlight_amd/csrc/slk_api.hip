@@ -182,6 +182,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_debug = (int)value;
     } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
         ctx->opt_epoch_dense_elems = value;
+    } else if (!strcmp(name, "adaptive_late_min_batch") && value >= 0) {
+        ctx->opt_adaptive_late_min_batch = value;
     } else if (!strcmp(name, "shuffle_band") && value >= 0 && value <= 1024) {
         ctx->opt_shuffle_band = (int)value;
     } else if (!strcmp(name, "nt") && value >= 0 && value <= 15) {
