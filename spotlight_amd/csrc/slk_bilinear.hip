@@ -698,7 +698,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // of looked-up rows whose gradient is zero.
     // Below `adaptive_late_min_batch` interactions per minibatch the per-minibatch sort of the live occurrences (half a dozen
     // small launches) costs more than the dead occurrences it removes from the item pass: all 1+n are sorted once per chunk.
-    const bool late = adaptive && optim->kind != SLK_OPT_SPARSE_ADAM && bsz >= ctx->opt_adaptive_late_min_batch;
+    const bool late = adaptive && optim->kind != SLK_OPT_SPARSE_ADAM && (Hi > 0 || bsz >= ctx->opt_adaptive_late_min_batch);
     // scratch.  With the "overlap_prep" option the value-independent part of a chunk (negatives,
     // sort by user, sort by item) is prepared on a second HIP stream while the previous chunk's
     // passes run, and those buffers exist twice (ctx->pb[0|1]).  Off by default: measured on

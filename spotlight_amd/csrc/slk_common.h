@@ -91,9 +91,10 @@ struct slk_ctx {
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
-    // adaptive hinge: smallest minibatch whose item side is re-sorted per minibatch after the selection (measured, plain tables:
-    // below ~10^5 one sort of all 1+n occurrences per chunk is faster -- profiles/r02_x_adaptive_small_batches.jsonl)
-    int64_t opt_adaptive_late_min_batch = (int64_t)1 << 17;
+    // adaptive hinge, plain item table: smallest minibatch whose item side is re-sorted per minibatch after the selection
+    // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
+    // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
+    int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     // minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip).  Defaults from the
     // same-box A/Bs in profiles/r02_c_small_batch.jsonl: the persistent route wins at 256 (13 vs 21 us per minibatch) and

@@ -57,13 +57,13 @@ def test_train_heavy_duplicates_and_tiny_tables(be):
 @pytest.mark.parametrize('late_min', [0, 1 << 40])
 def test_adaptive_hinge_item_side_sorted_per_minibatch_or_per_chunk(be, opt, late_min):
     """adaptive hinge's item side: only the live occurrences re-sorted per minibatch after the selection (the default from
-    2^17 interactions per minibatch), or all 1+n occurrences sorted once per chunk (the default below): both against the oracle"""
+    2^18 interactions per minibatch), or all 1+n occurrences sorted once per chunk (the default below): both against the oracle"""
     be.engine.set_option('adaptive_late_min_batch', late_min)
     try:
         ec.check_train_matches_oracle(be, 'adaptive_hinge', opt, 8, nn=4)
         ec.check_train_matches_oracle(be, 'adaptive_hinge', opt, 32, U=23, I=31, N=207, B=100, nn=3, epochs=1)
     finally:
-        be.engine.set_option('adaptive_late_min_batch', 1 << 17)
+        be.engine.set_option('adaptive_late_min_batch', 1 << 18)
 
 
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)

@@ -242,13 +242,13 @@ def test_minibatch_of_one_interaction(be):
 @pytest.mark.parametrize('opt', ['adagrad', 'adam_dense'])
 @pytest.mark.parametrize('late_min', [0, 1 << 40])
 def test_adaptive_hinge_item_side_sorted_per_minibatch_or_per_chunk(be, opt, late_min):
-    """adaptive hinge's item side re-sorted per minibatch after the selection (default from 2^17 interactions per minibatch)
+    """adaptive hinge's item side re-sorted per minibatch after the selection (default from 2^18 interactions per minibatch)
     or all 1+n occurrences sorted once per chunk (default below): both against the oracle"""
     be.engine.set_option('adaptive_late_min_batch', late_min)
     try:
         ec.check_train_matches_oracle(be, 'adaptive_hinge', opt, 64, U=3000, I=1000, N=30000, B=4096, nn=5, epochs=1, tol=1e-4)
     finally:
-        be.engine.set_option('adaptive_late_min_batch', 1 << 17)
+        be.engine.set_option('adaptive_late_min_batch', 1 << 18)
 
 
 # ---- persistent epoch kernel (csrc/slk_epoch.hip): one cooperative launch per chunk of minibatches ----
