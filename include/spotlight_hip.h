@@ -123,7 +123,15 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         chunk c trains (default 0: the passes are HBM-bound and lose more than
  *                         the prep they hide, see profiles/README.md)
  *   "item_grid_mult"      item pass: workgroups per CU (default 64)
- *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond) */
+ *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
+ *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
+ *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
+ *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
+ *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
+ *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)
+ *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
+ *                         > 1 a band that many times too narrow (test hook for the fall-back)
+ *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
  * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once). */
@@ -213,7 +221,7 @@ int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d
 /* spotlight/torch_utils.py:35-52 (shuffle): d_perm_out[0..n) = the array numpy's legacy
  * RandomState.shuffle(arange(n)) produces from the ctx RNG state, bit for bit (Fisher-Yates with
  * masked-rejection draws over the MT19937 stream), computed on the GPU; the RNG state afterwards is
- * numpy's.  Synchronises the stream a few dozen times (once per power-of-two range of the draw).
+ * numpy's.  Synchronises the stream once per power-of-two range of the draw (a few dozen times).
  * slk_gather_rows_i64: d_dst[r][:] = d_src[d_perm[r]][:] (the x[shuffle_indices] that follows). */
 int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, void *stream);
 int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int64_t *d_perm, int64_t n, int64_t row_len,
