@@ -141,6 +141,15 @@ def test_device_shuffle_full_sweeps_and_band_fallback(be, n, band):
     ec.check_shuffle_matches_numpy(be, n, seed=n + 11, burn=n % 3, band=band)
 
 
+def test_device_shuffle_random_sizes_and_states(be):
+    """sizes and RandomState positions drawn at random (every power-of-two range edge is somebody's neighbour): the banded
+    draws must agree with numpy and never need the fall-back"""
+    rs = np.random.RandomState(2024)
+    for _ in range(24):
+        n = int(rs.choice([rs.randint(2, 5000), rs.randint(4000, 9000), rs.randint(9000, 60000)]))
+        ec.check_shuffle_matches_numpy(be, n, seed=int(rs.randint(0, 2 ** 31 - 1)), burn=int(rs.randint(0, 1300)))
+
+
 def test_minibatch_of_one_interaction(be):
     """batch_size 1 (the reference crashes there: squeeze() collapses [1, D]) and a
     last minibatch of one interaction."""
