@@ -240,7 +240,13 @@ __global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float 
         lsum += (double)(x > 0.0f ? x : 0.0f);
         const float g = x >= 0.0f ? inv_b : 0.0f;
         gk[(size_t)(k0 + c) * NP] = -g;
-        gk[best_at] = g;
+        // the column's n draws are written by this thread alone, and the columns partition the n*B draws: every entry of
+        // gk gets its value here (no memset before the launch)
+        for (int r = 0; r < nn; ++r) {
+            const uint32_t f = (uint32_t)r * bm + c;
+            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
+            gk[at] = at == best_at ? g : 0.0f;
+        }
         if (live) {
             const uint32_t kb = (uint32_t)(best_at / (size_t)NP), sb = (uint32_t)(best_at - (size_t)kb * NP);
             live[2 * (size_t)c] = g != 0.0f ? qk[k0 + c] * (uint32_t)NP : 0xffffffffu;
@@ -943,7 +949,6 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 slk_prof_end(ctx, s);
             } else if (adaptive) {
                 slk_prof_begin(ctx, SLK_K_SCORE, s);
-                SLK_HIP(ctx, hipMemsetAsync((float *)ctx->gk.p + (size_t)b0 * NP, 0, (size_t)bm * NP * 4, s));
                 hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_score_pass");
                 const unsigned sgrid = slk_grid_for(ctx, bm, 256);
