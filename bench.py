@@ -199,8 +199,8 @@ def bench_c4(args):
     s1 = [torch.zeros_like(E), torch.zeros_like(bias)]
     tb = _native.make_seq_tables(E.data_ptr(), bias.data_ptr(), I, D)
     op = _native.make_optim('adagrad', [None, s1[0].data_ptr(), None, s1[1].data_ptr()], None, lr=1e-2)
-    seqs = torch.randint(1, I, ((W + K) * B, L), device=dev, dtype=torch.int64, generator=gen)
-    mb_loss = torch.zeros(W + K, device=dev)
+    seqs = torch.randint(1, I, ((W + 2 * K) * B, L), device=dev, dtype=torch.int64, generator=gen)  # W warm-up + K timed + K profiled
+    mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(5).get_state())
     stream = torch.cuda.current_stream(dev).cuda_stream
 
@@ -210,12 +210,16 @@ def bench_c4(args):
     eng.poolnet_reserve(tb, op, K * B, L, B, 'bpr', 1, stream=stream)  # scratch of the timed call's shape
     run(0, W)
     torch.cuda.synchronize(dev)
-    eng.profile_reset()
-    eng.profile_enable(True)
     t0 = time.perf_counter()
-    run(W, K)
+    run(W, K)  # timed region: no instrumentation inside
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    # per-kernel durations: K more steps with hipEvents around every launch (the records cost ~10 us per launch and, around
+    # the host-side parts of a chunk's preparation, also count the host's time)
+    eng.profile_reset()
+    eng.profile_enable(True)
+    run(W + K, K)
+    torch.cuda.synchronize(dev)
     eng.profile_enable(False)
     prof = eng.profile_read()
     ts = K * B * L
@@ -230,7 +234,7 @@ def bench_c4(args):
                         'step_achieved': ts * alg / elapsed / 1e9, 'step_frac_of_peak': ts * alg / elapsed / 1e9 / HBM_PEAK_GBS,
                         'kernels': kern,
                         'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep')}},
-           'final_minibatch_loss': float(mb_loss[-1].item())}
+           'final_minibatch_loss': float(mb_loss[W + K - 1].item())}
     print(json.dumps(out), flush=True)
 
 
