@@ -84,6 +84,9 @@ def parse():
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
     ap.add_argument('--slices', type=int, default=0, help='row-sharded path: user-slices per minibatch (0: default)')
+    ap.add_argument('--item-zipf', type=float, default=0.0,
+                    help='positive item ids drawn with probability ~ 1 / rank^s (s = this value; 0 = uniform, the default and the '
+                         'metric\'s distribution) through a random rank -> id map: a stress run for duplicate handling')
     ap.add_argument('--no-fit', action='store_true',
                     help='N=1, C2: skip the end-to-end ImplicitFactorizationModel.fit() measurement (the drop-in API around the engine)')
     ap.add_argument('--fit-interactions', type=int, default=1 << 25)
@@ -518,6 +521,13 @@ def main():
     I_global = I * world
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     items = torch.randint(0, I_global, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    if args.item_zipf > 0:
+        # SURVEY.md 8(d) "optional second distribution": Zipf item ids (the negatives stay uniform, as the reference draws them)
+        w = 1.0 / torch.arange(1, I_global + 1, device=dev, dtype=torch.float64) ** args.item_zipf
+        cdf = torch.cumsum(w / w.sum(), 0)
+        ranks = torch.searchsorted(cdf, torch.rand(n_total, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=I_global - 1)
+        items = torch.randperm(I_global, device=dev, generator=gen)[ranks]
+        del w, cdf, ranks
     mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
     # the engine runs on its own HIP stream (ordered against torch's current stream by events)
@@ -677,9 +687,11 @@ def main():
                          'launched_by': 'bench.py (torch.distributed.run)' if os.environ.get('SLK_BENCH_SPAWNED') else
                                         ('torchrun' if 'WORLD_SIZE' in os.environ else 'single process')},
                'config': {'workload': '%s: synthetic uniform ids, %d users x %d items, dim %d, %s loss, '
-                                      '%s lr=1e-2, minibatch %d%s, on-GPU numpy-exact negatives'
+                                      '%s lr=1e-2, minibatch %d%s, on-GPU numpy-exact negatives%s'
                                       % (args.workload.upper(), U * world, I * world, D, args.loss, args.opt, B * world,
-                                         '' if world == 1 else ' (= %d per GPU; tables and batch grow with N)' % B),
+                                         '' if world == 1 else ' (= %d per GPU; tables and batch grow with N)' % B,
+                                         '; POSITIVE ITEMS ZIPF(%g) -- a stress run, not the metric\'s distribution' % args.item_zipf
+                                         if args.item_zipf > 0 else ''),
                           'global_batch': B * world,
                           'parallelism': 'single GPU' if trainer is None else
                           'row-sharded x%d: users and items sharded cyclically; RCCL all-to-all of ids per chunk of '
