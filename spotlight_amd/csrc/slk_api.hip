@@ -131,7 +131,8 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     slk_buf *bufs[] = {&ctx->raw, &ctx->cnt, &ctx->neg32, &ctx->ukey[0], &ctx->ukey[1], &ctx->uval[0],
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
-                       &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3]};
+                       &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
+                       &ctx->ipart_meta};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -139,9 +140,10 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     for (slk_prep_bufs &pb : ctx->pb) {
         slk_buf *pbs[] = {&pb.neg32, &pb.ukey[0], &pb.ukey[1], &pb.uval[0], &pb.uval[1], &pb.uit, &pb.ikey[0],
                           &pb.ikey[1], &pb.ipay[0], &pb.ipay[1], &pb.bik[0], &pb.bik[1], &pb.bip[0], &pb.bip[1],
-                          &pb.buk[0], &pb.buk[1], &pb.bup[0], &pb.bup[1]};
+                          &pb.buk[0], &pb.buk[1], &pb.bup[0], &pb.bup[1], &pb.lflags};
         for (slk_buf *b : pbs)
             if (b->p) (void)hipFree(b->p);
+        if (pb.ev_lflags) (void)hipEventDestroy(pb.ev_lflags);
     }
     for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1]})
         if (e) (void)hipEventDestroy(e);

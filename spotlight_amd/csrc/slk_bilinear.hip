@@ -765,8 +765,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
 
     const int upd = slk_upd_for(optim->kind);
-    pass_fn upass = nullptr, ipass = nullptr, spass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr,
-            rpass_rows = nullptr;
+    pass_fn upass = nullptr, spass = nullptr;
+    slk_item_fns ipass = {nullptr, nullptr}, ipass_rows = ipass, ipass_bias = ipass, rpass_rows = ipass;
     const int umode = (expl && ctx->opt_explicit_fused) ? 2 : (pre ? 1 : 0);
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
@@ -853,6 +853,19 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                              (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
                                              ibits + mbbits, s)))
                 return rc;
+            // which minibatches hold a LONG run (one that wholly covers a tile of the item pass): ids only, so the answer is
+            // fetched once per chunk and the usual minibatch (none) gets the plain pass with no stitch kernel behind it
+            const uint32_t n_mb_c = (nc + (uint32_t)bsz - 1) / (uint32_t)bsz;
+            if ((rc = slk_ensure(ctx, pb.lflags, (size_t)n_mb_c * 4))) return rc;
+            SLK_HIP(ctx, hipMemsetAsync(pb.lflags.p, 0, (size_t)n_mb_c * 4, s));
+            hipLaunchKernelGGL(k_item_long_flags, dim3(slk_grid_for(ctx, nocc / (4 * gpb) + n_mb_c, 256)), dim3(256), 0, s,
+                               (const uint32_t *)pb.ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)NP, 4u * gpb,
+                               (uint32_t)((1ull << ibits) - 1), 0xffffffffu, 0xffffffffu, (int *)pb.lflags.p);
+            SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
+            pb.h_lflags.assign(n_mb_c, 1);
+            SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags.data(), pb.lflags.p, (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
+            if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
+            SLK_HIP(ctx, hipEventRecord(pb.ev_lflags, s));
         }
         if (Hi && !late) {
             hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,
@@ -889,6 +902,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const uint32_t *ukey = (const uint32_t *)pb.ukey[1].p;
         const uint32_t *uit = pre ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
         const uint32_t *uk = pre ? (const uint32_t *)pb.uval[1].p : nullptr;
+        bool lflags_ready = late;  // the chunk's long-run flags (do_sort): ONE host wait per chunk, behind the first user pass
         // ---- minibatches, in order
         for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
             const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
@@ -989,14 +1003,19 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             SLK_LAUNCH_CHECK(ctx, "k_user_pass");
             slk_prof_end(ctx, s);
 
+            if (!lflags_ready) {
+                // the first user pass of the chunk is already queued: the GPU is busy while the host waits for the read-back
+                if (pb.ev_lflags) SLK_HIP(ctx, hipEventSynchronize(pb.ev_lflags));
+                lflags_ready = true;
+            }
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                hipLaunchKernelGGL(ipass, dim3(igrid), dim3(256), 0, s, a);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass");
+                const bool may_long = late || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                hipLaunchKernelGGL(ipass_bias, dim3(igrid), dim3(256), 0, s, a);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<BIAS>");
+                const bool may_long = late || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", may_long))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
@@ -1025,9 +1044,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                     r.imask = 0xffffffffu;
                 }
                 r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
-                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
-                                   0, s, r);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROWS>");
+                if ((rc = slk_launch_item_pass(ctx, ipass_rows, r, g, s, "k_item_pass<ROWS>"))) return rc;
             }
             if (Hu) {
                 // owner pass over the hashed USER rows: table slot 1 of the pass is remapped onto
@@ -1046,9 +1063,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 r.imask = (uint32_t)((1ull << ucbits) - 1);
                 r.pad_item = tables->user_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->user_bloom->skip_row;
                 r.pad_item2 = ubd.rows;  // sentinel of non-head positions
-                hipLaunchKernelGGL(rpass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
-                                   0, s, r);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<ROW,ROWS>");
+                if ((rc = slk_launch_item_pass(ctx, rpass_rows, r, g, s, "k_item_pass<ROW,ROWS>"))) return rc;
             }
             slk_prof_end(ctx, s);
 

@@ -65,6 +65,9 @@ struct slk_rng_dev {
 struct slk_prep_bufs {
     slk_buf neg32, ukey[2], uval[2], uit, ikey[2], ipay[2];
     slk_buf bik[2], bip[2], buk[2], bup[2];  // BloomEmbedding hashed-row occurrence lists
+    slk_buf lflags;                 // per minibatch of the chunk: does a run of the item-sorted list wholly cover a tile?
+    std::vector<int> h_lflags;      //   (k_item_long_flags; read back once per chunk, see slk_launch_item_pass)
+    hipEvent_t ev_lflags = nullptr; //   recorded behind the read-back: the host waits for it, not for the stream
 };
 
 struct slk_prof_span {
@@ -83,7 +86,7 @@ struct slk_ctx {
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
-        sort_tmp, dgrad[4];
+        sort_tmp, dgrad[4], ipart, ipart_meta;
     size_t dgrad_elems[4] = {0, 0, 0, 0};
     // tuning (slk_ctx_set_option)
     int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
@@ -135,6 +138,7 @@ struct slk_ctx {
     int64_t em_occ = -1, em_rows = 0, em_segments = -1;
     int em_dim = 0;
 
+    uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
     int fy_fallbacks = 0;           //   ranges of the last call that left the band and were redone with the full sweeps
     int opt_shuffle_band = 1;       // slk_shuffle_perm: 1 banded draws (default), 0 full sweeps, > 1 band / value (test hook: forces fall-backs)

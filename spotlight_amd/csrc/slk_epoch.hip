@@ -386,25 +386,55 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             }
             float g = slk_ld_coh(e.gsn + (pay - ib0));
             slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
-            slk_vec<VEC> gv = zero;
-            float gb = 0.0f;
-            bool any = false;
+            // The run is summed as the launch path sums it (slk_kernels.h, k_item_pass + k_item_stitch): in occurrence order --
+            // unless it is LONG, i.e. wholly covers one of the launch path's (full) tiles of TT positions of the minibatch's
+            // occurrence list: then tile by tile (in occurrence order inside a tile), the tiles' sums added in order.
+            // Both sums are kept; which one applies is known when the run ends.
+            constexpr uint32_t TT = 4u * (256u / (uint32_t)G);
+            slk_vec<VEC> sq = zero, gv = zero, tv = zero;
+            float sqb = 0.0f, gb = 0.0f, tb = 0.0f;
+            bool any = false, first_tile = true, is_long = false;
+            const uint32_t p0 = r - ib0;
             uint32_t k = r;
             for (;;) {
                 if (g != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         const float cc = g * uo.v[i];
-                        gv.v[i] += cc;
+                        sq.v[i] += cc;
+                        tv.v[i] += cc;
                     }
-                    gb += g;
+                    sqb += g;
+                    tb += g;
                     any = true;
                 }
                 ++k;
-                if (!(k < ib1 && e.ikey[k] == key)) break;
+                const bool run_ends = !(k < ib1 && e.ikey[k] == key);
+                const uint32_t rel = k - ib0;
+                const bool boundary = rel % TT == 0u;
+                if (run_ends || boundary) {  // the tile [tile_start, rel) is done: its sum joins the run's
+                    const uint32_t tile_start = (rel - 1u) / TT * TT;
+                    is_long = is_long || (tile_start >= p0 && boundary);  // a FULL tile covered from its first to its last position
+                    if (first_tile) {
+                        gv = tv;
+                        gb = tb;
+                        first_tile = false;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gv.v[i] += tv.v[i];
+                        gb += tb;
+                    }
+                    tv = zero;
+                    tb = 0.0f;
+                }
+                if (run_ends) break;
                 pay = e.ipay[k];
                 g = slk_ld_coh(e.gsn + (pay - ib0));
                 uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
+            }
+            if (!is_long) {
+                gv = sq;
+                gb = sqb;
             }
 
             // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up

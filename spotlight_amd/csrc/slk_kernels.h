@@ -98,6 +98,11 @@ struct slk_pass_args {
     const uint32_t *ikey;    // (minibatch << ibits) | item, sorted
     uint32_t imask;
     const uint32_t *ipay;    // occurrence -> record reference (see slk_item_mode)
+    float *ipart;            // item pass: per-tile partial sums of the runs that cross tile boundaries, [2 * tile + which][IPS]
+    uint32_t *ipart_meta;    //   [2 * tile + which][2] = {key, flags}; which 0 = the run inherited from the previous tile, 1 = the
+    int IPS;                 //   run that continues into the next tile; IPS = floats per partial (row | bias gradient)
+    uint32_t ipart_gen;      //   stamp of this launch (flags of other launches' partials are stale); ipart_count: long runs
+    uint32_t *ipart_count;   //   that START in this launch's tiles (k_item_stitch leaves at once when there are none)
     uint32_t pad_item;       // occurrences of this item row are never updated (padding_idx); ~0u = none
     uint32_t pad_item2;      // a second never-updated key (sentinel of non-head positions); ~0u = none
     slk_bloom_dev ub, ib;    // BloomEmbedding user / item layers (n_hash == 0: plain)
@@ -273,13 +278,22 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 
 // A block walks tiles of T = 4 * (256/G) consecutive positions of the item-sorted occurrence
 // list.  Per tile: (1) keys + payloads -> LDS; wave 0 compacts the heads of the runs of equal keys
-// that START in the tile into a list, head r belongs to row group r mod GPB (an even 1-2 heads per
-// group); (2) a group issues the loads of its first head's item row + optimizer state TOGETHER
-// with its four record gathers (every load independent: one HBM round trip covers both) and parks
-// the contributions in LDS; (3) each run is summed from LDS by its owner group (runs that spill
-// past the tile end are finished from global memory; rows of a run that started in an earlier
-// tile are skipped -- its owner already took them) and the optimizer is applied to that item's
-// row and bias.  Block 0 also reduces the loss partials of the preceding pass into loss.item().
+// that START in the tile into a list (plus position 0 when it continues the previous tile's last run), head r belongs
+// to row group r mod GPB (an even 1-2 heads per group); (2) a group issues the loads of its first head's item row +
+// optimizer state TOGETHER with its four record gathers (every load independent: one HBM round trip covers both) and
+// parks the contributions in LDS; (3) each run is summed from LDS by its owner group (a run that spills into the next
+// tile is finished from global memory; rows of a run that started in the previous tile are skipped -- its owner already
+// took them) and the optimizer is applied to that item's row and bias.
+// LONG runs -- a run that wholly covers at least one tile: a popular item of a skewed dataset, a hashed row of a small
+// bloom table -- are not walked by their owner (one row group taking tens of thousands of records a batch of loads at a
+// time: Zipf(1.0) positives at C2 sizes cost 40 ms per item pass that way, profiles/README.md).  Every tile sums ITS part of
+// such a run from LDS and writes it out as a PARTIAL (row sum, bias-gradient sum, key, flags; at most two per tile: the
+// run inherited from the previous tile, the run handed to the next one), and k_item_stitch, launched behind the pass,
+// adds a long run's partials in tile order and applies the update.  Whether a run is long is decided the same way by
+// every tile that sees a piece of it (the head tile looks at the last position of the next tile, the tile a run ends in
+// at the first position of the previous one; a last tile of fewer than T positions never counts).  Short runs are summed in occurrence order exactly as before; a long run
+// tile by tile, tiles in order -- the persistent epoch kernel's serial walk applies the same rule, so the two routes stay
+// bit-identical.  Block 0 also reduces the loss partials of the preceding pass into loss.item().
 // Measured on MI355X (profiles/README.md, r01_e): 0.415 -> 0.351 ms against the first version,
 // which waited for the records, then made one dependent row round trip per head, back to back.
 // PART: which of the run owner's two updates are applied -- the embedding row (table slot 1), the
@@ -293,6 +307,7 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 #define SLK_ITEM_NPRE 1  // heads per group whose row + state loads ride along with the record gather; measured
                          // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
 #endif
+
 #ifndef SLK_SPILL_BATCH
 #define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
 #endif
@@ -329,14 +344,50 @@ __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t,
     }
 }
 
-template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH>
+// flags of a partial (slk_pass_args::ipart_meta[slot][1])
+enum { SLK_IPART_STARTS = 2, SLK_IPART_ENDS = 4, SLK_IPART_ANY = 8, SLK_IPART_GEN_SHIFT = 4 };  // flags | launch stamp << 4
+
+// Applies the summed gradient (gv, gb) of one item row: the update both k_item_pass (runs inside one tile) and
+// k_item_stitch (runs across tiles) end with.  `pre`: the row / bias and their first state were loaded early.
+template <int VEC, int G, int UPD, int PART>
+__device__ __forceinline__ void slk_item_apply(const slk_pass_args &a, uint32_t item, int D, int d0, int lane, bool rows_on,
+                                               bool nt_rows, bool any, const slk_vec<VEC> &gv, float gb, bool pre,
+                                               slk_vec<VEC> &p, slk_vec<VEC> &s, float bp, float bs) {
+    if (UPD != SLK_UPD_SPARSE_ADAM && !any) return;
+    const size_t voff = (size_t)item * D + d0;
+    if (rows_on) {
+        if (!pre && UPD != SLK_UPD_GRAD_ONLY) {
+            p = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
+            s = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+        }
+        slk_apply_vec_pre<VEC, UPD>(a, 1, voff, p, s, gv, nullptr, nt_rows);
+    }
+    if (lane == 0 && PART != SLK_PART_ROWS) {
+        if (UPD == SLK_UPD_ADAGRAD && gb == 0.0f) return;  // exact no-op
+        slk_vec<1> bpv, bsv, gbv;
+        if (pre || UPD == SLK_UPD_GRAD_ONLY) {
+            bpv.v[0] = bp;
+            bsv.v[0] = bs;
+        } else {
+            bpv.v[0] = a.P[3][item];
+            bsv.v[0] = a.S1[3][item];
+        }
+        gbv.v[0] = gb;
+        slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
+    }
+}
+
+// LONG = false: for a minibatch in which NO run wholly covers a tile (the host knows: k_item_long_flags) -- no run is long,
+// nothing is looked up or written for the partial scheme, no stitch kernel follows; results are those of LONG = true.
+template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH, bool LONG = true>
 __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
     constexpr int DL = G * VEC;  // LDS row length (>= D)
     constexpr int NPRE = SLK_ITEM_NPRE;  // heads per group whose rows are loaded early
     __shared__ double red[256];
-    __shared__ uint32_t s_key[T + 1];  // s_key[i] = key of position tb - 1 + i
+    __shared__ uint32_t s_key[T + 1 + (LONG ? 1 : 0)];  // s_key[i] = key of position tb - 1 + i (LONG: i = tn + 1 = the next tile's first key)
+    __shared__ uint32_t s_far[3];      // key of the previous tile's first position, of the next (full) tile's last position
     __shared__ uint32_t s_pay[T];
     __shared__ float s_g[T];
     __shared__ uint8_t s_live[T];
@@ -364,13 +415,36 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
         const uint32_t tb = ibegin + tile * T;
         const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
         const bool first_tile = tb == ibegin;
+        const bool has_next = tb + (uint32_t)tn < iend;
         __syncthreads();  // LDS of the previous tile no longer in use
-        for (int i = threadIdx.x; i <= tn; i += 256)
-            s_key[i] = (i == 0 && first_tile) ? 0u : slk_ld_u32(a.ikey + (tb - 1 + i), nt_keys);
+        for (int i = threadIdx.x; i <= tn + (LONG ? 1 : 0); i += 256) {
+            uint32_t kv = 0u;
+            if (i == 0) kv = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - 1), nt_keys);
+            else if (i <= tn) kv = slk_ld_u32(a.ikey + (tb - 1 + i), nt_keys);
+            else if (LONG && has_next) kv = slk_ld_u32(a.ikey + (tb + tn), nt_keys);
+            s_key[i] = kv;
+        }
         for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = slk_ld_u32(a.ipay + (tb + i), nt_keys);
+        if (LONG && threadIdx.x == 64) s_far[0] = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - T), nt_keys);
+        if (LONG && threadIdx.x == 65) {
+            // the next tile's last key -- if the next tile is a full one (only full tiles make a run long)
+            const bool next_full = has_next && iend - (tb + (uint32_t)tn) >= (uint32_t)T;
+            s_far[1] = next_full ? slk_ld_u32(a.ikey + (tb + 2u * (uint32_t)T - 1u), nt_keys) : 0u;
+            s_far[2] = next_full ? 1u : 0u;
+        }
         __syncthreads();
+        // the run the previous tile hands over, the run handed to the next tile; each of them is LONG (summed through
+        // partials) iff it wholly covers some tile: this one, the previous one (inherited run), the next one (handed over)
+        const bool inherits = !first_tile && s_key[1] == s_key[0];
+        // (LONG = false: whether the last run continues is found out by its owner's walk, as before the partial scheme)
+        const bool hands_over = LONG && has_next && s_key[tn + (LONG ? 1 : 0)] == s_key[tn];
+        const bool all_same = tn == T && s_key[1] == s_key[tn];  // this (full) tile is one run's
+        const bool inherits_long = LONG && inherits && (all_same || s_far[0] == s_key[0]);
+        const bool hands_over_long = LONG && hands_over && (all_same || (s_far[2] != 0u && s_far[1] == s_key[tn]));
+        (void)s_far;
 
-        // (1b) wave 0 compacts the heads of the runs that start in this tile
+        // (1b) wave 0 compacts the heads of the runs that start in this tile; position 0 is also listed when it
+        // continues a LONG run of the previous tile
         if (threadIdx.x < 64) {
             int base = 0;
             for (int c = 0; c < T; c += 64) {
@@ -380,7 +454,8 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                     const uint32_t key = s_key[j + 1];
                     const uint32_t item = key & a.imask;
                     // padding_idx rows receive no gradient: they never become heads
-                    f = (((j == 0 && first_tile) || key != s_key[j]) && item != a.pad_item && item != a.pad_item2) ? 1 : 0;
+                    f = (((j == 0 && (first_tile || inherits_long)) || key != s_key[j]) && item != a.pad_item &&
+                         item != a.pad_item2) ? 1 : 0;
                 }
                 int incl = f;
 #pragma unroll
@@ -395,6 +470,14 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
         }
         __syncthreads();
         const int nheads = s_nheads;
+        // A head's run gets its update here unless it is a piece of a LONG run: the inherited one (position 0) or the one
+        // that reaches the tile's end and is handed over (the LAST head).
+        auto completes = [&](int r) -> bool {
+            const int j = (int)s_head[r];
+            if (j == 0 && inherits_long) return false;
+            if (r == nheads - 1 && hands_over_long && s_key[j + 1] == s_key[tn]) return false;
+            return true;
+        };
 
         // (2a) early loads: row + state (+ bias) of this group's first NPRE heads
         slk_vec<VEC> pv[NPRE], sv[NPRE];
@@ -405,7 +488,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
             sv[h] = slk_vzero<VEC>();
             pb[h] = sb[h] = 0.0f;
             const int r = grp + h * GPB;
-            if (r < nheads) {
+            if (r < nheads && completes(r)) {
                 const uint32_t item = s_key[(int)s_head[r] + 1] & a.imask;
                 if (rows_on && UPD != SLK_UPD_GRAD_ONLY) {
                     const size_t voff = (size_t)item * D + d0;
@@ -427,8 +510,8 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
             const int j = grp + it * GPB;
             g[it] = 0.0f;
             c[it] = slk_vzero<VEC>();
-            // rows of the run inherited from the previous tile belong to that tile's owner
-            bool mine = j < tn && (first_tile || s_key[j + 1] != s_key[0]);
+            // rows of a SHORT run inherited from the previous tile belong to that tile's owner
+            bool mine = j < tn && (!inherits || inherits_long || s_key[j + 1] != s_key[0]);
             if (mine) {
                 // never-updated keys (padding_idx rows, the dead entries of a live list) have no
                 // record worth reading -- a dead entry's payload is not even a valid reference
@@ -450,8 +533,9 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
         }
         __syncthreads();
 
-        // (3) head r -> group r mod GPB
-        auto finish = [&](int j, bool pre, slk_vec<VEC> &p, slk_vec<VEC> &s, float bp, float bs) {
+        // (3) head r -> group r mod GPB: the in-tile part of its run, summed in occurrence order
+        auto finish = [&](int r, bool pre, slk_vec<VEC> &p, slk_vec<VEC> &s, float bp, float bs) {
+            const int j = (int)s_head[r];
             const uint32_t key = s_key[j + 1];
             const uint32_t item = key & a.imask;
             slk_vec<VEC> gv = slk_vzero<VEC>();
@@ -468,79 +552,141 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 }
                 ++k;
             } while (k < tn && s_key[k + 1] == key);
-            if (k == tn) {
-                // The run may continue in the following tiles (long runs: BloomEmbedding rows shared
-                // by many ids, skewed items).  The group reads G keys + payloads at once (the keys are
-                // sorted, so the lanes that still match are a prefix), then takes the occurrences
-                // SLK_SPILL_BATCH at a time: independent loads in flight, summed in occurrence order.
-                uint32_t q = tb + tn;
-                bool more = q < iend;
-                while (more) {
-                    const uint32_t qi = q + (uint32_t)lane;
-                    uint32_t pq = 0u;
-                    int cnt = 0;
-                    if (qi < iend && a.ikey[qi] == key) {
-                        pq = a.ipay[qi];
-                        cnt = 1;
-                    }
-#pragma unroll
-                    for (int m = G / 2; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, G);
-                    for (int j0 = 0; j0 < cnt; j0 += SLK_SPILL_BATCH) {
-                        slk_vec<VEC> cc[SLK_SPILL_BATCH];
-                        float gq[SLK_SPILL_BATCH];
-#pragma unroll
-                        for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
-                            gq[e] = 0.0f;
-                            cc[e] = slk_vzero<VEC>();
-                            const uint32_t pj = __shfl(pq, (j0 + e) & (G - 1), G);
-                            if (j0 + e < cnt) slk_item_contrib<VEC, MODE>(a, pj, D, d0, rows_on, cc[e], gq[e]);
+            const bool starts = !(j == 0 && inherits_long);
+            const bool ends = !(k == tn && hands_over_long);
+            if (starts && ends) {
+                if (k == tn && (LONG ? hands_over : has_next)) {
+                    // A SHORT run that spills into the next tile: the group reads G keys + payloads at once (the keys
+                    // are sorted, so the lanes that still match are a prefix), then takes the occurrences
+                    // SLK_SPILL_BATCH at a time: independent loads in flight, summed in occurrence order.
+                    uint32_t q = tb + tn;
+                    bool more = true;
+                    while (more) {
+                        const uint32_t qi = q + (uint32_t)lane;
+                        uint32_t pq = 0u;
+                        int cnt = 0;
+                        if (qi < iend && a.ikey[qi] == key) {
+                            pq = a.ipay[qi];
+                            cnt = 1;
                         }
 #pragma unroll
-                        for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
-                            if (j0 + e < cnt && (MODE != SLK_ITEM_SNAP || gq[e] != 0.0f)) {
+                        for (int m = G / 2; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, G);
+                        for (int j0 = 0; j0 < cnt; j0 += SLK_SPILL_BATCH) {
+                            slk_vec<VEC> cc[SLK_SPILL_BATCH];
+                            float gq[SLK_SPILL_BATCH];
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) gv.v[i] += cc[e].v[i];
-                                gb += gq[e];
-                                any = true;
+                            for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
+                                gq[e] = 0.0f;
+                                cc[e] = slk_vzero<VEC>();
+                                const uint32_t pj = __shfl(pq, (j0 + e) & (G - 1), G);
+                                if (j0 + e < cnt) slk_item_contrib<VEC, MODE>(a, pj, D, d0, rows_on, cc[e], gq[e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
+                                if (j0 + e < cnt && (MODE != SLK_ITEM_SNAP || gq[e] != 0.0f)) {
+#pragma unroll
+                                    for (int i = 0; i < VEC; ++i) gv.v[i] += cc[e].v[i];
+                                    gb += gq[e];
+                                    any = true;
+                                }
                             }
                         }
+                        more = cnt == G;
+                        q += (uint32_t)G;
                     }
-                    more = cnt == G;
-                    q += (uint32_t)G;
                 }
+                slk_item_apply<VEC, G, UPD, PART>(a, item, D, d0, lane, rows_on, nt_rows, any, gv, gb, pre, p, s, bp, bs);
+                return;
             }
-            if (UPD != SLK_UPD_SPARSE_ADAM && !any) return;
-            const size_t voff = (size_t)item * D + d0;
-            if (rows_on) {
-                if (!pre && UPD != SLK_UPD_GRAD_ONLY) {
-                    p = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-                    s = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
-                }
-                slk_apply_vec_pre<VEC, UPD>(a, 1, voff, p, s, gv, nullptr, nt_rows);
-            }
-            if (lane == 0 && PART != SLK_PART_ROWS) {
-                if (UPD == SLK_UPD_ADAGRAD && gb == 0.0f) return;  // exact no-op
-                slk_vec<1> bpv, bsv, gbv;
-                if (pre || UPD == SLK_UPD_GRAD_ONLY) {
-                    bpv.v[0] = bp;
-                    bsv.v[0] = bs;
-                } else {
-                    bpv.v[0] = a.P[3][item];
-                    bsv.v[0] = a.S1[3][item];
-                }
-                gbv.v[0] = gb;
-                slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
+            // a partial: slot 0 = the inherited run's part, slot 1 = the part of the run the next tile continues (a run
+            // that fills the whole tile is both: slot 0)
+            const size_t slot = 2 * (size_t)tile + (starts ? 1u : 0u);
+            float *pp = a.ipart + slot * (size_t)a.IPS;
+            if (rows_on) slk_vstore<VEC>(pp + d0, gv);
+            if (lane == 0) {
+                pp[a.IPS - 1] = gb;
+                a.ipart_meta[2 * slot] = key;
+                a.ipart_meta[2 * slot + 1] = (a.ipart_gen << SLK_IPART_GEN_SHIFT) | (starts ? (uint32_t)SLK_IPART_STARTS : 0u) |
+                                             (ends ? (uint32_t)SLK_IPART_ENDS : 0u) | (any ? (uint32_t)SLK_IPART_ANY : 0u);
+                if (starts) atomicAdd(a.ipart_count, 1u);
             }
         };
 #pragma unroll
         for (int h = 0; h < NPRE; ++h) {
             const int r = grp + h * GPB;
-            if (r < nheads) finish((int)s_head[r], true, pv[h], sv[h], pb[h], sb[h]);
+            if (r < nheads) finish(r, completes(r), pv[h], sv[h], pb[h], sb[h]);
         }
         for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
             slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
-            finish((int)s_head[r], false, p, s, 0.0f, 0.0f);
+            finish(r, false, p, s, 0.0f, 0.0f);
         }
+    }
+}
+
+// Behind k_item_pass: one row group per tile.  The group of the tile in which a tile-crossing run STARTS adds the run's
+// partials in tile order -- its own tile's slot 1, then slot 0 of the following tiles up to the one in which the run
+// ends -- and applies the update.  The metas of the next G tiles are read at once (the lanes that still belong to the
+// run are a prefix) and their partials are loaded G at a time: a run that fills a thousand tiles costs its owner a few
+// dozen round trips.
+template <int VEC, int G, int UPD, int PART>
+__global__ __launch_bounds__(256) void k_item_stitch(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    constexpr int T = 4 * GPB;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const bool rows_on = on && PART != SLK_PART_BIAS;
+    const bool nt_rows = (SLK_NT_OF(a) & 2) != 0;
+    const uint32_t ntiles = (a.iend - a.ibegin + T - 1) / T;
+    if (*a.ipart_count == 0u) return;  // no long run in this minibatch (the usual case)
+    const uint32_t gen = a.ipart_gen;
+    for (uint32_t tile = blockIdx.x * GPB + grp; tile < ntiles; tile += gridDim.x * GPB) {
+        const size_t slot = 2 * (size_t)tile + 1;
+        const uint32_t fl = a.ipart_meta[2 * slot + 1];
+        if ((fl >> SLK_IPART_GEN_SHIFT) != gen) continue;  // no long run leaves this tile
+        const uint32_t key = a.ipart_meta[2 * slot];
+        const float *pp = a.ipart + slot * (size_t)a.IPS;
+        slk_vec<VEC> gv = rows_on ? slk_vload<VEC>(pp + d0) : slk_vzero<VEC>();
+        float gb = pp[a.IPS - 1];
+        bool any = (fl & SLK_IPART_ANY) != 0;
+        uint32_t t2 = tile + 1;
+        bool more = true;
+        while (more) {
+            // lane l looks at tile t2 + l: part of this run iff every tile before it continued it
+            const uint32_t tl = t2 + (uint32_t)lane;
+            uint32_t f = 0u;
+            if (tl < ntiles) {
+                const size_t sl = 2 * (size_t)tl;
+                f = a.ipart_meta[2 * sl + 1];
+                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || a.ipart_meta[2 * sl] != key) f = 0u;
+                else f |= 1u;  // bit 0: part of this run
+            }
+            // cnt = tiles of this batch that belong to the run: up to and including the first one that ends it
+            int cnt = 0;
+            bool ended = false;
+            for (int l = 0; l < G; ++l) {
+                const uint32_t fl2 = __shfl(f, l, G);
+                if (ended || !(fl2 & 1u)) break;
+                ++cnt;
+                any = any || (fl2 & SLK_IPART_ANY) != 0;
+                ended = (fl2 & SLK_IPART_ENDS) != 0;
+            }
+            for (int l = 0; l < cnt; ++l) {
+                const float *q = a.ipart + 2 * (size_t)(t2 + (uint32_t)l) * (size_t)a.IPS;
+                if (rows_on) {
+                    const slk_vec<VEC> cc = slk_vload<VEC>(q + d0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
+                }
+                gb += q[a.IPS - 1];
+            }
+            more = !ended && cnt == G;
+            t2 += (uint32_t)G;
+        }
+        slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
+        slk_item_apply<VEC, G, UPD, PART>(a, key & a.imask, D, d0, lane, rows_on, nt_rows, any, gv, gb, false, p, s, 0.0f, 0.0f);
     }
 }
 
@@ -605,11 +751,86 @@ static inline bool slk_pick_layout(int D, int *vec, int *g) {
 
 typedef void (*slk_pass_fn)(slk_pass_args);
 
+// flags[mb] |= 1 iff some run of minibatch mb's window [mb * per_mb, min((mb + 1) * per_mb, n)) of the sorted occurrence
+// list wholly covers one of the item pass's tiles (T positions, aligned to the window): first key == last key of the tile,
+// for an item that is updated at all.  Ids only: computed once per chunk, read back by the host.
+static __global__ __launch_bounds__(256) void k_item_long_flags(const uint32_t *ikey, uint32_t n, uint32_t per_mb, uint32_t T,
+                                                         uint32_t imask, uint32_t pad_item, uint32_t pad_item2, int *flags) {
+    const uint32_t tiles_per_mb = (per_mb + T - 1) / T;
+    const uint32_t n_mb = (n + per_mb - 1) / per_mb;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_mb * tiles_per_mb; i += gridDim.x * 256) {
+        const uint32_t mb = i / tiles_per_mb, q = i - mb * tiles_per_mb;
+        const uint32_t w0 = mb * per_mb, w1 = (n - w0 < per_mb) ? n : w0 + per_mb;
+        const uint32_t t0 = w0 + q * T;
+        if (t0 >= w1) continue;
+        if (w1 - t0 < T) continue;  // only full tiles make a run long
+        const uint32_t t1 = t0 + T;
+        const uint32_t k0 = ikey[t0], k1 = ikey[t1 - 1];
+        const uint32_t item = k0 & imask;
+        if (k0 == k1 && item != pad_item && item != pad_item2) flags[mb] = 1;
+    }
+}
+
+// the item pass and the stitch kernel that goes behind it (slk_launch_item_pass)
+struct slk_item_fns {
+    slk_pass_fn pass, stitch, pass_short;  // pass_short: k_item_pass<..., LONG = false>
+};
+
 template <int VEC, int G, int MODE, int PART = SLK_PART_BOTH>
-static slk_pass_fn slk_item_pass_fn(int upd) {
-    if (upd == SLK_UPD_ADAGRAD) return k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART>;
-    if (upd == SLK_UPD_SPARSE_ADAM) return k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART>;
-    return k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART>;
+static slk_item_fns slk_item_pass_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD)
+        return {k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_ADAGRAD, PART>,
+                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART, false>};
+    if (upd == SLK_UPD_SPARSE_ADAM)
+        return {k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_SPARSE_ADAM, PART>,
+                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART, false>};
+    return {k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_GRAD_ONLY, PART>,
+            k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART, false>};
+}
+
+// Launches the item pass over a.ibegin .. a.iend and the stitch kernel behind it (partials in ctx scratch).
+// may_have_long = false: the caller KNOWS (k_item_long_flags, read back once per chunk) that no run of this window wholly
+// covers a tile -- the plain pass alone.
+static inline int slk_launch_item_pass(slk_ctx *ctx, const slk_item_fns &fns, slk_pass_args &a, int g, hipStream_t s,
+                                       const char *what, bool may_have_long = true) {
+    const unsigned gpb = 256u / (unsigned)g, T = 4u * gpb;
+    const size_t n = (size_t)(a.iend - a.ibegin);
+    if (n == 0) return SLK_OK;
+    const size_t ntiles = (n + T - 1) / T;
+    if (!may_have_long) {
+        a.ipart = nullptr;
+        a.ipart_meta = nullptr;
+        a.ipart_count = nullptr;
+        hipLaunchKernelGGL(fns.pass_short, dim3(slk_grid_for(ctx, n, T, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
+        SLK_LAUNCH_CHECK(ctx, what);
+        return SLK_OK;
+    }
+    const int ips = (a.D + 3) / 4 * 4 + 4;
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->ipart, 2 * ntiles * (size_t)ips * 4))) return rc;
+    // meta: [2 * ntiles][2] words, then the counter of long runs; flags carry the launch's stamp, so nothing is cleared
+    // between launches except the counter (a fresh or regrown buffer is zeroed once: stamp 0 is never used)
+    const size_t meta_bytes = 2 * ntiles * 8 + 64;
+    if (meta_bytes > ctx->ipart_meta.cap) {
+        if ((rc = slk_ensure(ctx, ctx->ipart_meta, meta_bytes))) return rc;
+        SLK_HIP(ctx, hipMemsetAsync(ctx->ipart_meta.p, 0, ctx->ipart_meta.cap, s));
+    }
+    if (ctx->ipart_gen >= 0x0ffffffeu) {  // the 28-bit stamp wraps: forget every old partial
+        SLK_HIP(ctx, hipMemsetAsync(ctx->ipart_meta.p, 0, ctx->ipart_meta.cap, s));
+        ctx->ipart_gen = 0u;
+    }
+    ++ctx->ipart_gen;
+    a.ipart = (float *)ctx->ipart.p;
+    a.ipart_meta = (uint32_t *)ctx->ipart_meta.p;
+    a.ipart_count = a.ipart_meta + 4 * ntiles;
+    a.ipart_gen = ctx->ipart_gen;
+    a.IPS = ips;
+    SLK_HIP(ctx, hipMemsetAsync(a.ipart_count, 0, 4, s));
+    hipLaunchKernelGGL(fns.pass, dim3(slk_grid_for(ctx, n, T, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
+    SLK_LAUNCH_CHECK(ctx, what);
+    hipLaunchKernelGGL(fns.stitch, dim3(slk_grid_for(ctx, ntiles, gpb)), dim3(256), 0, s, a);
+    SLK_LAUNCH_CHECK(ctx, "k_item_stitch");
+    return SLK_OK;
 }
 
 // Row-update mode of the fused passes for an optimizer kind.

@@ -643,7 +643,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
     }
     const int upd = slk_upd_for(optim->kind);
     seq_pass_fn spass = nullptr;
-    slk_pass_fn ipass = nullptr, ipass_rows = nullptr, ipass_bias = nullptr;
+    slk_item_fns ipass = {nullptr, nullptr}, ipass_rows = ipass, ipass_bias = ipass;
     // register-resident sequence pass when a group's chunk of timesteps fits 16 rows of VGPRs
     const bool reg_pass = L <= 256 && (L + NG - 1) / NG <= 16 && ctx->opt_seq_variant != 0;
 #define SLK_PICK(V_, G_)                                                                 \
@@ -787,14 +787,10 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             a.nt = ctx->opt_nt;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s,
-                                   a);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ>");
+                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>"))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                hipLaunchKernelGGL(ipass_bias, dim3(slk_grid_for(ctx, (size_t)(a.iend - a.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
-                                   0, s, a);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ,BIAS>");
+                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<SEQ,BIAS>"))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
@@ -804,9 +800,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
                 r.iend = a.iend * (uint32_t)Hi;
                 r.imask = (uint32_t)((1ull << icbits) - 1);
                 r.pad_item = tables->item_bloom->skip_row < 0 ? 0xffffffffu : (uint32_t)tables->item_bloom->skip_row;
-                hipLaunchKernelGGL(ipass_rows, dim3(slk_grid_for(ctx, (size_t)(r.iend - r.ibegin), 4 * gpb, ctx->opt_item_grid_mult)), dim3(256),
-                                   0, s, r);
-                SLK_LAUNCH_CHECK(ctx, "k_item_pass<SEQ,ROWS>");
+                if ((rc = slk_launch_item_pass(ctx, ipass_rows, r, g, s, "k_item_pass<SEQ,ROWS>"))) return rc;
             }
             slk_prof_end(ctx, s);
             if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, TM, s))) return rc;

@@ -629,15 +629,14 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
         a.imask = (uint32_t)((1ull << ibits) - 1);
         a.ipay = (const uint32_t *)ctx->ipay[1].p;
         a.mb_loss_out = nullptr;
-        slk_pass_fn ipass = nullptr;
+        slk_item_fns ipass = {nullptr, nullptr};
         const int upd = slk_upd_for(optim->kind);
 #define SLK_PICK(V_, G_) ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_BLK>(upd)
         SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
         const unsigned gpb = 256u / (unsigned)g;
         slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
-        hipLaunchKernelGGL(ipass, dim3(slk_grid_for(ctx, (size_t)nr, 4 * gpb, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
-        SLK_LAUNCH_CHECK(ctx, "k_item_pass<BLK>");
+        if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<BLK>"))) return rc;
         slk_prof_end(ctx, s);
     }
     if (dense && (rc = slk_dense_sweeps(ctx, local->d_param, optim, 15u, s))) return rc;

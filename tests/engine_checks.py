@@ -15,7 +15,16 @@ def rel_inf(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def assert_close_table(got, want, tol, what):
+def adagrad_well_conditioned(state_sum, rel=1e-6):
+    """Elements whose Adagrad update is well-posed: the accumulator sum of g^2 is not ~0 next to the table's largest.  Where
+    the only gradient an element ever saw is a residual of cancelling terms (|g| below `rel` of the table's gradient scale --
+    often exactly 0 in one summation order and 1e-11 in another), lr * g / (sqrt(g^2) + 1e-10) turns that noise into
+    anything up to lr: those elements are identified here BY THEIR GRADIENT MAGNITUDE and only bounded, not compared."""
+    g = np.sqrt(np.asarray(state_sum, np.float64).ravel())
+    return g > rel * max(g.max(), 1e-30)
+
+
+def assert_close_table(got, want, tol, what, cond=None, loose=None):
     """||got - want||inf <= tol * ||want||inf, except that tables with > 10k elements may
     hold up to 1e-4 of ill-conditioned elements: Adagrad's update lr*g/(sqrt(sum)+1e-10) is
     sign-like on its first step, so an element whose summed gradient happens to fall within
@@ -24,6 +33,9 @@ def assert_close_table(got, want, tol, what):
     and GPU builds disagree on exactly those elements."""
     got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
     bad = np.abs(got - want) > tol * max(np.abs(want).max(), 1e-30)
+    if cond is not None:  # ill-conditioned elements (adagrad_well_conditioned): within `loose` absolute, not compared
+        assert (np.abs(got - want)[~cond] <= loose).all(), (what, 'ill-conditioned element moved by more than lr * steps')
+        bad &= cond
     allowed = int(1e-4 * want.size) if want.size > 10000 else 0
     assert bad.sum() <= allowed, (what, int(bad.sum()), allowed, float(np.abs(got - want).max()))
 
@@ -113,11 +125,13 @@ def check_train_matches_oracle(be, loss, opt, D, U=37, I=29, N=150, B=64, nn=3, 
     assert rel_inf(be.get(out), score(pu, pi)) < 1e-5
 
 
-def check_single_step_gradients(be, loss, D, U=50, I=40, B=128, nn=3, seed=11):
+def check_single_step_gradients(be, loss, D, U=50, I=40, B=128, nn=3, seed=11, bias_tol=1e-5, emb_tol=1e-5):
     """Identical minibatch, identical parameters: loss within 1e-5 rel, summed gradients
     within 1e-5 of each table's inf-norm (bias tables: of their joint norm, the user-bias
     gradient being a sum of cancelling +g/-g terms).  The engine's gradient is read back
-    through the ADAM_DENSE accumulate-only mode with lr = 0 (parameters stay put)."""
+    through the ADAM_DENSE accumulate-only mode with lr = 0 (parameters stay put).
+    bias_tol / emb_tol: for tables of a handful of rows, where a bias gradient is a sum of thousands of cancelling +g/-g terms and the
+    oracle's own sequential fp32 sum is that far from the exact one."""
     eng = be.engine
     rs = np.random.RandomState(seed)
     users = rs.randint(0, U, B).astype(np.int64)
@@ -138,7 +152,7 @@ def check_single_step_gradients(be, loss, D, U=50, I=40, B=128, nn=3, seed=11):
     bscale = max(np.abs(want_g[2]).max(), np.abs(want_g[3]).max())
     for t in range(4):
         scale = np.abs(want_g[t]).max() if t < 2 else bscale
-        assert np.abs(got[t].ravel() - want_g[t].ravel()).max() <= 1e-5 * scale, t
+        assert np.abs(got[t].ravel() - want_g[t].ravel()).max() <= (emb_tol if t < 2 else bias_tol) * scale, t
     for t in range(4):  # lr = 0: parameters untouched
         assert np.array_equal(be.get(dev.p[t]).ravel(), np.asarray(params[t], np.float32).ravel())
 
@@ -354,10 +368,17 @@ def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3
                           d_neg_out=be.ptr(neg_out), stream=be.stream)
         assert (be.get(neg_out) == want_neg).all()
         got_loss = be.get(mb_loss)
-        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-5, (got_loss, want_loss)
+        # the first minibatch is a pure forward on identical parameters; later ones also see the (Adagrad: up to lr-sized)
+        # moves of ill-conditioned elements, see below
+        if epoch == 0:
+            assert abs(got_loss[0] - want_loss[0]) / abs(want_loss[0]) < 1e-5, (got_loss, want_loss)
+        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < (2e-4 if opt == 'adagrad' else 1e-5), (got_loss, want_loss)
     assert dev.optim.step == ora.step_count == epochs * n_mb
     for t in range(2):
-        assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t))
+        # Adagrad: an element whose accumulated g^2 is ~0 (a residual of cancelling terms) moves by up to lr per step whatever
+        # the summation order; it is bounded, the others are compared
+        cond = adagrad_well_conditioned(ora.s1[t]) if opt == 'adagrad' else None
+        assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t), cond=cond, loose=hp['lr'] * epochs * n_mb * 1.01)
         assert_close_table(be.get(dev.s1[t]), ora.s1[t], tol, ('state1', t))
         if opt in ('sparse_adam', 'adam_dense'):
             assert_close_table(be.get(dev.s2[t]), ora.s2[t], tol, ('state2', t))

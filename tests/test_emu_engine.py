@@ -66,6 +66,18 @@ def test_adaptive_hinge_item_side_sorted_per_minibatch_or_per_chunk(be, opt, lat
         be.engine.set_option('adaptive_late_min_batch', 1 << 18)
 
 
+@pytest.mark.parametrize('D,I,B,opt', [(64, 3, 4096, 'adagrad'), (64, 2, 3000, 'sparse_adam'), (8, 2, 3000, 'adam_dense'),
+                                        (32, 5, 2500, 'adagrad_dense')])
+def test_rows_that_collect_thousands_of_occurrences(be, D, I, B, opt):
+    """popular items: an item row's occurrences fill dozens of the item pass's tiles; their partial sums are added by
+    k_item_stitch (several batches of G tiles for D = 64) -- against the oracle's plain sequential sums"""
+    ec.check_train_matches_oracle(be, 'bpr', opt, D, U=600, I=I, N=2 * B + 50, B=B, epochs=1, degenerate=True)
+    ec.check_train_matches_oracle(be, 'pointwise', opt, D, U=3, I=I, N=B + 50, B=B, epochs=1, degenerate=True)
+    # the summed gradients of ONE such minibatch, within 1e-5 of each table's norm
+    ec.check_single_step_gradients(be, 'bpr', D, U=600, I=I, B=B, bias_tol=1e-2)  # a bias gradient here is what is left of thousands of cancelling +g / -g terms
+    ec.check_single_step_gradients(be, 'pointwise', D, U=3, I=I, B=B, bias_tol=1e-2, emb_tol=1e-4)  # 3 users: cancelling sums
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 def test_single_step_loss_and_gradients(be, loss):
     ec.check_single_step_gradients(be, loss, 16)
