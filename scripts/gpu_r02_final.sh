@@ -15,4 +15,6 @@ import json; d=json.load(open('$OUT/bench_$w.json')); r=d['roofline']; print('$w
 for B in 256 1024 65536 1048576; do S=$((4194304 / B)); [ $S -lt 16 ] && S=16; [ $S -gt 2000 ] && S=2000
 python bench.py --batch $B --steps $S --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_batch_$B.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('C2 tables batch $B: %.1f M interactions/s, %.1f us per minibatch' % (d['value']/1e6, d['ms_per_step']*1e3))"; done
+for z in 0.8 1.0 1.2; do python bench.py --item-zipf $z --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_zipf_$z.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, positive items Zipf($z): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"; done
 bash scripts/pmc_run.sh ${1:-r02_final}_pmc --no-probes --no-sharded-check > $GRAFT_REPO_ROOT/gpurun_out/${1:-r02_final}/pmc.log 2>&1; tail -5 $GRAFT_REPO_ROOT/gpurun_out/${1:-r02_final}/pmc.log

@@ -716,6 +716,21 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
                                          (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
                                          ibits + mbbits, s)))
             return rc;
+        // which minibatches hold a LONG run of the plain occurrence list (slk_kernels.h, k_item_long_flags): fetched once
+        // per chunk; the usual minibatch (none) gets the plain item pass with no stitch kernel behind it
+        slk_prep_bufs &fb = ctx->pb[0];
+        if ((rc = slk_ensure(ctx, fb.lflags, (size_t)n_mb * 4))) return rc;
+        SLK_HIP(ctx, hipMemsetAsync(fb.lflags.p, 0, (size_t)n_mb * 4, s));
+        hipLaunchKernelGGL(k_item_long_flags, dim3(slk_grid_for(ctx, nocc / (4 * gpb) + n_mb, 256)), dim3(256), 0, s,
+                           (const uint32_t *)ctx->ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)L * (uint32_t)NP, 4u * gpb,
+                           (uint32_t)((1ull << ibits) - 1), padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx, 0xffffffffu,
+                           (int *)fb.lflags.p);
+        SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
+        fb.h_lflags.assign(n_mb, 1);
+        SLK_HIP(ctx, hipMemcpyAsync(fb.h_lflags.data(), fb.lflags.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, s));
+        if (!fb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&fb.ev_lflags, hipEventDisableTiming));
+        SLK_HIP(ctx, hipEventRecord(fb.ev_lflags, s));
+        bool lflags_ready = false;
         if (Hi) {
             hipLaunchKernelGGL(k_seq_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s, cs,
                                (const uint32_t *)neg32, nocc, ns, (uint32_t)L, (uint32_t)NP, (uint32_t)bsz, icbits, ibd,
@@ -785,12 +800,17 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             a.inv_b = 1.0f;  // the sequence pass already divided its partials by mask.sum()
             slk_set_opt_coeffs(a, optim);
             a.nt = ctx->opt_nt;
+            if (!lflags_ready) {  // the chunk's first sequence pass is queued: the GPU is busy while the host waits
+                SLK_HIP(ctx, hipEventSynchronize(fb.ev_lflags));
+                lflags_ready = true;
+            }
+            const bool may_long = fb.h_lflags[mb] != 0;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>"))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>", may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<SEQ,BIAS>"))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<SEQ,BIAS>", may_long))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
