@@ -129,6 +129,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
  *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
  *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)
+ *   "item_long_gate"      1 (default): minibatches in which no item row's occurrences fill a whole 64-position tile of the
+ *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results)
  *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */

@@ -184,6 +184,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_debug = (int)value;
     } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
         ctx->opt_epoch_dense_elems = value;
+    } else if (!strcmp(name, "item_long_gate") && (value == 0 || value == 1)) {
+        ctx->opt_item_long_gate = (int)value;
     } else if (!strcmp(name, "adaptive_late_min_batch") && value >= 0) {
         ctx->opt_adaptive_late_min_batch = value;
     } else if (!strcmp(name, "shuffle_band") && value >= 0 && value <= 1024) {

@@ -1010,11 +1010,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             }
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                const bool may_long = late || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                const bool may_long = late || !ctx->opt_item_long_gate || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
                 if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                const bool may_long = late || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                const bool may_long = late || !ctx->opt_item_long_gate || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
                 if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", may_long))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;

@@ -98,6 +98,8 @@ struct slk_ctx {
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
+    int opt_item_long_gate = 1;    // 1: minibatches without a long run (k_item_long_flags) take the plain item pass; 0: every item
+                                   // pass is the partial-writing one + k_item_stitch (same results; a test / measurement switch)
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
     // minibatches <= opt_epoch_max_batch run inside ONE persistent launch per chunk (slk_epoch.hip).  Defaults from the
     // same-box A/Bs in profiles/r02_c_small_batch.jsonl: the persistent route wins at 256 (13 vs 21 us per minibatch) and

@@ -804,7 +804,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
                 SLK_HIP(ctx, hipEventSynchronize(fb.ev_lflags));
                 lflags_ready = true;
             }
-            const bool may_long = fb.h_lflags[mb] != 0;
+            const bool may_long = !ctx->opt_item_long_gate || fb.h_lflags[mb] != 0;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
                 if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>", may_long))) return rc;

@@ -1048,6 +1048,37 @@ def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=
     assert np.allclose(runs[0][2], runs[1][2], rtol=1e-6)
 
 
+def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41):
+    """The plain item pass (minibatches in which no run wholly covers a tile, chosen per chunk from k_item_long_flags) against
+    the partial-writing pass + k_item_stitch for every minibatch: every table and state tensor bit for bit."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    results = []
+    for gate in (1, 0):
+        eng.set_option('item_long_gate', gate)
+        eng.set_option('epoch_kernel', 0)  # the launch path under test
+        try:
+            dev = be.model(params, opt=opt, **hp)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+            eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1, be.ptr(mb_loss),
+                               stream=be.stream)
+            results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+        finally:
+            eng.set_option('item_long_gate', 1)
+            eng.set_option('epoch_kernel', 1)
+    for k, (a, b) in enumerate(zip(*results)):
+        assert np.array_equal(a, b), ('tensor %d differs between the gated and the ungated item pass' % k)
+
+
 # ---------------------------------------------------------------------------------------
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------

@@ -78,6 +78,13 @@ def test_rows_that_collect_thousands_of_occurrences(be, D, I, B, opt):
     ec.check_single_step_gradients(be, 'pointwise', D, U=3, I=I, B=B, bias_tol=1e-2, emb_tol=1e-4)  # 3 users: cancelling sums
 
 
+@pytest.mark.parametrize('D,U,I,N,B,opt', [(64, 300, 170, 2500, 512, 'adagrad'), (64, 300, 3, 9000, 4096, 'adagrad'),
+                                            (8, 50, 2, 7000, 3000, 'sparse_adam'), (32, 40, 30, 1000, 300, 'adam_dense')])
+def test_item_long_gate_is_bit_neutral(be, D, U, I, N, B, opt):
+    """short runs only, and tables of 2-3 items whose runs fill dozens of tiles: gated or not, the same bits"""
+    ec.check_item_long_gate_is_bit_neutral(be, 'bpr', opt, D, U, I, N, B)
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 def test_single_step_loss_and_gradients(be, loss):
     ec.check_single_step_gradients(be, loss, 16)

@@ -262,6 +262,12 @@ def test_rows_that_collect_thousands_of_occurrences(be, D, I, B):
     ec.check_train_matches_oracle(be, 'bpr', 'adagrad', D, U=5000, I=I, N=2 * B + 50, B=B, epochs=1, degenerate=True)
 
 
+@pytest.mark.parametrize('D,U,I,N,B', [(64, 3000, 1000, 50000, 8192), (64, 3000, 3, 200000, 65536), (32, 500, 40, 100000, 30000)])
+def test_item_long_gate_is_bit_neutral(be, D, U, I, N, B):
+    """the plain item pass for minibatches without long runs (per-chunk flags) against partials + stitch everywhere"""
+    ec.check_item_long_gate_is_bit_neutral(be, 'bpr', 'adagrad', D, U, I, N, B)
+
+
 # ---- persistent epoch kernel (csrc/slk_epoch.hip): one cooperative launch per chunk of minibatches ----
 @pytest.mark.parametrize('loss', ['pointwise', 'bpr', 'hinge'])
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
