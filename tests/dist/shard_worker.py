@@ -42,7 +42,9 @@ def main():
         stream = torch.cuda.current_stream(dev).cuda_stream
 
     U, I, B, n_mb = 41, 53, 96, 3
-    N = B * n_mb - 17  # short last minibatch
+    if os.environ.get('SHARD_TEST_SHAPE'):  # e.g. '300,4,1600,1': a handful of items whose lookups fill dozens of item-pass tiles
+        U, I, B, n_mb = (int(x) for x in os.environ['SHARD_TEST_SHAPE'].split(','))
+    N = B * n_mb - 17  # short last minibatch (or a short only one)
     rs = np.random.RandomState(123)
     users = rs.randint(0, U, N).astype(np.int64)
     items = rs.randint(0, I, N).astype(np.int64)

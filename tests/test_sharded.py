@@ -53,6 +53,13 @@ def test_sharded_world2_matches_oracle_and_single_device(loss, opt, D):
     run_world(2, [loss, opt, D])
 
 
+def test_sharded_popular_items_long_runs(monkeypatch):
+    """4 items in all: every owner's item pass sees runs of ~800 gradient slots (a dozen tiles at dim 64), summed through the
+    per-tile partials + k_item_stitch in the exchange-slot (BLK) mode"""
+    monkeypatch.setenv('SHARD_TEST_SHAPE', '300,4,1600,1')  # one minibatch: no trajectory to go chaotic
+    run_world(2, ['bpr', 'adagrad', 64, 'chunk', 2])
+
+
 @pytest.mark.parametrize('world,slices,loss,opt', [(2, 1, 'bpr', 'adagrad'), (2, 3, 'pointwise', 'sparse_adam'),
                                                    (3, 2, 'hinge', 'adam_dense'), (1, 2, 'bpr', 'adagrad')])
 def test_sharded_whole_chunk_with_slices(world, slices, loss, opt):
