@@ -23,6 +23,15 @@ def test_seq_train_matches_oracle(be, loss, opt):
     ec.check_seq_train_matches_oracle(be, loss, opt, 8)
 
 
+@pytest.mark.parametrize('loss', ['bpr', 'pointwise'])
+def test_seq_popular_items_long_runs(be, loss):
+    """3 items besides the padding row: every item row collects ~1600 occurrences of the minibatch (25 tiles of the item pass
+    at dim 64), summed through per-tile partials + k_item_stitch in the PoolNet (SEQ) mode; the oracle sums sequentially, so
+    the comparison allows what thousands of cancelling fp32 terms allow"""
+    ec.check_seq_single_step_gradients(be, loss, 64, I=4, B=60, L=40, tol=1e-4)
+    ec.check_seq_single_step_gradients(be, loss, 8, I=3, B=80, L=30, seed=5, tol=1e-4)
+
+
 @pytest.mark.parametrize('D,L,B', [(32, 20, 10), (64, 33, 6), (128, 5, 8), (6, 300, 3), (3, 1, 16), (16, 130, 4)])
 def test_seq_other_layouts_and_lengths(be, D, L, B):
     # L > number of row groups (several timesteps per chunk), L == 1, odd dims
