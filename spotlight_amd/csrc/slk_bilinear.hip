@@ -728,6 +728,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
         }
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
+        if (!late && (rc = slk_ensure(ctx, pb.lflags, (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk
     }
     enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN };  // ctx->extra slots
     const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
