@@ -35,6 +35,25 @@ int slk_ensure(slk_ctx *ctx, slk_buf &b, size_t bytes) {
     return SLK_OK;
 }
 
+int slk_ensure_lflags_host(slk_ctx *ctx, slk_prep_bufs &pb, size_t n) {
+    if (n > pb.h_lflags_cap) {
+        if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
+        pb.h_lflags = nullptr;
+        pb.h_lflags_cap = 0;
+        void *p = nullptr;
+        const size_t want = n + n / 4 + 64;
+        if (hipHostMalloc(&p, want * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return slk_fail(ctx, SLK_ENOMEM, "hipHostMalloc of %zu flag words failed", want);
+        }
+        pb.h_lflags = (int *)p;
+        pb.h_lflags_cap = want;
+    }
+    for (size_t i = 0; i < n; ++i) pb.h_lflags[i] = 1;
+    pb.h_lflags_n = n;
+    return SLK_OK;
+}
+
 void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s) {
     if (!ctx->prof_on) return;
     slk_prof_span sp;
@@ -144,6 +163,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         for (slk_buf *b : pbs)
             if (b->p) (void)hipFree(b->p);
         if (pb.ev_lflags) (void)hipEventDestroy(pb.ev_lflags);
+        if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
     }
     for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1]})
         if (e) (void)hipEventDestroy(e);

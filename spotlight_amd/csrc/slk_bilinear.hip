@@ -863,8 +863,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                (const uint32_t *)pb.ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)NP, 4u * gpb,
                                (uint32_t)((1ull << ibits) - 1), 0xffffffffu, 0xffffffffu, (int *)pb.lflags.p);
             SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
-            pb.h_lflags.assign(n_mb_c, 1);
-            SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags.data(), pb.lflags.p, (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = slk_ensure_lflags_host(ctx, pb, n_mb_c))) return rc;
+            SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags, pb.lflags.p, (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
             SLK_HIP(ctx, hipEventRecord(pb.ev_lflags, s));
         }
@@ -1011,11 +1011,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             }
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                const bool may_long = late || !ctx->opt_item_long_gate || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                const bool may_long = late || !ctx->opt_item_long_gate || b0 / (uint32_t)bsz >= pb.h_lflags_n || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
                 if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                const bool may_long = late || !ctx->opt_item_long_gate || pb.h_lflags.empty() || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
+                const bool may_long = late || !ctx->opt_item_long_gate || b0 / (uint32_t)bsz >= pb.h_lflags_n || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
                 if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", may_long))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;

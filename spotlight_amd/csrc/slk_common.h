@@ -66,7 +66,9 @@ struct slk_prep_bufs {
     slk_buf neg32, ukey[2], uval[2], uit, ikey[2], ipay[2];
     slk_buf bik[2], bip[2], buk[2], bup[2];  // BloomEmbedding hashed-row occurrence lists
     slk_buf lflags;                 // per minibatch of the chunk: does a run of the item-sorted list wholly cover a tile?
-    std::vector<int> h_lflags;      //   (k_item_long_flags; read back once per chunk, see slk_launch_item_pass)
+    int *h_lflags = nullptr;        //   (k_item_long_flags; read back once per chunk into PINNED host memory -- a pageable
+    size_t h_lflags_cap = 0;        //   destination makes the copy wait for the stream -- see slk_launch_item_pass)
+    size_t h_lflags_n = 0;
     hipEvent_t ev_lflags = nullptr; //   recorded behind the read-back: the host waits for it, not for the stream
 };
 
@@ -155,6 +157,7 @@ struct slk_ctx {
 
 int slk_fail(slk_ctx *ctx, int code, const char *fmt, ...);
 int slk_ensure(slk_ctx *ctx, slk_buf &b, size_t bytes);
+int slk_ensure_lflags_host(slk_ctx *ctx, slk_prep_bufs &pb, size_t n);  // pinned int[n], every entry 1 (= may hold a long run)
 void slk_prof_begin(slk_ctx *ctx, int cls, hipStream_t s);
 void slk_prof_end(slk_ctx *ctx, hipStream_t s);
 int slk_prof_drain(slk_ctx *ctx);

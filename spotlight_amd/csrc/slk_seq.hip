@@ -726,8 +726,8 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
                            (uint32_t)((1ull << ibits) - 1), padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx, 0xffffffffu,
                            (int *)fb.lflags.p);
         SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
-        fb.h_lflags.assign(n_mb, 1);
-        SLK_HIP(ctx, hipMemcpyAsync(fb.h_lflags.data(), fb.lflags.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, s));
+        if ((rc = slk_ensure_lflags_host(ctx, fb, n_mb))) return rc;
+        SLK_HIP(ctx, hipMemcpyAsync(fb.h_lflags, fb.lflags.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, s));
         if (!fb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&fb.ev_lflags, hipEventDisableTiming));
         SLK_HIP(ctx, hipEventRecord(fb.ev_lflags, s));
         bool lflags_ready = false;

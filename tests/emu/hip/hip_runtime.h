@@ -184,7 +184,10 @@ static inline T __ldg(const T *p) { return *p; }
 
 extern "C" {
 hipError_t hipMalloc(void **p, size_t n);
+#define hipHostMallocDefault 0u
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }  // host == device memory here
 hipError_t hipFree(void *p);
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemset(void *d, int v, size_t n);
