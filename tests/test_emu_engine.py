@@ -73,9 +73,9 @@ def test_rows_that_collect_thousands_of_occurrences(be, D, I, B, opt):
     k_item_stitch (several batches of G tiles for D = 64) -- against the oracle's plain sequential sums"""
     ec.check_train_matches_oracle(be, 'bpr', opt, D, U=600, I=I, N=2 * B + 50, B=B, epochs=1, degenerate=True)
     ec.check_train_matches_oracle(be, 'pointwise', opt, D, U=3, I=I, N=B + 50, B=B, epochs=1, degenerate=True)
-    # the summed gradients of ONE such minibatch, within 1e-5 of each table's norm
-    ec.check_single_step_gradients(be, 'bpr', D, U=600, I=I, B=B, bias_tol=1e-2)  # a bias gradient here is what is left of thousands of cancelling +g / -g terms
-    ec.check_single_step_gradients(be, 'pointwise', D, U=3, I=I, B=B, bias_tol=1e-2, emb_tol=1e-4)  # 3 users: cancelling sums
+    # the summed item gradients of ONE such minibatch against the exact (float64) ones
+    ec.check_long_run_gradients_against_exact(be, 'bpr', D, U=600, I=I, B=B)
+    ec.check_long_run_gradients_against_exact(be, 'pointwise', D, U=3, I=I, B=B)
 
 
 @pytest.mark.parametrize('D,U,I,N,B,opt', [(64, 300, 170, 2500, 512, 'adagrad'), (64, 300, 3, 9000, 4096, 'adagrad'),

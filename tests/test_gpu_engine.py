@@ -254,11 +254,9 @@ def test_adaptive_hinge_item_side_sorted_per_minibatch_or_per_chunk(be, opt, lat
 @pytest.mark.parametrize('D,I,B', [(64, 3, 1 << 16), (64, 50, 1 << 18), (32, 7, 40000), (128, 2, 30000)])
 def test_rows_that_collect_thousands_of_occurrences(be, D, I, B):
     """popular items: one item row's occurrences fill hundreds to thousands of the item pass's tiles; k_item_stitch adds their
-    partial sums.  Summed gradients of one minibatch against the oracle (1e-5 of each table's norm), then a training run."""
-    # tens of thousands of fp32 terms of both signs per row: the oracle's own SEQUENTIAL fp32 sum is ~1e-4 of the row's norm
-    # from the exact one at 2-3 items (this pass adds tile sums: closer to exact, not closer to sequential)
-    ec.check_single_step_gradients(be, 'bpr', D, U=5000, I=I, B=B, bias_tol=1e-2, emb_tol=1e-4 if I > 3 else 1e-3)
-    ec.check_single_step_gradients(be, 'pointwise', D, U=3, I=I, B=B, bias_tol=1e-2, emb_tol=1e-4 if I > 3 else 1e-3)  # 3 users: cancelling sums
+    partial sums.  Summed item gradients of one minibatch against the exact (float64) ones, then a training run."""
+    ec.check_long_run_gradients_against_exact(be, 'bpr', D, U=5000, I=I, B=B, tol=1e-5)
+    ec.check_long_run_gradients_against_exact(be, 'pointwise', D, U=3, I=I, B=B, tol=1e-5)
     ec.check_train_matches_oracle(be, 'bpr', 'adagrad', D, U=5000, I=I, N=2 * B + 50, B=B, epochs=1, degenerate=True)
 
 
