@@ -18,17 +18,18 @@ import sys
 import numpy as np
 import torch
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+
+from oracle.reference_import import golden_dir, import_reference, run_main  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 import spotlight.factorization.implicit as ref_implicit  # noqa: E402
 from spotlight.interactions import Interactions  # noqa: E402
 
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
 def optimizer_factory(kind):
@@ -155,7 +156,7 @@ def cases():
 
 
 def main():
-    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(golden_dir(), exist_ok=True)
     torch.set_num_threads(1)
     worst = 0.0
     for case in cases():
@@ -177,9 +178,9 @@ def main():
         # 2e-4 of the tensor's inf-norm (<= 2 %), not by the worst element.
         assert m_step < 1e-5, errs
         assert errs['loss'] < 1e-4 and max(fr.values()) <= 0.02, (errs, fr)
-        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **rec)
+        np.savez_compressed(os.path.join(golden_dir(), case['name'] + '.npz'), **rec)
     print('all cases pinned; worst %.2e' % worst)
 
 
 if __name__ == '__main__':
-    main()
+    run_main(main)

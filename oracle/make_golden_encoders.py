@@ -15,11 +15,13 @@ import sys
 import numpy as np
 import torch
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+
+from oracle.reference_import import golden_dir, import_reference, run_main  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 import spotlight.sequence.implicit as ref_seq  # noqa: E402
 from spotlight.interactions import SequenceInteractions  # noqa: E402
@@ -29,7 +31,6 @@ from spotlight.sequence.representations import CNNNet, LSTMNet, MixtureLSTMNet  
 from oracle.make_golden import optimizer_factory  # noqa: E402
 from oracle.make_golden_seq import make_sequences  # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
 def build_representation(case):
@@ -148,14 +149,14 @@ def cases():
 
 
 def main():
-    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(golden_dir(), exist_ok=True)
     torch.set_num_threads(1)
     for case in cases():
         rec = run_reference(case)
-        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **rec)
+        np.savez_compressed(os.path.join(golden_dir(), case['name'] + '.npz'), **rec)
         print('%-40s %d params, %d minibatches, loss %.4f -> %.4f' % (case['name'], len(rec['names']), len(rec['losses']),
                                                                     rec['losses'][0], rec['losses'][-1]))
 
 
 if __name__ == '__main__':
-    main()
+    run_main(main)

@@ -12,11 +12,13 @@ import sys
 import numpy as np
 import torch
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+
+from oracle.reference_import import golden_dir, import_reference, run_main  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 import spotlight.factorization.explicit as ref_exp  # noqa: E402
 from spotlight.interactions import Interactions  # noqa: E402
@@ -24,7 +26,6 @@ from spotlight.interactions import Interactions  # noqa: E402
 from oracle.make_golden import optimizer_factory  # noqa: E402
 from oracle.replay import replay_explicit_with_oracle  # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
 NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'user_biases.weight', 'item_biases.weight']
 
 
@@ -123,7 +124,7 @@ def cases():
 
 
 def main():
-    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(golden_dir(), exist_ok=True)
     torch.set_num_threads(1)
     for case in cases():
         rec = run_reference(case)
@@ -134,9 +135,9 @@ def main():
               % (case['name'], m_step, max(errs.values()), max(errs, key=errs.get), max(fr.values())))
         assert m_step < 1e-5, errs
         assert errs['loss'] < 1e-3 and max(fr.values()) <= case.get('frac_tol', 0.05), (errs, fr)
-        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **rec)
+        np.savez_compressed(os.path.join(golden_dir(), case['name'] + '.npz'), **rec)
     print('all explicit cases pinned')
 
 
 if __name__ == '__main__':
-    main()
+    run_main(main)

@@ -11,8 +11,12 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, '/root/reference')
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from oracle.reference_import import import_reference  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 import reference_floors as rf  # noqa: E402
 from spotlight.cross_validation import user_based_train_test_split  # noqa: E402

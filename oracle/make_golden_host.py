@@ -8,10 +8,13 @@ import sys
 
 import numpy as np
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from oracle.reference_import import golden_dir, import_reference, run_main  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 from spotlight.cross_validation import (random_train_test_split, shuffle_interactions,  # noqa: E402
                                         user_based_train_test_split)
@@ -86,9 +89,9 @@ def main():
                                learning_rate=1e-2, l2=1e-6, random_state=np.random.RandomState(25))
     sm.fit(sq_tr)
     rec['e2e_mrr_sequence'] = sequence_mrr_score(sm, sq_te)
-    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'host_api.npz'), **rec)
+    np.savez_compressed(os.path.join(golden_dir(), 'host_api.npz'), **rec)
     print('host_api.npz written:', {k: np.asarray(v).shape for k, v in rec.items()})
 
 
 if __name__ == '__main__':
-    main()
+    run_main(main)

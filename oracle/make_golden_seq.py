@@ -12,11 +12,13 @@ import sys
 import numpy as np
 import torch
 
-REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+
+from oracle.reference_import import golden_dir, import_reference, run_main  # noqa: E402
+
+import_reference()  # `spotlight` = the reference itself, never this repository's alias package onto the product
 
 import spotlight.sequence.implicit as ref_seq  # noqa: E402
 from spotlight.interactions import SequenceInteractions  # noqa: E402
@@ -24,7 +26,6 @@ from spotlight.interactions import SequenceInteractions  # noqa: E402
 from oracle.make_golden import optimizer_factory  # noqa: E402
 from oracle.replay import replay_seq_with_oracle  # noqa: E402
 
-OUT = os.path.join(ROOT, 'tests', 'golden')
 NAMES = ['item_embeddings.weight', 'item_biases.weight']
 
 
@@ -154,7 +155,7 @@ def bloom_cases():
 
 
 def main():
-    os.makedirs(OUT, exist_ok=True)
+    os.makedirs(golden_dir(), exist_ok=True)
     torch.set_num_threads(1)
     which = bloom_cases() if 'bloom' in sys.argv[1:] else cases()
     for case in which:
@@ -169,9 +170,9 @@ def main():
         # step is lr*sign(g), and the bias gradient of an item that is a positive target in one
         # timestep and a negative in another is cancellation noise at initialisation
         assert errs['loss'] < 1e-3 and max(fr.values()) <= case.get('frac_tol', 0.05), (errs, fr)
-        np.savez_compressed(os.path.join(OUT, case['name'] + '.npz'), **rec)
+        np.savez_compressed(os.path.join(golden_dir(), case['name'] + '.npz'), **rec)
     print('all sequence cases pinned')
 
 
 if __name__ == '__main__':
-    main()
+    run_main(main)
