@@ -55,7 +55,11 @@ def main():
         print(json.dumps({'error': 'oracle/_ref/spotlight is not staged: run `sh oracle/make_ref.sh` where '
                                    '/root/reference exists (build() does)'}))
         return 2
-    sys.path.insert(0, REF)
+    # `spotlight` = the staged reference, loaded from its explicit location (never this repository's alias package)
+    os.environ.setdefault('SPOTLIGHT_REFERENCE', REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.reference_import import import_reference
+    import_reference()
     import numpy as np
     import torch
     from spotlight.factorization.implicit import ImplicitFactorizationModel

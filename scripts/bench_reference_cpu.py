@@ -10,7 +10,9 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '/root/reference')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.reference_import import import_reference  # noqa: E402
+import_reference()  # the reference itself, not this repository's `spotlight` alias package
 from spotlight.factorization.implicit import ImplicitFactorizationModel  # noqa: E402
 from spotlight.interactions import Interactions  # noqa: E402
 

@@ -165,8 +165,10 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         if (pb.ev_lflags) (void)hipEventDestroy(pb.ev_lflags);
         if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
     }
-    for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1]})
+    for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_coef[0], ctx->ev_coef[1]})
         if (e) (void)hipEventDestroy(e);
+    for (void *h : ctx->h_coef)
+        if (h) (void)hipHostFree(h);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);

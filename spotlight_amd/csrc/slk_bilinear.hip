@@ -696,6 +696,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (mb_per_chunk < 1) mb_per_chunk = 1;
     if (bsz * occ_mult >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "batch_size * lookups per interaction must be < 2^31");
+    // the persistent route (slk_epoch.hip) keeps per-(minibatch, workgroup) loss partials and counts barriers in 32 bits:
+    // at most 2^13 minibatches per launch (16 MB of partials at 256 workgroups)
+    const bool maybe_epoch = ctx->opt_epoch_kernel && !ctx->epoch_refused && bsz <= ctx->opt_epoch_max_batch;
+    if (maybe_epoch && mb_per_chunk > ((int64_t)1 << 13)) mb_per_chunk = (int64_t)1 << 13;
     const int64_t chunk_cap = mb_per_chunk * bsz;
 
     // Adaptive hinge: only the positive and the selected negative of a column carry a gradient, so
@@ -760,6 +764,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     if (reserve_only) {
         if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
+        if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, expl))) return rc;
         // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;
         return slk_sort_reserve(ctx, nc_max * (size_t)occ_mult);
@@ -856,6 +861,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 return rc;
             // which minibatches hold a LONG run (one that wholly covers a tile of the item pass): ids only, so the answer is
             // fetched once per chunk and the usual minibatch (none) gets the plain pass with no stitch kernel behind it
+            if (!epoch_route) {  // (the persistent route walks the runs itself; its fall-back re-derives the flags, do_passes)
             const uint32_t n_mb_c = (nc + (uint32_t)bsz - 1) / (uint32_t)bsz;
             if ((rc = slk_ensure(ctx, pb.lflags, (size_t)n_mb_c * 4))) return rc;
             SLK_HIP(ctx, hipMemsetAsync(pb.lflags.p, 0, (size_t)n_mb_c * 4, s));
@@ -867,6 +873,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags, pb.lflags.p, (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
             SLK_HIP(ctx, hipEventRecord(pb.ev_lflags, s));
+            } else {
+                pb.h_lflags_n = 0;  // no flags for this chunk: every item pass of a fall-back takes the partial-writing form
+            }
         }
         if (Hi && !late) {
             hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,

@@ -117,7 +117,10 @@ struct slk_ctx {
     int64_t opt_epoch_dense_elems = (int64_t)1 << 18;  // dense optimizers: largest model (parameters) the persistent route takes:
                                    // every row group sweeps rows / row-groups rows per phase, so only models of the reference's own
                                    // scale (MovieLens-100K at dim 32: 87 K parameters)
-    std::vector<uint64_t> ep_coef; // host staging of the per-minibatch optimizer coefficients (slk_step_coef)
+    void *h_coef[2] = {nullptr, nullptr};  // pinned host staging of the per-minibatch optimizer coefficients (slk_step_coef),
+    size_t h_coef_cap[2] = {0, 0};         //   double-buffered: ev_coef[b] is recorded behind the copy issued from buffer b
+    hipEvent_t ev_coef[2] = {nullptr, nullptr};
+    int coef_flip = 0;
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
@@ -215,6 +218,7 @@ int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32
                       uint32_t *nseg_out, hipStream_t s);
 // slk_epoch.hip: the persistent route of slk_bilinear_train
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss, bool bloom);
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, bool expl);
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
                         int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
                         float *d_mb_loss, const float *d_ratings, hipStream_t s);

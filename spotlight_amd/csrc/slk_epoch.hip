@@ -70,7 +70,7 @@ struct slk_epoch_args {
     const slk_step_coef *coef;     // [n_mb]
     uint32_t *touch_u, *touch_i;   // dense optimizers: touch[row] = (last minibatch that looks the row up) + 1; zeroed before the launch
     unsigned *bar;                 // barrier counter, zeroed before the launch
-    int *status;                   // raised on a barrier time-out
+    int *status;                   // barrier time-out: the number (>= 1) of the barrier that was abandoned, 2 per minibatch
     int loss_kind;
     float eps, omb1, omb2, beta2, wd;
     int bar_kind;                  // 0: one arrival counter, 1: 8 sub-counters + a top counter
@@ -118,7 +118,7 @@ __device__ __forceinline__ bool slk_epoch_barrier(const slk_epoch_args &e, unsig
                 seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (++spins > SLK_EPOCH_MAX_SPINS) {  // a workgroup never arrived: give up, tell everyone
                     __hip_atomic_store(flag, SLK_EPOCH_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(e.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(e.status, (int)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // which barrier: 2 per minibatch
                     seen = SLK_EPOCH_ABORT;
                 }
             }
@@ -520,17 +520,25 @@ bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_
     return true;
 }
 
-// All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one cooperative launch.
-int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
-                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
-                        float *d_mb_loss, const float *d_ratings, hipStream_t s) {
-    const bool expl = loss >= SLK_LOSS_REGRESSION;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+enum { EP_COEF = 40, EP_BAR, EP_PARTIAL, EP_TOUCH };  // ctx->extra slots
+
+static int epoch_upd_of(const slk_optim *optim) {
+    switch (optim->kind) {
+        case SLK_OPT_ADAGRAD: return SLK_EUPD_ADAGRAD;
+        case SLK_OPT_SPARSE_ADAM: return SLK_EUPD_SPARSE_ADAM;
+        case SLK_OPT_ADAM_DENSE: return SLK_EUPD_ADAM_DENSE;
+        default: return SLK_EUPD_ADAGRAD_DENSE;
+    }
+}
+
+// Workgroups of the persistent launch: one position per row group in the (2x longer) item phase when the chip allows, at most
+// one workgroup per CU, and never more than the device can hold RESIDENT at once for this kernel (occupancy query x CUs: the
+// grid barrier needs every workgroup running; on gfx950 one 64-thread workgroup per CU always fits an idle device, the
+// query guards a build whose register / LDS footprint says otherwise).
+static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, bool expl, int g,
+                           slk_epoch_fn fn, size_t lds) {
     const unsigned np = expl ? 1u : 2u;
-    int vec, g, rc;
-    if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
-    const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
     const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
-    // one position per row group in the (2x longer) item phase when the chip allows: <= one workgroup per CU
     unsigned grid = (unsigned)((np * bsz + gpb - 1) / gpb);
     if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
         // the dense optimizers also sweep every row of the larger table once per phase: one row per row group if the chip allows
@@ -538,29 +546,84 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
         const unsigned by_rows = (unsigned)((rows + gpb - 1) / gpb);
         if (by_rows > grid) grid = by_rows;
     }
-    const unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
+    unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
+    int per_cu = 0;
+    if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SLK_EPOCH_TB, lds) == hipSuccess && per_cu >= 0) {
+        const unsigned resident = (unsigned)per_cu * (unsigned)ctx->num_cus;
+        if (resident < cap) cap = resident;  // 0: the kernel cannot be resident at all -> the caller takes the launch path
+    } else {
+        (void)hipGetLastError();
+    }
     if (grid > cap) grid = cap;
-    if (grid < 1) grid = 1;
+    return grid;
+}
 
-    enum { EP_COEF = 40, EP_BAR, EP_PARTIAL, EP_TOUCH };  // ctx->extra slots
+static slk_epoch_fn epoch_pick_fn(int vec, int g, int upd, bool expl) {
+    slk_epoch_fn fn = nullptr;
+#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd, expl)
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
+#undef SLK_PICK_EPOCH
+    return fn;
+}
+
+static const size_t kEpochLds = 4 * sizeof(double) + 16;
+
+// Scratch of the persistent route for chunks of up to n_mb minibatches: called by slk_bilinear_reserve (so that the training
+// call allocates nothing) and again, idempotently, by every slk_epoch_run_chunk.
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, bool expl) {
+    int vec, g, rc;
+    if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, expl, g, epoch_pick_fn(vec, g, epoch_upd_of(optim), expl), kEpochLds);
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 2048))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * grid * 8))) return rc;
-
-    slk_epoch_args e;
-    memset(&e, 0, sizeof(e));
-    int upd;
-    switch (optim->kind) {
-        case SLK_OPT_ADAGRAD: upd = SLK_EUPD_ADAGRAD; break;
-        case SLK_OPT_SPARSE_ADAM: upd = SLK_EUPD_SPARSE_ADAM; break;
-        case SLK_OPT_ADAM_DENSE: upd = SLK_EUPD_ADAM_DENSE; break;
-        default: upd = SLK_EUPD_ADAGRAD_DENSE; break;
+    if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * (grid ? grid : 1) * 8))) return rc;
+    if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
+        const size_t rows = (size_t)tables->num_users + (size_t)tables->num_items;
+        if ((rc = slk_ensure(ctx, ctx->extra[EP_TOUCH], rows * 4))) return rc;
     }
+    // pinned, double-buffered host staging of the per-minibatch coefficients (an asynchronous copy from pageable memory may
+    // read the host buffer after the call returned -- and the next chunk's call rewrites it)
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->h_coef_cap[b] >= n_mb) continue;
+        if (ctx->ev_coef[b]) SLK_HIP(ctx, hipEventSynchronize(ctx->ev_coef[b]));
+        if (ctx->h_coef[b]) SLK_HIP(ctx, hipHostFree(ctx->h_coef[b]));
+        ctx->h_coef[b] = nullptr;
+        ctx->h_coef_cap[b] = 0;
+        const size_t cap = n_mb < 1024 ? 1024 : n_mb;
+        SLK_HIP(ctx, hipHostMalloc(&ctx->h_coef[b], cap * sizeof(slk_step_coef), hipHostMallocDefault));
+        ctx->h_coef_cap[b] = cap;
+        if (!ctx->ev_coef[b]) SLK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_coef[b], hipEventDisableTiming));
+    }
+    return SLK_OK;
+}
+
+// All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one persistent launch.
+int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
+                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
+                        float *d_mb_loss, const float *d_ratings, hipStream_t s) {
+    const bool expl = loss >= SLK_LOSS_REGRESSION;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+    int vec, g, rc;
+    if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
+    const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
+    const int upd = epoch_upd_of(optim);
+    slk_epoch_fn fn = epoch_pick_fn(vec, g, upd, expl);
+    const size_t lds = kEpochLds;
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, expl, g, fn, lds);
+    if (grid == 0) {  // the occupancy query says no workgroup of this kernel fits a CU: nothing ran, take the launch path
+        slk_fail(ctx, SLK_EIO, "k_bilinear_epoch cannot be resident on this device (occupancy 0)");
+        ctx->epoch_refused = true;
+        return SLK_EAGAIN_EPOCH;
+    }
+    if ((rc = slk_epoch_reserve(ctx, tables, optim, n_mb, bsz, expl))) return rc;
+
     // per-step coefficients, in double like torch (slk_set_opt_coeffs / slk_dense_sweeps)
-    ctx->ep_coef.resize(n_mb);
+    const int cb = ctx->coef_flip;
+    ctx->coef_flip ^= 1;
+    SLK_HIP(ctx, hipEventSynchronize(ctx->ev_coef[cb]));  // the copy issued from this buffer two chunks ago (never recorded: returns at once)
+    slk_step_coef *hc = (slk_step_coef *)ctx->h_coef[cb];
     for (uint32_t m = 0; m < n_mb; ++m) {
         const double step = (double)(optim->step + 1 + m);
-        slk_step_coef &c = *reinterpret_cast<slk_step_coef *>(&ctx->ep_coef[m]);
+        slk_step_coef &c = hc[m];
         c.c0 = c.c1 = 0.0f;
         if (upd == SLK_EUPD_ADAGRAD || upd == SLK_EUPD_ADAGRAD_DENSE) {
             c.c0 = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
@@ -574,16 +637,17 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
             }
         }
     }
-    SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[EP_COEF].p, ctx->ep_coef.data(), (size_t)n_mb * sizeof(slk_step_coef),
-                                hipMemcpyHostToDevice, s));
+    SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[EP_COEF].p, hc, (size_t)n_mb * sizeof(slk_step_coef), hipMemcpyHostToDevice, s));
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_coef[cb], s));
     SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 2048, s));
     const bool dense_opt = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (dense_opt) {
         const size_t rows = (size_t)tables->num_users + (size_t)tables->num_items;
-        if ((rc = slk_ensure(ctx, ctx->extra[EP_TOUCH], rows * 4))) return rc;
         SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_TOUCH].p, 0, rows * 4, s));
     }
 
+    slk_epoch_args e;
+    memset(&e, 0, sizeof(e));
     for (int t = 0; t < 4; ++t) {
         e.P[t] = tables->d_param[t];
         e.S1[t] = optim->d_state1[t];
@@ -623,13 +687,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.bar_kind = ctx->opt_epoch_barrier >= 0 ? ctx->opt_epoch_barrier : (grid > 128 ? 1 : 0);
     e.debug = ctx->opt_epoch_debug;
 
-    slk_epoch_fn fn = nullptr;
-#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd, expl)
-    SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
-#undef SLK_PICK_EPOCH
     slk_prof_begin(ctx, SLK_K_EPOCH, s);
     void *kargs[1] = {&e};
-    const size_t lds = 4 * sizeof(double) + 16;
     // The grid (<= one wavefront-sized workgroup per CU) is resident as a whole on any device that is not saturated by other
     // work for seconds, which is what the barrier's bounded spins tolerate.  A plain launch lets kernels of other streams
     // (the next epoch's shuffle and negatives, implicit.py's pipelined fit) run beside it; the cooperative form adds a

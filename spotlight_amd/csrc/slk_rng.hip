@@ -378,11 +378,25 @@ SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     hipStream_t cs = slk_copy_stream(ctx);
     SLK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost, cs));
     SLK_HIP(ctx, hipStreamSynchronize(cs));
-    if (h.insufficient)
+    if (h.insufficient || h.epoch_abort) {
+        // Reported ONCE: the flags are cleared on the device (they used to stay raised until the next slk_rng_set_state, which
+        // a pipelined fit() never issues on its training ctx -- every later epoch then failed).  A barrier time-out also
+        // retires the persistent route on this ctx: the per-minibatch launches need no co-residency.
+        const int32_t zero2[2] = {0, 0};
+        SLK_HIP(ctx, hipMemcpyAsync(&ctx->d_rng->insufficient, zero2, 4, hipMemcpyHostToDevice, cs));
+        SLK_HIP(ctx, hipMemcpyAsync(&ctx->d_rng->epoch_abort, zero2 + 1, 4, hipMemcpyHostToDevice, cs));
+        SLK_HIP(ctx, hipStreamSynchronize(cs));
+        if (h.epoch_abort) {
+            ctx->epoch_refused = true;
+            return slk_fail(ctx, SLK_EIO,
+                            "persistent epoch kernel abandoned a launch at its grid barrier %d (minibatch %d of that launch): a "
+                            "workgroup never arrived -- the device is shared or the grid was not resident.  Minibatches before it "
+                            "are applied in full, that one in part: re-initialise the model.  This ctx now uses the per-minibatch "
+                            "launches (as with option epoch_kernel=0)",
+                            (int)h.epoch_abort, (int)((h.epoch_abort - 1) / 2));
+        }
         return slk_fail(ctx, SLK_EIO, "sampler ran out of generated words (rejection tail > 12 sigma)");
-    if (h.epoch_abort)
-        return slk_fail(ctx, SLK_EIO, "persistent epoch kernel abandoned a launch: a workgroup never reached the grid barrier "
-                                      "(set option epoch_kernel=0 for the per-minibatch launches)");
+    }
     memcpy(h_key, h.key, sizeof(h.key));
     *pos = h.pos;
     return SLK_OK;

@@ -214,3 +214,8 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 }
 template <class T>
 static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n); }
+// every kernel "fits": the emulator runs a resident grid's blocks as concurrent fibers whatever their footprint
+template <class F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 8; return hipSuccess; }
+template <class T>
+static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f) { return hipHostMalloc(reinterpret_cast<void **>(p), n, f); }
