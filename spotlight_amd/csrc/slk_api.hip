@@ -90,11 +90,46 @@ int slk_prof_drain(slk_ctx *ctx) {
     return SLK_OK;
 }
 
+// A CU mask with `n` of the device's CUs (take = true) or all the others (take = false).  The mask's bits are dealt to the
+// XCDs first and to the shader engines next (bit b -> XCD b mod 8), so the lowest n bits are n CUs spread evenly over the chip.
+static void slk_cu_mask(const slk_ctx *ctx, int n, bool take, uint32_t *words, uint32_t nwords) {
+    for (uint32_t w = 0; w < nwords; ++w) words[w] = 0u;
+    for (int b = 0; b < ctx->num_cus && b < (int)nwords * 32; ++b)
+        if ((b < n) == take) words[b >> 5] |= 1u << (b & 31);
+}
+
 int slk_prep_stream_init(slk_ctx *ctx) {
-    if (ctx->prep_stream) return SLK_OK;
-    SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1]})
-        SLK_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (ctx->prep_stream && ctx->prep_stream_cus == ctx->opt_prep_cus && ctx->prep_stream_prio == ctx->opt_prep_priority)
+        return SLK_OK;
+    if (ctx->prep_stream) {  // the partition options changed: both streams are re-created (idle: every call ends joined)
+        SLK_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
+        SLK_HIP(ctx, hipStreamDestroy(ctx->prep_stream));
+        ctx->prep_stream = nullptr;
+        if (ctx->pass_stream) {
+            SLK_HIP(ctx, hipStreamSynchronize(ctx->pass_stream));
+            SLK_HIP(ctx, hipStreamDestroy(ctx->pass_stream));
+            ctx->pass_stream = nullptr;
+        }
+    }
+    const int n = ctx->opt_prep_cus;
+    if (n > 0 && n < ctx->num_cus) {
+        uint32_t mask[32];
+        slk_cu_mask(ctx, n, true, mask, 32);
+        SLK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->prep_stream, 32, mask));
+        slk_cu_mask(ctx, n, false, mask, 32);
+        SLK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->pass_stream, 32, mask));
+    } else if (ctx->opt_prep_priority) {
+        int lo = 0, hi = 0;
+        SLK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SLK_HIP(ctx, hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi));
+    } else {
+        SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
+    }
+    ctx->prep_stream_cus = ctx->opt_prep_cus;
+    ctx->prep_stream_prio = ctx->opt_prep_priority;
+    for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1], &ctx->ev_pass_in,
+                          &ctx->ev_pass_out})
+        if (!*e) SLK_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SLK_OK;
 }
 
@@ -165,11 +200,13 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         if (pb.ev_lflags) (void)hipEventDestroy(pb.ev_lflags);
         if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
     }
-    for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_coef[0], ctx->ev_coef[1]})
+    for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_coef[0], ctx->ev_coef[1],
+                         ctx->ev_pass_in, ctx->ev_pass_out})
         if (e) (void)hipEventDestroy(e);
     for (void *h : ctx->h_coef)
         if (h) (void)hipHostFree(h);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
+    if (ctx->pass_stream) (void)hipStreamDestroy(ctx->pass_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
     if (ctx->d_jump) (void)hipFree(ctx->d_jump);
@@ -184,6 +221,10 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_chunk_interactions = value;
     } else if (!strcmp(name, "overlap_prep") && value >= 0 && value <= 2) {
         ctx->opt_overlap_prep = (int)value;
+    } else if (!strcmp(name, "prep_cus") && value >= 0 && value <= 1024) {
+        ctx->opt_prep_cus = (int)value;
+    } else if (!strcmp(name, "prep_priority") && (value == 0 || value == 1)) {
+        ctx->opt_prep_priority = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {

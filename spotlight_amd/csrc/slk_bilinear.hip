@@ -1115,6 +1115,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     hipStream_t ps = ctx->prep_stream;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
     SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+    // option "prep_cus": the chip is split between the two -- the passes run on the ctx's stream masked to the CUs the prep
+    // stream does not use, between two events on the caller's stream (`s` is what every launch below goes to)
+    hipStream_t caller = s;
+    if (ctx->pass_stream) {
+        SLK_HIP(ctx, hipStreamWaitEvent(ctx->pass_stream, ctx->ev_start, 0));
+        s = ctx->pass_stream;
+    }
     if ((rc = do_sample(0, ctx->pb[0], ps))) return rc;
     if (sort_ahead && (rc = do_sort(0, ctx->pb[0], ps))) return rc;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
@@ -1132,6 +1139,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = do_chunk(c0, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }
-    ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
+    if (s != caller) {
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_pass_out, s));
+        SLK_HIP(ctx, hipStreamWaitEvent(caller, ctx->ev_pass_out, 0));
+    }
+    ctx->last_stream = caller;  // every prep is ordered before the tail of the caller's stream
     return SLK_OK;
 }

@@ -93,6 +93,14 @@ struct slk_ctx {
     // tuning (slk_ctx_set_option)
     int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
     int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains
+    // Partition of the chip between the prep of chunk c+1 and the passes of chunk c (only with overlap_prep).  The row passes
+    // are grid-stride kernels that keep every wave slot of every CU for their whole run, so a second stream's kernels
+    // otherwise only run in the gaps: prep_cus > 0 gives the prep stream a CU mask of that many CUs (spread over the XCDs and
+    // shader engines) and runs the passes on a ctx-owned stream masked to the other CUs (ordered against the caller's
+    // stream by events); prep_priority = 1 creates the (unmasked) prep stream with the highest priority instead.
+    int opt_prep_cus = 0;
+    int opt_prep_priority = 0;
+    int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
@@ -125,6 +133,8 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
+    hipStream_t pass_stream = nullptr;  // prep_cus > 0: the passes' stream, masked to the CUs the prep stream does not use
+    hipEvent_t ev_pass_in = nullptr, ev_pass_out = nullptr;
     hipStream_t copy_stream = nullptr;  // small state copies (slk_rng_{set,get}_state): never the null stream
     hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)

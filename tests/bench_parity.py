@@ -59,6 +59,31 @@ def _assert_adagrad_update(p_got, p_want, s_got, s_want, s_pre, g, g_scale, lr, 
     return int((np.abs(p_got.astype(np.float64) - p_want.astype(np.float64)) > TOL * p_scale).sum())
 
 
+def _assert_sparse_adam_update(p_got, p_want, m_got, m_want, v_got, v_want, m_pre, v_pre, g, g_scale, lr_t, b1, b2, eps, what):
+    """SparseAdam (torch/optim/_functional.py:44-84): m' = m + (1-b1)(g-m); v' = v + (1-b2)(g^2-v);
+    p -= lr_t * m' / (sqrt(v') + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t).  Per-element bound = what a gradient perturbation
+    of dg = 1e-5 * ||g||inf moves the element by: d(update)/dg = lr_t * ((1-b1)/(sqrt(v')+eps) - m'(1-b2) g / (sqrt(v')(sqrt(v')+eps)^2));
+    like Adagrad's it is only large where v' ~ 0, i.e. zero second moment and a ~0 gradient."""
+    dg = TOL * g_scale
+    g64, m64, v64 = g.astype(np.float64), m_pre.astype(np.float64), v_pre.astype(np.float64)
+    m1 = m64 + (1 - b1) * (g64 - m64)
+    v1 = np.maximum(v64 + (1 - b2) * (g64 * g64 - v64), 0.0)
+    rt = np.sqrt(v1)
+    sens = (1 - b1) / (rt + eps) + np.abs(m1) * (1 - b2) * np.abs(g64) / (np.maximum(rt, 1e-30) * (rt + eps) ** 2)
+    p_scale = max(float(np.abs(p_want).max()), 1e-30)
+    tol_p = TOL * p_scale + lr_t * dg * sens
+    d = np.abs(p_got.astype(np.float64) - p_want.astype(np.float64))
+    bad = d > tol_p
+    assert not bad.any(), (what, 'param', int(bad.sum()), float(d.max()))
+    tol_m = TOL * max(float(np.abs(m_want).max()), 1e-30) + (1 - b1) * dg
+    bad = np.abs(m_got.astype(np.float64) - m_want.astype(np.float64)) > tol_m
+    assert not bad.any(), (what, 'exp_avg', int(bad.sum()))
+    tol_v = TOL * max(float(np.abs(v_want).max()), 1e-30) + (1 - b2) * 2.0 * np.abs(g64) * dg
+    bad = np.abs(v_got.astype(np.float64) - v_want.astype(np.float64)) > tol_v
+    assert not bad.any(), (what, 'exp_avg_sq', int(bad.sum()))
+    return int((d > TOL * p_scale).sum())
+
+
 def _changed_rows(after, before):
     d = after != before
     return torch.nonzero(d.any(dim=1) if d.dim() > 1 else d).squeeze(1)
@@ -66,10 +91,13 @@ def _changed_rows(after, before):
 
 def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1, scale=None, trained=False,
                               bloom_rows=0, n_hash=4, seed=0, check_grads=True, tables=None, state=None,
-                              users=None, items=None, rng_state=None, lr=1e-2):
+                              users=None, items=None, rng_state=None, lr=1e-2, opt='adagrad', state2=None, step0=0,
+                              bias_scale=0.1):
     """One minibatch of B interactions over U x I tables of dim D (item layer: BloomEmbedding with `bloom_rows`
-    compressed rows when > 0), Adagrad(lr).  Tables / Adagrad state / ids / RNG state are generated here on
-    the device unless given.  Returns a dict of diagnostics."""
+    compressed rows when > 0), Adagrad(lr) or SparseAdam(lr) (`opt`; `step0` minibatches already taken).  Tables /
+    optimizer state / ids / RNG state are generated here on the device unless given.  Returns a dict of diagnostics."""
+    assert opt in ('adagrad', 'sparse_adam')
+    betas = (0.9, 0.999)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + seed)
     rows_i = bloom_rows or I
@@ -79,15 +107,23 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
                   torch.empty(rows_i, D, device=dev).normal_(0, sc, generator=gen),
                   torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
         if trained:  # a model some way into training: non-trivial biases and accumulators
-            tables[2].normal_(0, 0.1, generator=gen)
-            tables[3].normal_(0, 0.1, generator=gen)
+            tables[2].normal_(0, bias_scale, generator=gen)
+            tables[3].normal_(0, bias_scale, generator=gen)
         if bloom_rows:
             tables[1][0] = 0  # the compressed table's padding row (layers.py:152-154)
     if state is None:
         state = [torch.zeros_like(t) for t in tables]
-        if trained:
+        if trained and opt == 'adagrad':
             for s in state:
                 s.uniform_(0.01, 1.0, generator=gen)
+        elif trained:  # first moments of either sign
+            for s in state:
+                s.normal_(0, 1e-3, generator=gen)
+    if opt == 'sparse_adam' and state2 is None:
+        state2 = [torch.zeros_like(t) for t in tables]
+        if trained:
+            for s in state2:
+                s.uniform_(1e-8, 1e-5, generator=gen)
     if users is None:
         users = torch.randint(0, U, (B,), device=dev, dtype=torch.int64, generator=gen)
         items = torch.randint(0, I, (B,), device=dev, dtype=torch.int64, generator=gen)
@@ -119,14 +155,16 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
     sel = lambda t, idx: _rows(t, idx) if idx is not None else _np(t)
     pre_p = [sel(tables[0], d_uu), sel(tables[1], d_iu), sel(tables[2], d_uu), sel(tables[3], d_iu)]
     pre_s = [sel(state[0], d_uu), sel(state[1], d_iu), sel(state[2], d_uu), sel(state[3], d_iu)]
+    pre_s2 = [sel(state2[0], d_uu), sel(state2[1], d_iu), sel(state2[2], d_uu), sel(state2[3], d_iu)] if state2 else None
 
     # ---- oracle on the compacted problem
     if bloom_rows:
+        assert opt == 'adagrad'
         ora = BloomBilinearOracle(*pre_p, item_bloom=bloom_desc(n_hash), opt='adagrad', lr=lr)
         for t in range(4):
             ora.s1[t][...] = pre_s[t]
     else:
-        ora = BilinearOracle(*pre_p, opt='adagrad', lr=lr, sparse_grads=True, state1=pre_s)
+        ora = BilinearOracle(*pre_p, opt=opt, lr=lr, sparse_grads=True, state1=pre_s, state2=pre_s2, betas=betas, step=step0)
     want_loss, want_g = ora.step(uinv, pos_c, neg_c, loss=loss, n_neg=nn, want_grads=True)
 
     # ---- engine, gradients: ADAM_DENSE accumulate-only (lr = 0, beta1 = 0 => exp_avg == the summed gradient)
@@ -157,9 +195,10 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
         del m1, m2, g_dev
         neg_out.fill_(-1)
 
-    # ---- engine, the real step (Adagrad, as bench.py runs it)
-    before = [t.clone() for t in tables] + [s.clone() for s in state]
-    op = _native.make_optim('adagrad', [s.data_ptr() for s in state], None, lr=lr)
+    # ---- engine, the real step (Adagrad, as bench.py runs it; or SparseAdam)
+    before = [t.clone() for t in tables] + [s.clone() for s in state] + ([s.clone() for s in state2] if state2 else [])
+    op = _native.make_optim(opt, [s.data_ptr() for s in state], [s.data_ptr() for s in state2] if state2 else None, lr=lr,
+                            betas=betas, step=step0)
     engine.rng_set_state(rng_state)
     engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), B, B, loss, nn, mb_loss.data_ptr(),
                           d_neg_out=neg_out.data_ptr(), stream=stream)
@@ -168,7 +207,7 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
     assert (got_rng[1] == want_rng[1]).all() and got_rng[2] == want_rng[2], 'RNG state after the draw'
     got_loss = float(mb_loss.item())
     assert abs(got_loss - want_loss) <= TOL * abs(want_loss), (got_loss, want_loss)
-    assert op.step == 1
+    assert op.step == step0 + 1
     out.update(loss=got_loss, loss_oracle=want_loss, users_touched=int(uu.size),
                items_touched=int(iu.size) if iu is not None else None)
 
@@ -179,15 +218,49 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
     cond = 0
     for t in range(4):
         p_got, s_got = sel(tables[t], idxs[t]), sel(state[t], idxs[t])
-        cond += _assert_adagrad_update(p_got.reshape(ora.p[t].shape), ora.p[t], s_got.reshape(ora.s1[t].shape), ora.s1[t],
-                                       pre_s[t].reshape(ora.s1[t].shape), want_g[t], gscale[t], lr, eps, ('table', t))
+        shp = ora.p[t].shape
+        if opt == 'adagrad':
+            cond += _assert_adagrad_update(p_got.reshape(shp), ora.p[t], s_got.reshape(shp), ora.s1[t],
+                                           pre_s[t].reshape(shp), want_g[t], gscale[t], lr, eps, ('table', t))
+        else:
+            tt = step0 + 1
+            lr_t = lr * np.sqrt(1.0 - betas[1] ** tt) / (1.0 - betas[0] ** tt)
+            v_got = sel(state2[t], idxs[t])
+            cond += _assert_sparse_adam_update(p_got.reshape(shp), ora.p[t], s_got.reshape(shp), ora.s1[t], v_got.reshape(shp),
+                                               ora.s2[t], pre_s[t].reshape(shp), pre_s2[t].reshape(shp), want_g[t], gscale[t],
+                                               lr_t, betas[0], betas[1], 1e-8, ('table', t))
         # rows the minibatch does not name: bit-identical
-        for after, bef, nm in ((tables[t], before[t], 'param'), (state[t], before[4 + t], 'state')):
+        pairs = [(tables[t], before[t], 'param'), (state[t], before[4 + t], 'state')]
+        if state2:
+            pairs.append((state2[t], before[8 + t], 'state2'))
+        for after, bef, nm in pairs:
             ch = _changed_rows(after, bef)
             if idxs[t] is not None:
                 assert bool(torch.isin(ch, idxs[t]).all()), ('row outside the minibatch changed', nm, t)
     out['elements_beyond_1e-5_but_within_conditioned_bound'] = cond
     return out
+
+
+def saturated_problem(dev, U, I, D, B, seed=0, row_scale=0.35, shift=2.0):
+    """A model that has LEARNED something, for the minibatch parity check (the N(0, 1/16) 'trained' state
+    keeps every score inside the sigmoid's linear regime, loss 0.49998): rows N(0, row_scale^2) -- a dim-64 dot product has a
+    standard deviation of 8 * row_scale^2 ~ 1 --, item biases +shift on the lower half of the ids and -shift on the upper half
+    (+ noise), positives drawn from the lower half only, negatives uniform as the reference draws them.  pos - neg is then
+    ~N(0, 1.5^2) for half of the pairs and ~N(2 * shift, 1.5^2) for the other half: |pos - neg| spans 0 .. 8, s(1 - s) goes
+    down to 1e-4 (saturated pairs, where the cancellation in the summed gradients is hardest) and the bpr loss is ~0.27."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7000 + seed)
+    tables = [torch.empty(U, D, device=dev).normal_(0, row_scale, generator=gen),
+              torch.empty(I, D, device=dev).normal_(0, row_scale, generator=gen),
+              torch.empty(U, device=dev).normal_(0, 0.3, generator=gen),
+              torch.empty(I, device=dev).normal_(0, 0.3, generator=gen)]
+    half = I // 2
+    tables[3][:half] += shift
+    tables[3][half:] -= shift
+    state = [torch.empty_like(t).uniform_(0.01, 1.0, generator=gen) for t in tables]
+    users = torch.randint(0, U, (B,), device=dev, dtype=torch.int64, generator=gen)
+    items = torch.randint(0, max(half, 1), (B,), device=dev, dtype=torch.int64, generator=gen)
+    return tables, state, users, items
 
 
 def poolnet_minibatch_parity(engine, dev, stream, I, D, B, L, loss='bpr', nn=1, scale=None, trained=False, seed=0,
@@ -260,7 +333,7 @@ def poolnet_minibatch_parity(engine, dev, stream, I, D, B, L, loss='bpr', nn=1, 
                 **{'elements_beyond_1e-5_but_within_conditioned_bound': cond})
 
 
-def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2):
+def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2, expect_route=None):
     """One slk_bilinear_train call over n_full * B + tail interactions (more than one prep chunk), bpr + Adagrad:
       * every negative of the call and the RNG state afterwards: bit-exact against numpy (one contiguous stream);
       * for every k in `check_at`: minibatch k is checked against the oracle by teacher forcing -- a second run
@@ -299,7 +372,15 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
                               d_neg_out=neg.data_ptr(), stream=stream)
         return t, s, _np(mb), neg, engine.rng_get_state(), op.step
 
+    if expect_route is not None:  # 'epoch' (the persistent kernel) / 'launch': the route the call takes is part of what is tested
+        engine.profile_reset()
+        engine.profile_enable(True)
     tF, sF, lossF, negF, rngF, steps = run(N)
+    if expect_route is not None:
+        engine.profile_enable(False)
+        prof = engine.profile_read()
+        took_epoch = prof['epoch'][0] > 0
+        assert took_epoch == (expect_route == 'epoch'), (expect_route, {k: v[0] for k, v in prof.items()})
     assert steps == n_mb
     assert np.array_equal(_np(negF), want_neg), 'negatives of the multi-chunk call differ from numpy'
     assert (rngF[1] == want_rng[1]).all() and rngF[2] == want_rng[2]
@@ -333,4 +414,68 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
                 assert torch.equal(tB[t], tF[t]) and torch.equal(sB[t], sF[t])
         out['checked'].append({'minibatch': k, 'loss': float(lossF[k]), 'loss_oracle': want_loss})
         del tA, sA, tB, sB
+    return out
+
+
+def sharded_world1_vs_fused(engine, dev, stream, U, I, D, B, n_mb=1, seed=0, lr=1e-2, block_rows=1 << 23):
+    """The row-sharded exchange path at world 1 (slk_shard_* + ShardedBilinearTrainer; every exchange is a local copy)
+    against the fused path (slk_bilinear_train) on the same tables, ids, RNG state: `n_mb` minibatches of B, bpr +
+    Adagrad from a trained state (accumulators >= 0.01, so a 1e-5-relative gradient difference moves no element by more
+    than 1e-6 of the table's norm).  Both paths sum a row's contributions before ONE update, in different association, so
+    the comparison is |d| <= 1e-5 * ||p||inf per element, row by row over the WHOLE tables (the fused path's own parity
+    with the oracle, including untouched rows staying bit-identical, is bilinear_minibatch_parity's job).  Needs an
+    initialised torch.distributed group of world size 1.  Tables are generated twice from one seed rather than cloned
+    (C5 shard: 32 GB item table + 32 GB accumulators per copy)."""
+    import torch.distributed as dist
+    from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
+    assert dist.is_initialized() and dist.get_world_size() == 1
+
+    def fresh():
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(9000 + seed)
+        t = [torch.empty(U, D, device=dev).normal_(0, 0.5 / np.sqrt(D), generator=gen),
+             torch.empty(I, D, device=dev).normal_(0, 0.5 / np.sqrt(D), generator=gen),
+             torch.empty(U, device=dev).normal_(0, 0.1, generator=gen), torch.empty(I, device=dev).normal_(0, 0.1, generator=gen)]
+        s = [torch.empty_like(x).uniform_(0.01, 1.0, generator=gen) for x in t]
+        users = torch.randint(0, U, (n_mb * B,), device=dev, dtype=torch.int64, generator=gen)
+        items = torch.randint(0, I, (n_mb * B,), device=dev, dtype=torch.int64, generator=gen)
+        return t, s, users, items
+
+    rng0 = np.random.RandomState(31 + seed).get_state()
+    tF, sF, users, items = fresh()
+    tb = _native.make_tables([x.data_ptr() for x in tF], U, I, D)
+    opF = _native.make_optim('adagrad', [x.data_ptr() for x in sF], None, lr=lr)
+    lossF = torch.zeros(n_mb, device=dev)
+    engine.rng_set_state(rng0)
+    engine.bilinear_train(tb, opF, users.data_ptr(), items.data_ptr(), n_mb * B, B, 'bpr', 1, lossF.data_ptr(), stream=stream)
+    rngF = engine.rng_get_state()
+
+    tS, sS, users2, items2 = fresh()
+    assert torch.equal(users, users2) and torch.equal(items, items2)
+    opS = _native.make_optim('adagrad', [x.data_ptr() for x in sS], None, lr=lr)
+    tr = ShardedBilinearTrainer(engine, tS, opS, I, stream=stream)
+    tr.reserve(B, n_mb)
+    lossS = torch.zeros(n_mb, device=dev)
+    engine.rng_set_state(rng0)
+    tr.train(users, items, B, loss='bpr', mb_loss=lossS, sample_chunk=n_mb)
+    rngS = engine.rng_get_state()
+    assert (rngF[1] == rngS[1]).all() and rngF[2] == rngS[2], 'the two paths consumed the RNG stream differently'
+    lf, ls = _np(lossF).astype(np.float64), _np(lossS).astype(np.float64)
+    assert np.all(np.abs(lf - ls) <= TOL * np.abs(lf)), (lf, ls)
+    assert opF.step == opS.step == n_mb
+    out = {'loss_fused': lf.tolist(), 'loss_sharded_world1': ls.tolist(), 'max_abs_diff': {}, 'rows_differing': {}}
+    for nm, a_list, b_list in (('param', tF, tS), ('adagrad_state', sF, sS)):
+        for t in range(4):
+            a, b = a_list[t], b_list[t]
+            scale = float(a.abs().max())
+            worst, nrows = 0.0, 0
+            for r0 in range(0, a.shape[0], block_rows):
+                d = (a[r0:r0 + block_rows] - b[r0:r0 + block_rows]).abs()
+                worst = max(worst, float(d.max()))
+                nz = d != 0
+                nrows += int((nz.any(dim=1) if nz.dim() > 1 else nz).sum())
+                del d, nz
+            assert worst <= TOL * scale, (nm, t, worst, scale)
+            out['max_abs_diff']['%s%d' % (nm, t)] = worst
+            out['rows_differing']['%s%d' % (nm, t)] = nrows
     return out

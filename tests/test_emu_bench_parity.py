@@ -44,3 +44,46 @@ def test_multi_chunk_teacher_forcing(emu):
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
     assert out['minibatches'] == 6 and len(out['checked']) == 2
+
+
+def test_bilinear_saturated_pairs(emu):
+    eng, dev, stream = emu
+    U, I, D, B = 5000, 900, 16, 700
+    tables, state, users, items = bp.saturated_problem(dev, U, I, D, B, seed=1, row_scale=0.7)
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, U, I, D, B, loss='bpr', tables=tables, state=state, users=users,
+                                       items=items, seed=11)
+    assert out['loss'] < 0.4, out
+
+
+@pytest.mark.parametrize('trained', [False, True])
+def test_bilinear_sparse_adam_minibatch(emu, trained):
+    eng, dev, stream = emu
+    bp.bilinear_minibatch_parity(eng, dev, stream, 5000, 900, 16, 700, loss='bpr', trained=trained,
+                                 scale=None if not trained else 0.5, bias_scale=0.5, seed=20 + int(trained), opt='sparse_adam',
+                                 step0=100 if trained else 0)
+
+
+@pytest.mark.parametrize('route', ['epoch', 'launch'])
+def test_small_minibatches_route_check(emu, route):
+    eng, dev, stream = emu
+    eng.set_option('epoch_kernel', 1 if route == 'epoch' else 0)
+    try:
+        out = bp.multi_chunk_parity(eng, dev, stream, 3000, 700, 16, 64, n_full=6, tail=23, check_at=(3, 6), seed=64,
+                                    expect_route=route)
+    finally:
+        eng.set_option('epoch_kernel', 1)
+    assert out['minibatches'] == 7
+
+
+def test_sharded_world1_vs_fused(emu):
+    import os
+    import torch.distributed as dist
+    eng, dev, stream = emu
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29462')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        out = bp.sharded_world1_vs_fused(eng, dev, stream, 3000, 5000, 16, 512, n_mb=2, seed=5, block_rows=1024)
+    finally:
+        dist.destroy_process_group()
+    assert out['rows_differing']['param1'] < 5000

@@ -69,3 +69,63 @@ def test_multi_chunk_call_at_bench_size(hip):
     out = bp.multi_chunk_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, n_full=10, tail=300_001,
                                 check_at=(8, 10))
     print('multi-chunk parity', out)
+
+
+# ---- round 3 (VERDICT r02 "Next round" 1b): the configurations the bench-size parity tests did not reach
+
+def test_c2_minibatch_saturated_pairs(hip):
+    """C2 at bench size from a state that has LEARNED something (bench_parity.saturated_problem): |pos - neg| spans 0 .. 8,
+    the sigmoid saturates for a good part of the pairs, the bpr loss is far from 0.5."""
+    eng, dev, stream = hip
+    U, I, D, B = 10_000_000, 1_000_000, 64, 1 << 20
+    tables, state, users, items = bp.saturated_problem(dev, U, I, D, B, seed=1)
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, U, I, D, B, loss='bpr', tables=tables, state=state, users=users,
+                                       items=items, seed=11)
+    print('C2 saturated parity', out)
+    assert out['loss'] < 0.4, out  # not the linear-sigmoid regime
+
+
+@pytest.mark.parametrize('trained', [False, True])
+def test_c2_minibatch_sparse_adam(hip, trained):
+    """C2 at bench size with SparseAdam (SURVEY 8(d) names it next to Adagrad; 72*D + 88 algorithmic bytes): from zero
+    moments at step 1, and from a trained state (moments of either sign, step 100)."""
+    eng, dev, stream = hip
+    out = bp.bilinear_minibatch_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, loss='bpr', trained=trained,
+                                       scale=None if not trained else 0.35, bias_scale=0.5, seed=20 + int(trained),
+                                       opt='sparse_adam', step0=100 if trained else 0)
+    print('C2 SparseAdam parity', out)
+
+
+@pytest.mark.parametrize('B,route', [(1024, 'epoch'), (1024, 'launch'), (65536, 'launch')])
+def test_c2_tables_small_and_mid_minibatches(hip, B, route):
+    """The reference's own batch sizes on the 10M x 1M tables ({1024, 65 536, 2^20}): B = 1024 through the
+    persistent epoch kernel (the default route there) and through the per-minibatch launches, B = 65 536 through the
+    launches; 40 (12) minibatches + a short tail in one call, negatives + RNG state bit-exact over the whole call, two
+    minibatches against the oracle by teacher forcing."""
+    eng, dev, stream = hip
+    eng.set_option('epoch_kernel', 1 if route == 'epoch' else 0)
+    try:
+        n_full = 40 if B == 1024 else 12
+        out = bp.multi_chunk_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, B, n_full=n_full, tail=B // 3 + 1,
+                                    check_at=(n_full // 2, n_full), seed=B, expect_route=route)
+    finally:
+        eng.set_option('epoch_kernel', 1)
+    print('C2 tables, minibatch', B, route, out)
+
+
+def test_c5_shard_sharded_world1_vs_fused(hip):
+    """One C5-shard step (12.5M users x 125M items, dim 64, minibatch 2^20) through the row-sharded exchange path at world
+    1, compared row by row with the fused path over the whole tables."""
+    import os
+    import torch.distributed as dist
+    eng, dev, stream = hip
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29461')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        out = bp.sharded_world1_vs_fused(eng, dev, stream, 12_500_000, 125_000_000, 64, 1 << 20, n_mb=1, seed=5)
+    finally:
+        dist.destroy_process_group()
+        torch.cuda.empty_cache()
+    print('C5-shard sharded(world 1) vs fused', out)
