@@ -386,14 +386,18 @@ def measured_stream_rates(be, stream):
     SURVEY.md 8(d) asks for next to the nominal peak."""
     n = (1 << 28) if be.kind == 'hip' else (1 << 12)
     a, b, c = (torch.ones(n, device=be.dev) for _ in range(3))
-    ms = {k: be.engine.probe_stream(k, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream) for k in range(6)}
+    ms = {k: be.engine.probe_stream(k, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream) for k in range(12)}
     del a, b, c
     gbs = {'copy_plain': 8.0 * n / ms[0] / 1e6, 'triad_plain': 12.0 * n / ms[1] / 1e6, 'copy_nt_x4': 8.0 * n / ms[2] / 1e6,
-           'triad_nt_x4': 12.0 * n / ms[3] / 1e6, 'read_only': 4.0 * n / ms[4] / 1e6, 'write_only': 4.0 * n / ms[5] / 1e6}
-    return {'copy_GBs': max(gbs['copy_plain'], gbs['copy_nt_x4']), 'triad_GBs': max(gbs['triad_plain'], gbs['triad_nt_x4']),
-            'variants_GBs': gbs,
+           'triad_nt_x4': 12.0 * n / ms[3] / 1e6, 'read_only': 4.0 * n / ms[4] / 1e6, 'write_only': 4.0 * n / ms[5] / 1e6,
+           'copy_chunk_x8': 8.0 * n / ms[6] / 1e6, 'copy_chunk_x8_nt': 8.0 * n / ms[7] / 1e6, 'copy_chunk_x4_16wg': 8.0 * n / ms[8] / 1e6,
+           'copy_chunk_x16_4wg': 8.0 * n / ms[9] / 1e6, 'copy_chunk_x8_ntload': 8.0 * n / ms[10] / 1e6,
+           'copy_chunk_x4_nt_32wg': 8.0 * n / ms[11] / 1e6}
+    return {'copy_GBs': max(v for k, v in gbs.items() if k.startswith('copy')),
+            'triad_GBs': max(gbs['triad_plain'], gbs['triad_nt_x4']), 'variants_GBs': gbs,
             'note': 'slk_probe_stream over 1 GiB buffers, hipEvents, 10 launches each: float4 copy / triad, plain grid-stride and '
-                    'non-temporal with 4 accesses in flight per lane; read-only and write-only streams'}
+                    'non-temporal with 4 accesses in flight per lane; read-only and write-only streams; chunked copies (a workgroup '
+                    'moves contiguous 16-64 KB chunks, 4-16 loads in flight per lane, plain / non-temporal); copy_GBs = the best copy'}
 
 
 def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):

@@ -377,7 +377,9 @@ int slk_profile_reset(slk_ctx *ctx);
  *  slk_probe_stream        kind 0: a = b (float4 copy, 8 B moved per float); kind 1: a = b + s*c (triad,
  *                          12 B per float) over caller-owned device buffers of n_floats (multiple of 4);
  *                          kinds 2 / 3: the same with four independent non-temporal 16-B accesses per lane per
- *                          iteration; kind 4: read only (4 B per float); kind 5: write only (4 B per float).
+ *                          iteration; kind 4: read only (4 B per float); kind 5: write only (4 B per float);
+ *                          kinds 6..11: chunked copies -- a workgroup moves contiguous chunks of 4 / 8 / 16 KB-per-wave
+ *                          accesses, every load of a chunk in flight before its first store, plain or non-temporal.
  *  slk_probe_step_ceiling  the BilinearNet training step's ALGORITHMIC row accesses and nothing else (no
  *                          sorts, no user->item records, no id / key streams, no biases), on the caller's live
  *                          tables (values are written back unchanged), in the passes' lane layout:

@@ -5,8 +5,8 @@ set -e
 TAG=$1; shift
 cd "$(dirname "$0")/../spotlight_amd/csrc"
 mkdir -p ab/$TAG
-for f in slk_api slk_sort slk_rng slk_mtjump slk_bilinear slk_shard slk_seq slk_eval slk_shuffle slk_seqprep slk_embed; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-function -Wno-pass-failed "$@" -c $f.hip -o ab/$TAG/$f.o &
+for f in *.hip; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-function -Wno-pass-failed "$@" -c $f -o ab/$TAG/${f%.hip}.o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libspotlight_hip_$TAG.so ab/$TAG/*.o

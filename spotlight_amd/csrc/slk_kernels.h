@@ -308,6 +308,15 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
                          // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
 #endif
 
+#ifndef SLK_ITEM_LATE_EARLY
+#define SLK_ITEM_LATE_EARLY 0  // 1: the row + state loads of a group's NEXT head (r = grp + NPRE * GPB) are issued before the group
+                               // sums its first head's run from LDS, instead of as a dependent round trip behind that run's stores
+#endif
+#ifndef SLK_ITEM_KEYPF
+#define SLK_ITEM_KEYPF 0       // 1: the keys + payloads of the workgroup's NEXT tile are fetched into registers behind the
+                               // record gathers of the current one (tiles of up to 254 positions, i.e. row groups of >= 4 lanes)
+#endif
+
 #ifndef SLK_SPILL_BATCH
 #define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
 #endif
@@ -411,12 +420,44 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
     }
 
     const uint32_t ntiles = (iend - ibegin + T - 1) / T;
+    // KEYPF: thread i holds key i - 1 (i <= tn + 1) and payload i (i < tn) of the NEXT tile, threads 64 / 65 its far keys
+    constexpr bool KEYPF = SLK_ITEM_KEYPF != 0 && T + 2 <= 256;
+    uint32_t pf_key = 0u, pf_pay = 0u, pf_far = 0u, pf_far2 = 0u;
+    auto tile_fetch = [&](uint32_t tile) {
+        const uint32_t tb = ibegin + tile * T;
+        const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
+        const bool first_tile = tb == ibegin;
+        const bool has_next = tb + (uint32_t)tn < iend;
+        const int i = (int)threadIdx.x;
+        pf_key = 0u;
+        if (i == 0) pf_key = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - 1), nt_keys);
+        else if (i <= tn) pf_key = slk_ld_u32(a.ikey + (tb - 1 + i), nt_keys);
+        else if (LONG && i == tn + 1 && has_next) pf_key = slk_ld_u32(a.ikey + (tb + tn), nt_keys);
+        if (i < tn) pf_pay = slk_ld_u32(a.ipay + (tb + i), nt_keys);
+        if (LONG && i == 64) pf_far = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - T), nt_keys);
+        if (LONG && i == 65) {
+            const bool next_full = has_next && iend - (tb + (uint32_t)tn) >= (uint32_t)T;
+            pf_far = next_full ? slk_ld_u32(a.ikey + (tb + 2u * (uint32_t)T - 1u), nt_keys) : 0u;
+            pf_far2 = next_full ? 1u : 0u;
+        }
+    };
+    if (KEYPF && blockIdx.x < ntiles) tile_fetch(blockIdx.x);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tb = ibegin + tile * T;
         const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
         const bool first_tile = tb == ibegin;
         const bool has_next = tb + (uint32_t)tn < iend;
         __syncthreads();  // LDS of the previous tile no longer in use
+        if (KEYPF) {
+            const int i = (int)threadIdx.x;
+            if (i <= tn + (LONG ? 1 : 0)) s_key[i] = pf_key;
+            if (i < tn) s_pay[i] = pf_pay;
+            if (LONG && i == 64) s_far[0] = pf_far;
+            if (LONG && i == 65) {
+                s_far[1] = pf_far;
+                s_far[2] = pf_far2;
+            }
+        } else {
         for (int i = threadIdx.x; i <= tn + (LONG ? 1 : 0); i += 256) {
             uint32_t kv = 0u;
             if (i == 0) kv = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - 1), nt_keys);
@@ -431,6 +472,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
             const bool next_full = has_next && iend - (tb + (uint32_t)tn) >= (uint32_t)T;
             s_far[1] = next_full ? slk_ld_u32(a.ikey + (tb + 2u * (uint32_t)T - 1u), nt_keys) : 0u;
             s_far[2] = next_full ? 1u : 0u;
+        }
         }
         __syncthreads();
         // the run the previous tile hands over, the run handed to the next tile; each of them is LONG (summed through
@@ -520,6 +562,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
             }
             if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, rows_on, c[it], g[it]);
         }
+        if (KEYPF && tile + gridDim.x < ntiles) tile_fetch(tile + gridDim.x);  // in flight behind the gathers
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int j = grp + it * GPB;
@@ -611,12 +654,37 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 if (starts) atomicAdd(a.ipart_count, 1u);
             }
         };
+#if SLK_ITEM_LATE_EARLY
+        // the group's next head: row + state on their way while the first head's run is summed (the registers of the record
+        // gather are free by now)
+        slk_vec<VEC> pv2 = slk_vzero<VEC>(), sv2 = slk_vzero<VEC>();
+        float pb2 = 0.0f, sb2 = 0.0f;
+        const int r2 = grp + NPRE * GPB;
+        const bool pre2 = r2 < nheads && completes(r2);
+        if (pre2) {
+            const uint32_t item = s_key[(int)s_head[r2] + 1] & a.imask;
+            if (rows_on && UPD != SLK_UPD_GRAD_ONLY) {
+                const size_t voff = (size_t)item * D + d0;
+                pv2 = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
+                sv2 = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+            }
+            if (PART != SLK_PART_ROWS && UPD != SLK_UPD_GRAD_ONLY) {
+                pb2 = a.P[3][item];
+                sb2 = a.S1[3][item];
+            }
+        }
+#endif
 #pragma unroll
         for (int h = 0; h < NPRE; ++h) {
             const int r = grp + h * GPB;
             if (r < nheads) finish(r, completes(r), pv[h], sv[h], pb[h], sb[h]);
         }
+#if SLK_ITEM_LATE_EARLY
+        if (r2 < nheads) finish(r2, pre2, pv2, sv2, pb2, sb2);
+        for (int r = r2 + GPB; r < nheads; r += GPB) {
+#else
         for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
+#endif
             slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
             finish(r, false, p, s, 0.0f, 0.0f);
         }

@@ -56,6 +56,30 @@ __global__ __launch_bounds__(256) void k_probe_stream4(float *__restrict__ a, co
     if (KIND == 4 && acc.v[0] + acc.v[1] + acc.v[2] + acc.v[3] == 12345.678f) slk_vstore<4>(a, acc);
 }
 
+// copy, chunked: a workgroup moves contiguous chunks of 256 * UNROLL float4 (every load of a chunk issued before its first
+// store; a wavefront's 64 lanes cover 1 KB per access), chunks dealt round-robin to the workgroups.  kinds 6..11 of
+// slk_probe_stream: (UNROLL, non-temporal loads, non-temporal stores, workgroups per CU)
+template <int UNROLL, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_probe_copy_chunk(float *__restrict__ a, const float *__restrict__ b, size_t n4) {
+    const size_t chunk = (size_t)256 * UNROLL;
+    for (size_t c0 = (size_t)blockIdx.x * chunk; c0 < n4; c0 += (size_t)gridDim.x * chunk) {
+        slk_vec<4> x[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const size_t j = c0 + (size_t)k * 256 + threadIdx.x;
+            if (j < n4) x[k] = NTL ? slk_vload_nt<4>(b + 4 * j) : slk_vload<4>(b + 4 * j);
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; ++k) {
+            const size_t j = c0 + (size_t)k * 256 + threadIdx.x;
+            if (j < n4) {
+                if (NTS) slk_vstore_nt<4>(a + 4 * j, x[k]);
+                else slk_vstore<4>(a + 4 * j, x[k]);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t slk_mix32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352du;
@@ -200,7 +224,7 @@ SLK_EXPORT int slk_probe_stream(slk_ctx *ctx, int32_t kind, float *d_a, const fl
                                 int64_t n_floats, int32_t iters, double *avg_ms, void *stream) {
     if (!ctx) return SLK_EINVAL;
     if (!d_a || !d_b || ((kind == 1 || kind == 3) && !d_c) || n_floats < 4 || (n_floats & 3) || iters < 1 || !avg_ms || kind < 0 ||
-        kind > 5)
+        kind > 11)
         return slk_fail(ctx, SLK_EINVAL, "slk_probe_stream: bad arguments");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
@@ -219,7 +243,13 @@ SLK_EXPORT int slk_probe_stream(slk_ctx *ctx, int32_t kind, float *d_a, const fl
             case 2: hipLaunchKernelGGL(k_probe_stream4<2>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
             case 3: hipLaunchKernelGGL(k_probe_stream4<3>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
             case 4: hipLaunchKernelGGL(k_probe_stream4<4>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
-            default: hipLaunchKernelGGL(k_probe_stream4<5>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+            case 5: hipLaunchKernelGGL(k_probe_stream4<5>, dim3(grid4), dim3(256), 0, s, a4, b4, c4, 0.5f, n4); break;
+            case 6: hipLaunchKernelGGL((k_probe_copy_chunk<8, false, false>), dim3(grid), dim3(256), 0, s, a4, b4, n4); break;
+            case 7: hipLaunchKernelGGL((k_probe_copy_chunk<8, true, true>), dim3(grid), dim3(256), 0, s, a4, b4, n4); break;
+            case 8: hipLaunchKernelGGL((k_probe_copy_chunk<4, false, false>), dim3(grid4), dim3(256), 0, s, a4, b4, n4); break;
+            case 9: hipLaunchKernelGGL((k_probe_copy_chunk<16, false, false>), dim3(grid / 2), dim3(256), 0, s, a4, b4, n4); break;
+            case 10: hipLaunchKernelGGL((k_probe_copy_chunk<8, true, false>), dim3(grid), dim3(256), 0, s, a4, b4, n4); break;
+            default: hipLaunchKernelGGL((k_probe_copy_chunk<4, true, true>), dim3(grid4 * 2), dim3(256), 0, s, a4, b4, n4); break;
         }
     });
 }

@@ -39,19 +39,13 @@ class PoolNet(nn.Module):
         return [self.item_embeddings.weight, self.item_biases.weight]
 
     def _embed(self, ids):
-        """Embedding vectors of `ids` (any shape) -> [..., D]; a BloomEmbedding layer sums its hashed rows
-        (layers.py:236-242), computed here with plain torch ops for prediction-time API parity."""
+        """Embedding vectors of `ids` (any shape) -> [..., D]: the layer's own lookup, i.e. the gfx950 gather / in-kernel
+        hashed-row sum of csrc/slk_embed.hip (spotlight_amd/embedding.py) for plain and BloomEmbedding layers alike."""
+        from spotlight_amd.embedding import lookup
         layer = self.item_embeddings
-        if not isinstance(layer, BloomEmbedding):
-            return layer.weight[ids]
-        import numpy as np
-        from sklearn.utils import murmurhash3_32
-        flat = ids.reshape(-1).cpu().numpy().astype(np.int32)
-        rows = np.stack([murmurhash3_32(flat, seed=seed) % layer.compressed_num_embeddings
-                         for seed in layer._masks], axis=1).astype(np.int64)
-        rows[flat == layer.padding_idx] = 0
-        w = layer.weight
-        return w[torch.from_numpy(rows).to(w.device)].sum(1).reshape(tuple(ids.shape) + (w.shape[1],))
+        if isinstance(layer, BloomEmbedding):
+            return lookup(layer.weight, ids, bloom=layer.descriptor(), padding_idx=layer.padding_idx)
+        return lookup(layer.weight, ids, padding_idx=getattr(layer, 'padding_idx', None))
 
     def user_representation(self, item_sequences):
         """(all_representations [B, D, L], final_representation [B, D]) as in the reference

@@ -7,7 +7,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'spotlight_amd', 'csrc')
-OUT = os.path.join(HERE, '_build')
+# SLK_EMU_CXXFLAGS: extra -D flags (the kernels' build-time variants, e.g. -DSLK_ITEM_KEYPF=1), each set built into its own directory
+EXTRA = os.environ.get('SLK_EMU_CXXFLAGS', '').split()
+OUT = os.path.join(HERE, '_build' + (''.join(c if c.isalnum() else '_' for c in '_'.join(EXTRA)) if EXTRA else ''))
 LIB = os.path.join(OUT, 'libspotlight_emu.so')
 
 
@@ -35,7 +37,7 @@ def _build(force):
         o = os.path.join(OUT, os.path.basename(s) + '.o')
         objs.append(o)
         cmd = ['g++', '-std=c++17', '-O1', '-g', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
-               '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas', '-I', HERE, '-x', 'c++', '-c', s, '-o', o]
+               '-Wall', '-Wno-unused-function', '-Wno-unknown-pragmas'] + EXTRA + ['-I', HERE, '-x', 'c++', '-c', s, '-o', o]
         procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:

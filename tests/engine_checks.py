@@ -9,6 +9,11 @@ import numpy as np
 from oracle.oracle import BilinearOracle, Rng
 from oracle.replay import ORACLE_OPT, oracle_hparams
 
+# open-loop drift bounds (assert_open_loop_drift): relative 2-norm.  Measured over the 45 recordings (emulator build): embedding
+# tables <= 6.5e-4, bias tables (a few hundred elements, where one sign-flipped first step shows) <= 6.7e-2
+OPEN_LOOP_DRIFT_ROWS = 5e-3
+OPEN_LOOP_DRIFT_BIAS = 0.2
+
 
 def rel_inf(a, b):
     a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
@@ -24,20 +29,32 @@ def adagrad_well_conditioned(state_sum, rel=1e-6):
     return g > rel * max(g.max(), 1e-30)
 
 
+def assert_open_loop_drift(got, ref, what, bound=None):
+    """Open-loop replays (several epochs from zero accumulators, one engine call per epoch) are chaotic at the 1e-3 level element
+    by element (see check_replays_reference_fixture), so what they pin is the loss trajectory; for the tables themselves this is a
+    quota-free NORM statement: ||got - ref||_2 <= bound * ||ref||_2 (a handful of sign-flipped lr-sized steps are invisible in it,
+    a wrong update rule or a missed row is not).  The element-wise statement is the closed loop."""
+    is_bias = np.ndim(ref) < 2 or np.shape(ref)[-1] == 1
+    got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+    if os.environ.get('SLK_PRINT_DRIFT'):
+        print('DRIFT', what, rel)
+    if bound is None:
+        bound = OPEN_LOOP_DRIFT_BIAS if is_bias else OPEN_LOOP_DRIFT_ROWS
+    assert rel <= bound, ('open-loop drift', what, rel, bound)
+
+
 def assert_close_table(got, want, tol, what, cond=None, loose=None):
-    """||got - want||inf <= tol * ||want||inf, except that tables with > 10k elements may
-    hold up to 1e-4 of ill-conditioned elements: Adagrad's update lr*g/(sqrt(sum)+1e-10) is
-    sign-like on its first step, so an element whose summed gradient happens to fall within
-    ~1e-9 of zero (expected ~2e-4 of the elements of a minibatch of difference-of-two-terms
-    gradients) turns 1-ulp sigmoid/FMA differences into O(lr) differences.  torch's own CPU
-    and GPU builds disagree on exactly those elements."""
+    """||got - want||inf <= tol * ||want||inf for EVERY element (no outlier allowance).  Adagrad's update
+    lr*g/(sqrt(sum)+1e-10) is sign-like on its first step, so callers whose runs start from zero accumulators pass `cond`
+    (adagrad_well_conditioned: the elements whose accumulated gradient is not a residual of cancelling terms); the
+    others are bounded by `loose`, identified by their gradient magnitude."""
     got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
     bad = np.abs(got - want) > tol * max(np.abs(want).max(), 1e-30)
     if cond is not None:  # ill-conditioned elements (adagrad_well_conditioned): within `loose` absolute, not compared
         assert (np.abs(got - want)[~cond] <= loose).all(), (what, 'ill-conditioned element moved by more than lr * steps')
         bad &= cond
-    allowed = int(1e-4 * want.size) if want.size > 10000 else 0
-    assert bad.sum() <= allowed, (what, int(bad.sum()), allowed, float(np.abs(got - want).max()))
+    assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - want).max()))
 
 
 def check_sampler_bit_exact(be, num_items, counts=(1, 5, 700, 3000)):
@@ -309,8 +326,7 @@ def check_replays_reference_fixture(be, golden_dir, name):
     open_tables = [be.get(dev.p[t]).copy() for t in range(4)]
     for t in range(4):  # coarse drift sanity only (see the docstring): the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
-        bad = np.abs(open_tables[t].reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= 0.05, ('open-loop drift', t, bad.mean())
+        assert_open_loop_drift(open_tables[t], ref, (name, t))
 
     # ---- the first minibatch's summed gradients against the reference's recorded p.grad: ADAM_DENSE accumulate-only mode
     # (lr = 0, beta1 = 0 => exp_avg == the gradient), the recorded negatives
@@ -506,8 +522,7 @@ def check_seq_replays_reference_fixture(be, golden_dir, name):
     assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
     for t in range(2):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
-        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+        assert_open_loop_drift(be.get(dev.p[t]), ref, (name, t))
     open_tables = [be.get(dev.p[t]).copy() for t in range(2)]
     # ---- closed loop (see check_replays_reference_fixture): every minibatch from the engine's own tables, one oracle step
     from oracle.oracle import PoolNetOracle
@@ -671,8 +686,7 @@ def check_bloom_replays_reference_fixture(be, golden_dir, name):
     assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
     for t in range(4):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
-        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+        assert_open_loop_drift(be.get(dev.p[t]), ref, (name, t))
     open_tables = [be.get(dev.p[t]).copy() for t in range(4)]
     # ---- closed loop (see check_replays_reference_fixture)
     from oracle.oracle import BloomBilinearOracle
@@ -894,8 +908,7 @@ def check_explicit_replays_reference_fixture(be, golden_dir, name):
     assert np.max(np.abs(losses - rec['losses']) / np.abs(rec['losses'])) < 1e-3
     for t in range(4):  # coarse open-loop drift sanity; the element-wise statement is the closed loop below
         ref = rec['final_%d' % t]
-        bad = np.abs(be.get(dev.p[t]).reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= max(0.05, float(case.get('frac_tol', 0.05))), (t, bad.mean())
+        assert_open_loop_drift(be.get(dev.p[t]), ref, (name, t))
     open_tables = [be.get(dev.p[t]).copy() for t in range(4)]
     # ---- closed loop (see check_replays_reference_fixture)
     opt, hp = ORACLE_OPT[str(case['opt'])], _oracle_hparams(case)

@@ -61,8 +61,7 @@ def test_fit_predict_match_reference_run(name):
         assert np.array_equal(w.detach().cpu().numpy().reshape(want[t].shape), want[t]), ('fit() vs engine replay', t)
     for t, w in enumerate(model._net.tables()):  # coarse drift sanity for the recordings without an engine-level replay
         ref = rec['final_%d' % t]
-        bad = np.abs(w.detach().cpu().numpy().reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= 0.05
+        ec.assert_open_loop_drift(w.detach().cpu().numpy().reshape(ref.shape), ref, (name, t))
     pred = model.predict(3)
     assert pred.dtype == np.float32 and pred.shape == (int(case['I']),)
     assert np.abs(pred - rec['predict_user3_all']).max() <= 2e-3 * np.abs(rec['predict_user3_all']).max()
