@@ -87,6 +87,9 @@ def parse():
     ap.add_argument('--item-zipf', type=float, default=0.0,
                     help='positive item ids drawn with probability ~ 1 / rank^s (s = this value; 0 = uniform, the default and the '
                          'metric\'s distribution) through a random rank -> id map: a stress run for duplicate handling')
+    ap.add_argument('--user-zipf', type=float, default=0.0,
+                    help='user ids drawn with probability ~ 1 / rank^s through a random rank -> id map (0 = uniform, the default and '
+                         'the metric\'s distribution): power users, a stress run for the user pass\'s long-run form')
     ap.add_argument('--no-fit', action='store_true',
                     help='N=1, C2: skip the end-to-end ImplicitFactorizationModel.fit() measurement (the drop-in API around the engine)')
     ap.add_argument('--fit-interactions', type=int, default=1 << 25)
@@ -525,13 +528,16 @@ def main():
     I_global = I * world
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     items = torch.randint(0, I_global, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    def zipf_ids(n_ids, s_exp):
+        w = 1.0 / torch.arange(1, n_ids + 1, device=dev, dtype=torch.float64) ** s_exp
+        cdf = torch.cumsum(w / w.sum(), 0)
+        ranks = torch.searchsorted(cdf, torch.rand(n_total, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=n_ids - 1)
+        return torch.randperm(n_ids, device=dev, generator=gen)[ranks]
     if args.item_zipf > 0:
         # SURVEY.md 8(d) "optional second distribution": Zipf item ids (the negatives stay uniform, as the reference draws them)
-        w = 1.0 / torch.arange(1, I_global + 1, device=dev, dtype=torch.float64) ** args.item_zipf
-        cdf = torch.cumsum(w / w.sum(), 0)
-        ranks = torch.searchsorted(cdf, torch.rand(n_total, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=I_global - 1)
-        items = torch.randperm(I_global, device=dev, generator=gen)[ranks]
-        del w, cdf, ranks
+        items = zipf_ids(I_global, args.item_zipf)
+    if args.user_zipf > 0:
+        users = zipf_ids(U, args.user_zipf)
     mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(1 + rank).get_state())
     # the engine runs on its own HIP stream (ordered against torch's current stream by events)
@@ -694,8 +700,10 @@ def main():
                                       '%s lr=1e-2, minibatch %d%s, on-GPU numpy-exact negatives%s'
                                       % (args.workload.upper(), U * world, I * world, D, args.loss, args.opt, B * world,
                                          '' if world == 1 else ' (= %d per GPU; tables and batch grow with N)' % B,
-                                         '; POSITIVE ITEMS ZIPF(%g) -- a stress run, not the metric\'s distribution' % args.item_zipf
-                                         if args.item_zipf > 0 else ''),
+                                         ('; POSITIVE ITEMS ZIPF(%g) -- a stress run, not the metric\'s distribution' % args.item_zipf
+                                          if args.item_zipf > 0 else '') +
+                                         ('; USERS ZIPF(%g) -- a stress run, not the metric\'s distribution' % args.user_zipf
+                                          if args.user_zipf > 0 else '')),
                           'global_batch': B * world,
                           'parallelism': 'single GPU' if trainer is None else
                           'row-sharded x%d: users and items sharded cyclically; RCCL all-to-all of ids per chunk of '

@@ -119,9 +119,10 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
 
 /* Tuning knobs (none changes results):
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
- *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while
- *                         chunk c trains (default 0: the passes are HBM-bound and lose more than
- *                         the prep they hide, see profiles/README.md)
+ *   "overlap_prep"        1 (default): the negatives + sorts of chunk c+1 run on a second HIP stream while
+ *                         chunk c trains; 2: only the negatives; 0: everything in order on the caller's stream
+ *   "chunk_ramp"          1 (default): with overlap_prep the first chunks of a call ramp up from ~2^20 interactions
+ *                         (the first chunk's prep is the one nothing hides)
  *   "item_grid_mult"      item pass: workgroups per CU (default 64)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
@@ -130,13 +131,19 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
  *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)
  *   "item_long_gate"      1 (default): minibatches in which no item row's occurrences fill a whole 64-position tile of the
- *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results)
+ *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results).
+ *                         The same switch gates the user pass's long-run form (hot users: runs that fill a 32-position tile).
+ *   "user_lat_max_batch"  minibatches up to this size (default 2^17) take the latency-bound form of the pair-mode user pass
+ *   "prep_cus", "prep_priority"  with overlap_prep: CU-mask partition of the chip between the prep stream and the passes /
+ *                         a high-priority prep stream (measured, profiles/r03_a_*: the masks slow the passes by more than
+ *                         the prep they hide; defaults 0)
  *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
- * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once). */
+ * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once),
+ * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
 
 /* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference

@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from spotlight_amd import _native  # noqa: E402
 
-DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 0, 'item_grid_mult': 64, 'user_grid_mult': 8, 'prep_cus': 0,
-            'prep_priority': 0, 'nt': 3}
+DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 1, 'chunk_ramp': 1, 'item_grid_mult': 64, 'user_grid_mult': 8, 'prep_cus': 0,
+            'prep_priority': 0, 'nt': 3, 'user_lat_max_batch': 1 << 17, 'item_long_gate': 1}
 
 
 def main():
@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--opt', default='adagrad')
     ap.add_argument('--loss', default='bpr')
+    ap.add_argument('--user-zipf', type=float, default=0.0)
+    ap.add_argument('--item-zipf', type=float, default=0.0)
     ap.add_argument('--repeat', type=int, default=2, help='timed calls per configuration (the minimum is reported too)')
     ap.add_argument('--out', default='')
     ap.add_argument('--configs', nargs='*', default=[])
@@ -53,6 +55,15 @@ def main():
     n_total = (W + K) * B
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     items = torch.randint(0, I, (n_total,), device=dev, dtype=torch.int64, generator=gen)
+    def zipf_ids(n_ids, s_exp):
+        w = 1.0 / torch.arange(1, n_ids + 1, device=dev, dtype=torch.float64) ** s_exp
+        cdf = torch.cumsum(w / w.sum(), 0)
+        ranks = torch.searchsorted(cdf, torch.rand(n_total, device=dev, dtype=torch.float64, generator=gen)).clamp_(max=n_ids - 1)
+        return torch.randperm(n_ids, device=dev, generator=gen)[ranks]
+    if args.item_zipf > 0:
+        items = zipf_ids(I, args.item_zipf)
+    if args.user_zipf > 0:
+        users = zipf_ids(U, args.user_zipf)
     mb_loss = torch.zeros(W + K, device=dev)
     side = torch.cuda.Stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))

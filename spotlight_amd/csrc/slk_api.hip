@@ -221,6 +221,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_chunk_interactions = value;
     } else if (!strcmp(name, "overlap_prep") && value >= 0 && value <= 2) {
         ctx->opt_overlap_prep = (int)value;
+    } else if (!strcmp(name, "chunk_ramp") && (value == 0 || value == 1)) {
+        ctx->opt_chunk_ramp = (int)value;
     } else if (!strcmp(name, "prep_cus") && value >= 0 && value <= 1024) {
         ctx->opt_prep_cus = (int)value;
     } else if (!strcmp(name, "prep_priority") && (value == 0 || value == 1)) {
@@ -247,6 +249,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_debug = (int)value;
     } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
         ctx->opt_epoch_dense_elems = value;
+    } else if (!strcmp(name, "user_lat_max_batch") && value >= 0) {
+        ctx->opt_user_lat_max_batch = value;
     } else if (!strcmp(name, "item_long_gate") && (value == 0 || value == 1)) {
         ctx->opt_item_long_gate = (int)value;
     } else if (!strcmp(name, "adaptive_late_min_batch") && value >= 0) {
@@ -267,6 +271,8 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     if (!strcmp(name, "shuffle_sweeps")) *value = ctx->fy_sweeps;
     else if (!strcmp(name, "shuffle_fallbacks")) *value = ctx->fy_fallbacks;
     else if (!strcmp(name, "epoch_refused")) *value = ctx->epoch_refused ? 1 : 0;
+    else if (!strcmp(name, "user_long_launches")) *value = ctx->stat_user_long;
+    else if (!strcmp(name, "item_long_launches")) *value = ctx->stat_item_long;
     else return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_stat: unknown statistic %s", name);
     return SLK_OK;
 }

@@ -37,8 +37,25 @@
 // not applied here but parked in a.urec for a ROW-mode owner pass over the hashed user rows.
 // UMODE: 0 = the (positive, negative) pair's scores, loss and dL/dscore formed here; 1 = dL/dscore read from a.gk
 // (adaptive hinge, staged explicit route); 2 = explicit feedback, fused: one pair, score + loss against a.ratings
-template <int VEC, int G, int UPD, int UMODE, bool BLOOM>
+// LAT (pair mode, plain tables): the latency-bound form for minibatches that do not fill the chip (a few thousand to ~10^5
+// interactions: every row group then handles one or two positions and the pass is a chain of dependent round trips, not a
+// stream).  The position's item pair is fetched WITH its key (before the head test: wasted for the few non-head positions)
+// and the user row's optimizer state with the row, so a position costs two round trips -- (key, pair), then (user row +
+// state, both item rows, the three biases) -- instead of four.  Same arithmetic in the same order: bit-identical results.
+// ULONG (plain user table): HOT USERS.  A user's occurrences in the minibatch are walked by ONE row group; a power user
+// with thousands of them is a serial tail longer than the whole pass.  As in the item pass, a run that wholly covers an
+// aligned tile of SLK_USER_TILE positions is LONG: it is cut at the tile boundaries, every segment is walked by its own row
+// group from the same pre-step user row (records, dL/dscore and loss terms as usual) and leaves its part of the user
+// gradient as a PARTIAL (a.upart / upart_meta, at most two per tile); nobody updates U[u] here -- k_user_stitch, behind the
+// pass, adds a long run's partials in tile order and applies the one update.  Every position of a run decides "long" the
+// same way (a head looks at the first aligned tile behind it, a boundary position at the tile before and the tile behind
+// it).  Short runs are walked and applied exactly as in the plain form; the host launches this form only for minibatches
+// that hold a long run (k_user_long_flags).
+template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
+    static_assert(!LAT || (UMODE == 0 && !BLOOM), "LAT is the pair mode over plain tables");
+    static_assert(!ULONG || !BLOOM, "long user runs: plain tables");
+    constexpr uint32_t S = SLK_USER_TILE;
     constexpr bool PRE = UMODE != 0;
     constexpr bool EXPL = UMODE == 2;
     __shared__ double red[256];
@@ -54,7 +71,32 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
         const bool nt_keys = (SLK_NT_OF(a) & 8) != 0;
         const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
-        if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
+        uint32_t lat_ip = 0u, lat_in = 0u;
+        bool is_head;
+        if (LAT) {
+            const uint32_t prev = p > a.begin ? a.ukey[p - 1] : ~key;
+            lat_ip = a.uit[2 * (size_t)p];
+            lat_in = a.uit[2 * (size_t)p + 1];
+            is_head = prev != key;
+        } else {
+            is_head = !(p > a.begin && a.ukey[p - 1] == key);
+        }
+        bool run_long = false;
+        uint32_t seg_limit = a.end;  // the walk stops here at the latest
+        if (ULONG) {
+            const uint32_t rel = p - a.begin;
+            if (is_head) {
+                const uint32_t t0 = a.begin + (rel + S - 1u) / S * S;  // the first aligned tile behind the head
+                run_long = t0 + S <= a.end && a.ukey[t0 + S - 1u] == key;
+            } else if (rel % S == 0u) {
+                run_long = (rel >= S && a.ukey[p - S] == key) || (p + S <= a.end && a.ukey[p + S - 1u] == key);
+                is_head = false;
+            }
+            if (!is_head && !(run_long && rel % S == 0u)) continue;
+            if (run_long) seg_limit = a.begin + (rel / S + 1u) * S < a.end ? a.begin + (rel / S + 1u) * S : a.end;
+        } else if (!is_head) {
+            continue;  // not the head of its user segment
+        }
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
         slk_vec<VEC> u;
@@ -66,7 +108,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
         // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
         // fetching early there only lengthens register lifetimes)
-        constexpr bool EARLY_STATE = EXPL && !BLOOM && UPD == SLK_UPD_ADAGRAD;
+        constexpr bool EARLY_STATE = (EXPL || LAT) && !BLOOM && UPD == SLK_UPD_ADAGRAD;
         slk_vec<VEC> su = slk_vzero<VEC>();
         if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
         float sbu = 0.0f;
@@ -78,7 +120,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         // (latency-bound modes only: same-box A/B, +5 % on the adaptive pass, -1 % on the bandwidth-bound pair pass)
         constexpr bool NEXT_KEY = UMODE != 0;
         uint32_t next_key = 0;
-        if (NEXT_KEY) next_key = (q + 1 < a.end) ? a.ukey[q + 1] : ~key;
+        if (NEXT_KEY) next_key = (q + 1 < seg_limit) ? a.ukey[q + 1] : ~key;
         do {
             float *rec = a.snap + (size_t)(q - a.begin) * a.RS;
             // explicit feedback: the rating's gather is issued first so that it overlaps the item row's
@@ -90,7 +132,14 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             }
             if (on) slk_vstore<VEC>(rec + d0, u);
             if (!PRE) {
-                const uint32_t ip = slk_ld_u32(a.uit + 2 * (size_t)q, nt_keys), in = slk_ld_u32(a.uit + 2 * (size_t)q + 1, nt_keys);
+                uint32_t ip, in;
+                if (LAT && q == p) {
+                    ip = lat_ip;
+                    in = lat_in;
+                } else {
+                    ip = slk_ld_u32(a.uit + 2 * (size_t)q, nt_keys);
+                    in = slk_ld_u32(a.uit + 2 * (size_t)q + 1, nt_keys);
+                }
                 slk_vec<VEC> vi, vj;
                 if (BLOOM) {
                     vi = slk_emb_vec<VEC>(a.P[1], a.ib, ip, D, d0, on);
@@ -99,8 +148,9 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
                     vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
                 }
-                const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + a.P[3][ip];
-                const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + a.P[3][in];
+                const float bip = a.P[3][ip], bin = a.P[3][in];  // issued with the rows, not behind the dots' shuffles
+                const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bip;
+                const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bin;
                 float l, gp, gn;
                 slk_pair_loss(a.loss_kind, sp, sn, a.inv_b, l, gp, gn);
 #pragma unroll
@@ -152,12 +202,27 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             ++q;
             if (NEXT_KEY) {
                 if (next_key != key) break;
-                next_key = (q + 1 < a.end) ? a.ukey[q + 1] : ~key;
-            } else if (!(q < a.end && a.ukey[q] == key)) {
+                next_key = (q + 1 < seg_limit) ? a.ukey[q + 1] : ~key;
+            } else if (!(q < seg_limit && a.ukey[q] == key)) {
                 break;
             }
         } while (true);
 
+        if (ULONG && run_long) {
+            // a segment of a long run: its part of the user gradient, for k_user_stitch
+            const bool ends = !(q < a.end && a.ukey[q] == key);
+            const size_t slot = 2 * (size_t)((p - a.begin) / S) + (is_head ? 1u : 0u);
+            float *pp = a.upart + slot * (size_t)a.UPS;
+            if (on) slk_vstore<VEC>(pp + d0, gu);
+            if (lane == 0) {
+                pp[a.UPS - 1] = gbu;
+                a.upart_meta[2 * slot] = key;
+                a.upart_meta[2 * slot + 1] = (a.upart_gen << SLK_IPART_GEN_SHIFT) | (is_head ? (uint32_t)SLK_IPART_STARTS : 0u) |
+                                             (ends ? (uint32_t)SLK_IPART_ENDS : 0u);
+                if (is_head) atomicAdd(a.upart_count, 1u);
+            }
+            continue;
+        }
         if (BLOOM && a.ub.n_hash) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
@@ -181,6 +246,86 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     if (!PRE || EXPL) {
         const double tot = slk_block_sum_256((double)loss_acc, red);
         if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot;
+    }
+}
+
+// Behind k_user_pass<..., ULONG>: one row group per tile of SLK_USER_TILE positions.  The group of the tile in which a long
+// run STARTS adds the run's partials in tile order -- its own tile's slot 1, then slot 0 of the following tiles up to the
+// one in which the run ends (the next G tiles' metas are read at once, the lanes that still belong to the run are a
+// prefix) -- and applies the one update of U[u] and its bias.
+template <int VEC, int G, int UPD>
+__global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    constexpr uint32_t S = SLK_USER_TILE;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t ntiles = (a.end - a.begin + S - 1u) / S;
+    if (*a.upart_count == 0u) return;
+    const uint32_t gen = a.upart_gen;
+    for (uint32_t tile = blockIdx.x * GPB + grp; tile < ntiles; tile += gridDim.x * GPB) {
+        const size_t slot = 2 * (size_t)tile + 1;
+        const uint32_t fl = a.upart_meta[2 * slot + 1];
+        if ((fl >> SLK_IPART_GEN_SHIFT) != gen) continue;  // no long run starts in this tile
+        const uint32_t key = a.upart_meta[2 * slot];
+        const float *pp = a.upart + slot * (size_t)a.UPS;
+        slk_vec<VEC> gu = on ? slk_vload<VEC>(pp + d0) : slk_vzero<VEC>();
+        float gbu = pp[a.UPS - 1];
+        uint32_t t2 = tile + 1;
+        bool more = (fl & SLK_IPART_ENDS) == 0;
+        while (more) {
+            const uint32_t tl = t2 + (uint32_t)lane;
+            uint32_t f = 0u;
+            if (tl < ntiles) {
+                const size_t sl = 2 * (size_t)tl;
+                f = a.upart_meta[2 * sl + 1];
+                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || a.upart_meta[2 * sl] != key) f = 0u;
+                else f |= 1u;
+            }
+            int cnt = 0;
+            bool ended = false;
+            for (int l = 0; l < G; ++l) {
+                const uint32_t f2 = __shfl(f, l, G);
+                if (ended || !(f2 & 1u)) break;
+                ++cnt;
+                ended = (f2 & SLK_IPART_ENDS) != 0;
+            }
+            for (int l = 0; l < cnt; ++l) {
+                const float *q = a.upart + 2 * (size_t)(t2 + (uint32_t)l) * (size_t)a.UPS;
+                if (on) {
+                    const slk_vec<VEC> cc = slk_vload<VEC>(q + d0);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gu.v[i] += cc.v[i];
+                }
+                gbu += q[a.UPS - 1];
+            }
+            more = !ended && cnt == G;
+            t2 += (uint32_t)G;
+        }
+        const uint32_t user = key & a.umask;
+        const size_t uoff = (size_t)user * D + d0;
+        if (on) {
+            slk_vec<VEC> u = slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
+            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
+        }
+        if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
+    }
+}
+
+// flags[mb] |= 1 iff some user run of minibatch mb's window of the user-sorted list wholly covers an aligned tile of
+// SLK_USER_TILE positions (ids only: once per chunk, read back by the host with the item pass's flags)
+__global__ __launch_bounds__(256) void k_user_long_flags(const uint32_t *ukey, uint32_t n, uint32_t per_mb, int *flags) {
+    constexpr uint32_t S = SLK_USER_TILE;
+    const uint32_t tiles_per_mb = (per_mb + S - 1) / S;
+    const uint32_t n_mb = (n + per_mb - 1) / per_mb;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_mb * tiles_per_mb; i += gridDim.x * 256) {
+        const uint32_t mb = i / tiles_per_mb, q = i - mb * tiles_per_mb;
+        const uint32_t w0 = mb * per_mb, w1 = (n - w0 < per_mb) ? n : w0 + per_mb;
+        const uint32_t t0 = w0 + q * S;
+        if (t0 >= w1 || w1 - t0 < S) continue;  // only full tiles make a run long
+        if (ukey[t0] == ukey[t0 + S - 1]) flags[mb] = 1;
     }
 }
 
@@ -466,6 +611,34 @@ static pass_fn user_pass_fn2(int upd, int umode) {
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, BLOOM>;
 }
 
+// the latency-bound form of the pair-mode user pass over plain tables (k_user_pass<..., LAT = true>)
+template <int VEC, int G, bool ULONG = false>
+static pass_fn user_pass_lat_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, false, true, ULONG>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, false, true, ULONG>;
+    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, false, true, ULONG>;
+}
+
+// plain tables, minibatches that hold a long user run (k_user_pass<..., ULONG = true>) and the stitch kernel behind it
+template <int VEC, int G, int UMODE>
+static pass_fn user_pass_long_fn1(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, UMODE, false, false, true>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, UMODE, false, false, true>;
+    return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, UMODE, false, false, true>;
+}
+template <int VEC, int G>
+static pass_fn user_pass_long_fn(int upd, int umode) {
+    if (umode == 2) return user_pass_long_fn1<VEC, G, 2>(upd);
+    if (umode == 1) return user_pass_long_fn1<VEC, G, 1>(upd);
+    return user_pass_long_fn1<VEC, G, 0>(upd);
+}
+template <int VEC, int G>
+static pass_fn user_stitch_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_user_stitch<VEC, G, SLK_UPD_ADAGRAD>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_stitch<VEC, G, SLK_UPD_SPARSE_ADAM>;
+    return k_user_stitch<VEC, G, SLK_UPD_GRAD_ONLY>;
+}
+
 template <int VEC, int G>
 static pass_fn user_pass_fn(int upd, int umode, bool bloom) {
     return bloom ? user_pass_fn2<VEC, G, true>(upd, umode) : user_pass_fn2<VEC, G, false>(upd, umode);
@@ -711,11 +884,29 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const bool late = adaptive && optim->kind != SLK_OPT_SPARSE_ADAM && (Hi > 0 || bsz >= ctx->opt_adaptive_late_min_batch);
     // scratch.  With the "overlap_prep" option the value-independent part of a chunk (negatives,
     // sort by user, sort by item) is prepared on a second HIP stream while the previous chunk's
-    // passes run, and those buffers exist twice (ctx->pb[0|1]).  Off by default: measured on
-    // MI355X (profiles/README.md) the passes are HBM-bound and slow down by more than the prep
-    // they hide.
+    // passes run, and those buffers exist twice (ctx->pb[0|1]).  On by default since round 3 (profiles/r03_a_*, r03_b_*: with
+    // two of the user pass's eight workgroups per CU left to the prep stream the step gains 3 % at 32 minibatches per call,
+    // 8 % in the steady state of a long epoch; round 1 had measured no gain with the pass holding every wave slot).
     const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
-    const int nsets = (ctx->opt_overlap_prep && n > chunk_cap) ? 2 : 1;
+    // chunk boundaries.  In order on one stream: chunks of chunk_cap.  Overlapped (prep of chunk c+1 beside the passes of
+    // chunk c): the first chunk's prep is the one nothing hides, so the chunks ramp up -- ~2^20 interactions, then doubling to
+    // chunk_cap (the small sorts of the first chunks are less efficient, but they run beside passes).  Chunking is
+    // value-neutral: the negatives of a call are one contiguous draw however it is cut.
+    std::vector<int64_t> cb;
+    cb.push_back(0);
+    {
+        int64_t ramp = ((int64_t)1 << 20) / bsz;
+        if (ramp < 1) ramp = 1;
+        if (!ctx->opt_overlap_prep || !ctx->opt_chunk_ramp) ramp = mb_per_chunk;
+        while (cb.back() < n) {
+            if (ramp > mb_per_chunk) ramp = mb_per_chunk;
+            const int64_t next = cb.back() + ramp * bsz;
+            cb.push_back(next < n ? next : n);
+            ramp *= 2;
+        }
+    }
+    const size_t n_chunks = cb.size() - 1;
+    const int nsets = (ctx->opt_overlap_prep && n_chunks > 1) ? 2 : 1;
     for (int st = 0; st < nsets; ++st) {
         slk_prep_bufs &pb = ctx->pb[st];
         if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;
@@ -732,9 +923,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
         }
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
-        if (!late && (rc = slk_ensure(ctx, pb.lflags, (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk
+        if ((rc = slk_ensure(ctx, pb.lflags, 2 * (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk: items, users
     }
-    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN };  // ctx->extra slots
+    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_UPART_META };  // ctx->extra slots
     const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * 4))) return rc;  // dL/dscore per (position, pair)
@@ -749,6 +940,17 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = slk_ensure(ctx, ctx->extra[BL_LIVE], nl * 4))) return rc;
         for (int b = 0; b < 4; ++b)
             if ((rc = slk_ensure(ctx, ctx->extra[BL_LK0 + b], nlh * 4))) return rc;
+    }
+    // hot users (k_user_pass<..., ULONG>): two partials per tile of SLK_USER_TILE positions, metas + the long-run counter
+    const int UPS = RS + 4;
+    const size_t utiles = ((size_t)bsz + SLK_USER_TILE - 1) / SLK_USER_TILE;
+    if (!bloom) {
+        if ((rc = slk_ensure(ctx, ctx->extra[BL_UPART], 2 * utiles * (size_t)UPS * 4))) return rc;
+        const size_t meta_bytes = 2 * utiles * 8 + 64;
+        if (meta_bytes > ctx->extra[BL_UPART_META].cap) {
+            if ((rc = slk_ensure(ctx, ctx->extra[BL_UPART_META], meta_bytes))) return rc;
+            SLK_HIP(ctx, hipMemsetAsync(ctx->extra[BL_UPART_META].p, 0, ctx->extra[BL_UPART_META].cap, s));  // stamp 0 is never used
+        }
     }
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
@@ -771,12 +973,16 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
 
     const int upd = slk_upd_for(optim->kind);
-    pass_fn upass = nullptr, spass = nullptr;
+    pass_fn upass = nullptr, spass = nullptr, upass_lat = nullptr, upass_long = nullptr, upass_lat_long = nullptr, ustitch = nullptr;
     slk_item_fns ipass = {nullptr, nullptr}, ipass_rows = ipass, ipass_bias = ipass, rpass_rows = ipass;
     const int umode = (expl && ctx->opt_explicit_fused) ? 2 : (pre ? 1 : 0);
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
         upass = user_pass_fn<V_, G_>(upd, umode, bloom);                                  \
+        if (umode == 0 && !bloom) upass_lat = user_pass_lat_fn<V_, G_>(upd);              \
+        if (umode == 0 && !bloom) upass_lat_long = user_pass_lat_fn<V_, G_, true>(upd);   \
+        if (!bloom) upass_long = user_pass_long_fn<V_, G_>(upd, umode);                   \
+        if (!bloom) ustitch = user_stitch_fn<V_, G_>(upd);                                \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
         spass = k_score_pass<V_, G_>;                                                     \
         if (bloom) {                                                                      \
@@ -791,9 +997,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     // ---- prep of one chunk into buffer set `pb` (value-independent: ids only), in two halves:
     // the negatives (ALU/latency-bound MT19937 generator), then the sorts (HBM-bound)
-    auto do_sample = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
+    auto do_sample = [&](size_t ck, slk_prep_bufs &pb, hipStream_t s) -> int {
         int rc;
-        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const int64_t c0 = cb[ck];
+        const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         uint32_t *neg32 = (uint32_t *)pb.neg32.p;
 
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
@@ -814,9 +1021,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         }
         return SLK_OK;
     };
-    auto do_sort = [&](int64_t c0, slk_prep_bufs &pb, hipStream_t s) -> int {
+    auto do_sort = [&](size_t ck, slk_prep_bufs &pb, hipStream_t s) -> int {
         int rc;
-        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const int64_t c0 = cb[ck];
+        const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         const uint32_t nocc = nc * (uint32_t)NP;
         const int64_t *cu = d_users + c0, *ci = d_items + c0;
         uint32_t *neg32 = (uint32_t *)pb.neg32.p;
@@ -859,23 +1067,31 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                              (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
                                              ibits + mbbits, s)))
                 return rc;
-            // which minibatches hold a LONG run (one that wholly covers a tile of the item pass): ids only, so the answer is
-            // fetched once per chunk and the usual minibatch (none) gets the plain pass with no stitch kernel behind it
-            if (!epoch_route) {  // (the persistent route walks the runs itself; its fall-back re-derives the flags, do_passes)
+        }
+        // which minibatches hold a LONG run (an item run that wholly covers a tile of the item pass, [0, n_mb); a user run that
+        // wholly covers a tile of the user pass, [n_mb, 2 n_mb)): ids only, so the answer is fetched once per chunk and the usual
+        // minibatch (none) gets the plain passes with no stitch kernel behind them
+        if (!epoch_route) {  // (the persistent route walks the runs itself; its fall-back takes the long forms, do_passes)
             const uint32_t n_mb_c = (nc + (uint32_t)bsz - 1) / (uint32_t)bsz;
-            if ((rc = slk_ensure(ctx, pb.lflags, (size_t)n_mb_c * 4))) return rc;
-            SLK_HIP(ctx, hipMemsetAsync(pb.lflags.p, 0, (size_t)n_mb_c * 4, s));
-            hipLaunchKernelGGL(k_item_long_flags, dim3(slk_grid_for(ctx, nocc / (4 * gpb) + n_mb_c, 256)), dim3(256), 0, s,
-                               (const uint32_t *)pb.ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)NP, 4u * gpb,
-                               (uint32_t)((1ull << ibits) - 1), 0xffffffffu, 0xffffffffu, (int *)pb.lflags.p);
-            SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
-            if ((rc = slk_ensure_lflags_host(ctx, pb, n_mb_c))) return rc;
-            SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags, pb.lflags.p, (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = slk_ensure(ctx, pb.lflags, 2 * (size_t)n_mb_c * 4))) return rc;
+            SLK_HIP(ctx, hipMemsetAsync(pb.lflags.p, 0, 2 * (size_t)n_mb_c * 4, s));
+            if (!late) {
+                hipLaunchKernelGGL(k_item_long_flags, dim3(slk_grid_for(ctx, nocc / (4 * gpb) + n_mb_c, 256)), dim3(256), 0, s,
+                                   (const uint32_t *)pb.ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)NP, 4u * gpb,
+                                   (uint32_t)((1ull << ibits) - 1), 0xffffffffu, 0xffffffffu, (int *)pb.lflags.p);
+                SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
+            }
+            if (!bloom) {
+                hipLaunchKernelGGL(k_user_long_flags, dim3(slk_grid_for(ctx, nc / SLK_USER_TILE + n_mb_c, 256)), dim3(256), 0, s,
+                                   (const uint32_t *)ukey, nc, (uint32_t)bsz, (int *)pb.lflags.p + n_mb_c);
+                SLK_LAUNCH_CHECK(ctx, "k_user_long_flags");
+            }
+            if ((rc = slk_ensure_lflags_host(ctx, pb, 2 * (size_t)n_mb_c))) return rc;
+            SLK_HIP(ctx, hipMemcpyAsync(pb.h_lflags, pb.lflags.p, 2 * (size_t)n_mb_c * 4, hipMemcpyDeviceToHost, s));
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
             SLK_HIP(ctx, hipEventRecord(pb.ev_lflags, s));
-            } else {
-                pb.h_lflags_n = 0;  // no flags for this chunk: every item pass of a fall-back takes the partial-writing form
-            }
+        } else {
+            pb.h_lflags_n = 0;  // no flags for this chunk: every pass of a fall-back takes the partial-writing form
         }
         if (Hi && !late) {
             hipLaunchKernelGGL(k_build_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s,
@@ -906,13 +1122,15 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     int64_t mb_global = 0;
     // ---- the minibatches of one prepared chunk, in order, on the caller's stream
-    auto do_passes = [&](int64_t c0, slk_prep_bufs &pb) -> int {
+    auto do_passes = [&](size_t ck, slk_prep_bufs &pb) -> int {
         int rc;
-        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+        const int64_t c0 = cb[ck];
+        const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         const uint32_t *ukey = (const uint32_t *)pb.ukey[1].p;
         const uint32_t *uit = pre ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
         const uint32_t *uk = pre ? (const uint32_t *)pb.uval[1].p : nullptr;
-        bool lflags_ready = late;  // the chunk's long-run flags (do_sort): ONE host wait per chunk, behind the first user pass
+        bool lflags_ready = false;  // the chunk's long-run flags (do_sort): ONE host wait per chunk, before the first user pass
+        const uint32_t n_mb_c = (nc + (uint32_t)bsz - 1) / (uint32_t)bsz;
         // ---- minibatches, in order
         for (uint32_t b0 = 0; b0 < nc; b0 += (uint32_t)bsz, ++mb_global) {
             const uint32_t b1 = (nc - b0 < (uint32_t)bsz) ? nc : b0 + (uint32_t)bsz;
@@ -953,7 +1171,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
             a.nt = ctx->opt_nt;
-            const unsigned ugrid = slk_grid_for(ctx, bm, gpb);
+            // overlapped prep: the user pass is a grid-stride kernel whose workgroups hold their wave slots for the whole run; two
+            // of the eight per CU are left to the prep stream's kernels (measured, profiles/r03_a_*: 8 -> 6 costs the pass
+            // nothing by itself and gives the overlap 2 % more)
+            const unsigned ugrid = slk_grid_for(ctx, bm, gpb, nsets == 2 && ctx->opt_user_grid_mult > 6 ? 6 : 0);
             const unsigned igrid = slk_grid_for(ctx, late ? (size_t)bm * 2 : (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
             if (expl && ctx->opt_explicit_fused) {
@@ -1008,24 +1229,47 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 a.n_loss_partial = (int)ugrid;
             }
 
-            slk_prof_begin(ctx, SLK_K_USER_PASS, s);
-            hipLaunchKernelGGL(upass, dim3(ugrid), dim3(256), 0, s, a);
-            SLK_LAUNCH_CHECK(ctx, "k_user_pass");
-            slk_prof_end(ctx, s);
-
             if (!lflags_ready) {
-                // the first user pass of the chunk is already queued: the GPU is busy while the host waits for the read-back
-                if (pb.ev_lflags) SLK_HIP(ctx, hipEventSynchronize(pb.ev_lflags));
+                // the flags are produced by the chunk's sorts, long before the previous chunk's passes are through: the GPU has
+                // work queued while the host waits for the read-back
+                if (pb.ev_lflags && pb.h_lflags_n) SLK_HIP(ctx, hipEventSynchronize(pb.ev_lflags));
                 lflags_ready = true;
             }
+            const uint32_t mb_c = b0 / (uint32_t)bsz;
+            const bool have_flags = pb.h_lflags_n >= 2 * (size_t)n_mb_c;
+            const bool item_may_long = late || !ctx->opt_item_long_gate || !have_flags || pb.h_lflags[mb_c] != 0;
+            const bool user_may_long = !bloom && (!ctx->opt_item_long_gate || !have_flags || pb.h_lflags[n_mb_c + mb_c] != 0);
+
+            slk_prof_begin(ctx, SLK_K_USER_PASS, s);
+            const bool lat = upass_lat && (int64_t)bm <= ctx->opt_user_lat_max_batch;
+            if (user_may_long) {
+                if (ctx->upart_gen >= 0x0ffffffeu) {  // the 28-bit stamp wraps: forget every old partial
+                    SLK_HIP(ctx, hipMemsetAsync(ctx->extra[BL_UPART_META].p, 0, ctx->extra[BL_UPART_META].cap, s));
+                    ctx->upart_gen = 0u;
+                }
+                ++ctx->upart_gen;
+                a.upart = (float *)ctx->extra[BL_UPART].p;
+                a.upart_meta = (uint32_t *)ctx->extra[BL_UPART_META].p;
+                a.upart_count = a.upart_meta + 4 * utiles;
+                a.upart_gen = ctx->upart_gen;
+                a.UPS = UPS;
+                SLK_HIP(ctx, hipMemsetAsync(a.upart_count, 0, 4, s));
+                hipLaunchKernelGGL(lat ? upass_lat_long : upass_long, dim3(ugrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_user_pass<ULONG>");
+                ++ctx->stat_user_long;
+                hipLaunchKernelGGL(ustitch, dim3(slk_grid_for(ctx, ((size_t)bm + SLK_USER_TILE - 1) / SLK_USER_TILE, gpb)), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_user_stitch");
+            } else {
+                hipLaunchKernelGGL(lat ? upass_lat : upass, dim3(ugrid), dim3(256), 0, s, a);
+                SLK_LAUNCH_CHECK(ctx, "k_user_pass");
+            }
+            slk_prof_end(ctx, s);
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                const bool may_long = late || !ctx->opt_item_long_gate || b0 / (uint32_t)bsz >= pb.h_lflags_n || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
-                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", may_long))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", item_may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                const bool may_long = late || !ctx->opt_item_long_gate || b0 / (uint32_t)bsz >= pb.h_lflags_n || pb.h_lflags[b0 / (uint32_t)bsz] != 0;
-                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", may_long))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", item_may_long))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
@@ -1083,15 +1327,16 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return SLK_OK;
     };
 
-    auto do_chunk = [&](int64_t c0, slk_prep_bufs &pb) -> int {
-        if (!epoch_route) return do_passes(c0, pb);
-        const uint32_t nc = (uint32_t)((n - c0 < chunk_cap) ? (n - c0) : chunk_cap);
+    auto do_chunk = [&](size_t ck, slk_prep_bufs &pb) -> int {
+        if (!epoch_route) return do_passes(ck, pb);
+        const int64_t c0 = cb[ck];
+        const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, RS, (float *)ctx->snap.p,
                                      (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, expl ? d_ratings + c0 : nullptr, s);
         if (rc == SLK_EAGAIN_EPOCH) {  // cooperative launch refused: nothing ran; per-minibatch launches from here on
             epoch_route = false;
             if (dense && (rc = ensure_dense_buffers())) return rc;
-            return do_passes(c0, pb);
+            return do_passes(ck, pb);
         }
         mb_global += (nc + bsz - 1) / bsz;
         return rc;
@@ -1099,10 +1344,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     if (nsets == 1) {
         // everything in order on the caller's stream
-        for (int64_t c0 = 0; c0 < n; c0 += chunk_cap) {
-            if ((rc = do_sample(c0, ctx->pb[0], s))) return rc;
-            if ((rc = do_sort(c0, ctx->pb[0], s))) return rc;
-            if ((rc = do_chunk(c0, ctx->pb[0]))) return rc;
+        for (size_t ck = 0; ck < n_chunks; ++ck) {
+            if ((rc = do_sample(ck, ctx->pb[0], s))) return rc;
+            if ((rc = do_sort(ck, ctx->pb[0], s))) return rc;
+            if ((rc = do_chunk(ck, ctx->pb[0]))) return rc;
         }
         ctx->last_stream = s;
         return SLK_OK;
@@ -1126,17 +1371,17 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (sort_ahead && (rc = do_sort(0, ctx->pb[0], ps))) return rc;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
     int set = 0;
-    for (int64_t c0 = 0; c0 < n; c0 += chunk_cap, set ^= 1) {
+    for (size_t ck = 0; ck < n_chunks; ++ck, set ^= 1) {
         SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
-        if (!sort_ahead && (rc = do_sort(c0, ctx->pb[set], s))) return rc;
-        if (c0 + chunk_cap < n) {
+        if (!sort_ahead && (rc = do_sort(ck, ctx->pb[set], s))) return rc;
+        if (ck + 1 < n_chunks) {
             // the other buffer set was last read by the passes of the previous chunk
-            if (c0 > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
-            if ((rc = do_sample(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
-            if (sort_ahead && (rc = do_sort(c0 + chunk_cap, ctx->pb[set ^ 1], ps))) return rc;
+            if (ck > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
+            if ((rc = do_sample(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
+            if (sort_ahead && (rc = do_sort(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
         }
-        if ((rc = do_chunk(c0, ctx->pb[set]))) return rc;
+        if ((rc = do_chunk(ck, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }
     if (s != caller) {

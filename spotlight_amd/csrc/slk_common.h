@@ -92,12 +92,13 @@ struct slk_ctx {
     size_t dgrad_elems[4] = {0, 0, 0, 0};
     // tuning (slk_ctx_set_option)
     int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
-    int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains
+    int opt_overlap_prep = 1;      // 1: prep of chunk c+1 on a second stream while chunk c trains (2: only its negatives)
     // Partition of the chip between the prep of chunk c+1 and the passes of chunk c (only with overlap_prep).  The row passes
     // are grid-stride kernels that keep every wave slot of every CU for their whole run, so a second stream's kernels
     // otherwise only run in the gaps: prep_cus > 0 gives the prep stream a CU mask of that many CUs (spread over the XCDs and
     // shader engines) and runs the passes on a ctx-owned stream masked to the other CUs (ordered against the caller's
     // stream by events); prep_priority = 1 creates the (unmasked) prep stream with the highest priority instead.
+    int opt_chunk_ramp = 1;        // overlapped prep: the first chunks of a call ramp up from ~2^20 interactions (slk_bilinear.hip)
     int opt_prep_cus = 0;
     int opt_prep_priority = 0;
     int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
@@ -108,6 +109,8 @@ struct slk_ctx {
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
+    int64_t opt_user_lat_max_batch = (int64_t)1 << 17;  // minibatches up to this size take the latency-bound form of the pair-mode
+                                   // user pass (k_user_pass<..., LAT>): two round trips per position instead of four
     int opt_item_long_gate = 1;    // 1: minibatches without a long run (k_item_long_flags) take the plain item pass; 0: every item
                                    // pass is the partial-writing one + k_item_stitch (same results; a test / measurement switch)
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first
@@ -156,6 +159,8 @@ struct slk_ctx {
     int em_dim = 0;
 
     uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)
+    uint32_t upart_gen = 0;         // user pass, long runs: likewise (slk_bilinear.hip)
+    int64_t stat_user_long = 0, stat_item_long = 0;  // launches of the partial-writing forms (slk_ctx_get_stat)
     int fy_sweeps = 0;              // slk_shuffle_perm: fixpoint sweeps of the last call (diagnostic)
     int fy_fallbacks = 0;           //   ranges of the last call that left the band and were redone with the full sweeps
     int opt_shuffle_band = 1;       // slk_shuffle_perm: 1 banded draws (default), 0 full sweeps, > 1 band / value (test hook: forces fall-backs)

@@ -286,8 +286,15 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             slk_vec<VEC> vj = (on && !EXPL) ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
             float bi = slk_ld_coh(e.P[3] + ip), bj = EXPL ? 0.0f : slk_ld_coh(e.P[3] + in);
             float rating = EXPL ? e.ratings[in] : 0.0f;  // an input of the call: plain load
-            slk_vec<VEC> gu = zero;
-            float gbu = 0.0f;
+            // The user's run is summed as the launch path sums it (slk_bilinear.hip, k_user_pass<ULONG> + k_user_stitch): in
+            // occurrence order -- unless it is LONG, i.e. wholly covers an aligned tile of SLK_USER_TILE positions of the
+            // minibatch: then tile by tile, the tiles' sums added in order.  Both sums are kept; which one applies is known
+            // when the run ends.
+            constexpr uint32_t TU = SLK_USER_TILE;
+            slk_vec<VEC> gu = zero, tu = zero, gl = zero;
+            float gbu = 0.0f, tbu = 0.0f, gbl = 0.0f;
+            bool u_first_tile = true, u_long = false;
+            const uint32_t up0 = p - b0;
             uint32_t q = p;
             for (;;) {
                 if (on) slk_vstore_coh<VEC>(e.snap + (size_t)(q - b0) * e.RS + d0, u);
@@ -302,6 +309,8 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                     if (g != 0.0f) {
                         slk_vaxpy<VEC>(gu, g, vi);
                         gbu += g;
+                        slk_vaxpy<VEC>(tu, g, vi);
+                        tbu += g;
                     }
                 } else {
                     const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
@@ -309,8 +318,13 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                     float l, gp, gn;
                     slk_pair_loss(e.loss_kind, sp, sn, inv_b, l, gp, gn);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
+                    for (int i = 0; i < VEC; ++i) {
+                        const float cc = gp * vi.v[i] + gn * vj.v[i];
+                        gu.v[i] += cc;
+                        tu.v[i] += cc;
+                    }
                     gbu += gp + gn;
+                    tbu += gp + gn;
                     if (lane == 0) {
                         slk_st_coh(e.gsn + 2 * (size_t)(q - b0), gp);
                         slk_st_coh(e.gsn + 2 * (size_t)(q - b0) + 1, gn);
@@ -318,6 +332,26 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                     }
                 }
                 ++q;
+                {
+                    const bool run_ends = !(q < b1 && e.ukey[q] == key);
+                    const uint32_t rel = q - b0;
+                    const bool boundary = rel % TU == 0u;
+                    if (run_ends || boundary) {  // the tile's part of the run is complete: it joins the run's tile-wise sum
+                        const uint32_t tile_start = (rel - 1u) / TU * TU;
+                        u_long = u_long || (tile_start >= up0 && boundary);
+                        if (u_first_tile) {
+                            gl = tu;
+                            gbl = tbu;
+                            u_first_tile = false;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) gl.v[i] += tu.v[i];
+                            gbl += tbu;
+                        }
+                        tu = zero;
+                        tbu = 0.0f;
+                    }
+                }
                 if (!(q < b1 && e.ukey[q] == key)) break;
                 ip = e.uit[NP * (size_t)q];  // further occurrences of the same user in this minibatch
                 vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
@@ -331,6 +365,10 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 }
             }
 
+            if (u_long) {
+                gu = gl;
+                gbu = gbl;
+            }
             if (on) slk_epoch_update<VEC, UPD>(e, c, 0, uoff, u, su1, su2, gu);
             if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gbu == 0.0f)) {  // zero gradient: an exact no-op for Adagrad
                 slk_vec<1> bp, bg;

@@ -103,6 +103,11 @@ struct slk_pass_args {
     int IPS;                 //   run that continues into the next tile; IPS = floats per partial (row | bias gradient)
     uint32_t ipart_gen;      //   stamp of this launch (flags of other launches' partials are stale); ipart_count: long runs
     uint32_t *ipart_count;   //   that START in this launch's tiles (k_item_stitch leaves at once when there are none)
+    float *upart;            // user pass, long runs (hot users): per-tile partial sums of the user gradient, [2 * tile + which][UPS],
+    uint32_t *upart_meta;    //   metas and stamp exactly as for the item pass's partials (k_user_pass<..., ULONG>, k_user_stitch)
+    int UPS;
+    uint32_t upart_gen;
+    uint32_t *upart_count;
     uint32_t pad_item;       // occurrences of this item row are never updated (padding_idx); ~0u = none
     uint32_t pad_item2;      // a second never-updated key (sentinel of non-head positions); ~0u = none
     slk_bloom_dev ub, ib;    // BloomEmbedding user / item layers (n_hash == 0: plain)
@@ -308,13 +313,15 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
                          // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
 #endif
 
-#ifndef SLK_ITEM_LATE_EARLY
-#define SLK_ITEM_LATE_EARLY 0  // 1: the row + state loads of a group's NEXT head (r = grp + NPRE * GPB) are issued before the group
-                               // sums its first head's run from LDS, instead of as a dependent round trip behind that run's stores
-#endif
 #ifndef SLK_ITEM_KEYPF
-#define SLK_ITEM_KEYPF 0       // 1: the keys + payloads of the workgroup's NEXT tile are fetched into registers behind the
-                               // record gathers of the current one (tiles of up to 254 positions, i.e. row groups of >= 4 lanes)
+#define SLK_ITEM_KEYPF 1       // 1: the keys + payloads of the workgroup's NEXT tile are fetched into registers behind the
+                               // record gathers of the current one (tiles of up to 254 positions, i.e. row groups of >= 4 lanes):
+                               // one dependent round trip less per tile.  Same-box A/B (profiles/r03_b_*): C2 item pass
+                               // 0.3135 -> 0.2935 ms, minibatch 65 536 45.3 -> 43.1 us, C5 shard unchanged
+#endif
+
+#ifndef SLK_USER_TILE
+#define SLK_USER_TILE 32  // user pass: a user run that wholly covers an aligned tile of this many positions is LONG (k_user_pass<ULONG>)
 #endif
 
 #ifndef SLK_SPILL_BATCH
@@ -654,37 +661,14 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 if (starts) atomicAdd(a.ipart_count, 1u);
             }
         };
-#if SLK_ITEM_LATE_EARLY
-        // the group's next head: row + state on their way while the first head's run is summed (the registers of the record
-        // gather are free by now)
-        slk_vec<VEC> pv2 = slk_vzero<VEC>(), sv2 = slk_vzero<VEC>();
-        float pb2 = 0.0f, sb2 = 0.0f;
-        const int r2 = grp + NPRE * GPB;
-        const bool pre2 = r2 < nheads && completes(r2);
-        if (pre2) {
-            const uint32_t item = s_key[(int)s_head[r2] + 1] & a.imask;
-            if (rows_on && UPD != SLK_UPD_GRAD_ONLY) {
-                const size_t voff = (size_t)item * D + d0;
-                pv2 = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-                sv2 = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
-            }
-            if (PART != SLK_PART_ROWS && UPD != SLK_UPD_GRAD_ONLY) {
-                pb2 = a.P[3][item];
-                sb2 = a.S1[3][item];
-            }
-        }
-#endif
 #pragma unroll
         for (int h = 0; h < NPRE; ++h) {
             const int r = grp + h * GPB;
             if (r < nheads) finish(r, completes(r), pv[h], sv[h], pb[h], sb[h]);
         }
-#if SLK_ITEM_LATE_EARLY
-        if (r2 < nheads) finish(r2, pre2, pv2, sv2, pb2, sb2);
-        for (int r = r2 + GPB; r < nheads; r += GPB) {
-#else
+        // (issuing the row + state loads of the group's NEXT head before summing the first one's run -- the registers of the
+        // record gather are free by then -- was measured and does not pay: 0.315 vs 0.313 ms at C2, profiles/r03_b_*)
         for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
-#endif
             slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
             finish(r, false, p, s, 0.0f, 0.0f);
         }
@@ -896,6 +880,7 @@ static inline int slk_launch_item_pass(slk_ctx *ctx, const slk_item_fns &fns, sl
     SLK_HIP(ctx, hipMemsetAsync(a.ipart_count, 0, 4, s));
     hipLaunchKernelGGL(fns.pass, dim3(slk_grid_for(ctx, n, T, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
     SLK_LAUNCH_CHECK(ctx, what);
+    ++ctx->stat_item_long;
     hipLaunchKernelGGL(fns.stitch, dim3(slk_grid_for(ctx, ntiles, gpb)), dim3(256), 0, s, a);
     SLK_LAUNCH_CHECK(ctx, "k_item_stitch");
     return SLK_OK;

@@ -219,6 +219,63 @@ def check_long_run_gradients_against_exact(be, loss, D, U, I, B, seed=11, tol=2e
     return ours, theirs
 
 
+def check_long_user_run_gradients_against_exact(be, loss, D, U, I, B, seed=12, tol=2e-6):
+    """USER rows that collect hundreds or thousands of occurrences in one minibatch (k_user_pass<ULONG> partials +
+    k_user_stitch): the engine's summed user-embedding and user-bias gradients against the EXACT ones (closed-form backward
+    in float64), to 2e-6 of the table's norm; the oracle's sequential fp32 sums are held to 1e-3 as a sanity check only."""
+    assert loss in ('bpr', 'pointwise')
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, B).astype(np.int64)
+    items = rs.randint(0, I, B).astype(np.int64)
+    negs = rs.randint(0, I, B).astype(np.int64)
+    params = [rs.normal(0, 0.5, (U, D)), rs.normal(0, 0.5, (I, D)), rs.normal(0, 0.2, U), rs.normal(0, 0.2, I)]
+    P, Q, bu, bi = [np.asarray(p, np.float32).astype(np.float64) for p in params]
+    sp = (P[users] * Q[items]).sum(1) + bu[users] + bi[items]
+    sn = (P[users] * Q[negs]).sum(1) + bu[users] + bi[negs]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    if loss == 'bpr':
+        s = sig(sp - sn)
+        gp = -(s * (1.0 - s)) / B
+        gn = -gp
+        want_loss = float((1.0 - s).mean())
+    else:
+        a, b = sig(sp), sig(sn)
+        gp, gn = -(a * (1.0 - a)) / B, (b * (1.0 - b)) / B
+        want_loss = float(((1.0 - a) + b).mean())
+    exact = np.zeros_like(P)
+    np.add.at(exact, users, gp[:, None] * Q[items] + gn[:, None] * Q[negs])
+    exact_b = np.zeros_like(bu)
+    np.add.at(exact_b, users, gp + gn)
+    _, ora_g = BilinearOracle(*params, opt='adagrad', sparse_grads=True).step(users, items, negs, loss=loss, n_neg=1,
+                                                                             want_grads=True)
+    dev = be.model(params, opt='adam_dense', lr=0.0, betas=(0.0, 0.999))  # exp_avg after one step == the gradient
+    mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+    d_users, d_items, d_negs = be.alloc(users), be.alloc(items), be.alloc(negs)
+    long_before = eng.get_stat('user_long_launches')
+    eng.set_option('epoch_kernel', 0)  # the launch path's hot-user form is what is under test
+    try:
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), B, B, loss, 1, be.ptr(mb_loss),
+                           d_neg_in=be.ptr(d_negs), stream=be.stream)
+    finally:
+        eng.set_option('epoch_kernel', 1)
+    if B // U >= 96:  # every run then covers a tile of 32 positions
+        assert eng.get_stat('user_long_launches') == long_before + 1, 'the long-run form of the user pass was not taken'
+    assert abs(float(be.get(mb_loss)[0]) - want_loss) / abs(want_loss) < 1e-5
+    got = be.get(dev.s1[0]).astype(np.float64).reshape(exact.shape)
+    scale = np.abs(exact).max()
+    ours = np.abs(got - exact).max() / scale
+    theirs = np.abs(np.asarray(ora_g[0], np.float64).reshape(exact.shape) - exact).max() / scale
+    assert ours <= tol, (ours, theirs)
+    assert theirs <= 1e-3, (ours, theirs)
+    if loss == 'pointwise':  # (bpr: the user-bias gradient is a sum of exactly cancelling +g / -g pairs)
+        got_b = be.get(dev.s1[2]).astype(np.float64).ravel()
+        assert np.abs(got_b - exact_b).max() <= tol * np.abs(exact_b).max(), (np.abs(got_b - exact_b).max(), np.abs(exact_b).max())
+    else:
+        assert (be.get(dev.s1[2]) == 0).all()
+    return ours, theirs
+
+
 def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, bias_tables=(2, 3)):
     """Per element: how far ONE optimizer step may move a parameter / its state when the summed gradient is perturbed by
     delta = rel_delta * ||g||inf (per embedding table, the bias tables against their joint norm; touched rows only) --
@@ -266,6 +323,72 @@ def assert_step_within_bounds(be, dev, ora, pre_p, pre_s1, pre_s2, g, step, opt,
             tol = 1e-5 * max(np.abs(w64).max(), 1e-30) + bound.reshape(w64.shape)
             assert not (d > tol).any(), ('%s step %d table %d %s: %d elements beyond the conditioned bound'
                                          % (what, step, t, nm, int((d > tol).sum())), float(d.max()))
+
+
+def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5):
+    """Multi-minibatch training against the oracle WITHOUT an outlier allowance: one engine call over the whole run (open
+    loop: negatives and RNG state bit-exact against the host stream, the first minibatch's loss within 1e-5, later losses
+    within 1e-3 -- from zero accumulators a trajectory is chaotic element by element, see check_replays_reference_fixture),
+    then the same run one minibatch per call (closed loop): before every minibatch the engine's tables and state go to the
+    oracle, which takes that one step with the same negatives; loss within 1e-5, every element of every table / state
+    tensor within the bound a 1e-5-relative gradient perturbation implies for that step (step_update_bounds).  The two
+    runs must end bit-identical (chunking is value-neutral), so the per-step statement covers the one-call tables."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+    state = np.random.RandomState(9).get_state()
+    n_mb = (N + B - 1) // B
+    NN = nn if loss == 'adaptive_hinge' else 1
+    # ---- open loop
+    ora = BilinearOracle(*params, opt=opt, sparse_grads=True, **hp)
+    dev = be.model(params, opt=opt, **hp)
+    orng = Rng(state=state)
+    eng.rng_set_state(state)
+    d_users, d_items = be.alloc(users), be.alloc(items)
+    all_negs = []
+    for epoch in range(epochs):
+        want_loss, want_neg = ora.train(orng, users, items, B, loss=loss, n_neg=nn, want_negs=True)
+        mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+        neg_out = be.alloc(np.full(want_neg.size, -1, dtype=np.int64))
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn, be.ptr(mb_loss),
+                           d_neg_out=be.ptr(neg_out), stream=be.stream)
+        assert (be.get(neg_out) == want_neg).all()
+        all_negs.append(want_neg)
+        got_loss = be.get(mb_loss)
+        if epoch == 0:
+            assert abs(got_loss[0] - want_loss[0]) <= 1e-5 * abs(want_loss[0])
+        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-3
+    got, ref = eng.rng_get_state(), orng.get_state()
+    assert (got[1] == ref[1]).all() and got[2] == ref[2]
+    open_tables = [be.get(x).copy() for x in dev.p + dev.s1 + dev.s2]
+    for t in range(4):
+        assert_open_loop_drift(open_tables[t], ora.p[t], ('closed-loop check, open-loop run', t))
+    # ---- closed loop
+    dev2 = be.model(params, opt=opt, **hp)
+    step = 0
+    for epoch in range(epochs):
+        for off in range(0, N, B):
+            hi = min(off + B, N)
+            neg = all_negs[epoch][off * NN:hi * NN]
+            pre_p = [be.get(x).copy() for x in dev2.p]
+            pre_s1 = [be.get(x).copy() for x in dev2.s1]
+            pre_s2 = [be.get(x).copy() for x in dev2.s2]
+            o1 = BilinearOracle(*pre_p, opt=opt, sparse_grads=True, state1=pre_s1, state2=pre_s2, step=step, **hp)
+            want_loss, g = o1.step(users[off:hi], items[off:hi], neg, loss=loss, n_neg=nn, want_grads=True)
+            step += 1
+            d_su, d_si, d_neg = be.alloc(users[off:hi]), be.alloc(items[off:hi]), be.alloc(neg)
+            mb_loss = be.alloc(np.zeros(1, dtype=np.float32))
+            eng.bilinear_train(dev2.tables, dev2.optim, be.ptr(d_su), be.ptr(d_si), hi - off, B, loss, nn, be.ptr(mb_loss),
+                               d_neg_in=be.ptr(d_neg), stream=be.stream)
+            assert dev2.optim.step == step
+            assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (epoch, off)
+            assert_step_within_bounds(be, dev2, o1, pre_p, pre_s1, pre_s2, g, step, opt, hp, what='%s/%s' % (loss, opt))
+    for k, x in enumerate(dev2.p + dev2.s1 + dev2.s2):
+        assert np.array_equal(be.get(x), open_tables[k]), ('closed-loop run differs from the open-loop one', k)
 
 
 def check_replays_reference_fixture(be, golden_dir, name):
@@ -757,7 +880,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
                            [be.get(x) for x in dev.p + dev.s1 + dev.s2])
         finally:
             eng.set_option('chunk_interactions', 1 << 23)
-            eng.set_option('overlap_prep', 0)
+            eng.set_option('overlap_prep', 1)
             if nt is not None:
                 eng.set_option('nt', 3)
     for k, (a, b) in enumerate(zip(*results)):

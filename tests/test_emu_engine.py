@@ -130,7 +130,7 @@ def test_pipelined_chunks_match_single_chunk(be):
         ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, N=450, B=32, epochs=1)
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
-        eng.set_option('overlap_prep', 0)
+        eng.set_option('overlap_prep', 1)
         eng.set_option('item_grid_mult', 64)
         eng.set_option('user_grid_mult', 8)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100)
@@ -227,3 +227,35 @@ def test_device_to_sequence_argument_errors(be):
     with pytest.raises(_native.SlkError):  # no plan pending
         eng.to_sequence_fill(be.ptr(d), be.ptr(d), stream=be.stream)
 
+
+
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('pointwise', 'sparse_adam'), ('adaptive_hinge', 'adagrad'),
+                                       ('hinge', 'adam_dense')])
+def test_train_closed_loop_several_minibatches(be, loss, opt):
+    """the quota-free form of the multi-minibatch comparison (the GPU suite runs it at 50k interactions)"""
+    ec.check_train_closed_loop(be, loss, opt, 16, U=300, I=100, N=1300, B=256, nn=3, epochs=2)
+
+
+@pytest.mark.parametrize('D,U,B', [(64, 3, 4096), (16, 2, 1000), (32, 40, 3000), (8, 1, 700)])
+def test_users_that_collect_thousands_of_occurrences(be, D, U, B):
+    """hot users: a user's occurrences fill dozens of the user pass's tiles (k_user_pass<ULONG>: one row group per tile-sized
+    segment, k_user_stitch adds the partials) -- the summed user gradients against the exact (float64) ones, every loss;
+    U = 40: runs of ~75 that cover one or two tiles next to runs that cover none"""
+    ec.check_long_user_run_gradients_against_exact(be, 'bpr', D, U=U, I=5000, B=B)
+    ec.check_long_user_run_gradients_against_exact(be, 'pointwise', D, U=U, I=300, B=B)
+
+
+@pytest.mark.parametrize('loss,opt', [('pointwise', 'adagrad'), ('bpr', 'sparse_adam'), ('hinge', 'adam_dense'),
+                                       ('adaptive_hinge', 'adagrad')])
+def test_hot_users_closed_loop(be, loss, opt):
+    """minibatches of 1500 over 25 users (runs of ~60: some cover a tile of the user pass, some do not) against the oracle,
+    step by step and element by element"""
+    ec.check_train_closed_loop(be, loss, opt, 16, U=25, I=4000, N=3300, B=1500, nn=3, epochs=1, seed=8)
+
+
+@pytest.mark.parametrize('D,U,I,N,B,opt', [(64, 300, 170, 2500, 512, 'adagrad'), (16, 3, 2000, 5000, 2048, 'adagrad'),
+                                            (8, 2, 50, 7000, 3000, 'sparse_adam')])
+def test_user_long_gate_is_bit_neutral(be, D, U, I, N, B, opt):
+    """the plain user pass for minibatches without a long user run (k_user_long_flags) against the partial-writing form +
+    k_user_stitch for every minibatch: same bits (short runs are walked identically; long ones take the long form either way)"""
+    ec.check_item_long_gate_is_bit_neutral(be, 'bpr', opt, D, U, I, N, B)
