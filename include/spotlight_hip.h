@@ -55,12 +55,15 @@ enum slk_loss {
  *  SPARSE_ADAM   torch.optim.SparseAdam (sparse=True): looked-up rows only, stale moments
  *  ADAM_DENSE    torch.optim.Adam (+weight_decay=l2), the reference default: every step
  *                sweeps every row of all four tables
- *  ADAGRAD_DENSE torch.optim.Adagrad with weight_decay != 0: full sweep */
+ *  ADAGRAD_DENSE torch.optim.Adagrad with weight_decay != 0: full sweep
+ *  SGD           torch.optim.SGD(lr) with momentum == 0 and weight_decay == 0 (torch/optim/sgd.py: param.add_(grad, alpha=-lr)):
+ *                stateless, touched rows only -- dense and sparse gradients give the same update; d_state1 / d_state2 unused */
 enum slk_opt {
     SLK_OPT_ADAGRAD = 0,
     SLK_OPT_SPARSE_ADAM = 1,
     SLK_OPT_ADAM_DENSE = 2,
-    SLK_OPT_ADAGRAD_DENSE = 3
+    SLK_OPT_ADAGRAD_DENSE = 3,
+    SLK_OPT_SGD = 4
 };
 
 /* spotlight/layers.py:74-244 BloomEmbedding(num_embeddings, embedding_dim, compression_ratio,
@@ -121,8 +124,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
  *   "overlap_prep"        1 (default): the negatives + sorts of chunk c+1 run on a second HIP stream while
  *                         chunk c trains; 2: only the negatives; 0: everything in order on the caller's stream
- *   "chunk_ramp"          1 (default): with overlap_prep the first chunks of a call ramp up from ~2^20 interactions
- *                         (the first chunk's prep is the one nothing hides)
+ *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
+ *   "chunk_ramp"          1: with overlap_prep the first chunks of a call ramp up from ~2^20 interactions (default 0:
+ *                         measured slower at every call length, profiles/r03_c_*)
  *   "item_grid_mult"      item pass: workgroups per CU (default 64)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
@@ -133,7 +137,7 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "item_long_gate"      1 (default): minibatches in which no item row's occurrences fill a whole 64-position tile of the
  *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results).
  *                         The same switch gates the user pass's long-run form (hot users: runs that fill a 32-position tile).
- *   "user_lat_max_batch"  minibatches up to this size (default 2^17) take the latency-bound form of the pair-mode user pass
+ *   "user_lat_max_batch"  minibatches up to this size (default 2^14) take the latency-bound form of the pair-mode user pass
  *   "prep_cus", "prep_priority"  with overlap_prep: CU-mask partition of the chip between the prep stream and the passes /
  *                         a high-priority prep stream (measured, profiles/r03_a_*: the masks slow the passes by more than
  *                         the prep they hide; defaults 0)

@@ -41,6 +41,8 @@ def optimizer_factory(kind):
         return lambda params: torch.optim.SparseAdam(list(params), lr=0.01)
     if kind == 'adagrad_dense_wd':
         return lambda params: torch.optim.Adagrad(params, lr=0.05, weight_decay=1e-3)
+    if kind in ('sgd', 'sgd_sparse'):
+        return lambda params: torch.optim.SGD(params, lr=0.05)
     raise ValueError(kind)
 
 
@@ -55,7 +57,7 @@ def run_reference(case):
         loss=case['loss'], embedding_dim=case['D'], n_iter=case['n_iter'],
         batch_size=case['B'], l2=case.get('l2', 0.0), learning_rate=case.get('lr', 1e-2),
         optimizer_func=optimizer_factory(case['opt']),
-        sparse=case['opt'] in ('adagrad_sparse', 'sparse_adam'),
+        sparse=case['opt'] in ('adagrad_sparse', 'sparse_adam', 'sgd_sparse'),
         random_state=model_rs, num_negative_samples=case.get('n_neg', 5))
     model._initialize(inter)
     names = ['user_embeddings.weight', 'item_embeddings.weight', 'user_biases.weight',
@@ -116,6 +118,8 @@ def run_reference(case):
         s = st[params[nm]]
         if 'sum' in s:
             rec['state1_%d' % t] = s['sum'].detach().numpy().copy()
+        elif 'exp_avg' not in s:  # SGD without momentum: stateless
+            rec['state1_%d' % t] = np.zeros_like(rec['final_%d' % t])
         else:
             rec['state1_%d' % t] = s['exp_avg'].detach().numpy().copy()
             rec['state2_%d' % t] = s['exp_avg_sq'].detach().numpy().copy()
@@ -150,6 +154,12 @@ def cases():
                     B=256, n_iter=2, seed=1, data_seed=0))
     out.append(dict(name='d64_adaptive_sparse_adam', loss='adaptive_hinge', opt='sparse_adam', U=200,
                     I=150, N=1500, D=64, B=256, n_iter=2, seed=1, data_seed=0, n_neg=5))
+    # any torch optimizer goes through optimizer_func (implicit.py:150): plain SGD, dense and sparse gradients
+    out.append(dict(name='bpr_sgd', loss='bpr', opt='sgd', U=30, I=40, N=200, D=8, B=32, n_iter=2, seed=42, data_seed=7))
+    out.append(dict(name='adaptive_hinge_sgd_sparse', loss='adaptive_hinge', opt='sgd_sparse', U=30, I=40, N=200, D=8, B=32,
+                    n_iter=2, seed=42, data_seed=7, n_neg=3))
+    out.append(dict(name='d64_pointwise_sgd', loss='pointwise', opt='sgd', U=200, I=150, N=1500, D=64, B=256, n_iter=2, seed=1,
+                    data_seed=0))
     out.append(dict(name='d12_pointwise_adagrad_wd', loss='pointwise', opt='adagrad_dense_wd', U=50,
                     I=33, N=300, D=12, B=64, n_iter=2, seed=3, data_seed=5))
     return out

@@ -18,7 +18,7 @@ _SO = os.path.join(_HERE, '_build', 'libslk_oracle.so')
 
 EXPLICIT_LOSSES = {'regression': 4, 'poisson': 5, 'logistic': 6}
 LOSSES = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3}
-OPTS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
+OPTS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3, 'sgd': 4}
 
 
 def build(force=False):

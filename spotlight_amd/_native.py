@@ -18,7 +18,7 @@ SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
               'regression': 4, 'poisson': 5, 'logistic': 6}
-OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3}
+OPT_KINDS = {'adagrad': 0, 'sparse_adam': 1, 'adam_dense': 2, 'adagrad_dense': 3, 'sgd': 4}
 KERNEL_CLASSES = {'sample': 0, 'prep': 1, 'user_pass': 2, 'item_pass': 3, 'dense_sweep': 4, 'score': 5,
                   'exchange': 6, 'seq_pass': 7, 'epoch': 8}
 
@@ -438,6 +438,6 @@ def make_optim(kind, state1, state2=None, lr=1e-2, eps=None, betas=(0.9, 0.999),
     o.lr, o.eps, o.beta1, o.beta2 = float(lr), float(eps), float(betas[0]), float(betas[1])
     o.weight_decay, o.lr_decay = float(weight_decay), float(lr_decay)
     for i in range(4):
-        o.d_state1[i] = state1[i]
+        o.d_state1[i] = state1[i] if state1 is not None else None
         o.d_state2[i] = state2[i] if state2 is not None else None
     return o

@@ -221,6 +221,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_chunk_interactions = value;
     } else if (!strcmp(name, "overlap_prep") && value >= 0 && value <= 2) {
         ctx->opt_overlap_prep = (int)value;
+    } else if (!strcmp(name, "overlap_min_batch") && value >= 0) {
+        ctx->opt_overlap_min_batch = value;
     } else if (!strcmp(name, "chunk_ramp") && (value == 0 || value == 1)) {
         ctx->opt_chunk_ramp = (int)value;
     } else if (!strcmp(name, "prep_cus") && value >= 0 && value <= 1024) {

@@ -68,7 +68,17 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     const uint32_t stride = gridDim.x * GPB;
     float loss_acc = 0.0f;
 
-    for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
+    // ULONG: sweep k of the grid-stride loop is rotated by k row groups.  The segments of a long run start at every
+    // SLK_USER_TILE-th position; with a stride that is a multiple of the tile the plain map would hand ALL of them to
+    // 1 / SLK_USER_TILE of the row groups (measured: Zipf(1.0) users 2.9 ms per pass instead of ~0.5).
+    for (uint32_t p0 = a.begin, sweep = 0; p0 < a.end; p0 += stride, ++sweep) {
+        uint32_t p = p0 + blockIdx.x * GPB + grp;
+        if (ULONG) {
+            uint32_t off = blockIdx.x * GPB + grp + sweep % stride;
+            if (off >= stride) off -= stride;
+            p = p0 + off;
+        }
+        if (p >= a.end) continue;
         const bool nt_keys = (SLK_NT_OF(a) & 8) != 0;
         const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
         uint32_t lat_ip = 0u, lat_in = 0u;
@@ -599,15 +609,18 @@ static pass_fn user_pass_fn2(int upd, int umode) {
     if (umode == 2) {
         if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 2, BLOOM>;
         if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 2, BLOOM>;
+        if (upd == SLK_UPD_SGD) return k_user_pass<VEC, G, SLK_UPD_SGD, 2, BLOOM>;
         return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 2, BLOOM>;
     }
     if (umode == 1) {
         if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 1, BLOOM>;
         if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 1, BLOOM>;
+        if (upd == SLK_UPD_SGD) return k_user_pass<VEC, G, SLK_UPD_SGD, 1, BLOOM>;
         return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 1, BLOOM>;
     }
     if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, BLOOM>;
     if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, BLOOM>;
+    if (upd == SLK_UPD_SGD) return k_user_pass<VEC, G, SLK_UPD_SGD, 0, BLOOM>;
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, BLOOM>;
 }
 
@@ -616,6 +629,7 @@ template <int VEC, int G, bool ULONG = false>
 static pass_fn user_pass_lat_fn(int upd) {
     if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, false, true, ULONG>;
     if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, false, true, ULONG>;
+    if (upd == SLK_UPD_SGD) return k_user_pass<VEC, G, SLK_UPD_SGD, 0, false, true, ULONG>;
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, false, true, ULONG>;
 }
 
@@ -624,6 +638,7 @@ template <int VEC, int G, int UMODE>
 static pass_fn user_pass_long_fn1(int upd) {
     if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, UMODE, false, false, true>;
     if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, UMODE, false, false, true>;
+    if (upd == SLK_UPD_SGD) return k_user_pass<VEC, G, SLK_UPD_SGD, UMODE, false, false, true>;
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, UMODE, false, false, true>;
 }
 template <int VEC, int G>
@@ -636,6 +651,7 @@ template <int VEC, int G>
 static pass_fn user_stitch_fn(int upd) {
     if (upd == SLK_UPD_ADAGRAD) return k_user_stitch<VEC, G, SLK_UPD_ADAGRAD>;
     if (upd == SLK_UPD_SPARSE_ADAM) return k_user_stitch<VEC, G, SLK_UPD_SPARSE_ADAM>;
+    if (upd == SLK_UPD_SGD) return k_user_stitch<VEC, G, SLK_UPD_SGD>;
     return k_user_stitch<VEC, G, SLK_UPD_GRAD_ONLY>;
 }
 
@@ -671,8 +687,12 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
 
 int slk_check_optim(slk_ctx *ctx, const slk_optim *optim, unsigned table_mask) {
     if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
-    if (optim->kind < SLK_OPT_ADAGRAD || optim->kind > SLK_OPT_ADAGRAD_DENSE)
+    if (optim->kind < SLK_OPT_ADAGRAD || optim->kind > SLK_OPT_SGD)
         return slk_fail(ctx, SLK_EINVAL, "unknown optimizer kind %d", optim->kind);
+    if (optim->kind == SLK_OPT_SGD) {  // stateless
+        if (optim->weight_decay != 0.0) return slk_fail(ctx, SLK_EINVAL, "SGD: weight_decay must be 0 (a full-table sweep per step is not built)");
+        return SLK_OK;
+    }
     const bool need_s2 = optim->kind == SLK_OPT_SPARSE_ADAM || optim->kind == SLK_OPT_ADAM_DENSE;
     for (int i = 0; i < 4; ++i) {
         if (!((table_mask >> i) & 1u)) continue;
@@ -897,7 +917,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     {
         int64_t ramp = ((int64_t)1 << 20) / bsz;
         if (ramp < 1) ramp = 1;
-        if (!ctx->opt_overlap_prep || !ctx->opt_chunk_ramp) ramp = mb_per_chunk;
+        if (!ctx->opt_overlap_prep || !ctx->opt_chunk_ramp || bsz < ctx->opt_overlap_min_batch) ramp = mb_per_chunk;
         while (cb.back() < n) {
             if (ramp > mb_per_chunk) ramp = mb_per_chunk;
             const int64_t next = cb.back() + ramp * bsz;
@@ -906,7 +926,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         }
     }
     const size_t n_chunks = cb.size() - 1;
-    const int nsets = (ctx->opt_overlap_prep && n_chunks > 1) ? 2 : 1;
+    const int nsets = (ctx->opt_overlap_prep && n_chunks > 1 && bsz >= ctx->opt_overlap_min_batch) ? 2 : 1;
     for (int st = 0; st < nsets; ++st) {
         slk_prep_bufs &pb = ctx->pb[st];
         if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;

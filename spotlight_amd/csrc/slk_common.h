@@ -98,7 +98,11 @@ struct slk_ctx {
     // otherwise only run in the gaps: prep_cus > 0 gives the prep stream a CU mask of that many CUs (spread over the XCDs and
     // shader engines) and runs the passes on a ctx-owned stream masked to the other CUs (ordered against the caller's
     // stream by events); prep_priority = 1 creates the (unmasked) prep stream with the highest priority instead.
-    int opt_chunk_ramp = 1;        // overlapped prep: the first chunks of a call ramp up from ~2^20 interactions (slk_bilinear.hip)
+    int opt_chunk_ramp = 0;        // overlapped prep: 1 = the first chunks of a call ramp up from ~2^20 interactions.  Measured
+                                   // (profiles/r03_c_*): worse at every call length (0.797 vs 0.758 ms per step at 20 minibatches per call,
+                                   // 0.765 vs 0.751 at 64) -- small chunks pay the sampler's jump-ahead and the sorts' fixed costs again
+    int64_t opt_overlap_min_batch = (int64_t)1 << 16;  // the prep overlaps the passes only for minibatches of at least this size
+                                   // (measured: +3 % at 8192, where the passes are short latency-bound kernels; -1..-3 % at 65 536)
     int opt_prep_cus = 0;
     int opt_prep_priority = 0;
     int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
@@ -109,7 +113,8 @@ struct slk_ctx {
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
-    int64_t opt_user_lat_max_batch = (int64_t)1 << 17;  // minibatches up to this size take the latency-bound form of the pair-mode
+    int64_t opt_user_lat_max_batch = (int64_t)1 << 14;  // (measured, profiles/r03_c_*: user pass 9.2 -> 8.1 us at 2048, 11.6 -> 10.3 at
+                                   // 8192, but 29.3 -> 31.3 at 65 536)  // minibatches up to this size take the latency-bound form of the pair-mode
                                    // user pass (k_user_pass<..., LAT>): two round trips per position instead of four
     int opt_item_long_gate = 1;    // 1: minibatches without a long run (k_item_long_flags) take the plain item pass; 0: every item
                                    // pass is the partial-writing one + k_item_stitch (same results; a test / measurement switch)

@@ -39,7 +39,9 @@
 // spread over 4x as many CUs the same work measured 18.8 -> see profiles/ us per minibatch at C1 shape, minibatch 1024.
 #define SLK_EPOCH_TB 64
 
-enum { SLK_EUPD_ADAGRAD = 0, SLK_EUPD_SPARSE_ADAM = 1, SLK_EUPD_ADAM_DENSE = 2, SLK_EUPD_ADAGRAD_DENSE = 3 };
+enum { SLK_EUPD_ADAGRAD = 0, SLK_EUPD_SPARSE_ADAM = 1, SLK_EUPD_ADAM_DENSE = 2, SLK_EUPD_ADAGRAD_DENSE = 3, SLK_EUPD_SGD = 4 };
+// a zero summed gradient leaves the row exactly as it is: row-sparse Adagrad and SGD
+#define SLK_EUPD_ZERO_IS_NOOP(UPD) ((UPD) == SLK_EUPD_ADAGRAD || (UPD) == SLK_EUPD_SGD)
 
 #define SLK_EPOCH_ABORT 0xffffffffu
 #define SLK_EPOCH_MAX_SPINS (1u << 24)  // x (s_sleep + one fabric round trip): seconds
@@ -151,6 +153,9 @@ __device__ __forceinline__ void slk_epoch_update(const slk_epoch_args &e, const 
         }
         slk_vstore_coh<VEC>(e.S1[t] + off, s1);
         slk_vstore_coh<VEC>(e.S2[t] + off, s2);
+    } else if (UPD == SLK_EUPD_SGD) {  // torch/optim/sgd.py, momentum 0, weight_decay 0: param.add_(grad, alpha=-lr)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.v[i] += -c.c0 * g.v[i];
     } else if (UPD == SLK_EUPD_ADAM_DENSE) {  // torch/optim/adam.py:414-546 (k_dense_sweep_all)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -179,6 +184,10 @@ __device__ __forceinline__ void slk_epoch_update(const slk_epoch_args &e, const 
 template <int UPD>
 __device__ __forceinline__ constexpr bool slk_epoch_has_s2() {
     return UPD == SLK_EUPD_SPARSE_ADAM || UPD == SLK_EUPD_ADAM_DENSE;
+}
+template <int UPD>
+__device__ __forceinline__ constexpr bool slk_epoch_has_s1() {
+    return UPD != SLK_EUPD_SGD;
 }
 template <int UPD>
 __device__ __forceinline__ constexpr bool slk_epoch_dense() {
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
     constexpr int GPB = TB / G;
     constexpr bool DENSE = slk_epoch_dense<UPD>();
     constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
+    constexpr bool HAS_S1 = slk_epoch_has_s1<UPD>();
     const int lane = threadIdx.x % G, grp = threadIdx.x / G;
     const int D = e.D, d0 = lane * VEC;
     const bool on = d0 < D;
@@ -274,12 +284,12 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             const size_t uoff = (size_t)user * D + d0;
             // every coherent load whose address is known goes out before the first use: ONE fabric round trip
             slk_vec<VEC> u = on ? slk_vload_coh<VEC>(e.P[0] + uoff) : zero;
-            const slk_vec<VEC> su1 = on ? slk_vload_coh<VEC>(e.S1[0] + uoff) : zero;
+            const slk_vec<VEC> su1 = (on && HAS_S1) ? slk_vload_coh<VEC>(e.S1[0] + uoff) : zero;
             const slk_vec<VEC> su2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[0] + uoff) : zero;
             const float bu = slk_ld_coh(e.P[2] + user);
             slk_vec<1> bus1 = zero1, bus2 = zero1;
             if (lane == 0) {
-                bus1 = slk_vload_coh<1>(e.S1[2] + user);
+                if (HAS_S1) bus1 = slk_vload_coh<1>(e.S1[2] + user);
                 if (HAS_S2) bus2 = slk_vload_coh<1>(e.S2[2] + user);
             }
             slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 gbu = gbl;
             }
             if (on) slk_epoch_update<VEC, UPD>(e, c, 0, uoff, u, su1, su2, gu);
-            if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gbu == 0.0f)) {  // zero gradient: an exact no-op for Adagrad
+            if (lane == 0 && !(SLK_EUPD_ZERO_IS_NOOP(UPD) && gbu == 0.0f)) {  // zero gradient: an exact no-op for Adagrad
                 slk_vec<1> bp, bg;
                 bp.v[0] = bu;
                 bg.v[0] = gbu;
@@ -414,12 +424,12 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             const uint32_t item = key & e.imask;
             const size_t voff = (size_t)item * D + d0;
             const slk_vec<VEC> v = on ? slk_vload_coh<VEC>(e.P[1] + voff) : zero;
-            const slk_vec<VEC> sv1 = on ? slk_vload_coh<VEC>(e.S1[1] + voff) : zero;
+            const slk_vec<VEC> sv1 = (on && HAS_S1) ? slk_vload_coh<VEC>(e.S1[1] + voff) : zero;
             const slk_vec<VEC> sv2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[1] + voff) : zero;
             const float bi = slk_ld_coh(e.P[3] + item);
             slk_vec<1> bis1 = zero1, bis2 = zero1;
             if (lane == 0) {
-                bis1 = slk_vload_coh<1>(e.S1[3] + item);
+                if (HAS_S1) bis1 = slk_vload_coh<1>(e.S1[3] + item);
                 if (HAS_S2) bis2 = slk_vload_coh<1>(e.S2[3] + item);
             }
             float g = slk_ld_coh(e.gsn + (pay - ib0));
@@ -477,9 +487,9 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
 
             // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
             // row; the dense optimizers update every row anyway
-            if (!(UPD == SLK_EUPD_ADAGRAD && !any)) {
+            if (!(SLK_EUPD_ZERO_IS_NOOP(UPD) && !any)) {
                 if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v, sv1, sv2, gv);
-                if (lane == 0 && !(UPD == SLK_EUPD_ADAGRAD && gb == 0.0f)) {
+                if (lane == 0 && !(SLK_EUPD_ZERO_IS_NOOP(UPD) && gb == 0.0f)) {
                     slk_vec<1> bp, bg;
                     bp.v[0] = bi;
                     bg.v[0] = gb;
@@ -536,6 +546,7 @@ static slk_epoch_fn epoch_fn_of(int upd) {
         case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD, EXPL>;
         case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM, EXPL>;
         case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE, EXPL>;
+        case SLK_EUPD_SGD: return k_bilinear_epoch<VEC, G, SLK_EUPD_SGD, EXPL>;
         default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE, EXPL>;
     }
 }
@@ -565,6 +576,7 @@ static int epoch_upd_of(const slk_optim *optim) {
         case SLK_OPT_ADAGRAD: return SLK_EUPD_ADAGRAD;
         case SLK_OPT_SPARSE_ADAM: return SLK_EUPD_SPARSE_ADAM;
         case SLK_OPT_ADAM_DENSE: return SLK_EUPD_ADAM_DENSE;
+        case SLK_OPT_SGD: return SLK_EUPD_SGD;
         default: return SLK_EUPD_ADAGRAD_DENSE;
     }
 }
@@ -663,7 +675,9 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
         const double step = (double)(optim->step + 1 + m);
         slk_step_coef &c = hc[m];
         c.c0 = c.c1 = 0.0f;
-        if (upd == SLK_EUPD_ADAGRAD || upd == SLK_EUPD_ADAGRAD_DENSE) {
+        if (upd == SLK_EUPD_SGD) {
+            c.c0 = (float)optim->lr;
+        } else if (upd == SLK_EUPD_ADAGRAD || upd == SLK_EUPD_ADAGRAD_DENSE) {
             c.c0 = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
         } else {
             const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);

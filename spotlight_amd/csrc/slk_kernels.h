@@ -129,7 +129,11 @@ struct slk_pass_args {
     int nt;                // cache-policy bits (ctx option "nt")
 };
 
-enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2 };
+enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_UPD_SGD = 3 };
+// a zero summed gradient leaves the row exactly as it is (no write needed): Adagrad (sum += 0, p -= 0) and SGD (p -= 0)
+#define SLK_UPD_ZERO_IS_NOOP(UPD) ((UPD) == SLK_UPD_ADAGRAD || (UPD) == SLK_UPD_SGD)
+// the row update reads first-state rows (S1): not SGD (stateless), not GRAD_ONLY (S1 is the gradient buffer it writes)
+#define SLK_UPD_HAS_STATE(UPD) ((UPD) == SLK_UPD_ADAGRAD || (UPD) == SLK_UPD_SPARSE_ADAM)
 
 // How the item pass turns an occurrence payload r into a gradient contribution:
 //   SNAP  r = pos*NP + s; record(pos) = [u_old (D)], g_s = gsn[r - begin*NP];  vec = g_s * u_old, bias g_s
@@ -182,6 +186,11 @@ __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, siz
         slk_vstore_if_nt<VEC>(a.S1[t] + off, m, nt);
         slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
         slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+    } else if (UPD == SLK_UPD_SGD) {
+        // torch/optim/sgd.py (momentum 0, weight_decay 0): param.add_(grad, alpha=-lr)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.v[i] += -a.c_lr * g.v[i];
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
     } else {
         slk_vstore<VEC>(a.S1[t] + off, g);
     }
@@ -191,7 +200,7 @@ template <int UPD>
 __device__ __forceinline__ void slk_apply_bias(const slk_pass_args &a, int t, size_t row, float g) {
     slk_vec<1> gv;
     gv.v[0] = g;
-    if (UPD == SLK_UPD_ADAGRAD && g == 0.0f) return;  // exact no-op: sum += 0, p -= 0
+    if (SLK_UPD_ZERO_IS_NOOP(UPD) && g == 0.0f) return;  // exact no-op: sum += 0, p -= 0
     slk_vec<1> p = slk_vload<1>(a.P[t] + row);
     slk_apply_vec<1, UPD>(a, t, row, p, gv);
 }
@@ -355,6 +364,10 @@ __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t,
         slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
         slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
         slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+    } else if (UPD == SLK_UPD_SGD) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) p.v[i] += -a.c_lr * g.v[i];
+        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
     } else {
         slk_vstore<VEC>(a.S1[t] + off, g);
     }
@@ -374,19 +387,19 @@ __device__ __forceinline__ void slk_item_apply(const slk_pass_args &a, uint32_t 
     if (rows_on) {
         if (!pre && UPD != SLK_UPD_GRAD_ONLY) {
             p = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-            s = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+            if (SLK_UPD_HAS_STATE(UPD)) s = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
         }
         slk_apply_vec_pre<VEC, UPD>(a, 1, voff, p, s, gv, nullptr, nt_rows);
     }
     if (lane == 0 && PART != SLK_PART_ROWS) {
-        if (UPD == SLK_UPD_ADAGRAD && gb == 0.0f) return;  // exact no-op
+        if (SLK_UPD_ZERO_IS_NOOP(UPD) && gb == 0.0f) return;  // exact no-op
         slk_vec<1> bpv, bsv, gbv;
         if (pre || UPD == SLK_UPD_GRAD_ONLY) {
             bpv.v[0] = bp;
             bsv.v[0] = bs;
         } else {
             bpv.v[0] = a.P[3][item];
-            bsv.v[0] = a.S1[3][item];
+            bsv.v[0] = SLK_UPD_HAS_STATE(UPD) ? a.S1[3][item] : 0.0f;
         }
         gbv.v[0] = gb;
         slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
@@ -542,11 +555,11 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 if (rows_on && UPD != SLK_UPD_GRAD_ONLY) {
                     const size_t voff = (size_t)item * D + d0;
                     pv[h] = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-                    sv[h] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+                    if (SLK_UPD_HAS_STATE(UPD)) sv[h] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
                 }
                 if (PART != SLK_PART_ROWS && UPD != SLK_UPD_GRAD_ONLY) {
                     pb[h] = a.P[3][item];
-                    sb[h] = a.S1[3][item];
+                    if (SLK_UPD_HAS_STATE(UPD)) sb[h] = a.S1[3][item];
                 }
             }
         }
@@ -836,6 +849,9 @@ static slk_item_fns slk_item_pass_fn(int upd) {
     if (upd == SLK_UPD_SPARSE_ADAM)
         return {k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_SPARSE_ADAM, PART>,
                 k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART, false>};
+    if (upd == SLK_UPD_SGD)
+        return {k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_SGD, PART>,
+                k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART, false>};
     return {k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_GRAD_ONLY, PART>,
             k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART, false>};
 }
@@ -890,6 +906,7 @@ static inline int slk_launch_item_pass(slk_ctx *ctx, const slk_item_fns &fns, sl
 static inline int slk_upd_for(int opt_kind) {
     if (opt_kind == SLK_OPT_ADAGRAD) return SLK_UPD_ADAGRAD;
     if (opt_kind == SLK_OPT_SPARSE_ADAM) return SLK_UPD_SPARSE_ADAM;
+    if (opt_kind == SLK_OPT_SGD) return SLK_UPD_SGD;
     return SLK_UPD_GRAD_ONLY;
 }
 
@@ -897,7 +914,9 @@ static inline int slk_upd_for(int opt_kind) {
 static inline void slk_set_opt_coeffs(slk_pass_args &a, const slk_optim *optim) {
     const double step = (double)(optim->step + 1);
     a.c_eps = (float)optim->eps;
-    if (optim->kind == SLK_OPT_ADAGRAD) {
+    if (optim->kind == SLK_OPT_SGD) {
+        a.c_lr = (float)optim->lr;
+    } else if (optim->kind == SLK_OPT_ADAGRAD) {
         a.c_lr = (float)(optim->lr / (1.0 + (step - 1.0) * optim->lr_decay));
     } else if (optim->kind == SLK_OPT_SPARSE_ADAM) {
         const double bc1 = 1.0 - pow(optim->beta1, step), bc2 = 1.0 - pow(optim->beta2, step);

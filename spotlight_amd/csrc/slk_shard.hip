@@ -519,6 +519,7 @@ template <int VEC, int G>
 static slk_pass_fn shard_user_pass_fn(int upd) {
     if (upd == SLK_UPD_ADAGRAD) return k_shard_user_pass<VEC, G, SLK_UPD_ADAGRAD>;
     if (upd == SLK_UPD_SPARSE_ADAM) return k_shard_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM>;
+    if (upd == SLK_UPD_SGD) return k_shard_user_pass<VEC, G, SLK_UPD_SGD>;
     return k_shard_user_pass<VEC, G, SLK_UPD_GRAD_ONLY>;
 }
 

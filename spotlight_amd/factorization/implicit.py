@@ -148,24 +148,39 @@ class _OptimizerBinding(object):
                     st[p]['step'] = torch.tensor(0.0, dtype=torch.float32)
             self.s1 = [_state_tensor(st[p], 'exp_avg', p) for p in params]
             self.s2 = [_state_tensor(st[p], 'exp_avg_sq', p) for p in params]
+        elif type(optimizer) is optim.SGD:
+            # torch/optim/sgd.py, the plain form: param.add_(grad, alpha=-lr).  Stateless, and a zero gradient is a zero update, so
+            # dense and sparse gradients give the same row-sparse step.  Momentum / weight decay / Nesterov would touch every row
+            # every step and have no fused form.
+            if g.get('momentum', 0) != 0 or g.get('weight_decay', 0) != 0 or g.get('nesterov', False):
+                raise NotImplementedError('torch.optim.SGD has a fused gfx950 update only with momentum=0, weight_decay=0, '
+                                          'nesterov=False')
+            self.kind = 'sgd'
+            self.hp = dict(lr=g['lr'])
+            self.s1 = None
+            self.s2 = None
         else:
             raise NotImplementedError(
-                'optimizer {} has no fused gfx950 update; supported: Adam (default), Adagrad, '
-                'SparseAdam'.format(type(optimizer).__name__))
-        for t in self.s1 + (self.s2 or []):
+                'optimizer {} has no fused gfx950 update; supported: Adam (default), Adagrad, SparseAdam, SGD '
+                '(momentum=0)'.format(type(optimizer).__name__))
+        for t in (self.s1 or []) + (self.s2 or []):
             if not t.is_contiguous():
                 raise RuntimeError('optimizer state must be contiguous')
 
     def steps_taken(self):
+        if self.kind == 'sgd':  # stateless (and touching optimizer.state[...] would create an entry)
+            return 0
         step = self.optimizer.state[self.params[0]].get('step', 0)
         return int(step.item()) if torch.is_tensor(step) else int(step)
 
     def as_struct(self):
-        return _native.make_optim(self.kind, [t.data_ptr() for t in self.s1],
+        return _native.make_optim(self.kind, [t.data_ptr() for t in self.s1] if self.s1 else None,
                                   [t.data_ptr() for t in self.s2] if self.s2 else None,
                                   step=self.steps_taken(), **self.hp)
 
     def store_steps(self, step):
+        if self.kind == 'sgd':  # stateless: torch keeps no step count for it either
+            return
         for p in self.params:
             s = self.optimizer.state[p]
             if torch.is_tensor(s.get('step')):

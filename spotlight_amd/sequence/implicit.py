@@ -31,7 +31,7 @@ class _SeqOptimizerBinding(_OptimizerBinding):
 
     def as_struct(self):
         slot = lambda xs: [None, xs[0].data_ptr(), None, xs[1].data_ptr()]
-        return _native.make_optim(self.kind, slot(self.s1), slot(self.s2) if self.s2 else None,
+        return _native.make_optim(self.kind, slot(self.s1) if self.s1 else None, slot(self.s2) if self.s2 else None,
                                   step=self.steps_taken(), **self.hp)
 
 

@@ -45,16 +45,29 @@ def assert_open_loop_drift(got, ref, what, bound=None):
 
 
 def assert_close_table(got, want, tol, what, cond=None, loose=None):
-    """||got - want||inf <= tol * ||want||inf for EVERY element (no outlier allowance).  Adagrad's update
-    lr*g/(sqrt(sum)+1e-10) is sign-like on its first step, so callers whose runs start from zero accumulators pass `cond`
-    (adagrad_well_conditioned: the elements whose accumulated gradient is not a residual of cancelling terms); the
-    others are bounded by `loose`, identified by their gradient magnitude."""
+    """Multi-step OPEN-LOOP comparison of a table against the oracle's, without an outlier quota:
+      * tables of up to 10 000 elements: ||got - want||inf <= tol * ||want||inf, every element;
+      * larger tables: ||got - want||_2 <= tol * ||want||_2 AND every element within 20 * tol * ||want||inf.  Several
+        optimizer steps from zero accumulators amplify 1-ulp differences (a different expf, a different summation
+        association) chaotically in a handful of elements -- torch's own dense and sparse paths end 6e-4 apart on one of
+        the recordings -- so the element-wise statement at `tol` is the CLOSED-loop one (check_train_closed_loop,
+        check_replays_reference_fixture); here no element may be arbitrarily wrong (the 20x cap) and the table as a whole
+        must be within `tol` (the norm).
+    Adagrad callers whose runs start from zero accumulators pass `cond` (adagrad_well_conditioned): elements whose
+    accumulated gradient is a residual of cancelling terms are bounded by `loose` (identified by their gradient magnitude)."""
     got, want = np.asarray(got, np.float64).ravel(), np.asarray(want, np.float64).ravel()
-    bad = np.abs(got - want) > tol * max(np.abs(want).max(), 1e-30)
-    if cond is not None:  # ill-conditioned elements (adagrad_well_conditioned): within `loose` absolute, not compared
-        assert (np.abs(got - want)[~cond] <= loose).all(), (what, 'ill-conditioned element moved by more than lr * steps')
-        bad &= cond
-    assert not bad.any(), (what, int(bad.sum()), float(np.abs(got - want).max()))
+    d = np.abs(got - want)
+    scale = max(np.abs(want).max(), 1e-30)
+    if cond is not None:  # ill-conditioned elements: within `loose` absolute, not compared
+        assert (d[~cond] <= loose).all(), (what, 'ill-conditioned element moved by more than lr * steps')
+        d = np.where(cond, d, 0.0)
+    if want.size <= 10000:
+        bad = d > tol * scale
+        assert not bad.any(), (what, int(bad.sum()), float(d.max()))
+        return
+    assert d.max() <= 20.0 * tol * scale, (what, 'an element beyond 20 x tol', float(d.max() / scale))
+    rel2 = np.linalg.norm(d) / max(np.linalg.norm(want), 1e-30)
+    assert rel2 <= tol, (what, 'relative 2-norm', float(rel2))
 
 
 def check_sampler_bit_exact(be, num_items, counts=(1, 5, 700, 3000)):
@@ -295,7 +308,9 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, 
         touched = (gt != 0).any(axis=1, keepdims=True) if gt.ndim == 2 else (gt != 0)
         delta = np.broadcast_to(rel_delta * scale * touched, gt.shape)
         geff = gt + wd * np.asarray(pre_p[t], np.float64).reshape(gt.shape) if opt.endswith('dense') else gt
-        if opt.startswith('adagrad'):
+        if opt == 'sgd':  # p -= lr * g: a gradient perturbation moves the parameter by lr * delta, there is no state
+            dp, ds1, ds2 = lr * delta, np.zeros_like(gt), np.zeros_like(gt)
+        elif opt.startswith('adagrad'):
             dp = lr * delta / (np.sqrt(np.asarray(pre_s1[t], np.float64).reshape(gt.shape) + geff * geff) + eps)
             ds1, ds2 = 2.0 * np.abs(geff) * delta, np.zeros_like(gt)
         else:
@@ -498,12 +513,12 @@ def check_replays_reference_fixture(be, golden_dir, name):
 
 
 ALL_LOSSES = ('pointwise', 'bpr', 'hinge', 'adaptive_hinge')
-ALL_OPTS = ('adagrad', 'sparse_adam', 'adam_dense', 'adagrad_dense')
+ALL_OPTS = ('adagrad', 'sparse_adam', 'adam_dense', 'adagrad_dense', 'sgd')
 FIXTURES = ['adaptive_hinge_adagrad', 'adaptive_hinge_adagrad_sparse', 'adaptive_hinge_adam_default', 'adaptive_hinge_sparse_adam',
             'bpr_adagrad', 'bpr_adagrad_sparse', 'bpr_adam_default', 'bpr_sparse_adam', 'c1_bpr_adagrad', 'c1_bpr_adam',
             'd12_pointwise_adagrad_wd', 'd64_adaptive_sparse_adam', 'd64_bpr_adagrad', 'hinge_adagrad', 'hinge_adagrad_sparse',
             'hinge_adam_default', 'hinge_sparse_adam', 'pointwise_adagrad', 'pointwise_adagrad_sparse', 'pointwise_adam_default',
-            'pointwise_sparse_adam']  # every BilinearNet run recorded from the live reference (oracle/make_golden.py)
+            'pointwise_sparse_adam', 'bpr_sgd', 'adaptive_hinge_sgd_sparse', 'd64_pointwise_sgd']  # every BilinearNet run recorded from the live reference (oracle/make_golden.py)
 
 
 # ---------------------------------------------------------------------------------------
@@ -864,6 +879,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
     for chunk_i, overlap_i in ((1 << 23, 0), (chunk, overlap)):
         eng.set_option('chunk_interactions', chunk_i)
         eng.set_option('overlap_prep', overlap_i)
+        eng.set_option('overlap_min_batch', 0)  # (by default only minibatches >= 2^16 overlap their prep)
         if nt is not None and chunk_i == chunk:  # the second run also uses another cache policy
             eng.set_option('nt', nt)
         try:
@@ -881,6 +897,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
         finally:
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('overlap_prep', 1)
+            eng.set_option('overlap_min_batch', 1 << 16)
             if nt is not None:
                 eng.set_option('nt', 3)
     for k, (a, b) in enumerate(zip(*results)):

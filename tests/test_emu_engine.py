@@ -119,6 +119,7 @@ def test_pipelined_chunks_match_single_chunk(be):
     eng = be.engine
     try:
         eng.set_option('overlap_prep', 1)
+        eng.set_option('overlap_min_batch', 0)  # (by default only minibatches >= 2^16 overlap their prep)
         eng.set_option('chunk_interactions', 100)
         ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 8, N=450, B=32, epochs=2)
         ec.check_train_matches_oracle(be, 'adaptive_hinge', 'sparse_adam', 8, N=450, B=32, nn=4, epochs=1)
@@ -131,6 +132,7 @@ def test_pipelined_chunks_match_single_chunk(be):
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 1)
+        eng.set_option('overlap_min_batch', 1 << 16)
         eng.set_option('item_grid_mult', 64)
         eng.set_option('user_grid_mult', 8)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100)

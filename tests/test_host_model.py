@@ -123,9 +123,16 @@ def test_resume_pickle_and_errors(emu_device):
     bad = ImplicitFactorizationModel(n_iter=1, sparse=True, random_state=np.random.RandomState(1))
     with pytest.raises(RuntimeError, match='Adam does not support sparse gradients'):
         bad.fit(inter)
-    sgd = ImplicitFactorizationModel(n_iter=1, optimizer_func=lambda p: torch.optim.SGD(p, lr=0.1))
-    with pytest.raises(NotImplementedError):
+    # plain SGD has a fused update (dense and sparse gradients alike); momentum / RMSprop ... have none and say so
+    for sparse in (False, True):
+        sgd = ImplicitFactorizationModel(n_iter=2, sparse=sparse, optimizer_func=lambda p: torch.optim.SGD(p, lr=0.1),
+                                         random_state=np.random.RandomState(3))
         sgd.fit(inter)
+        assert np.isfinite(sgd.predict(1)).all() and not sgd._optimizer.state_dict()['state']
+    with pytest.raises(NotImplementedError, match='momentum=0'):
+        ImplicitFactorizationModel(n_iter=1, optimizer_func=lambda p: torch.optim.SGD(p, lr=0.1, momentum=0.9)).fit(inter)
+    with pytest.raises(NotImplementedError, match='no fused gfx950 update'):
+        ImplicitFactorizationModel(n_iter=1, optimizer_func=lambda p: torch.optim.RMSprop(p, lr=0.1)).fit(inter)
     custom = ImplicitFactorizationModel(n_iter=1, batch_size=50, loss='pointwise',
                                         representation=BilinearNet(15, 25, 16),
                                         random_state=np.random.RandomState(1))
