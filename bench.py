@@ -69,17 +69,21 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--users', type=int, default=10_000_000)
-    ap.add_argument('--items', type=int, default=1_000_000)
+    ap.add_argument('--users', type=int, default=None, help='user rows per GPU (default: the workload\'s)')
+    ap.add_argument('--items', type=int, default=None, help='item rows per GPU (default: the workload\'s)')
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--batch', type=int, default=1 << 20)
     ap.add_argument('--loss', default='bpr')
     ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam', 'adam_dense'],
                     help='adam_dense = the reference default: Adam(lr=1e-2, weight_decay=1e-6) over every row every step')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3', 'c4', 'c5'],
-                    help='c2: BilinearNet BPR step (the headline metric); c3: adaptive hinge n=5 over a BloomEmbedding '
-                         'item table, dim 128; c4: PoolNet sequence step; c5: the per-GPU shard of the 1B-item x '
-                         '100M-user table (12.5M users x 125M items per GPU; at --gpus 8 the full C5)')
+    ap.add_argument('--workload', default=None, choices=['c2', 'c3', 'c4', 'c5'],
+                    help='c2: BilinearNet BPR step (the headline metric; the default at --gpus 1); c3: adaptive hinge n=5 over a '
+                         'BloomEmbedding item table, dim 128; c4: PoolNet sequence step; c5: the per-GPU shard of the 1B-item x '
+                         '100M-user table (12.5M users x 125M items per GPU; at --gpus 8 the full C5; the default at --gpus > 1: '
+                         'the row-sharded configuration BASELINE.json names).  Explicit --users / --items override the shape.')
+    ap.add_argument('--no-denominators', action='store_true',
+                    help='N > 1: skip rank 0\'s world-1 runs of the same per-GPU shape (fused path, row-sharded path) that give '
+                         'the scaling factor its stated denominators')
     ap.add_argument('--seq-len', type=int, default=200)
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
@@ -108,7 +112,14 @@ def parse():
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=30.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    custom = args.users is not None or args.items is not None
+    if args.workload is None:
+        args.workload = 'c5' if (args.gpus > 1 and not custom) else 'c2'
+    shape = {'c5': (12_500_000, 125_000_000)}.get(args.workload, (10_000_000, 1_000_000))
+    args.users = args.users if args.users is not None else shape[0]
+    args.items = args.items if args.items is not None else shape[1]
+    return args
 
 
 def reference_cpu_baseline(args, seconds):
@@ -450,7 +461,7 @@ def fit_end_to_end(be, args):
     """The drop-in API around the engine, end to end: ImplicitFactorizationModel.fit() (spotlight/factorization/implicit.py:184-252)
     on the workload's shapes -- per epoch the numpy-exact device shuffle, the id gathers, every minibatch, the loss read-back; the
     ids are uploaded once per fit() (host -> HBM, included).  One warm fit() first (table initialisation, scratch), then a timed
-    fit() of 2 epochs."""
+    fit() of 3 epochs."""
     from spotlight_amd.factorization.implicit import ImplicitFactorizationModel
     from spotlight_amd.interactions import Interactions
     n = int(args.fit_interactions)
@@ -466,12 +477,13 @@ def fit_end_to_end(be, args):
     model.fit(inter)
     be.sync()
     first = time.perf_counter() - t0
-    model._n_iter = 2
+    epochs = 3  # the id upload amortises over the epochs as it does for a user (the reference's default n_iter is 10)
+    model._n_iter = epochs
     t0 = time.perf_counter()
     model.fit(inter)
     be.sync()
-    dt = (time.perf_counter() - t0) / 2
-    return {'interactions_per_epoch': n, 'epochs_timed': 2, 'seconds_per_epoch': dt, 'interactions_per_s': n / dt,
+    dt = (time.perf_counter() - t0) / epochs
+    return {'interactions_per_epoch': n, 'epochs_timed': epochs, 'seconds_per_epoch': dt, 'interactions_per_s': n / dt,
             'first_fit_seconds': first,
             'what': 'ImplicitFactorizationModel.fit(): id upload (once per fit), per epoch the numpy-exact device shuffle + id '
                     'gathers + %d minibatches + the loss read-back; first_fit_seconds also holds table initialisation on the '
@@ -490,8 +502,6 @@ def main():
         return bench_c4(args)
     if args.workload == 'c3':
         return bench_c3(args)
-    if args.workload == 'c5':
-        args.users, args.items = 12_500_000, 125_000_000
     # libraries (RCCL's version banner, rocm-smi) write to fd 1; keep stdout clean for the ONE
     # JSON line the driver parses: everything else goes to stderr until the final print.
     sys.stdout.flush()
@@ -607,6 +617,46 @@ def main():
         dist.all_gather_object(seen, ranks_seen[0])
         ranks_seen = seen
         assert dist.get_world_size() == world == args.gpus or args.sharded, (dist.get_world_size(), world, args.gpus)
+    denominators = None
+    if world > 1 and not args.no_denominators:
+        # What the N-GPU value is a multiple OF (--gpus 1 runs the fused path on C2, --gpus N the row-sharded
+        # path): rank 0 runs the SAME per-GPU shape alone, through the fused path and through the row-sharded path at world 1.
+        g1 = dist.new_group([0])  # every rank makes the call
+        if rank == 0:
+            try:
+                from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
+                denominators = {}
+                for path in ('fused', 'sharded_world1'):
+                    for t in tables + s1 + (s2 or []):
+                        t.zero_()
+                    for t in tables[:2]:
+                        t.normal_(0, 1.0 / D, generator=gen)
+                    op1 = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None, lr=1e-2)
+                    it1 = items % I
+                    mb1 = torch.zeros(W + K, device=dev)
+                    if path == 'fused':
+                        eng.bilinear_reserve(tb, op1, K * B, B, args.loss, 1, stream=stream)
+                        go = lambda lo, nmb: eng.bilinear_train(tb, op1, users[lo * B:].data_ptr(), it1[lo * B:].data_ptr(), nmb * B, B,
+                                                                args.loss, 1, mb1[lo:].data_ptr(), stream=stream)
+                    else:
+                        tr1 = ShardedBilinearTrainer(eng, tables, op1, I, group=g1, stream=stream, slices=args.slices or None)
+                        tr1.reserve(B, args.shard_chunk)
+                        go = lambda lo, nmb: tr1.train(users[lo * B:(lo + nmb) * B], it1[lo * B:(lo + nmb) * B], B, loss=args.loss,
+                                                       mb_loss=mb1[lo:lo + nmb], sample_chunk=args.shard_chunk)
+                    if W:
+                        go(0, W)
+                    be.sync()
+                    t1 = time.perf_counter()
+                    go(W, K)
+                    be.sync()
+                    dt = time.perf_counter() - t1
+                    denominators[path] = {'interactions_per_s': K * B / dt, 'ms_per_step': dt / K * 1e3}
+                denominators['note'] = ('rank 0 alone, after the timed region, on the same per-GPU shape (%d users x %d items, minibatch %d): '
+                                        'the fused single-GPU path and the row-sharded path at world 1 (every exchange a local copy)'
+                                        % (U, I, B))
+            except Exception as e:
+                denominators = {'error': repr(e)[:300]}
+        dist.barrier()
     probes = ceiling = shard_check = None
     if rank == 0 and world == 1 and trainer is None and not args.no_probes:
         probes = measured_stream_rates(be, stream)
@@ -678,6 +728,17 @@ def main():
             roof['xgmi'].update({'link_peak_GBs_each_way': peak,
                                  'achieved_GBs_each_way_over_the_whole_step': xb / (elapsed / K) / 1e9,
                                  'min_ms_per_step_at_link_peak': xb / (peak * 1e9) * 1e3 if world > 1 else 0.0})
+            if world > 1:
+                # the curve is to be read against the wire, not against N x one GPU: every interaction moves, per GPU and direction,
+                # 2 lookups x (N-1)/N remote x (id 4 B + row (D+1)*4 B, then gradient (D+1)*4 B) over N-1 links of 76.8 GB/s
+                roof['xgmi']['bound_%d_gpus' % world] = {
+                    'interactions_per_s_at_link_peak': world * B / (xb / (peak * 1e9)),
+                    'note': 'whole-job rate at which the exchange alone saturates every xGMI link (exact fp32 rows on the wire)'}
+                if denominators is not None:
+                    roof['xgmi']['denominators_1_gpu'] = denominators
+                    for k in ('fused', 'sharded_world1'):
+                        if isinstance(denominators.get(k), dict):
+                            denominators[k]['scaling_factor_of_this_run'] = value / denominators[k]['interactions_per_s']
             if world == 1:
                 # a MODEL, not a measurement: what this rank's measured kernel time and the wire allow at 8 GPUs.  Per
                 # direction a GPU moves, for 7/8 of its 2B lookups, the id + the row (as requester in, as owner out)

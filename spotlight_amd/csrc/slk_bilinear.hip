@@ -68,17 +68,17 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     const uint32_t stride = gridDim.x * GPB;
     float loss_acc = 0.0f;
 
-    // ULONG: sweep k of the grid-stride loop is rotated by k row groups.  The segments of a long run start at every
-    // SLK_USER_TILE-th position; with a stride that is a multiple of the tile the plain map would hand ALL of them to
-    // 1 / SLK_USER_TILE of the row groups (measured: Zipf(1.0) users 2.9 ms per pass instead of ~0.5).
-    for (uint32_t p0 = a.begin, sweep = 0; p0 < a.end; p0 += stride, ++sweep) {
-        uint32_t p = p0 + blockIdx.x * GPB + grp;
-        if (ULONG) {
-            uint32_t off = blockIdx.x * GPB + grp + sweep % stride;
-            if (off >= stride) off -= stride;
-            p = p0 + off;
-        }
-        if (p >= a.end) continue;
+    // Plain form: row group g takes positions g, g + stride, ... (one position per turn).  ULONG: row group g takes TILES g,
+    // g + stride, ... and walks the positions of a tile itself, run piece by run piece.  A segment of a long run is one tile's
+    // worth of occurrences walked by ONE row group; with one position per turn the segment heads (every SLK_USER_TILE-th
+    // position) land on one row group of a wavefront while its other three idle behind the divergent walk -- measured,
+    // profiles/r03_c_*, r03_d_*: Zipf(1.0) users 2.0-2.9 ms per pass.  With a tile per row group the four groups of a
+    // wavefront each walk their own tile, hot or not, at the plain form's memory parallelism.
+    const uint32_t n_turns = ULONG ? (a.end - a.begin + S - 1u) / S : a.end - a.begin;
+    for (uint32_t turn = blockIdx.x * GPB + grp; turn < n_turns; turn += stride) {
+    const uint32_t p_lo = a.begin + (ULONG ? turn * S : turn);
+    const uint32_t p_hi = ULONG ? (p_lo + S < a.end ? p_lo + S : a.end) : p_lo + 1u;
+    for (uint32_t p = p_lo; p < p_hi; ++p) {
         const bool nt_keys = (SLK_NT_OF(a) & 8) != 0;
         const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
         uint32_t lat_ip = 0u, lat_in = 0u;
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                                              (ends ? (uint32_t)SLK_IPART_ENDS : 0u);
                 if (is_head) atomicAdd(a.upart_count, 1u);
             }
+            p = q - 1u;  // (a run that ends inside the tile: the walk goes on with the run behind it)
             continue;
         }
         if (BLOOM && a.ub.n_hash) {
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         } else if (lane == 0) {
             slk_apply_bias<UPD>(a, 2, user, gbu);
         }
+        if (ULONG) p = q - 1u;  // the run's other positions (in this tile; beyond it the loop ends) are done
+    }
     }
     if (!PRE || EXPL) {
         const double tot = slk_block_sum_256((double)loss_acc, red);
@@ -290,8 +293,9 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
             uint32_t f = 0u;
             if (tl < ntiles) {
                 const size_t sl = 2 * (size_t)tl;
-                f = a.upart_meta[2 * sl + 1];
-                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || a.upart_meta[2 * sl] != key) f = 0u;
+                const uint2 kf = *reinterpret_cast<const uint2 *>(a.upart_meta + 2 * sl);  // {key, flags}: one 8-B load
+                f = kf.y;
+                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || kf.x != key) f = 0u;
                 else f |= 1u;
             }
             int cnt = 0;
@@ -302,14 +306,27 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                 ++cnt;
                 ended = (f2 & SLK_IPART_ENDS) != 0;
             }
-            for (int l = 0; l < cnt; ++l) {
-                const float *q = a.upart + 2 * (size_t)(t2 + (uint32_t)l) * (size_t)a.UPS;
-                if (on) {
-                    const slk_vec<VEC> cc = slk_vload<VEC>(q + d0);
+            for (int l0 = 0; l0 < cnt; l0 += SLK_STITCH_BATCH) {  // loads in batches, adds in tile order (k_item_stitch)
+                slk_vec<VEC> cc[SLK_STITCH_BATCH];
+                float cb[SLK_STITCH_BATCH];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) gu.v[i] += cc.v[i];
+                for (int e = 0; e < SLK_STITCH_BATCH; ++e) {
+                    cc[e] = slk_vzero<VEC>();
+                    cb[e] = 0.0f;
+                    if (l0 + e < cnt) {
+                        const float *q = a.upart + 2 * (size_t)(t2 + (uint32_t)(l0 + e)) * (size_t)a.UPS;
+                        if (on) cc[e] = slk_vload<VEC>(q + d0);
+                        cb[e] = q[a.UPS - 1];
+                    }
                 }
-                gbu += q[a.UPS - 1];
+#pragma unroll
+                for (int e = 0; e < SLK_STITCH_BATCH; ++e) {
+                    if (l0 + e < cnt) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gu.v[i] += cc[e].v[i];
+                        gbu += cb[e];
+                    }
+                }
             }
             more = !ended && cnt == G;
             t2 += (uint32_t)G;

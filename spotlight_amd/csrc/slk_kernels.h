@@ -333,6 +333,11 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 #define SLK_USER_TILE 32  // user pass: a user run that wholly covers an aligned tile of this many positions is LONG (k_user_pass<ULONG>)
 #endif
 
+#ifndef SLK_STITCH_BATCH
+#define SLK_STITCH_BATCH 8  // partials of a long run in flight per row group in the stitch kernels (a dynamic-trip-count loop of
+                            // dependent load + add round trips otherwise: ~1 us per tile of a run that fills thousands)
+#endif
+
 #ifndef SLK_SPILL_BATCH
 #define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
 #endif
@@ -724,8 +729,9 @@ __global__ __launch_bounds__(256) void k_item_stitch(slk_pass_args a) {
             uint32_t f = 0u;
             if (tl < ntiles) {
                 const size_t sl = 2 * (size_t)tl;
-                f = a.ipart_meta[2 * sl + 1];
-                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || a.ipart_meta[2 * sl] != key) f = 0u;
+                const uint2 kf = *reinterpret_cast<const uint2 *>(a.ipart_meta + 2 * sl);  // {key, flags}: one 8-B load
+                f = kf.y;
+                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || kf.x != key) f = 0u;
                 else f |= 1u;  // bit 0: part of this run
             }
             // cnt = tiles of this batch that belong to the run: up to and including the first one that ends it
@@ -738,14 +744,28 @@ __global__ __launch_bounds__(256) void k_item_stitch(slk_pass_args a) {
                 any = any || (fl2 & SLK_IPART_ANY) != 0;
                 ended = (fl2 & SLK_IPART_ENDS) != 0;
             }
-            for (int l = 0; l < cnt; ++l) {
-                const float *q = a.ipart + 2 * (size_t)(t2 + (uint32_t)l) * (size_t)a.IPS;
-                if (rows_on) {
-                    const slk_vec<VEC> cc = slk_vload<VEC>(q + d0);
+            // the partials of the batch: loaded SLK_STITCH_BATCH at a time (independent loads in flight), added in tile order
+            for (int l0 = 0; l0 < cnt; l0 += SLK_STITCH_BATCH) {
+                slk_vec<VEC> cc[SLK_STITCH_BATCH];
+                float cb[SLK_STITCH_BATCH];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) gv.v[i] += cc.v[i];
+                for (int e = 0; e < SLK_STITCH_BATCH; ++e) {
+                    cc[e] = slk_vzero<VEC>();
+                    cb[e] = 0.0f;
+                    if (l0 + e < cnt) {
+                        const float *q = a.ipart + 2 * (size_t)(t2 + (uint32_t)(l0 + e)) * (size_t)a.IPS;
+                        if (rows_on) cc[e] = slk_vload<VEC>(q + d0);
+                        cb[e] = q[a.IPS - 1];
+                    }
                 }
-                gb += q[a.IPS - 1];
+#pragma unroll
+                for (int e = 0; e < SLK_STITCH_BATCH; ++e) {
+                    if (l0 + e < cnt) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gv.v[i] += cc[e].v[i];
+                        gb += cb[e];
+                    }
+                }
             }
             more = !ended && cnt == G;
             t2 += (uint32_t)G;

@@ -81,7 +81,9 @@ def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
     drawn from the engine's RNG state (slk_shuffle_perm: the reference's `shuffle`, torch_utils.py:35-52).
     If the device shuffle reports a failure (it cannot, short of a 12-sigma rejection tail) the
     permutation is drawn by numpy on the host from `random_state`, as the reference does, and the
-    engine's RNG state is re-synchronised -- the results are identical either way."""
+    engine's RNG state is re-synchronised -- the results are identical either way.
+    `arrays` may be a callable returning the list: it is called AFTER the permutation has been drawn (the permutation
+    needs only n, so an upload of the ids can still be in flight while it is computed: IdUpload)."""
     try:
         engine.shuffle_perm(n, d_perm.data_ptr(), stream=stream)
     except _native.SlkError:
@@ -89,8 +91,41 @@ def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
         random_state.shuffle(order)
         d_perm.copy_(torch.from_numpy(order))
         engine.rng_set_state(random_state.get_state())
+    if callable(arrays):
+        arrays = arrays()
     for d_src, d_dst, row_len in arrays:
         engine.gather_rows_i64(d_src.data_ptr(), d_perm.data_ptr(), n, row_len, d_dst.data_ptr(), stream=stream)
+
+
+class IdUpload(object):
+    """The host -> HBM copy of fit()'s id arrays on a worker thread (ids_to_device; the copies release the GIL), so that the
+    first epoch's permutation -- which needs only len(ids) -- is drawn on the GPU meanwhile.  result() joins and returns the
+    int64 device tensors; the copies run on the worker's (default) stream, and a pageable copy has completed when the call
+    returns, so after the join the data is in place for any stream."""
+
+    def __init__(self, arrays, device):
+        import threading
+        self._out = [None] * len(arrays)
+        self._err = []
+
+        def work():
+            try:
+                if device.type == 'cuda':
+                    torch.cuda.set_device(device)
+                for k, a in enumerate(arrays):
+                    self._out[k] = ids_to_device(a, device)
+                if device.type == 'cuda':
+                    torch.cuda.current_stream(device).synchronize()  # the widening kernels on this thread's stream
+            except BaseException as e:  # re-raised by result()
+                self._err.append(e)
+        self._thread = threading.Thread(target=work, name='spotlight-id-upload')
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if self._err:
+            raise self._err[0]
+        return self._out
 
 
 def _reject_negative_ids(ids):
@@ -312,21 +347,28 @@ class ImplicitFactorizationModel(object):
 
         engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
                                 self._num_negative_samples, stream=stream)
-        # ids go to the device once; every epoch's permutation x[shuffle_indices] of them
-        # (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
-        d_users0 = ids_to_device(user_ids, device)
-        d_items0 = ids_to_device(item_ids, device)
+        # ids go to the device once (on a worker thread: the first epoch's permutation is drawn meanwhile); every epoch's
+        # permutation x[shuffle_indices] of them (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
+        upload = IdUpload([user_ids, item_ids], device)
         nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
         if self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS:
+            d_users0, d_items0 = upload.result()
             return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose)
-        d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
+        d_users = torch.empty(n, dtype=torch.int64, device=device)
+        d_items = torch.empty(n, dtype=torch.int64, device=device)
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
+        d_users0 = d_items0 = None
+
+        def sources():
+            nonlocal d_users0, d_items0
+            if d_users0 is None:
+                d_users0, d_items0 = upload.result()
+            return [(d_users0, d_users, 1), (d_items0, d_items, 1)]
         for epoch_num in range(self._n_iter):
             # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as
             # numpy would consume it on the host
             engine.rng_set_state(self._random_state.get_state())
-            device_epoch_shuffle(engine, self._random_state, n, d_perm, [(d_users0, d_users, 1), (d_items0, d_items, 1)],
-                                 stream)
+            device_epoch_shuffle(engine, self._random_state, n, d_perm, sources, stream)
             ostruct = binding.as_struct()
             engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
                                   self._batch_size, self._loss, self._num_negative_samples,

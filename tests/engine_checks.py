@@ -1274,7 +1274,11 @@ def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41):
             eng.set_option('item_long_gate', 1)
             eng.set_option('epoch_kernel', 1)
     for k, (a, b) in enumerate(zip(*results)):
-        assert np.array_equal(a, b), ('tensor %d differs between the gated and the ungated item pass' % k)
+        if k == 0:  # the minibatch losses: the two forms of the user pass hand positions to row groups differently, so the fp32
+            # per-thread loss sums associate differently (the model state below does not depend on them)
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (a, b)
+            continue
+        assert np.array_equal(a, b), ('tensor %d differs between the gated and the ungated passes' % k)
 
 
 # ---------------------------------------------------------------------------------------

@@ -57,7 +57,14 @@ def test_gpus_n_spawns_n_ranks_itself(n):
     assert sorted(d['rank'] for d in rec['ranks']['devices']) == list(range(n))
     assert rec['ranks']['launched_by'].startswith('bench.py')
     assert rec['config']['global_batch'] == 256 * n and rec['scaling'] == 'weak'
-    assert rec['roofline']['xgmi']['rows_per_step_per_gpu'] > 0
+    xg = rec['roofline']['xgmi']
+    assert xg['rows_per_step_per_gpu'] > 0
+    # the curve's stated bound and denominators: the wire bound of this world size, and rank 0's own
+    # world-1 runs of the same per-GPU shape through the fused and the row-sharded path
+    assert xg['bound_%d_gpus' % n]['interactions_per_s_at_link_peak'] > 0
+    den = xg['denominators_1_gpu']
+    assert den['fused']['interactions_per_s'] > 0 and den['sharded_world1']['interactions_per_s'] > 0
+    assert abs(den['fused']['scaling_factor_of_this_run'] * den['fused']['interactions_per_s'] - rec['value']) < 1e-6 * rec['value']
 
 
 def test_world_size_mismatch_fails_loudly():
