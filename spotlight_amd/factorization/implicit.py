@@ -232,8 +232,13 @@ class ImplicitFactorizationModel(object):
 
     * `use_cuda` is accepted for signature compatibility; the model always lives on the HIP
       device (there is no CPU path).
-    * `representation` may be a :class:`BilinearNet`; arbitrary modules have no fused kernel
-      and raise NotImplementedError.
+    * `representation` may be a :class:`BilinearNet` (fused kernels) or any torch module with the reference's
+      `forward(user_ids, item_ids)` contract; a custom module, or an `optimizer_func` whose optimizer has no fused update
+      (anything but Adam / Adagrad / SparseAdam / plain SGD), trains through the AUTOGRAD ROUTE: the reference's own
+      minibatch loop (implicit.py:208-252) in stock PyTorch-ROCm ops on the HIP device -- host numpy shuffle and
+      negatives exactly as the reference draws them, the embedding gathers and their backward through this package's
+      kernels when the module is built from this package's layers.  Slower than the fused path by the reference's own
+      per-minibatch overheads, never on the CPU.
     """
 
     def __init__(self, loss='pointwise', embedding_dim=32, n_iter=10, batch_size=256, l2=0.0,
@@ -261,6 +266,7 @@ class ImplicitFactorizationModel(object):
         self._optimizer = None
         self._loss_func = None
         self._binding = None
+        self._autograd_route = False
 
         # consumes one draw of the stream, like the reference (implicit.py:114-115)
         set_seed(self._random_state.randint(-10**8, 10**8), cuda=self._use_cuda)
@@ -279,18 +285,21 @@ class ImplicitFactorizationModel(object):
 
     def _initialize(self, interactions):
         self._num_users, self._num_items = interactions.num_users, interactions.num_items
+        self._autograd_route = False
         if self._representation is not None:
             net = self._representation
-            if not isinstance(net, BilinearNet):
-                raise NotImplementedError('only BilinearNet representations have a fused gfx950 path')
         else:
             net = BilinearNet(self._num_users, self._num_items, self._embedding_dim,
                               sparse=self._sparse)
-        for layer in (net.user_embeddings, net.item_embeddings):
-            if not isinstance(layer, (ScaledEmbedding, BloomEmbedding)) and type(layer) is not torch.nn.Embedding:
-                raise NotImplementedError('embedding layer {} has no fused gfx950 path yet'
-                                          .format(type(layer).__name__))
-        assert isinstance(net.user_biases, (ZeroEmbedding, torch.nn.Embedding))
+        if not isinstance(net, BilinearNet):
+            self._autograd_route = True  # an arbitrary module: the reference's loop through autograd (see the class docstring)
+            self._batch_scores = None    # (evaluation's whole-table fast path needs BilinearNet's tables; predict() serves it)
+        else:
+            for layer in (net.user_embeddings, net.item_embeddings):
+                if not isinstance(layer, (ScaledEmbedding, BloomEmbedding)) and type(layer) is not torch.nn.Embedding:
+                    self._autograd_route = True
+            if not isinstance(net.user_biases, (ZeroEmbedding, torch.nn.Embedding)):
+                self._autograd_route = True
         self._net = net.to(_model_device())
 
         if self._optimizer_func is None:
@@ -300,6 +309,13 @@ class ImplicitFactorizationModel(object):
             self._optimizer = self._optimizer_func(self._net.parameters())
         self._loss_func = self._loss  # the loss is fused into the kernel; kept for introspection
         self._binding = None
+        if not self._autograd_route:
+            try:
+                self._bind()
+            except NotImplementedError:
+                # an optimizer without a fused update (RMSprop, SGD with momentum, ...): the reference accepts any
+                # optimizer_func (implicit.py:150), so does this model -- through the autograd route
+                self._autograd_route = True
 
     def _bind(self):
         if self._binding is None:
@@ -336,6 +352,8 @@ class ImplicitFactorizationModel(object):
 
         self._check_input(user_ids, item_ids)
 
+        if getattr(self, '_autograd_route', False):
+            return self._fit_autograd(user_ids, item_ids, verbose)
         binding = self._bind()
         device = self._net.tables()[0].device
         engine = _engine_for(device)
@@ -430,11 +448,63 @@ class ImplicitFactorizationModel(object):
                 self._random_state.set_state(state_after_epoch)
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
 
+    def _fit_autograd(self, user_ids, item_ids, verbose):
+        """The reference's epoch / minibatch loop (implicit.py:208-252, 254-275) for models without a fused path: host numpy
+        shuffle and negatives from `random_state` (the reference's exact consumption of the stream), forward / loss /
+        backward / optimizer.step() as stock torch ops on the HIP device."""
+        from spotlight_amd import losses as _losses
+        from spotlight_amd.sampling import sample_items
+        from spotlight_amd.torch_utils import minibatch, shuffle
+        loss_func = {'pointwise': _losses.pointwise_loss, 'bpr': _losses.bpr_loss, 'hinge': _losses.hinge_loss,
+                     'adaptive_hinge': _losses.adaptive_hinge_loss}[self._loss]
+        device = next(self._net.parameters()).device
+        self._net.train(True)
+
+        def negatives_for(batch_user, n_draws):
+            return torch.from_numpy(sample_items(self._num_items, n_draws, random_state=self._random_state)).to(device)
+
+        for epoch_num in range(self._n_iter):
+            users, items = shuffle(user_ids, item_ids, random_state=self._random_state)
+            user_ids_tensor = torch.from_numpy(np.ascontiguousarray(users).astype(np.int64)).to(device)
+            item_ids_tensor = torch.from_numpy(np.ascontiguousarray(items).astype(np.int64)).to(device)
+            epoch_loss, n_mb = 0.0, 0
+            for batch_user, batch_item in minibatch(user_ids_tensor, item_ids_tensor, batch_size=self._batch_size):
+                positive_prediction = self._net(batch_user, batch_item)
+                if self._loss == 'adaptive_hinge':
+                    # implicit.py:266-275: users repeated user-major, ONE draw of B * n, scores viewed as [n, B]
+                    n = self._num_negative_samples
+                    batch_size = batch_user.size(0)
+                    negative_items = negatives_for(batch_user, batch_size * n).view(batch_size * n)
+                    batch_user_rep = batch_user.view(batch_size, 1).expand(batch_size, n).reshape(-1)
+                    negative_prediction = self._net(batch_user_rep, negative_items).view(n, batch_size)
+                else:
+                    negative_prediction = self._net(batch_user, negatives_for(batch_user, len(batch_user)))
+                self._optimizer.zero_grad()
+                loss = loss_func(positive_prediction, negative_prediction)
+                epoch_loss += loss.item()
+                loss.backward()
+                self._optimizer.step()
+                n_mb += 1
+            epoch_loss /= n_mb
+            if verbose:
+                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+            if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+
     def predict(self, user_ids, item_ids=None):
         """Scores for one user against all/some items, or for explicit (user, item) pairs;
         returns a flat np.float32 array (implicit.py:277-311)."""
         self._check_input(user_ids, item_ids, allow_items_none=True)
         self._net.train(False)
+
+        if getattr(self, '_autograd_route', False) and not isinstance(self._net, BilinearNet):
+            # a custom module scores with its own forward, as in the reference
+            users, items, n = _predict_process_ids(user_ids, item_ids, self._num_items)
+            device = next(self._net.parameters()).device
+            d_users = torch.from_numpy(np.broadcast_to(users, (n,)).astype(np.int64)).to(device)
+            d_items = torch.from_numpy(items if items is not None else np.arange(self._num_items, dtype=np.int64)).to(device)
+            with torch.no_grad():
+                return self._net(d_users, d_items).cpu().numpy().flatten()
 
         users, items, n = _predict_process_ids(user_ids, item_ids, self._num_items)
         device = self._net.tables()[0].device

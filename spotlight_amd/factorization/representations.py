@@ -44,9 +44,18 @@ class BilinearNet(nn.Module):
                                    user_bloom=bloom[0], item_bloom=bloom[1])
 
     def forward(self, user_ids, item_ids):
-        """score[k] = <U[user_k], V[item_k]> + bu[user_k] + bi[item_k]  (no autograd: the
-        backward of this model lives in the fused training kernels)."""
+        """score[k] = <U[user_k], V[item_k]> + bu[user_k] + bi[item_k]  (factorization/representations.py:61-91).
+        In eval mode or under torch.no_grad() -- prediction -- this is the fused predict kernel.  In training mode with autograd recording (the model's
+        autograd route: an optimizer without a fused update) the four gathers go through the layers' own lookups
+        (spotlight_amd/embedding.py: gfx950 gather forward, sorted-ownership scatter backward) and the product / sum through
+        torch, exactly the reference's expression, so that loss.backward() reaches the tables."""
         from spotlight_amd.factorization import implicit as host
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            user_embedding = self.user_embeddings(user_ids).squeeze()
+            item_embedding = self.item_embeddings(item_ids).squeeze()
+            user_bias = self.user_biases(user_ids).squeeze()
+            item_bias = self.item_biases(item_ids).squeeze()
+            return (user_embedding * item_embedding).sum(1) + user_bias + item_bias
         w = self.tables()
         if w[0].device.type != host._model_device().type:
             raise RuntimeError('BilinearNet.forward runs on the HIP device only (no CPU path)')

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
+import engine_checks as ec
 from emu_backend import emu_lib
 from oracle.replay import case_from_rec
 from spotlight_amd import _native
@@ -38,6 +39,10 @@ def _optimizer_factory(kind):
         return lambda params: torch.optim.SparseAdam(list(params), lr=0.01)
     if kind == 'adagrad_dense_wd':
         return lambda params: torch.optim.Adagrad(params, lr=0.05, weight_decay=1e-3)
+    if kind in ('sgd', 'sgd_sparse'):
+        return lambda params: torch.optim.SGD(params, lr=0.05)
+    if kind == 'rmsprop':
+        return lambda params: torch.optim.RMSprop(params, lr=0.01)
     raise ValueError(kind)
 
 
@@ -50,12 +55,13 @@ def _model_for(case):
         loss=str(case['loss']), embedding_dim=int(case['D']), n_iter=int(case['n_iter']),
         batch_size=int(case['B']), l2=float(case.get('l2', 0.0)), learning_rate=float(case.get('lr', 1e-2)),
         optimizer_func=_optimizer_factory(str(case['opt'])),
-        sparse=str(case['opt']) in ('adagrad_sparse', 'sparse_adam'),
+        sparse=str(case['opt']) in ('adagrad_sparse', 'sparse_adam', 'sgd_sparse'),
         random_state=np.random.RandomState(int(case['seed'])), num_negative_samples=int(case.get('n_neg', 5)))
 
 
 @pytest.mark.parametrize('name', ['bpr_adam_default', 'hinge_adagrad_sparse', 'pointwise_sparse_adam',
-                                  'adaptive_hinge_adagrad', 'c1_bpr_adam'])
+                                  'adaptive_hinge_adagrad', 'c1_bpr_adam', 'bpr_sgd', 'adaptive_hinge_sgd_sparse',
+                                  'bpr_rmsprop', 'adaptive_hinge_rmsprop'])
 def test_fit_predict_match_reference_run(emu_device, name):
     rec = np.load(os.path.join(GOLDEN, name + '.npz'))
     case = case_from_rec(rec)
@@ -70,8 +76,7 @@ def test_fit_predict_match_reference_run(emu_device, name):
     assert (st[1] == rec['rng_key_after_fit']).all() and st[2] == int(rec['rng_pos_after_fit'])
     for t, w in enumerate(model._net.tables()):
         ref = rec['final_%d' % t]
-        bad = np.abs(w.detach().numpy().reshape(ref.shape) - ref) > 1e-3 * np.abs(ref).max()
-        assert bad.mean() <= 0.05
+        ec.assert_open_loop_drift(w.detach().numpy().reshape(ref.shape), ref, (name, t))
     pred = model.predict(3)
     assert pred.dtype == np.float32 and pred.shape == (int(case['I']),)
     assert np.abs(pred - rec['predict_user3_all']).max() <= 2e-3 * np.abs(rec['predict_user3_all']).max()
@@ -79,7 +84,10 @@ def test_fit_predict_match_reference_run(emu_device, name):
     assert np.abs(pairs - rec['predict_pairs']).max() <= 2e-3 * np.abs(rec['predict_pairs']).max()
     # optimizer bookkeeping stays where torch expects it
     steps = int(case['n_iter']) * ((int(case['N']) + int(case['B']) - 1) // int(case['B']))
-    assert model._binding.steps_taken() == steps
+    if 'rmsprop' in name:  # no fused update: the reference's loop through autograd, on the device
+        assert model._autograd_route and model._binding is None
+    elif 'sgd' not in name:  # (plain SGD keeps no step count, in torch or here)
+        assert model._binding.steps_taken() == steps
 
 
 def test_predict_call_forms_agree_exactly(emu_device):
@@ -129,10 +137,11 @@ def test_resume_pickle_and_errors(emu_device):
                                          random_state=np.random.RandomState(3))
         sgd.fit(inter)
         assert np.isfinite(sgd.predict(1)).all() and not sgd._optimizer.state_dict()['state']
-    with pytest.raises(NotImplementedError, match='momentum=0'):
-        ImplicitFactorizationModel(n_iter=1, optimizer_func=lambda p: torch.optim.SGD(p, lr=0.1, momentum=0.9)).fit(inter)
-    with pytest.raises(NotImplementedError, match='no fused gfx950 update'):
-        ImplicitFactorizationModel(n_iter=1, optimizer_func=lambda p: torch.optim.RMSprop(p, lr=0.1)).fit(inter)
+    # optimizers without a fused update train through the autograd route (the reference's loop on the device)
+    for make in (lambda p: torch.optim.SGD(p, lr=0.1, momentum=0.9), lambda p: torch.optim.RMSprop(p, lr=0.01)):
+        m2 = ImplicitFactorizationModel(n_iter=2, batch_size=50, optimizer_func=make, random_state=np.random.RandomState(3))
+        m2.fit(inter)
+        assert m2._autograd_route and np.isfinite(m2.predict(1)).all()
     custom = ImplicitFactorizationModel(n_iter=1, batch_size=50, loss='pointwise',
                                         representation=BilinearNet(15, 25, 16),
                                         random_state=np.random.RandomState(1))
@@ -272,3 +281,51 @@ def check_pipelined_fit_is_value_neutral(use_cuda=False, to_numpy=lambda w: w.de
 
 def test_pipelined_fit_is_value_neutral(emu_device):
     check_pipelined_fit_is_value_neutral()
+
+
+
+class _TwoTower(torch.nn.Module):
+    """A representation that is NOT BilinearNet (the reference accepts any module with forward(user_ids, item_ids),
+    spotlight/factorization/implicit.py:131-139): a tanh layer on the user side, this package's embedding layers below it."""
+
+    def __init__(self, num_users, num_items, dim=8):
+        super(_TwoTower, self).__init__()
+        from spotlight_amd.layers import ScaledEmbedding, ZeroEmbedding
+        self.user_embeddings = ScaledEmbedding(num_users, dim)
+        self.item_embeddings = ScaledEmbedding(num_items, dim)
+        self.item_biases = ZeroEmbedding(num_items, 1)
+        self.mix = torch.nn.Linear(dim, dim)
+
+    def forward(self, user_ids, item_ids):
+        u = torch.tanh(self.mix(self.user_embeddings(user_ids)))
+        return (u * self.item_embeddings(item_ids)).sum(1) + self.item_biases(item_ids).squeeze()
+
+
+@pytest.mark.parametrize('loss', ['bpr', 'adaptive_hinge'])
+def test_custom_representation_trains_through_the_autograd_route(emu_device, loss):
+    rs = np.random.RandomState(0)
+    users = rs.randint(0, 15, 400).astype(np.int32)
+    items = ((users * 3 + rs.randint(0, 2, 400)) % 25).astype(np.int32)  # learnable structure
+    inter = Interactions(users, items, num_users=15, num_items=25)
+    torch.manual_seed(0)
+    model = ImplicitFactorizationModel(loss=loss, n_iter=1, batch_size=64, learning_rate=5e-2, representation=_TwoTower(15, 25),
+                                       random_state=np.random.RandomState(2), num_negative_samples=3)
+    before = np.random.RandomState(2)
+    before.randint(-10**8, 10**8)  # the constructor's draw
+    model.fit(inter)
+    assert model._autograd_route and model._binding is None
+    # the RandomState was consumed as the reference consumes it: one shuffle + one randint per minibatch, on the host
+    order = np.arange(400)
+    before.shuffle(order)
+    for lo in range(0, 400, 64):
+        before.randint(0, 25, (min(64, 400 - lo)) * (3 if loss == 'adaptive_hinge' else 1), dtype=np.int64)
+    assert (model._random_state.get_state()[1] == before.get_state()[1]).all()
+    first = model.predict(1)
+    model._n_iter = 15
+    model.fit(inter)
+    pred = model.predict(1)
+    assert pred.shape == (25,) and pred.dtype == np.float32 and np.isfinite(pred).all()
+    pos = np.unique(items[users == 1])
+    neg = np.setdiff1d(np.arange(25), pos)
+    assert pred[pos].mean() > pred[neg].mean() and not np.array_equal(first, pred)
+    assert np.array_equal(model.predict(np.array([1, 1]), np.array([3, 4])), pred[[3, 4]])
