@@ -298,6 +298,23 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                 if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || kf.x != key) f = 0u;
                 else f |= 1u;
             }
+            // groups of up to 16 lanes: the G partials this round can consume are fetched WITH the metas (their addresses do not
+            // depend on them) -- one round trip per G tiles of a long run instead of three; what the run does not reach is dropped
+            constexpr bool SPEC = G <= 16;
+            slk_vec<VEC> sc[SPEC ? G : 1];
+            float sb[SPEC ? G : 1];
+            if (SPEC) {
+#pragma unroll
+                for (int e = 0; e < (SPEC ? G : 1); ++e) {
+                    sc[e] = slk_vzero<VEC>();
+                    sb[e] = 0.0f;
+                    if (t2 + (uint32_t)e < ntiles) {
+                        const float *q = a.upart + 2 * (size_t)(t2 + (uint32_t)e) * (size_t)a.UPS;
+                        if (on) sc[e] = slk_vload<VEC>(q + d0);
+                        sb[e] = q[a.UPS - 1];
+                    }
+                }
+            }
             int cnt = 0;
             bool ended = false;
             for (int l = 0; l < G; ++l) {
@@ -306,7 +323,17 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                 ++cnt;
                 ended = (f2 & SLK_IPART_ENDS) != 0;
             }
-            for (int l0 = 0; l0 < cnt; l0 += SLK_STITCH_BATCH) {  // loads in batches, adds in tile order (k_item_stitch)
+            if (SPEC) {
+#pragma unroll
+                for (int e = 0; e < (SPEC ? G : 1); ++e) {
+                    if (e < cnt) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gu.v[i] += sc[e].v[i];
+                        gbu += sb[e];
+                    }
+                }
+            }
+            for (int l0 = 0; !SPEC && l0 < cnt; l0 += SLK_STITCH_BATCH) {  // loads in batches, adds in tile order (k_item_stitch)
                 slk_vec<VEC> cc[SLK_STITCH_BATCH];
                 float cb[SLK_STITCH_BATCH];
 #pragma unroll
