@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 5
+#define SLK_ABI_VERSION 6
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -155,6 +155,13 @@ int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
  * uint32[624].  get_state synchronises the stream last used by this ctx. */
 int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos);
 int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
+/* The same hand-over, waiting only for the LAST DRAW of negatives this ctx enqueued (a training call's, slk_sample_items')
+ * instead of the whole stream: a training call draws a chunk's negatives ahead of its passes, so the position the next
+ * epoch's `shuffle` continues from (spotlight/factorization/implicit.py:213-216 -> torch_utils.py:46-47) is known while the
+ * epoch's last passes are still running -- fit() draws that shuffle on a second ctx / stream beside them.  Falls back to
+ * slk_rng_get_state when nothing was drawn since slk_rng_set_state / slk_shuffle_perm.  Failures of kernels that are still
+ * running are reported by the next slk_rng_get_state. */
+int slk_rng_get_state_sampled(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
 
 /* spotlight/sampling.py:8-36 sample_items(num_items, shape, random_state): `count` uniform
  * ids in [0, num_items) by numpy's masked rejection over the ctx's MT19937 stream,

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 5
+SLK_ABI_VERSION = 6
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -55,6 +55,7 @@ _PROTOTYPES = {
     'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    'slk_rng_get_state_sampled': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     'slk_sample_items': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_bilinear_train': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p,
                                      C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
@@ -204,6 +205,14 @@ class Engine(object):
         key = np.empty(624, dtype=np.uint32)
         pos = C.c_int32()
         self._check(self._lib.slk_rng_get_state(self._ctx, key.ctypes.data, C.byref(pos)))
+        return ('MT19937', key, int(pos.value), 0, 0.0)
+
+    def rng_get_state_sampled(self):
+        """The stream position after the last draw of negatives this ctx enqueued, without waiting for the passes that consume
+        them (include/spotlight_hip.h: slk_rng_get_state_sampled)."""
+        key = np.empty(624, dtype=np.uint32)
+        pos = C.c_int32()
+        self._check(self._lib.slk_rng_get_state_sampled(self._ctx, key.ctypes.data, C.byref(pos)))
         return ('MT19937', key, int(pos.value), 0, 0.0)
 
     def check(self):

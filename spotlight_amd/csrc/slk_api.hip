@@ -201,7 +201,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
     }
     for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_coef[0], ctx->ev_coef[1],
-                         ctx->ev_pass_in, ctx->ev_pass_out})
+                         ctx->ev_pass_in, ctx->ev_pass_out, ctx->ev_sampled})
         if (e) (void)hipEventDestroy(e);
     for (void *h : ctx->h_coef)
         if (h) (void)hipHostFree(h);

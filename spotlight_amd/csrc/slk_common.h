@@ -143,6 +143,8 @@ struct slk_ctx {
     hipStream_t prep_stream = nullptr;
     hipStream_t pass_stream = nullptr;  // prep_cus > 0: the passes' stream, masked to the CUs the prep stream does not use
     hipEvent_t ev_pass_in = nullptr, ev_pass_out = nullptr;
+    hipEvent_t ev_sampled = nullptr;    // behind the last draw of negatives (slk_sample_u32): slk_rng_get_state_sampled
+    bool sampled_valid = false;         //   false after slk_rng_set_state / a shuffle (whose end only the stream sync knows)
     hipStream_t copy_stream = nullptr;  // small state copies (slk_rng_{set,get}_state): never the null stream
     hipEvent_t ev_start = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     slk_buf extra[SLK_EXTRA_BUFS];  // path-specific scratch (slk_shard.hip, slk_seq.hip)

@@ -322,6 +322,9 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
                          // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
 #endif
 
+#ifndef SLK_ITEM_LATE_ALL
+#define SLK_ITEM_LATE_ALL 0    // 1: the row + state loads of ALL further heads of a group are issued before its first run is summed
+#endif
 #ifndef SLK_ITEM_KEYPF
 #define SLK_ITEM_KEYPF 1       // 1: the keys + payloads of the workgroup's NEXT tile are fetched into registers behind the
                                // record gathers of the current one (tiles of up to 254 positions, i.e. row groups of >= 4 lanes):
@@ -679,17 +682,54 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 if (starts) atomicAdd(a.ipart_count, 1u);
             }
         };
+#if SLK_ITEM_LATE_ALL
+        // every further head of the group (a tile of 4 * GPB positions gives a group at most four): row + state + bias of all of
+        // them on their way before the first run is summed (the registers of the record gather are free by now) -- the regime of
+        // tables much larger than the minibatch, where nearly every occurrence is a head (C5: 125 M item rows)
+        constexpr int NL = 4 - NPRE;
+        slk_vec<VEC> lp[NL], ls[NL];
+        float lbp[NL], lbs[NL];
+        bool lpre[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            lp[j] = slk_vzero<VEC>();
+            ls[j] = slk_vzero<VEC>();
+            lbp[j] = lbs[j] = 0.0f;
+            const int r = grp + (NPRE + j) * GPB;
+            lpre[j] = r < nheads && completes(r) && UPD != SLK_UPD_GRAD_ONLY;
+            if (lpre[j]) {
+                const uint32_t item = s_key[(int)s_head[r] + 1] & a.imask;
+                if (rows_on) {
+                    const size_t voff = (size_t)item * D + d0;
+                    lp[j] = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
+                    if (SLK_UPD_HAS_STATE(UPD)) ls[j] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
+                }
+                if (PART != SLK_PART_ROWS) {
+                    lbp[j] = a.P[3][item];
+                    if (SLK_UPD_HAS_STATE(UPD)) lbs[j] = a.S1[3][item];
+                }
+            }
+        }
+#endif
 #pragma unroll
         for (int h = 0; h < NPRE; ++h) {
             const int r = grp + h * GPB;
             if (r < nheads) finish(r, completes(r), pv[h], sv[h], pb[h], sb[h]);
         }
+#if SLK_ITEM_LATE_ALL
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int r = grp + (NPRE + j) * GPB;
+            if (r < nheads) finish(r, lpre[j], lp[j], ls[j], lbp[j], lbs[j]);
+        }
+#else
         // (issuing the row + state loads of the group's NEXT head before summing the first one's run -- the registers of the
-        // record gather are free by then -- was measured and does not pay: 0.315 vs 0.313 ms at C2, profiles/r03_b_*)
+        // record gather are free by then -- was measured and does not pay at C2: 0.315 vs 0.313 ms, profiles/r03_b_*)
         for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
             slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
             finish(r, false, p, s, 0.0f, 0.0f);
         }
+#endif
     }
 }
 

@@ -321,6 +321,10 @@ int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_o
                        (unsigned long long)count);
     SLK_LAUNCH_CHECK(ctx, "k_rng_finalize");
     slk_prof_end(ctx, s);
+    // the stream position after this draw is final on the device once this event has fired (slk_rng_get_state_sampled)
+    if (!ctx->ev_sampled) SLK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_sampled, hipEventDisableTiming));
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_sampled, s));
+    ctx->sampled_valid = true;
     return SLK_OK;
 }
 
@@ -356,6 +360,7 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
     // the stream the ctx's kernels were last enqueued on -- which may be the null stream (torch's default): a null handle is
     // a stream to wait for, not "no stream" (the state copy below no longer synchronises with it implicitly)
     SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    ctx->sampled_valid = false;
     slk_rng_dev h;
     memset(&h, 0, sizeof(h));
     memcpy(h.key, h_key, sizeof(h.key));
@@ -368,12 +373,32 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
     return SLK_OK;
 }
 
+static int rng_read_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
+
 SLK_EXPORT int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     if (!ctx || !h_key || !pos) return SLK_EINVAL;
     SLK_HIP(ctx, hipSetDevice(ctx->device));
     // the stream the ctx's kernels were last enqueued on -- which may be the null stream (torch's default): a null handle is
     // a stream to wait for, not "no stream" (the state copy below no longer synchronises with it implicitly)
     SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    return rng_read_state(ctx, h_key, pos);
+}
+
+// The stream position after the LAST DRAW this ctx enqueued (negatives of a training call, slk_sample_items), without waiting
+// for the kernels that consume those negatives: a training call draws a chunk's negatives well ahead of its passes, so when
+// slk_bilinear_train returns the last draw has completed (the call waits for that chunk's long-run flags, produced behind
+// the draw) while up to two chunks of passes are still queued.  The caller (fit()) uses it to start the NEXT epoch's shuffle
+// -- which continues the same MT19937 stream, torch_utils.py:46-47 -- on another ctx / stream beside those passes.  Errors
+// raised by kernels still running are reported by the next slk_rng_get_state.
+SLK_EXPORT int slk_rng_get_state_sampled(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
+    if (!ctx || !h_key || !pos) return SLK_EINVAL;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->sampled_valid || !ctx->ev_sampled) return slk_rng_get_state(ctx, h_key, pos);  // nothing drawn since the state was set
+    SLK_HIP(ctx, hipEventSynchronize(ctx->ev_sampled));
+    return rng_read_state(ctx, h_key, pos);
+}
+
+static int rng_read_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     slk_rng_dev h;
     hipStream_t cs = slk_copy_stream(ctx);
     SLK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost, cs));

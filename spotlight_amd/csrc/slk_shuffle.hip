@@ -547,6 +547,7 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     if (n == 0) return SLK_OK;
     if (!d_perm_out) return slk_fail(ctx, SLK_EINVAL, "slk_shuffle_perm: d_perm_out is NULL");
     SLK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->sampled_valid = false;  // the shuffle moves the stream position: only slk_rng_get_state (stream sync) sees its end
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
     const uint32_t N = (uint32_t)n;

@@ -372,36 +372,57 @@ class ImplicitFactorizationModel(object):
         if self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS:
             d_users0, d_items0 = upload.result()
             return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose)
-        d_users = torch.empty(n, dtype=torch.int64, device=device)
-        d_items = torch.empty(n, dtype=torch.int64, device=device)
+        # Large epochs.  The stream is consumed in the reference's order -- shuffle of epoch e, negatives of epoch e (drawn
+        # inside the training call, a chunk of minibatches ahead of its passes), shuffle of epoch e + 1 -- so the position
+        # epoch e + 1's shuffle starts from is known as soon as epoch e's LAST draw has completed, about a chunk of passes
+        # before the epoch ends (slk_rng_get_state_sampled): that shuffle and its id gathers run on the second slk_ctx / HIP
+        # stream beside those passes, into the other pair of id buffers.  Same ids, same negatives, same RandomState
+        # afterwards, bit-identical tables (tests/test_host_model.py); at 2^25 interactions per epoch the shuffle is
+        # 5 of 37 ms.
+        prep, prep_stream = _prep_lane_for(device)
+        bufs = [(torch.empty(n, dtype=torch.int64, device=device), torch.empty(n, dtype=torch.int64, device=device))
+                for _ in range(2 if self._n_iter > 1 else 1)]
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         d_users0 = d_items0 = None
 
-        def sources():
-            nonlocal d_users0, d_items0
-            if d_users0 is None:
-                d_users0, d_items0 = upload.result()
-            return [(d_users0, d_users, 1), (d_items0, d_items, 1)]
+        def shuffle_into(slot, state):
+            """bufs[slot] = ids[numpy-exact shuffle] drawn from `state` on the prep lane; returns the state behind the shuffle
+            (reading it waits for the prep lane's stream: the gathers are complete)."""
+            def sources():
+                nonlocal d_users0, d_items0
+                if d_users0 is None:
+                    d_users0, d_items0 = upload.result()
+                return [(d_users0, bufs[slot][0], 1), (d_items0, bufs[slot][1], 1)]
+            self._random_state.set_state(state)  # (device_epoch_shuffle's host fall-back draws from it)
+            prep.rng_set_state(state)
+            device_epoch_shuffle(prep, self._random_state, n, d_perm, sources, prep_stream)
+            return prep.rng_get_state()
+
+        state = shuffle_into(0, self._random_state.get_state())
         for epoch_num in range(self._n_iter):
-            # shuffle, then the negatives: one MT19937 stream, consumed on the GPU exactly as
-            # numpy would consume it on the host
-            engine.rng_set_state(self._random_state.get_state())
-            device_epoch_shuffle(engine, self._random_state, n, d_perm, sources, stream)
+            d_users, d_items = bufs[epoch_num % len(bufs)]
+            engine.rng_set_state(state)  # behind shuffle(e): the negatives of this epoch continue from here
             ostruct = binding.as_struct()
             engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
                                   self._batch_size, self._loss, self._num_negative_samples,
                                   mb_loss.data_ptr(), stream=stream)
             binding.store_steps(ostruct.step)
-            self._random_state.set_state(engine.rng_get_state())  # synchronises the stream
+            state_after_epoch = engine.rng_get_state_sampled()  # waits for the epoch's last draw, not for its passes
+            if epoch_num + 1 < self._n_iter:
+                state = shuffle_into((epoch_num + 1) % 2, state_after_epoch)  # beside the last passes of this epoch
 
-            # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch
+            # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
             epoch_loss = float(mb_loss.double().mean().item())
+            engine.check()  # errors the training kernels can only report through the ctx
 
             if verbose:
                 print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
             if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                # the reference stops here having consumed the stream up to this epoch's negatives only
+                self._random_state.set_state(state_after_epoch)
                 raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+        self._random_state.set_state(state_after_epoch)
 
     def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):
         """The epoch loop for datasets of the reference's own scale (MovieLens-100K: 80 000 interactions per epoch): there an
