@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
 }
 
 // one thread per column c of the [n, B] candidate matrix; k0 = chunk-local index of the
-// minibatch's first interaction.  gk must be zero on entry for this minibatch.
+// minibatch's first interaction.  every entry of gk that belongs to this minibatch is written here (no memset before the launch).
 //
 // qk / live (optional): the two occurrences of column c that carry a gradient -- the positive of
 // interaction k0 + c and the selected negative -- as item-pass payloads r = position * NP + pair
