@@ -40,13 +40,35 @@ def main():
     model.fit(inter)  # table initialisation, scratch
     torch.cuda.synchronize()
     model._n_iter = n_iter
+    # where the host spends the wall time of fit(): every engine call (both lanes) timed on the host
+    eng = host._engine_for(dev)
+    prep, _ = host._prep_lane_for(dev)
+    acc = {}
+
+    def wrap(obj, name, tag):
+        f = getattr(obj, name)
+
+        def g(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                acc[tag] = acc.get(tag, 0.0) + time.perf_counter() - t0
+        setattr(obj, name, g)
+    for nm in ('rng_set_state', 'rng_get_state', 'rng_get_state_sampled', 'shuffle_perm', 'gather_rows_i64', 'bilinear_train',
+               'bilinear_reserve'):
+        wrap(eng, nm, 'train_lane.' + nm)
+        if prep is not eng:
+            wrap(prep, nm, 'prep_lane.' + nm)
     for label, max_draws in (('in_line', 1 << 22), ('prepared_ahead', 1 << 40), ('in_line_again', 1 << 22)):
+        acc.clear()
         host._PIPELINE_MAX_DRAWS = max_draws
         t0 = time.perf_counter()
         model.fit(inter)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_iter
-        out[label] = {'s_per_epoch': dt, 'G_interactions_per_s': n / dt / 1e9}
+        out[label] = {'s_per_epoch': dt, 'G_interactions_per_s': n / dt / 1e9,
+                      'host_ms_per_epoch_by_call': {k: round(v / n_iter * 1e3, 3) for k, v in sorted(acc.items())}}
     print(json.dumps(out))
 
 

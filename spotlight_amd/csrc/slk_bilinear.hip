@@ -288,24 +288,32 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
         float gbu = pp[a.UPS - 1];
         uint32_t t2 = tile + 1;
         bool more = (fl & SLK_IPART_ENDS) == 0;
+        // A round looks at the next TPR = R * G tiles: lane l reads the metas of tiles t2 + l + j * G ({key, flags}: one 8-B load;
+        // the tiles that continue this run are a prefix), and the partials the round can consume are fetched WITH the metas --
+        // their addresses do not depend on them -- so a run that fills thousands of tiles costs its owner one round trip per TPR
+        // tiles (measured before: one per tile, then three per G tiles; profiles/r03_*).  What the run does not reach is
+        // dropped.  The sums are added in tile order, as the persistent kernel's walk adds them.
+        constexpr int R = G <= 16 ? 2 : 1;
+        constexpr int TPR = R * G;
+        constexpr bool SPEC = G <= 16;  // wider groups: partials fetched after the metas, SLK_STITCH_BATCH at a time
         while (more) {
-            const uint32_t tl = t2 + (uint32_t)lane;
-            uint32_t f = 0u;
-            if (tl < ntiles) {
-                const size_t sl = 2 * (size_t)tl;
-                const uint2 kf = *reinterpret_cast<const uint2 *>(a.upart_meta + 2 * sl);  // {key, flags}: one 8-B load
-                f = kf.y;
-                if ((f >> SLK_IPART_GEN_SHIFT) != gen || (f & SLK_IPART_STARTS) || kf.x != key) f = 0u;
-                else f |= 1u;
+            uint32_t f[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint32_t tl = t2 + (uint32_t)(lane + j * G);
+                f[j] = 0u;
+                if (tl < ntiles) {
+                    const uint2 kf = *reinterpret_cast<const uint2 *>(a.upart_meta + 4 * (size_t)tl);
+                    f[j] = kf.y;
+                    if ((f[j] >> SLK_IPART_GEN_SHIFT) != gen || (f[j] & SLK_IPART_STARTS) || kf.x != key) f[j] = 0u;
+                    else f[j] |= 1u;  // bit 0: part of this run
+                }
             }
-            // groups of up to 16 lanes: the G partials this round can consume are fetched WITH the metas (their addresses do not
-            // depend on them) -- one round trip per G tiles of a long run instead of three; what the run does not reach is dropped
-            constexpr bool SPEC = G <= 16;
-            slk_vec<VEC> sc[SPEC ? G : 1];
-            float sb[SPEC ? G : 1];
+            slk_vec<VEC> sc[SPEC ? TPR : 1];
+            float sb[SPEC ? TPR : 1];
             if (SPEC) {
 #pragma unroll
-                for (int e = 0; e < (SPEC ? G : 1); ++e) {
+                for (int e = 0; e < (SPEC ? TPR : 1); ++e) {
                     sc[e] = slk_vzero<VEC>();
                     sb[e] = 0.0f;
                     if (t2 + (uint32_t)e < ntiles) {
@@ -315,17 +323,21 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                     }
                 }
             }
+            // cnt = tiles of this round that belong to the run: up to and including the first one that ends it
             int cnt = 0;
             bool ended = false;
-            for (int l = 0; l < G; ++l) {
-                const uint32_t f2 = __shfl(f, l, G);
-                if (ended || !(f2 & 1u)) break;
-                ++cnt;
-                ended = (f2 & SLK_IPART_ENDS) != 0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                for (int l = 0; l < G; ++l) {
+                    const uint32_t f2 = __shfl(f[j], l, G);
+                    if (ended || !(f2 & 1u) || cnt != j * G + l) break;
+                    ++cnt;
+                    ended = (f2 & SLK_IPART_ENDS) != 0;
+                }
             }
             if (SPEC) {
 #pragma unroll
-                for (int e = 0; e < (SPEC ? G : 1); ++e) {
+                for (int e = 0; e < (SPEC ? TPR : 1); ++e) {
                     if (e < cnt) {
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) gu.v[i] += sc[e].v[i];
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                     }
                 }
             }
-            for (int l0 = 0; !SPEC && l0 < cnt; l0 += SLK_STITCH_BATCH) {  // loads in batches, adds in tile order (k_item_stitch)
+            for (int l0 = 0; !SPEC && l0 < cnt; l0 += SLK_STITCH_BATCH) {
                 slk_vec<VEC> cc[SLK_STITCH_BATCH];
                 float cb[SLK_STITCH_BATCH];
 #pragma unroll
@@ -355,8 +367,8 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                     }
                 }
             }
-            more = !ended && cnt == G;
-            t2 += (uint32_t)G;
+            more = !ended && cnt == TPR;
+            t2 += (uint32_t)TPR;
         }
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
