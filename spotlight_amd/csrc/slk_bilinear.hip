@@ -297,18 +297,8 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
         constexpr int TPR = R * G;
         constexpr bool SPEC = G <= 16;  // wider groups: partials fetched after the metas, SLK_STITCH_BATCH at a time
         while (more) {
-            uint32_t f[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const uint32_t tl = t2 + (uint32_t)(lane + j * G);
-                f[j] = 0u;
-                if (tl < ntiles) {
-                    const uint2 kf = *reinterpret_cast<const uint2 *>(a.upart_meta + 4 * (size_t)tl);
-                    f[j] = kf.y;
-                    if ((f[j] >> SLK_IPART_GEN_SHIFT) != gen || (f[j] & SLK_IPART_STARTS) || kf.x != key) f[j] = 0u;
-                    else f[j] |= 1u;  // bit 0: part of this run
-                }
-            }
+            // every load of the round is issued before anything waits: the partials first, then the metas (the compiler keeps
+            // program order, and a compare right behind a meta load would put a full round trip in front of the partial loads)
             slk_vec<VEC> sc[SPEC ? TPR : 1];
             float sb[SPEC ? TPR : 1];
             if (SPEC) {
@@ -322,6 +312,23 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                         sb[e] = q[a.UPS - 1];
                     }
                 }
+            }
+            uint2 kf[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint32_t tl = t2 + (uint32_t)(lane + j * G);
+                kf[j] = make_uint2(0u, 0u);
+                if (tl < ntiles) kf[j] = *reinterpret_cast<const uint2 *>(a.upart_meta + 4 * (size_t)tl);
+            }
+            uint32_t f[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                f[j] = kf[j].y;
+                if (t2 + (uint32_t)(lane + j * G) >= ntiles || (f[j] >> SLK_IPART_GEN_SHIFT) != gen || (f[j] & SLK_IPART_STARTS) ||
+                    kf[j].x != key)
+                    f[j] = 0u;
+                else
+                    f[j] |= 1u;  // bit 0: part of this run
             }
             // cnt = tiles of this round that belong to the run: up to and including the first one that ends it
             int cnt = 0;

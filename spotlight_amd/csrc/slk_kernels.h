@@ -322,9 +322,6 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
                          // (profiles/sweeps/r01_x): 7 waves x 1 head beats 6 x 2 (C2 0.340 -> 0.332, C5 0.651 -> 0.601 ms)
 #endif
 
-#ifndef SLK_ITEM_LATE_ALL
-#define SLK_ITEM_LATE_ALL 0    // 1: the row + state loads of ALL further heads of a group are issued before its first run is summed
-#endif
 #ifndef SLK_ITEM_KEYPF
 #define SLK_ITEM_KEYPF 1       // 1: the keys + payloads of the workgroup's NEXT tile are fetched into registers behind the
                                // record gathers of the current one (tiles of up to 254 positions, i.e. row groups of >= 4 lanes):
@@ -682,54 +679,18 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_p
                 if (starts) atomicAdd(a.ipart_count, 1u);
             }
         };
-#if SLK_ITEM_LATE_ALL
-        // every further head of the group (a tile of 4 * GPB positions gives a group at most four): row + state + bias of all of
-        // them on their way before the first run is summed (the registers of the record gather are free by now) -- the regime of
-        // tables much larger than the minibatch, where nearly every occurrence is a head (C5: 125 M item rows)
-        constexpr int NL = 4 - NPRE;
-        slk_vec<VEC> lp[NL], ls[NL];
-        float lbp[NL], lbs[NL];
-        bool lpre[NL];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            lp[j] = slk_vzero<VEC>();
-            ls[j] = slk_vzero<VEC>();
-            lbp[j] = lbs[j] = 0.0f;
-            const int r = grp + (NPRE + j) * GPB;
-            lpre[j] = r < nheads && completes(r) && UPD != SLK_UPD_GRAD_ONLY;
-            if (lpre[j]) {
-                const uint32_t item = s_key[(int)s_head[r] + 1] & a.imask;
-                if (rows_on) {
-                    const size_t voff = (size_t)item * D + d0;
-                    lp[j] = slk_vload_if_nt<VEC>(a.P[1] + voff, nt_rows);
-                    if (SLK_UPD_HAS_STATE(UPD)) ls[j] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
-                }
-                if (PART != SLK_PART_ROWS) {
-                    lbp[j] = a.P[3][item];
-                    if (SLK_UPD_HAS_STATE(UPD)) lbs[j] = a.S1[3][item];
-                }
-            }
-        }
-#endif
 #pragma unroll
         for (int h = 0; h < NPRE; ++h) {
             const int r = grp + h * GPB;
             if (r < nheads) finish(r, completes(r), pv[h], sv[h], pb[h], sb[h]);
         }
-#if SLK_ITEM_LATE_ALL
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int r = grp + (NPRE + j) * GPB;
-            if (r < nheads) finish(r, lpre[j], lp[j], ls[j], lbp[j], lbs[j]);
-        }
-#else
-        // (issuing the row + state loads of the group's NEXT head before summing the first one's run -- the registers of the
-        // record gather are free by then -- was measured and does not pay at C2: 0.315 vs 0.313 ms, profiles/r03_b_*)
+        // (issuing the row + state loads of the group's further heads before its first run is summed -- the registers of the
+        // record gather are free by then -- was measured twice and does not pay: one more head 0.315 vs 0.313 ms at C2; all of
+        // them (up to three more: +30 VGPRs) 0.443 vs 0.291 ms at C2 and 0.70 vs 0.56-0.66 ms at the C5 shard, profiles/r03_*)
         for (int r = grp + NPRE * GPB; r < nheads; r += GPB) {
             slk_vec<VEC> p = slk_vzero<VEC>(), s = slk_vzero<VEC>();
             finish(r, false, p, s, 0.0f, 0.0f);
         }
-#endif
     }
 }
 
@@ -772,18 +733,8 @@ __global__ __launch_bounds__(256) void k_item_stitch(slk_pass_args a) {
         constexpr int TPR = R * G;
         constexpr bool SPEC = G <= 16;  // wider groups: partials fetched after the metas, SLK_STITCH_BATCH at a time
         while (more) {
-            uint32_t f[R];
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const uint32_t tl = t2 + (uint32_t)(lane + j * G);
-                f[j] = 0u;
-                if (tl < ntiles) {
-                    const uint2 kf = *reinterpret_cast<const uint2 *>(a.ipart_meta + 4 * (size_t)tl);
-                    f[j] = kf.y;
-                    if ((f[j] >> SLK_IPART_GEN_SHIFT) != gen || (f[j] & SLK_IPART_STARTS) || kf.x != key) f[j] = 0u;
-                    else f[j] |= 1u;  // bit 0: part of this run
-                }
-            }
+            // every load of the round is issued before anything waits: the partials first, then the metas (the compiler keeps
+            // program order, and a compare right behind a meta load would put a full round trip in front of the partial loads)
             slk_vec<VEC> sc[SPEC ? TPR : 1];
             float sb[SPEC ? TPR : 1];
             if (SPEC) {
@@ -797,6 +748,23 @@ __global__ __launch_bounds__(256) void k_item_stitch(slk_pass_args a) {
                         sb[e] = q[a.IPS - 1];
                     }
                 }
+            }
+            uint2 kf[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const uint32_t tl = t2 + (uint32_t)(lane + j * G);
+                kf[j] = make_uint2(0u, 0u);
+                if (tl < ntiles) kf[j] = *reinterpret_cast<const uint2 *>(a.ipart_meta + 4 * (size_t)tl);
+            }
+            uint32_t f[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                f[j] = kf[j].y;
+                if (t2 + (uint32_t)(lane + j * G) >= ntiles || (f[j] >> SLK_IPART_GEN_SHIFT) != gen || (f[j] & SLK_IPART_STARTS) ||
+                    kf[j].x != key)
+                    f[j] = 0u;
+                else
+                    f[j] |= 1u;  // bit 0: part of this run
             }
             // cnt = tiles of this round that belong to the run: up to and including the first one that ends it
             int cnt = 0;
