@@ -331,15 +331,23 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
                     f[j] |= 1u;  // bit 0: part of this run
             }
             // cnt = tiles of this round that belong to the run: up to and including the first one that ends it
+            // (the lanes' flags as bit masks of the group, OR-reduced in log2(G) exchanges: a loop of G dependent
+            // lane-to-lane reads per round was what the stitch of a run over thousands of tiles spent its time in)
             int cnt = 0;
             bool ended = false;
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                for (int l = 0; l < G; ++l) {
-                    const uint32_t f2 = __shfl(f[j], l, G);
-                    if (ended || !(f2 & 1u) || cnt != j * G + l) break;
-                    ++cnt;
-                    ended = (f2 & SLK_IPART_ENDS) != 0;
+                if (!ended && cnt == j * G) {
+                    const unsigned long long valid = slk_group_or<G>((f[j] & 1u) ? 1ull << lane : 0ull);
+                    const unsigned long long ends = slk_group_or<G>((f[j] & SLK_IPART_ENDS) ? 1ull << lane : 0ull);
+                    const unsigned long long full = G == 64 ? ~0ull : (1ull << G) - 1ull;
+                    int c = (valid & full) == full ? G : __builtin_ctzll(~valid);      // the leading lanes that continue the run
+                    const unsigned long long e_in = ends & (c == 64 ? ~0ull : (1ull << c) - 1ull);
+                    if (e_in) {
+                        c = __builtin_ctzll(e_in) + 1;                                 // ... up to and including the one that ends it
+                        ended = true;
+                    }
+                    cnt += c;
                 }
             }
             if (SPEC) {

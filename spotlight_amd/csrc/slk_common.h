@@ -267,6 +267,14 @@ __device__ __forceinline__ float slk_group_sum(float x) {
     return x;
 }
 
+// Bitwise OR over the G lanes of a row group (every lane receives the result): log2(G) exchanges.
+template <int G>
+__device__ __forceinline__ unsigned long long slk_group_or(unsigned long long x) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) x |= __shfl_xor(x, m, G);
+    return x;
+}
+
 // VEC consecutive fp32 of an embedding row held by one lane: VEC == 4 moves 16 B per lane
 // (a D=64 row = 16 lanes x 16 B = one 256-B line), VEC == 1 is the odd-dim fallback.
 template <int VEC>
