@@ -1016,7 +1016,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, pb.lflags, 2 * (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk: items, users
     }
-    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_UPART_META };  // ctx->extra slots
+    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_UPART_META, BL_LATE_SORT };  // ctx->extra slots
     const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * 4))) return rc;  // dL/dscore per (position, pair)
@@ -1027,6 +1027,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = slk_ensure(ctx, ctx->sk, nc_max * NP * 4))) return rc;
     }
     if (late) {
+        // (the live lists are sorted per minibatch on the PASSES' stream; with the overlapped prep another chunk's sorts run on
+        // the prep stream at the same time, so these sorts have temporary storage of their own: BL_LATE_SORT, not ctx->sort_tmp)
         const size_t nl = 2 * (size_t)bsz, nlh = nl * (size_t)(Hi ? Hi : 1);
         if ((rc = slk_ensure(ctx, ctx->extra[BL_LIVE], nl * 4))) return rc;
         for (int b = 0; b < 4; ++b)
@@ -1303,7 +1305,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                        (const uint32_t *)ctx->extra[BL_LIVE].p, uit, nl, ibd, false,
                                        (uint32_t *)ctx->extra[BL_LK0].p, (uint32_t *)ctx->extra[BL_LV0].p);
                     SLK_LAUNCH_CHECK(ctx, "k_build_live_keys");
-                    if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_LK0].p,
+                    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[BL_LATE_SORT], (const uint32_t *)ctx->extra[BL_LK0].p,
                                                      (uint32_t *)ctx->extra[BL_LK1].p,
                                                      (const uint32_t *)ctx->extra[BL_LV0].p,
                                                      (uint32_t *)ctx->extra[BL_LV1].p, nl, ibits + 1, s)))  // + the dead entries' bit
@@ -1377,7 +1379,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                        (const uint32_t *)ctx->extra[BL_LIVE].p, uit, 2 * bm, ibd, true,
                                        (uint32_t *)ctx->extra[BL_LK0].p, (uint32_t *)ctx->extra[BL_LV0].p);
                     SLK_LAUNCH_CHECK(ctx, "k_build_live_keys<hashed>");
-                    if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[BL_LK0].p,
+                    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[BL_LATE_SORT], (const uint32_t *)ctx->extra[BL_LK0].p,
                                                      (uint32_t *)ctx->extra[BL_LK1].p,
                                                      (const uint32_t *)ctx->extra[BL_LV0].p,
                                                      (uint32_t *)ctx->extra[BL_LV1].p, nlh, icbits + 1, s)))

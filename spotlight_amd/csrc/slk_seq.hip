@@ -22,7 +22,7 @@
 
 #include "slk_kernels.h"
 
-enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1, SQ_GSN = 23 };  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
+enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1, SQ_GSN = 23, SQ_MCOUNT_B = 30 };  // (24, 25: slk_bilinear.hip, whose slot 24 keeps stamps across calls)  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
 
 struct slk_seq_args {
     const float *E;         // item_embeddings
@@ -623,19 +623,28 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
     const size_t ns_max = (size_t)(chunk_seqs < n_seq ? chunk_seqs : n_seq);
     const size_t nts_max = ns_max * L;
 
-    if ((rc = slk_ensure(ctx, ctx->neg32, nts_max * nn * 4))) return rc;
-    for (int b = 0; b < 2; ++b) {
-        if ((rc = slk_ensure(ctx, ctx->ikey[b], nts_max * NP * 4))) return rc;
-        if ((rc = slk_ensure(ctx, ctx->ipay[b], nts_max * NP * 4))) return rc;
-        if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIK0 + b], nts_max * NP * Hi * 4))) return rc;
-        if (Hi && (rc = slk_ensure(ctx, ctx->extra[SQ_BIP0 + b], nts_max * NP * Hi * 4))) return rc;
+    // The value-independent prep of a chunk (negatives, mask counts, the sort of the occurrences by item, the long-run flags)
+    // is prepared on the ctx's second stream while the previous chunk's passes run, as in slk_bilinear_train (option
+    // "overlap_prep"; timesteps per minibatch >= "overlap_min_batch"): its buffers exist per set (ctx->pb[0|1]).
+    const int64_t n_chunks = (n_seq + chunk_seqs - 1) / chunk_seqs;
+    const int nsets = (ctx->opt_overlap_prep && n_chunks > 1 && bsz * L >= ctx->opt_overlap_min_batch) ? 2 : 1;
+    for (int st = 0; st < nsets; ++st) {
+        slk_prep_bufs &pb = ctx->pb[st];
+        if ((rc = slk_ensure(ctx, pb.neg32, nts_max * nn * 4))) return rc;
+        for (int b = 0; b < 2; ++b) {
+            if ((rc = slk_ensure(ctx, pb.ikey[b], nts_max * NP * 4))) return rc;
+            if ((rc = slk_ensure(ctx, pb.ipay[b], nts_max * NP * 4))) return rc;
+            if (Hi && (rc = slk_ensure(ctx, pb.bik[b], nts_max * NP * Hi * 4))) return rc;
+            if (Hi && (rc = slk_ensure(ctx, pb.bip[b], nts_max * NP * Hi * 4))) return rc;
+        }
+        if ((rc = slk_ensure(ctx, pb.lflags, (size_t)mb_per_chunk * 4))) return rc;
+        if ((rc = slk_ensure(ctx, ctx->extra[SQ_MCOUNT + (st ? SQ_MCOUNT_B - SQ_MCOUNT : 0)], (size_t)mb_per_chunk * 4))) return rc;
     }
     const int RS = 2 * ((D + 3) / 4 * 4);  // record = [representation | history gradient], 16-B granular halves
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * L * RS * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[SQ_GSN], (size_t)bsz * L * NP * 4))) return rc;  // dL/dscore per (timestep, pair)
     const unsigned max_grid = (unsigned)ctx->num_cus * 8;
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->extra[SQ_MCOUNT], (size_t)mb_per_chunk * 4))) return rc;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (dense) {
         const size_t elems[4] = {0, (size_t)(Hi ? ibd.rows : tables->num_items) * D, 0, (size_t)tables->num_items};
@@ -671,17 +680,21 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
     const unsigned gpb = 256u / (unsigned)g;
 
     if (reserve_only) {
+        if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
         // sampler and sort scratch of the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nts_max * nn))) return rc;
         return slk_sort_reserve(ctx, nts_max * (size_t)occ_mult);
     }
     int64_t mb_global = 0;
-    for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs) {
+    // ---- prep of the chunk starting at sequence c0 into buffer set `set`, on stream s (ids only: value-independent)
+    auto do_prep = [&](int64_t c0, int set, hipStream_t s) -> int {
+        int rc;
+        slk_prep_bufs &fb = ctx->pb[set];
         const uint32_t ns = (uint32_t)((n_seq - c0 < chunk_seqs) ? (n_seq - c0) : chunk_seqs);
         const uint32_t nts = ns * (uint32_t)L;
         const uint32_t nocc = nts * (uint32_t)NP;
         const int64_t *cs = d_sequences + c0 * L;
-        uint32_t *neg32 = (uint32_t *)ctx->neg32.p;
+        uint32_t *neg32 = (uint32_t *)fb.neg32.p;
         const uint32_t n_mb = (uint32_t)((ns + bsz - 1) / bsz);
         // ---- negatives: one randint per minibatch == one contiguous draw over the chunk
         if (d_neg_in) {
@@ -698,7 +711,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         }
         // ---- prep: mask counts; occurrences sorted by (minibatch, item)
         slk_prof_begin(ctx, SLK_K_PREP, s);
-        uint32_t *mcount = (uint32_t *)ctx->extra[SQ_MCOUNT].p;
+        uint32_t *mcount = (uint32_t *)ctx->extra[set ? SQ_MCOUNT_B : SQ_MCOUNT].p;
         SLK_HIP(ctx, hipMemsetAsync(mcount, 0, (size_t)n_mb * 4, s));
         {
             unsigned gx = (unsigned)(((size_t)bsz * L + 8191) / 8192);
@@ -710,19 +723,18 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         const unsigned mbbits = slk_bits_for((uint64_t)(n_mb - 1));
         hipLaunchKernelGGL(k_seq_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, cs,
                            (const uint32_t *)neg32, nocc, ns, (uint32_t)L, (uint32_t)NP, (uint32_t)bsz, ibits,
-                           (uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ipay[0].p);
+                           (uint32_t *)fb.ikey[0].p, (uint32_t *)fb.ipay[0].p);
         SLK_LAUNCH_CHECK(ctx, "k_seq_item_keys");
-        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
-                                         (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, nocc,
+        if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)fb.ikey[0].p, (uint32_t *)fb.ikey[1].p,
+                                         (const uint32_t *)fb.ipay[0].p, (uint32_t *)fb.ipay[1].p, nocc,
                                          ibits + mbbits, s)))
             return rc;
         // which minibatches hold a LONG run of the plain occurrence list (slk_kernels.h, k_item_long_flags): fetched once
         // per chunk; the usual minibatch (none) gets the plain item pass with no stitch kernel behind it
-        slk_prep_bufs &fb = ctx->pb[0];
         if ((rc = slk_ensure(ctx, fb.lflags, (size_t)n_mb * 4))) return rc;
         SLK_HIP(ctx, hipMemsetAsync(fb.lflags.p, 0, (size_t)n_mb * 4, s));
         hipLaunchKernelGGL(k_item_long_flags, dim3(slk_grid_for(ctx, nocc / (4 * gpb) + n_mb, 256)), dim3(256), 0, s,
-                           (const uint32_t *)ctx->ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)L * (uint32_t)NP, 4u * gpb,
+                           (const uint32_t *)fb.ikey[1].p, nocc, (uint32_t)bsz * (uint32_t)L * (uint32_t)NP, 4u * gpb,
                            (uint32_t)((1ull << ibits) - 1), padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx, 0xffffffffu,
                            (int *)fb.lflags.p);
         SLK_LAUNCH_CHECK(ctx, "k_item_long_flags");
@@ -730,20 +742,30 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         SLK_HIP(ctx, hipMemcpyAsync(fb.h_lflags, fb.lflags.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, s));
         if (!fb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&fb.ev_lflags, hipEventDisableTiming));
         SLK_HIP(ctx, hipEventRecord(fb.ev_lflags, s));
-        bool lflags_ready = false;
         if (Hi) {
             hipLaunchKernelGGL(k_seq_item_bloom_keys, dim3(slk_grid_for(ctx, (size_t)nocc * Hi, 256)), dim3(256), 0, s, cs,
                                (const uint32_t *)neg32, nocc, ns, (uint32_t)L, (uint32_t)NP, (uint32_t)bsz, icbits, ibd,
-                               (uint32_t *)ctx->extra[SQ_BIK0].p, (uint32_t *)ctx->extra[SQ_BIP0].p);
+                               (uint32_t *)fb.bik[0].p, (uint32_t *)fb.bip[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_seq_item_bloom_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[SQ_BIK0].p,
-                                             (uint32_t *)ctx->extra[SQ_BIK1].p,
-                                             (const uint32_t *)ctx->extra[SQ_BIP0].p,
-                                             (uint32_t *)ctx->extra[SQ_BIP1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)fb.bik[0].p,
+                                             (uint32_t *)fb.bik[1].p,
+                                             (const uint32_t *)fb.bip[0].p,
+                                             (uint32_t *)fb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
                 return rc;
         }
         slk_prof_end(ctx, s);
+        return SLK_OK;
+    };
 
+    // ---- the minibatches of one prepared chunk, in order, on the caller's stream
+    auto do_passes = [&](int64_t c0, int set) -> int {
+        int rc;
+        slk_prep_bufs &fb = ctx->pb[set];
+        const uint32_t ns = (uint32_t)((n_seq - c0 < chunk_seqs) ? (n_seq - c0) : chunk_seqs);
+        const int64_t *cs = d_sequences + c0 * L;
+        uint32_t *neg32 = (uint32_t *)fb.neg32.p;
+        uint32_t *mcount = (uint32_t *)ctx->extra[set ? SQ_MCOUNT_B : SQ_MCOUNT].p;
+        bool lflags_ready = false;
         for (uint32_t b0 = 0, mb = 0; b0 < ns; b0 += (uint32_t)bsz, ++mb, ++mb_global) {
             const uint32_t b1 = (ns - b0 < (uint32_t)bsz) ? ns : b0 + (uint32_t)bsz;
             slk_seq_args q;
@@ -788,9 +810,9 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             a.gsn = (float *)ctx->extra[SQ_GSN].p;
             a.ibegin = a.begin * (uint32_t)NP;
             a.iend = a.end * (uint32_t)NP;
-            a.ikey = (const uint32_t *)ctx->ikey[1].p;
+            a.ikey = (const uint32_t *)fb.ikey[1].p;
             a.imask = (uint32_t)((1ull << ibits) - 1);
-            a.ipay = (const uint32_t *)ctx->ipay[1].p;
+            a.ipay = (const uint32_t *)fb.ipay[1].p;
             a.pad_item = padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx;
             a.pad_item2 = 0xffffffffu;
             a.loss_partial = (double *)ctx->losspart.p;
@@ -814,8 +836,8 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;
-                r.ikey = (const uint32_t *)ctx->extra[SQ_BIK1].p;
-                r.ipay = (const uint32_t *)ctx->extra[SQ_BIP1].p;
+                r.ikey = (const uint32_t *)fb.bik[1].p;
+                r.ipay = (const uint32_t *)fb.bip[1].p;
                 r.ibegin = a.ibegin * (uint32_t)Hi;
                 r.iend = a.iend * (uint32_t)Hi;
                 r.imask = (uint32_t)((1ull << icbits) - 1);
@@ -826,7 +848,35 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             if (dense && (rc = slk_dense_sweeps(ctx, tables->d_param, optim, TM, s))) return rc;
             optim->step += 1;
         }
+        return SLK_OK;
+    };
+
+    if (nsets == 1) {
+        for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs) {
+            if ((rc = do_prep(c0, 0, s))) return rc;
+            if ((rc = do_passes(c0, 0))) return rc;
+        }
+        return SLK_OK;
     }
+    // pipeline: prep(c + 1) on ctx->prep_stream beside passes(c) on the caller's stream (slk_bilinear.hip)
+    if ((rc = slk_prep_stream_init(ctx))) return rc;
+    hipStream_t ps = ctx->prep_stream;
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));  // inputs produced on the caller's stream
+    SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+    if ((rc = do_prep(0, 0, ps))) return rc;
+    SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
+    int set = 0;
+    for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs, set ^= 1) {
+        SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
+        if (c0 + chunk_seqs < n_seq) {
+            if (c0 > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));  // that set's last reader: the chunk before
+            if ((rc = do_prep(c0 + chunk_seqs, set ^ 1, ps))) return rc;
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
+        }
+        if ((rc = do_passes(c0, set))) return rc;
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
+    }
+    ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
     return SLK_OK;
 }
 

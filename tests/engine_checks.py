@@ -597,6 +597,43 @@ def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3
     assert rel_inf(be.get(out), po.predict(seqs[1], some)) < 1e-5
 
 
+def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=32, nn=3, chunk=2048, overlap=1, bloom=0, seed=17):
+    """PoolNet training in ONE prep chunk against the same call cut into several chunks of `chunk` timesteps with the prep of
+    chunk c + 1 (negatives, occurrence sort, flags) on the second stream while chunk c trains (slk_seq.hip: the pipeline of
+    slk_bilinear_train): losses, negatives, RNG state, tables and optimizer state bit for bit."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    seqs = make_sequences(rs, N, L, I, 0.3)
+    params = _seq_params(rs, I, D, rows=int(0.4 * I) if bloom else None)
+    from oracle.oracle import bloom_desc
+    desc = bloom_desc(n_hash=bloom) if bloom else None
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    n_draw = N * L * (nn if loss == 'adaptive_hinge' else 1)
+    results = []
+    for chunk_i, overlap_i in ((1 << 23, 0), (chunk, overlap)):
+        eng.set_option('chunk_interactions', chunk_i)
+        eng.set_option('overlap_prep', overlap_i)
+        eng.set_option('overlap_min_batch', 0)
+        try:
+            dev = be.seq_model(params, opt=opt, item_bloom=desc, lr=0.05)
+            eng.rng_set_state(state)
+            d_seqs = be.alloc(seqs)
+            mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+            neg_out = be.alloc(np.full(n_draw, -1, dtype=np.int64))
+            for _ in range(2):
+                eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), N, L, B, loss, nn, be.ptr(mb_loss),
+                                  d_neg_out=be.ptr(neg_out), stream=be.stream)
+            st = eng.rng_get_state()
+            results.append([be.get(mb_loss), be.get(neg_out), st[1], np.array(st[2])] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+        finally:
+            eng.set_option('chunk_interactions', 1 << 23)
+            eng.set_option('overlap_prep', 1)
+            eng.set_option('overlap_min_batch', 1 << 16)
+    for k, (a, b) in enumerate(zip(*results)):
+        assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined chunks' % k)
+
+
 def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11, bloom=0, ratio=0.4, tol=1e-5):
     """Identical minibatch and parameters: loss within 1e-5 rel, summed gradients within 1e-5 of
     each table's inf-norm; read back through ADAM_DENSE with lr = 0, beta1 = 0."""

@@ -80,3 +80,12 @@ def test_seq_argument_errors(be):
         eng.poolnet_train(dev.tables, dev.optim, 7, be.ptr(seqs), 2, 4, 2, 'bpr', 1, be.ptr(loss))  # padding_idx
     with pytest.raises(_native.SlkError):
         eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(seqs), 2, 100000, 2, 'bpr', 1, be.ptr(loss))  # LDS
+
+
+
+@pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('pointwise', 'adam_dense', 0),
+                                            ('bpr', 'adagrad', 4)])
+@pytest.mark.parametrize('overlap', [0, 1])
+def test_seq_chunked_and_pipelined_prep_is_bit_neutral(be, loss, opt, bloom, overlap):
+    """PoolNet: several prep chunks per call, in line and with the next chunk's prep on the second stream"""
+    ec.check_seq_chunking_is_bit_neutral(be, loss, opt, 16, bloom=bloom, overlap=overlap)

@@ -171,6 +171,15 @@ def test_pipelined_chunks_match_oracle(be):
         ec.check_chunking_is_bit_neutral(be, 'hinge', 'adam_dense', 16, N=12000, chunk=2048, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'pointwise', 'adagrad', 64, user_bloom=2, item_bloom=4, I=5000,
                                          N=20000, B=512, overlap=overlap)
+        # adaptive hinge over a bloom item table: the live occurrences are re-sorted per minibatch on the passes' stream while
+        # the next chunk's sorts run on the prep stream (separate temporary storage, slk_bilinear.hip BL_LATE_SORT)
+        ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'adagrad', 32, item_bloom=4, I=5000, N=20000, B=512,
+                                         overlap=overlap)
+        be.engine.set_option('adaptive_late_min_batch', 0)  # ... and over a plain table
+        try:
+            ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'adagrad', 32, N=20000, B=512, overlap=overlap)
+        finally:
+            be.engine.set_option('adaptive_late_min_batch', 1 << 18)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, U=200000, I=50000, N=600000, B=65536, chunk=131072)
     # the cache-policy option (non-temporal hints on once-per-pass rows) is bit-neutral
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, U=200000, I=50000, N=600000, B=65536, chunk=131072,
@@ -307,3 +316,12 @@ def test_epoch_kernel_many_minibatches_and_chunks(be):
     """400 minibatches in 4 launches (chunks of 100): thousands of grid barriers back to back"""
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=102400, B=256, epochs=1, chunk=25600)
 
+
+
+
+@pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('pointwise', 'adam_dense', 0),
+                                            ('bpr', 'adagrad', 4)])
+@pytest.mark.parametrize('overlap', [0, 1])
+def test_seq_chunked_and_pipelined_prep_is_bit_neutral(be, loss, opt, bloom, overlap):
+    """PoolNet: several prep chunks per call, in line and with the next chunk's prep on the second stream"""
+    ec.check_seq_chunking_is_bit_neutral(be, loss, opt, 16, bloom=bloom, overlap=overlap)

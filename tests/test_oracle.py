@@ -15,6 +15,8 @@ from oracle.replay import (case_from_rec, replay_bloom_with_oracle, replay_expli
 def test_oracle_replays_reference_run(name):
     rec = np.load(os.path.join(GOLDEN, name + '.npz'))
     case = case_from_rec(rec)
+    if case.get('no_oracle'):
+        pytest.skip('recorded for the autograd route (an optimizer the C oracle does not restate): tests/test_host_model.py')
     errs, frac = replay_with_oracle(case, rec)  # asserts bit-exact shuffles/negatives/rng state
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss')
     assert step < 1e-5, errs          # north-star tolerance on identical minibatches
