@@ -605,6 +605,28 @@ def main():
     eng.profile_enable(False)
     prof = eng.profile_read()
     xgmi_rows[0] = xg
+    # the same K steps once more with everything in line on one stream (option overlap_prep = 0): the timed region above runs
+    # the next chunk's negatives + sorts on a second stream beside the passes, which makes the step shorter and every pass a
+    # little longer; both sets of kernel durations go into the line
+    prof_in_line = elapsed_in_line = None
+    if trainer is None and world == 1:
+        eng.set_option('overlap_prep', 0)
+        try:
+            run(W + K, K)  # warm this configuration's scratch
+            be.sync()
+            eng.profile_reset()
+            eng.profile_enable(True)
+            t2 = time.perf_counter()
+            run(W + K, K)
+            be.sync()
+            elapsed_in_line = time.perf_counter() - t2
+            eng.profile_enable(False)
+            prof_in_line = eng.profile_read()
+        finally:
+            eng.set_option('overlap_prep', 1)
+            for kv in args.set:
+                name, value = kv.split('=')
+                eng.set_option(name, int(value))
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
         dist.barrier()
@@ -701,6 +723,18 @@ def main():
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
                 'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange', 'dense_sweep', 'epoch')}}
+        if prof_in_line is not None:
+            kin = {}
+            for name, per_int in (('user_pass', ub), ('item_pass', ib)):
+                n, ms = prof_in_line[name]
+                avg_s = ms / max(n, 1) * 1e-3
+                kin[name] = {'avg_ms': ms / max(n, 1), 'achieved_GBs': per_int * B / avg_s / 1e9 if avg_s > 0 else 0.0,
+                             'frac': per_int * B / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0}
+            roof['in_line'] = {'kernels': kin, 'ms_per_step_with_kernel_timers': elapsed_in_line / K * 1e3,
+                               'other_ms_per_step': {k: prof_in_line[k][1] / K for k in ('sample', 'prep')},
+                               'note': 'the same K minibatches with option overlap_prep = 0 (negatives, sorts and passes in order on one '
+                                       'stream): each pass by itself; `kernels` above are the passes as they ran in the timed '
+                                       'configuration, beside the next chunk\'s prep on a second stream'}
         if prof['epoch'][0]:
             roof['persistent_epoch_kernel'] = {'launches': prof['epoch'][0], 'us_per_minibatch': prof['epoch'][1] / K * 1e3,
                                                'note': 'every minibatch of a chunk inside one cooperative launch (slk_epoch.hip)'}
