@@ -381,7 +381,10 @@ def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5
     assert (got[1] == ref[1]).all() and got[2] == ref[2]
     open_tables = [be.get(x).copy() for x in dev.p + dev.s1 + dev.s2]
     for t in range(4):
-        assert_open_loop_drift(open_tables[t], ora.p[t], ('closed-loop check, open-loop run', t))
+        # coarse sanity only (a wrong update rule or a missed row shows; the element-wise statement is the closed loop below):
+        # random data from zero accumulators at lr 0.05 drifts further than the recordings the default bounds were measured on --
+        # adaptive hinge's arg-max flips on 1-ulp score differences, a handful of users collect every gradient
+        assert_open_loop_drift(open_tables[t], ora.p[t], ('closed-loop check, open-loop run', t), bound=0.25)
     # ---- closed loop
     dev2 = be.model(params, opt=opt, **hp)
     step = 0
