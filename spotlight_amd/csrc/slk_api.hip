@@ -125,6 +125,14 @@ int slk_prep_stream_init(slk_ctx *ctx) {
     } else {
         SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
     }
+    // the runtime sets a stream's hardware queue up at its first launch (measured: ~2 ms, once per stream -- the first
+    // overlapped training call of a process ran 0.86 instead of 0.75 ms per step, profiles/r03_e_*): done here, in the
+    // reserve / first-use path, not in a timed call
+    for (hipStream_t st : {ctx->prep_stream, ctx->pass_stream}) {
+        if (!st) continue;
+        SLK_HIP(ctx, hipMemsetAsync(&ctx->d_rng->pad_, 0, sizeof(int32_t), st));
+        SLK_HIP(ctx, hipStreamSynchronize(st));
+    }
     ctx->prep_stream_cus = ctx->opt_prep_cus;
     ctx->prep_stream_prio = ctx->opt_prep_priority;
     for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1], &ctx->ev_pass_in,
