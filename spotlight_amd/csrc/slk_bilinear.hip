@@ -1059,6 +1059,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     if (reserve_only) {
         if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
+        // the pinned read-back buffers and events of the long-run flags, per buffer set: hipHostMalloc inside a training call
+        // costs a device synchronisation (measured: the first overlapped call of a process 0.85 instead of 0.745 ms per step)
+        for (int st = 0; st < nsets; ++st) {
+            slk_prep_bufs &pb = ctx->pb[st];
+            if ((rc = slk_ensure_lflags_host(ctx, pb, 2 * (size_t)mb_per_chunk))) return rc;
+            pb.h_lflags_n = 0;
+            if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
+        }
         if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, expl))) return rc;
         // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;

@@ -681,6 +681,12 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
 
     if (reserve_only) {
         if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
+        for (int st = 0; st < nsets; ++st) {  // pinned read-back buffers + events of the long-run flags (slk_bilinear.hip)
+            slk_prep_bufs &pb = ctx->pb[st];
+            if ((rc = slk_ensure_lflags_host(ctx, pb, (size_t)mb_per_chunk))) return rc;
+            pb.h_lflags_n = 0;
+            if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
+        }
         // sampler and sort scratch of the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nts_max * nn))) return rc;
         return slk_sort_reserve(ctx, nts_max * (size_t)occ_mult);
