@@ -1067,6 +1067,40 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             pb.h_lflags_n = 0;
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
         }
+        if (nsets == 2 && !ctx->prep_warmed && nn > 0 && nc_max >= 4096) {
+            // One tiny prep on the prep stream, ordered against the caller's stream by the pipeline's own events: whatever the
+            // runtime sets up the first time these kernels (sampler, rocPRIM sorts) run on a stream and the first time two
+            // streams wait for each other's events then happens here and not inside the first overlapped training call
+            // (measured: that call ran 0.81-0.87 instead of 0.75-0.77 ms per step; a prior overlapped call of two minibatches
+            // removes it, profiles/r03_p_*).  The RNG state is put back afterwards.
+            hipStream_t ps = ctx->prep_stream;
+            slk_prep_bufs &pb = ctx->pb[1];
+            if ((rc = slk_ensure(ctx, ctx->extra[BL_LIVE], sizeof(slk_rng_dev) + 64))) return rc;
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));
+            SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+            SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[BL_LIVE].p, ctx->d_rng, sizeof(slk_rng_dev), hipMemcpyDeviceToDevice, ps));
+            if ((rc = slk_sample_u32(ctx, tables->num_items, 4096, (uint32_t *)pb.neg32.p, nullptr, ps))) return rc;
+            SLK_HIP(ctx, hipMemcpyAsync(ctx->d_rng, ctx->extra[BL_LIVE].p, sizeof(slk_rng_dev), hipMemcpyDeviceToDevice, ps));
+            SLK_HIP(ctx, hipMemsetAsync(pb.ukey[0].p, 0, 4096 * 4, ps));
+            if ((rc = slk_sort_pairs_u32_u64(ctx, (const uint32_t *)pb.ukey[0].p, (uint32_t *)pb.ukey[1].p, (const uint64_t *)pb.uval[0].p,
+                                             (uint64_t *)pb.uval[1].p, 4096, 20, ps)))
+                return rc;
+            if (!late) {
+                SLK_HIP(ctx, hipMemsetAsync(pb.ikey[0].p, 0, 4096 * 4, ps));
+                if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p, (const uint32_t *)pb.ipay[0].p,
+                                                 (uint32_t *)pb.ipay[1].p, 4096, 20, ps)))
+                    return rc;
+            }
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[1], ps));
+            SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[1], 0));
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_done[1], s));
+            SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[1], 0));
+            SLK_HIP(ctx, hipStreamSynchronize(ps));
+            SLK_HIP(ctx, hipStreamSynchronize(s));
+            ctx->last_stream = s;
+            ctx->sampled_valid = false;
+            ctx->prep_warmed = true;
+        }
         if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, expl))) return rc;
         // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;

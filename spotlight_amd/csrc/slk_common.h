@@ -141,6 +141,7 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
+    bool prep_warmed = false;           // the one-off tiny prep on the prep stream has run (slk_bilinear_reserve)
     hipStream_t pass_stream = nullptr;  // prep_cus > 0: the passes' stream, masked to the CUs the prep stream does not use
     hipEvent_t ev_pass_in = nullptr, ev_pass_out = nullptr;
     hipEvent_t ev_sampled = nullptr;    // behind the last draw of negatives (slk_sample_u32): slk_rng_get_state_sampled
