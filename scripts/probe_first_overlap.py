@@ -23,6 +23,8 @@ side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev));
 stream = torch.cuda.current_stream(dev).cuda_stream if mode != 'nullstream' else 0
 def run(first, n_mb):
     eng.bilinear_train(tb, op, users[first * B:].data_ptr(), items[first * B:].data_ptr(), n_mb * B, B, 'bpr', 1, mb[first:].data_ptr(), stream=stream)
+if mode == 'inline':
+    eng.set_option('overlap_prep', 0)
 eng.rng_set_state(np.random.RandomState(1).get_state())
 eng.bilinear_reserve(tb, op, K * B, B, 'bpr', 1, stream=stream)
 run(0, W)
