@@ -122,8 +122,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
 
 /* Tuning knobs (none changes results):
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
- *   "overlap_prep"        1 (default): the negatives + sorts of chunk c+1 run on a second HIP stream while
- *                         chunk c trains; 2: only the negatives; 0: everything in order on the caller's stream
+ *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while chunk c trains (what this
+ *                         package's fit() sets for its epochs: +1.5..4 % in the steady state of a run of training calls);
+ *                         2: only the negatives; 0 (default of a bare ctx): everything in order on the caller's stream
  *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
  *   "chunk_ramp"          1: with overlap_prep the first chunks of a call ramp up from ~2^20 interactions (default 0:
  *                         measured slower at every call length, profiles/r03_c_*)

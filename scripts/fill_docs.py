@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Fills the @@...@@ markers of DESIGN.md / profiles/README.md / README.md from profiles/r03_final_*.json (run once, after the
+round's last verification pass)."""
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, 'profiles')
+
+
+def L(name):
+    return json.load(open(os.path.join(P, name)))
+
+
+b = L('r03_final_bench.json')
+r = b['roofline']
+k, ov = r['kernels'], r['overlapped']
+fit = b.get('fit_end_to_end', {})
+sh = b.get('sharded_world1_consistency', {}).get('ms_per_step_second_call', {})
+cpu = b.get('cpu_baseline', {})
+stats = open(os.path.join(P, 'r03_final_kernel_stats.md')).read()
+m_u = re.search(r'k_user_pass<[^|]*\| (\d+) \| [\d.]+ \| ([\d.]+)', stats)
+m_i = re.search(r'k_item_pass<[^|]*\| (\d+) \| [\d.]+ \| ([\d.]+)', stats)
+headline = (
+    "Driver-style run (`bench.py --steps 20 --warmup 5`, `profiles/r03_final_bench.json`; a bare ctx: negatives, sorts and passes in "
+    "order on one stream): **%.3f G interactions/s**, %.4f ms per minibatch, whole step **%.3f** of 8 TB/s on the 3136 algorithmic "
+    "bytes (r02: 1.275 G/s, 0.822 ms, 0.500) = user pass %.4f ms + item pass %.4f ms + sampler %.3f + sorts %.3f (+ gaps); dominant "
+    "kernel (user pass) 1576 B × 2²⁰ ÷ %.4f ms = %.2f TB/s = **%.3f**, item pass 1560 B × 2²⁰ ÷ %.4f ms = %.2f TB/s = **%.3f** (r02: "
+    "0.635 / 0.631).  rocprofv3 of the same command (`r03_final_kernel_stats.md`): user pass %s µs, item pass %s µs (means over %s "
+    "launches).  `roofline.overlapped`, the same minibatches the way `fit()` runs them (next chunk's negatives + sorts on a second "
+    "stream; second call of its kind): **%.4f ms per step = %.3f G/s (%.3f)** with the passes at %.4f + %.4f ms beside the sorts.  "
+    "`bench.py` times the FIRST 20-minibatch call of the process, which is 3–6 %% slower than the calls after it whether the prep "
+    "overlaps or not (`r03_p_first_call_of_a_process.txt`).  `fit_end_to_end` (the drop-in `fit()`, 2²⁵ interactions × 10 epochs, id "
+    "upload included): **%.3f G interactions/s** (r02: 0.81).  Row-sharded path at world 1: %.2f ms per step against %.2f fused (r02: "
+    "2.39 / 0.94).  Probes: best copy %.2f TB/s (chunked, non-temporal), plain grid-stride copy %.2f, triad %.2f; the step's "
+    "algorithmic accesses alone %.3f ms.  CPU baseline, same run: the reference itself %.3f M interactions/s at %d threads, the C "
+    "port %.3f M/s on one core."
+    % (b['value'] / 1e9, b['ms_per_step'], r['step_frac_of_peak'], k['user_pass']['avg_ms'], k['item_pass']['avg_ms'],
+       r['other_ms_per_step']['sample'], r['other_ms_per_step']['prep'],
+       k['user_pass']['avg_ms'], k['user_pass']['achieved_GBs'] / 1e3, k['user_pass']['achieved_GBs'] / 8000.0,
+       k['item_pass']['avg_ms'], k['item_pass']['achieved_GBs'] / 1e3, k['item_pass']['achieved_GBs'] / 8000.0,
+       m_u.group(2) if m_u else '?', m_i.group(2) if m_i else '?', m_u.group(1) if m_u else '?',
+       ov['ms_per_step'], ov['interactions_per_s'] / 1e9, ov['step_frac_of_peak'], ov['kernels']['user_pass']['avg_ms'],
+       ov['kernels']['item_pass']['avg_ms'],
+       fit.get('interactions_per_s', 0) / 1e9, sh.get('sharded_world1', 0), sh.get('fused', 0),
+       r['measured']['copy_GBs'] / 1e3, r['measured']['variants_GBs']['copy_plain'] / 1e3, r['measured']['triad_GBs'] / 1e3,
+       r['ceiling']['ms_per_step'], cpu.get('value', 0) / 1e6, cpu.get('cores', 0), cpu.get('port', {}).get('value', 0) / 1e6))
+
+
+def zl(fmt, names, key):
+    out = []
+    for n in names:
+        d = L(fmt % n)
+        out.append('%.2f' % d['roofline']['kernels'][key]['avg_ms'])
+    return ' / '.join(out)
+
+
+zu = '**' + zl('r03_final_bench_userzipf_%s.json', ('0.8', '1.0', '1.2'), 'user_pass') + '**'
+zi = '**' + zl('r03_final_bench_zipf_%s.json', ('0.8', '1.0', '1.2'), 'item_pass') + '**'
+c3, c4, c5, sa = (L('r03_final_bench_%s.json' % w) for w in ('c3', 'c4', 'c5', 'sparse_adam'))
+bt = {n: L('r03_final_bench_batch_%s.json' % n) for n in ('256', '1024', '65536', '1048576')}
+other = ("C3 %.0f M interactions/s (%.2f; r02 138, 0.46), C4 %.2f G timesteps/s (%.2f; r02 1.31, 0.34 — the prep overlap and the key "
+         "prefetch), C5 shard %.2f G/s (%.2f; r02 0.89, 0.35), SparseAdam on C2 %.2f G/s (%.2f of its 4696-B roofline).  Minibatch lines "
+         "on the C2 tables: 256 → %.1f µs, 1024 → %.1f µs (both the persistent kernel), 65 536 → %.0f µs, 2²⁰ → %.0f µs."
+         % (c3['value'] / 1e6, c3['roofline']['step_frac_of_peak'], c4['value'] / 1e9, c4['roofline']['step_frac_of_peak'],
+            c5['value'] / 1e9, c5['roofline']['step_frac_of_peak'], sa['value'] / 1e9, sa['roofline']['step_frac_of_peak'],
+            bt['256']['ms_per_step'] * 1e3, bt['1024']['ms_per_step'] * 1e3, bt['65536']['ms_per_step'] * 1e3, bt['1048576']['ms_per_step'] * 1e3))
+final_row = ("`scripts/gpu_r03_final.sh`: the round's last verification pass on one box — `pytest -m gpu` tail, the default bench line (with "
+             "`roofline.overlapped`, the probes, `fit_end_to_end`, the sharded world-1 check, the reference CPU baseline), rocprofv3 kernel stats and "
+             "PMC traffic of the same workload (`pmc_traffic.json` is refreshed from it), C3 / C4 / C5, SparseAdam, the minibatch-size lines, "
+             "Zipf items / users / both: **%.3f G interactions/s, %.4f ms per step (0.%s of the roofline), fit() %.2f G/s**"
+             % (b['value'] / 1e9, b['ms_per_step'], ('%.3f' % r['step_frac_of_peak'])[2:], fit.get('interactions_per_s', 0) / 1e9))
+subs = {'@@HEADLINE@@': headline, '@@ZIPF_USERS@@': zu, '@@ZIPF_ITEMS@@': zi, '@@OTHER@@': other, '@@FINAL@@': final_row}
+for fn in ('DESIGN.md', 'profiles/README.md', 'README.md'):
+    p = os.path.join(ROOT, fn)
+    s = open(p).read()
+    for a, v in subs.items():
+        s = s.replace(a, v)
+    open(p, 'w').write(s)
+print(headline)
+print(other)

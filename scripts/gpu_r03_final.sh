@@ -10,16 +10,16 @@ import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']; print('C2', 
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit > $OUT/prof_bench.json 2> $OUT/prof.err)
 db=$(find $OUT/prof -name "*.db" | head -1)
 [ -n "$db" ] && python scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -12 $OUT/kernel_stats.md
-for w in c3 c4 c5; do timeout 600 python bench.py --workload $w --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check > $OUT/bench_$w.json 2>/dev/null; python -c "
+for w in c3 c4 c5; do timeout 600 python bench.py --workload $w --steps 32 --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check > $OUT/bench_$w.json 2>/dev/null; python -c "
 import json; d=json.load(open('$OUT/bench_$w.json')); r=d['roofline']; print('$w', d['value']/1e9, d['unit'], d['ms_per_step'], r.get('step_frac_of_peak'))"; done
-for B in 256 1024 65536 1048576; do S=$((4194304 / B)); [ $S -lt 16 ] && S=16; [ $S -gt 2000 ] && S=2000
+for B in 256 1024 65536 1048576; do S=$((16777216 / B)); [ $S -lt 32 ] && S=32; [ $S -gt 2000 ] && S=2000
 python bench.py --batch $B --steps $S --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_batch_$B.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('C2 tables batch $B: %.1f M interactions/s, %.1f us per minibatch' % (d['value']/1e6, d['ms_per_step']*1e3))"; done
-for z in 0.8 1.0 1.2; do python bench.py --item-zipf $z --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_zipf_$z.json | python -c "
+for z in 0.8 1.0 1.2; do python bench.py --item-zipf $z --steps 16 --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_zipf_$z.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, positive items Zipf($z): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"; done
-for z in 0.8 1.0 1.2; do python bench.py --user-zipf $z --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_userzipf_$z.json | python -c "
+for z in 0.8 1.0 1.2; do python bench.py --user-zipf $z --steps 16 --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_userzipf_$z.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, users Zipf($z): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"; done
-python bench.py --user-zipf 1.0 --item-zipf 1.0 --steps 8 --warmup 2 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_bothzipf_1.0.json | python -c "
+python bench.py --user-zipf 1.0 --item-zipf 1.0 --steps 16 --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_bothzipf_1.0.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, users and positive items Zipf(1.0): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"
 for opt in sparse_adam; do python bench.py --opt $opt --steps 16 --warmup 4 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_$opt.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 $opt: %.3f G interactions/s, %.4f ms, step frac %.3f' % (d['value']/1e9, d['ms_per_step'], r['step_frac_of_peak']))"; done

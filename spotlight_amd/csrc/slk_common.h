@@ -92,7 +92,11 @@ struct slk_ctx {
     size_t dgrad_elems[4] = {0, 0, 0, 0};
     // tuning (slk_ctx_set_option)
     int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
-    int opt_overlap_prep = 1;      // 1: prep of chunk c+1 on a second stream while chunk c trains (2: only its negatives)
+    int opt_overlap_prep = 0;      // 1: prep of chunk c+1 on a second stream while chunk c trains (2: only its negatives).  The host
+                                   // models switch it on for their epochs (spotlight_amd/factorization/implicit.py::_engine_for): in the
+                                   // steady state of a run of training calls it gains 1.5-4 % (profiles/r03_*); a lone call of a few
+                                   // chunks gains nothing, every pass runs ~10 % longer beside the sorts, and kernel timings under a
+                                   // tracer stop agreeing with the untraced ones -- so a bare ctx keeps everything on one stream
     // Partition of the chip between the prep of chunk c+1 and the passes of chunk c (only with overlap_prep).  The row passes
     // are grid-stride kernels that keep every wave slot of every CU for their whole run, so a second stream's kernels
     // otherwise only run in the gaps: prep_cus > 0 gives the prep stream a CU mask of that many CUs (spread over the XCDs and

@@ -27,6 +27,9 @@ def _engine_for(device):
     index = device.index if device.index is not None else torch.cuda.current_device()
     if index not in _ENGINES:
         _ENGINES[index] = _native.Engine(index)
+        # epochs are runs of multi-chunk training calls: the next chunk's negatives + sorts go to the ctx's second stream beside
+        # the current chunk's passes (include/spotlight_hip.h, option "overlap_prep"; a bare ctx keeps them in line)
+        _ENGINES[index].set_option('overlap_prep', 1)
     return _ENGINES[index]
 
 

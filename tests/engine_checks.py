@@ -631,7 +631,7 @@ def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=3
             results.append([be.get(mb_loss), be.get(neg_out), st[1], np.array(st[2])] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
         finally:
             eng.set_option('chunk_interactions', 1 << 23)
-            eng.set_option('overlap_prep', 1)
+            eng.set_option('overlap_prep', 0)
             eng.set_option('overlap_min_batch', 1 << 16)
     for k, (a, b) in enumerate(zip(*results)):
         assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined chunks' % k)
@@ -936,7 +936,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
                            [be.get(x) for x in dev.p + dev.s1 + dev.s2])
         finally:
             eng.set_option('chunk_interactions', 1 << 23)
-            eng.set_option('overlap_prep', 1)
+            eng.set_option('overlap_prep', 0)
             eng.set_option('overlap_min_batch', 1 << 16)
             if nt is not None:
                 eng.set_option('nt', 3)

@@ -131,7 +131,7 @@ def test_pipelined_chunks_match_single_chunk(be):
         ec.check_train_matches_oracle(be, 'hinge', 'adam_dense', 8, N=450, B=32, epochs=1)
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
-        eng.set_option('overlap_prep', 1)
+        eng.set_option('overlap_prep', 0)
         eng.set_option('overlap_min_batch', 1 << 16)
         eng.set_option('item_grid_mult', 64)
         eng.set_option('user_grid_mult', 8)

@@ -163,7 +163,7 @@ def test_pipelined_chunks_match_oracle(be):
             ec.check_train_matches_oracle(be, 'bpr', 'adagrad', 64, U=3000, I=1000, N=50000, B=1024, epochs=1, tol=1e-4)
     finally:
         eng.set_option('chunk_interactions', 1 << 23)
-        eng.set_option('overlap_prep', 1)
+        eng.set_option('overlap_prep', 0)
         eng.set_option('overlap_min_batch', 1 << 16)
     for overlap in (0, 1, 2):
         ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, overlap=overlap)
