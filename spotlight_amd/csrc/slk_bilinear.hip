@@ -975,9 +975,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const bool late = adaptive && optim->kind != SLK_OPT_SPARSE_ADAM && (Hi > 0 || bsz >= ctx->opt_adaptive_late_min_batch);
     // scratch.  With the "overlap_prep" option the value-independent part of a chunk (negatives,
     // sort by user, sort by item) is prepared on a second HIP stream while the previous chunk's
-    // passes run, and those buffers exist twice (ctx->pb[0|1]).  On by default since round 3 (profiles/r03_a_*, r03_b_*: with
-    // two of the user pass's eight workgroups per CU left to the prep stream the step gains 3 % at 32 minibatches per call,
-    // 8 % in the steady state of a long epoch; round 1 had measured no gain with the pass holding every wave slot).
+    // passes run, and those buffers exist twice (ctx->pb[0|1]).  What fit() sets for its epochs (profiles/r03_a_*, r03_b_*: with
+    // two of the user pass's eight workgroups per CU left to the prep stream the steady state of a run of training calls gains
+    // 1.5-4 %; round 1 had measured no gain with the pass holding every wave slot); off on a bare ctx (slk_common.h).
     const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
     // chunk boundaries.  In order on one stream: chunks of chunk_cap.  Overlapped (prep of chunk c+1 beside the passes of
     // chunk c): the first chunk's prep is the one nothing hides, so the chunks ramp up -- ~2^20 interactions, then doubling to
