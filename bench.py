@@ -109,6 +109,9 @@ def parse():
     ap.add_argument('--no-probes', action='store_true', help='skip the copy / triad / step-ceiling bandwidth probes')
     ap.add_argument('--no-sharded-check', action='store_true',
                     help='N=1: skip the consistency run of the row-sharded path (world 1) against the fused path')
+    ap.add_argument('--no-overlapped', action='store_true',
+                    help='skip the secondary roofline.overlapped measurement (three more K-step calls with option overlap_prep = 1): what '
+                         'the rocprofv3 / PMC commands use, so that their per-kernel means are those of the timed configuration only')
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=30.0)
@@ -612,7 +615,7 @@ def main():
     # minibatches are run that way three more times -- untimed warm-up, un-instrumented, with the kernel timers -- and go
     # into the line as roofline.overlapped: the steady state a training run of many calls sees.
     prof_ov = elapsed_ov = elapsed_ov_prof = None
-    if trainer is None and world == 1 and not any(kv.startswith('overlap_prep=') for kv in args.set):
+    if trainer is None and world == 1 and not args.no_overlapped and not any(kv.startswith('overlap_prep=') for kv in args.set):
         eng.set_option('overlap_prep', 1)
         try:
             eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # the second buffer set, the prep stream

@@ -7,9 +7,9 @@ timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"; python -c "
 import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']; print('C2', d['value']/1e9, 'G/s', d['ms_per_step'], 'frac', r['frac'], 'step', r['step_frac_of_peak'], r['measured']['variants_GBs'], r['ceiling']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['cpu_baseline'].get('interactions_per_s_by_threads'))"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit > $OUT/prof_bench.json 2> $OUT/prof.err)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit --no-overlapped > $OUT/prof_bench.json 2> $OUT/prof.err)
 db=$(find $OUT/prof -name "*.db" | head -1)
-[ -n "$db" ] && python scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -12 $OUT/kernel_stats.md
+[ -n "$db" ] && python scripts/summarize_prof.py "$db" $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-probes --no-sharded-check --no-fit --no-overlapped ($TAG)" $OUT/prof_bench.json && rm -rf $OUT/prof && head -12 $OUT/kernel_stats.md
 for w in c3 c4 c5; do timeout 600 python bench.py --workload $w --steps 32 --warmup 8 --no-cpu-baseline --no-probes --no-sharded-check > $OUT/bench_$w.json 2>/dev/null; python -c "
 import json; d=json.load(open('$OUT/bench_$w.json')); r=d['roofline']; print('$w', d['value']/1e9, d['unit'], d['ms_per_step'], r.get('step_frac_of_peak'))"; done
 for B in 256 1024 65536 1048576; do S=$((16777216 / B)); [ $S -lt 32 ] && S=32; [ $S -gt 2000 ] && S=2000
@@ -23,4 +23,4 @@ python bench.py --user-zipf 1.0 --item-zipf 1.0 --steps 16 --warmup 8 --no-cpu-b
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, users and positive items Zipf(1.0): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"
 for opt in sparse_adam; do python bench.py --opt $opt --steps 16 --warmup 4 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_$opt.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 $opt: %.3f G interactions/s, %.4f ms, step frac %.3f' % (d['value']/1e9, d['ms_per_step'], r['step_frac_of_peak']))"; done
-bash scripts/pmc_run.sh ${1:-r03_final}_pmc --no-probes --no-sharded-check > $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log 2>&1; tail -5 $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log
+bash scripts/pmc_run.sh ${1:-r03_final}_pmc --no-probes --no-sharded-check --no-overlapped > $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log 2>&1; tail -5 $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log
