@@ -34,8 +34,17 @@ if mode == 'tiny':      # a tiny overlapped call first: 2 chunks of one minibatc
     eng.set_option('chunk_interactions', 1 << 23)
 elif mode == 'w9':      # warm-up long enough to be overlapped itself
     run(0, 9)
+elif mode == 'w5x2':    # the same 5-minibatch warm-up twice
+    run(0, W)
+elif mode == 'busy':    # ~100 ms of copy kernels right before the timed calls (clock / power state, not the ids)
+    n = 1 << 28
+    bufs = [torch.empty(n, device=dev) for _ in range(3)]
+    for _ in range(3):
+        eng.probe_stream(0, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), n, iters=10, stream=stream)
 torch.cuda.synchronize(dev)
 out = []
-for _ in range(3):
+for j in range(4 if mode == 'idle' else 3):
+    if mode == 'idle' and j == 3:
+        time.sleep(0.5)  # an idle GPU before the fourth call: does the first-call figure come back?
     t0 = time.perf_counter(); run(W, K); torch.cuda.synchronize(dev); out.append(round((time.perf_counter() - t0) / K * 1e3, 4))
 print(mode, out)
