@@ -586,6 +586,13 @@ def main():
             dist.barrier()
             be.sync()
 
+    # The copy / triad probes (own buffers, the tables untouched) go BEFORE the warm-up: a GPU coming out of idle runs its first
+    # ~20 ms 4-6 % slower (profiles/r03_t_first_call_after_idle.txt: the figure returns after 0.5 s of idle), and W = 5 warm-up
+    # minibatches are 4 ms.  The timed region itself is unchanged: W untimed steps, then exactly K.
+    probes = ceiling = shard_check = None
+    want_probes = rank == 0 and world == 1 and trainer is None and not args.no_probes
+    if want_probes:
+        probes = measured_stream_rates(be, stream)
     if trainer is None:
         eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # scratch for the timed call's shape
     if W:
@@ -687,9 +694,7 @@ def main():
             except Exception as e:
                 denominators = {'error': repr(e)[:300]}
         dist.barrier()
-    probes = ceiling = shard_check = None
-    if rank == 0 and world == 1 and trainer is None and not args.no_probes:
-        probes = measured_stream_rates(be, stream)
+    if want_probes:
         um, im, touched = eng.probe_step_ceiling(tb, op, B, iters=10, stream=stream)
         ceiling = {'user_side_ms': um, 'item_side_ms': im, 'items_touched': touched}
     if want_sharded_check and rank == 0:
