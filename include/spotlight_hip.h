@@ -132,6 +132,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
  *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
+ *   "epoch_adaptive"      1 (default): adaptive hinge takes the persistent kernel too (score phase + in-phase selection),
+ *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 512)
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
  *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
  *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)

@@ -1048,7 +1048,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     // minibatches of a few thousand interactions: every minibatch of a chunk inside ONE persistent launch (slk_epoch.hip)
-    bool epoch_route = (!pre || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    bool epoch_route = (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
     auto ensure_dense_buffers = [&]() -> int {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
@@ -1101,7 +1101,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             ctx->sampled_valid = false;
             ctx->prep_warmed = true;
         }
-        if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, expl))) return rc;
+        if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, (int)loss, NP))) return rc;
         // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;
         return slk_sort_reserve(ctx, nc_max * (size_t)occ_mult);
@@ -1466,7 +1466,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (!epoch_route) return do_passes(ck, pb);
         const int64_t c0 = cb[ck];
         const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
-        int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, RS, (float *)ctx->snap.p,
+        int rc = slk_epoch_run_chunk(ctx, tables, optim, pb, nc, bsz, ubits, ibits, (int)loss, NP, RS, (float *)ctx->snap.p,
                                      (float *)ctx->extra[BL_GSN].p, d_mb_loss + mb_global, expl ? d_ratings + c0 : nullptr, s);
         if (rc == SLK_EAGAIN_EPOCH) {  // cooperative launch refused: nothing ran; per-minibatch launches from here on
             epoch_route = false;

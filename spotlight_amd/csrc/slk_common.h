@@ -129,6 +129,10 @@ struct slk_ctx {
     int opt_epoch_kernel = 1;
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
+    int opt_epoch_adaptive = 1;    // adaptive hinge on the persistent route (score phase + the selection inside the user phase)
+    int64_t opt_epoch_adaptive_max_batch = 512;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
+                                   // interaction: same-box A/B in profiles/r03_u_*, r03_v_*)
+    int epoch_bars_per_mb = 2;     // grid barriers per minibatch of the last persistent launch (the time-out report names the minibatch)
     int opt_epoch_barrier = -1;    // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters), -1 by grid size
     int opt_epoch_cooperative = 0; // 1: hipLaunchCooperativeKernel (launch-time residency check; it also keeps kernels of OTHER streams
                                    // from running beside it, measured: profiles/r02_h_c1_fit_timeline_adagrad.json), 0: plain launch
@@ -245,9 +249,9 @@ int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32
                       uint32_t *nseg_out, hipStream_t s);
 // slk_epoch.hip: the persistent route of slk_bilinear_train
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss, bool bloom);
-int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, bool expl);
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP);
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
-                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
+                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int NP, int RS, float *snap, float *gsn,
                         float *d_mb_loss, const float *d_ratings, hipStream_t s);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);

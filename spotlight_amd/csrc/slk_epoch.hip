@@ -17,6 +17,13 @@
 //                g * u_old over the run in occurrence order, updates V[i] and its bias
 //   -- grid barrier --
 //
+// Adaptive hinge (implicit.py:266-275, losses.py:127-166; n negatives per interaction, default 5): a SCORE PHASE in front --
+// one row group per interaction: its 1 + n scores, k_score_pass's arithmetic -- and a grid barrier; the user phase then
+// evaluates, per interaction, the 1 + n columns of the reference's view(n, B) candidate matrix that decide its pairs (one
+// column per lane: the positive's own column and the column each of its draws sits in; k_adaptive_select's selection, first
+// maximum wins), so dL/dscore needs no phase and no barrier of its own: three barriers per minibatch instead of the launch
+// path's four launches.
+//
 // i.e. the two ownership passes of the launch path (same sorted lists, same summation order, same arithmetic: the
 // trained tables are BIT-IDENTICAL to the per-minibatch launches, which the tests assert), with the launch boundaries
 // replaced by an in-kernel barrier.  The dense optimizers (the reference's default Adam + l2, Adagrad + weight decay:
@@ -61,6 +68,8 @@ struct slk_epoch_args {
     const uint32_t *ukey, *uit;    // (minibatch << ubits) | user, sorted; [2 * position] = (pos item, neg item)
     const uint32_t *uk;            // explicit feedback: uit[position] = item, uk[position] = the interaction's index in
     const float *ratings;          //   ratings[] (chunk-local)
+    int NP;                        // adaptive hinge: uit[NP * position + s] = the positive (s = 0) and the n draws of the interaction
+    float *sk;                     //   uk[position] (chunk-local); sk[NP * interaction + s] = their scores (score phase)
     uint32_t umask;
     const uint32_t *ikey, *ipay;   // (minibatch << ibits) | item, sorted; occurrence -> 2 * position + pair (explicit: position)
     uint32_t imask;
@@ -72,7 +81,7 @@ struct slk_epoch_args {
     const slk_step_coef *coef;     // [n_mb]
     uint32_t *touch_u, *touch_i;   // dense optimizers: touch[row] = (last minibatch that looks the row up) + 1; zeroed before the launch
     unsigned *bar;                 // barrier counter, zeroed before the launch
-    int *status;                   // barrier time-out: the number (>= 1) of the barrier that was abandoned, 2 per minibatch
+    int *status;                   // barrier time-out: the number (>= 1) of the barrier that was abandoned, 2 per minibatch (adaptive: 3)
     int loss_kind;
     float eps, omb1, omb2, beta2, wd;
     int bar_kind;                  // 0: one arrival counter, 1: 8 sub-counters + a top counter
@@ -227,9 +236,12 @@ __device__ __forceinline__ void slk_epoch_sweep_untouched(const slk_epoch_args &
     }
 }
 
-template <int VEC, int G, int UPD, bool EXPL>
+enum { SLK_EMODE_PAIR = 0, SLK_EMODE_EXPLICIT = 1, SLK_EMODE_ADAPTIVE = 2 };
+
+template <int VEC, int G, int UPD, int MODE>
 __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args e) {
-    constexpr uint32_t NP = EXPL ? 1u : 2u;  // score pairs (= item occurrences) per interaction
+    constexpr bool EXPL = MODE == SLK_EMODE_EXPLICIT, ADP = MODE == SLK_EMODE_ADAPTIVE;
+    const uint32_t NP = ADP ? (uint32_t)e.NP : (EXPL ? 1u : 2u);  // score pairs (= item occurrences) per interaction
     HIP_DYNAMIC_SHARED(double, s_wave_sums)      // [4] per-wave loss sums (unused slots stay 0) + the barrier's two flag words
     int *s_flags = reinterpret_cast<int *>(s_wave_sums + 4);
     if (threadIdx.x < 4) s_wave_sums[threadIdx.x] = 0.0;
@@ -249,12 +261,27 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
     // The sorted id lists are immutable: what a row group needs of them for its FIRST position of the next phase is
     // fetched before the barrier it is about to wait at, off the critical path.
     uint32_t nx_key = 0, nx_prev = 0, nx_a = 0, nx_b = 0;
-    if (gslot < (e.nc < e.bsz ? e.nc : e.bsz)) {
+    if (!ADP && gslot < (e.nc < e.bsz ? e.nc : e.bsz)) {
         nx_key = e.ukey[gslot];
         nx_prev = gslot ? e.ukey[gslot - 1] : 0u;
         nx_a = e.uit[NP * (size_t)gslot];
         nx_b = EXPL ? e.uk[gslot] : e.uit[2 * (size_t)gslot + 1];
     }
+    // adaptive hinge, score phase: a UNIT is one position's scores SB at a time (1 + 5 draws: two units per position, so that
+    // a minibatch of 256 spreads over 512 row groups); the ids of a row group's first unit travel ahead like nx_*
+    constexpr int SB = 3;
+    const uint32_t nch = ADP ? (NP + SB - 1u) / SB : 1u;
+    uint32_t sc_key = 0, sc_k = 0, sc_it[SB] = {0u, 0u, 0u};
+    auto score_prefetch = [&](uint32_t b0, uint32_t b1) {
+        if (gslot < (b1 - b0) * nch) {
+            const uint32_t p = b0 + gslot / nch, s0 = (gslot % nch) * SB;
+            sc_key = e.ukey[p];
+            sc_k = e.uk[p];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) sc_it[j] = s0 + j < NP ? e.uit[(size_t)p * NP + s0 + j] : 0u;
+        }
+    };
+    if (ADP) score_prefetch(0u, e.nc < e.bsz ? e.nc : e.bsz);
 
     if (DENSE) {  // prologue: the users of minibatch 0
         const uint32_t nb1 = e.nc < e.bsz ? e.nc : e.bsz;
@@ -270,15 +297,61 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         const float inv_b = 1.0f / (float)(b1 - b0);
         const slk_step_coef c = e.coef[mb];
 
+        // ------------------------------------------------ SCORE PHASE (adaptive hinge): k_score_pass's arithmetic
+        if (ADP) {
+            const uint32_t n_units = (b1 - b0) * nch;
+            for (uint32_t unit = gslot; unit < n_units && !(e.debug & 1); unit += gstride) {
+                const bool pre = unit == gslot;
+                const uint32_t p = b0 + unit / nch, s0 = (unit % nch) * SB;
+                const uint32_t user = (pre ? sc_key : e.ukey[p]) & e.umask;
+                const size_t kb = (size_t)(pre ? sc_k : e.uk[p]) * NP, qb = (size_t)p * NP;
+                uint32_t it[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) it[j] = pre ? sc_it[j] : (s0 + j < NP ? e.uit[qb + s0 + j] : 0u);
+                const slk_vec<VEC> u = on ? slk_vload_coh<VEC>(e.P[0] + (size_t)user * D + d0) : zero;
+                const float bu = slk_ld_coh(e.P[2] + user);
+                slk_vec<VEC> v[SB];
+                float bi[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    v[j] = zero;
+                    bi[j] = 0.0f;
+                    if (s0 + j < NP) {
+                        if (on) v[j] = slk_vload_coh<VEC>(e.P[1] + (size_t)it[j] * D + d0);
+                        bi[j] = slk_ld_coh(e.P[3] + it[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v[j])) + bu + bi[j];
+                    if (lane == 0 && s0 + j < NP) slk_st_coh(e.sk + kb + s0 + j, sc);
+                }
+            }
+            // this row group's first position of the user phase: key, interaction, and its pairs' items one per lane
+            if (b0 + gslot < b1) {
+                nx_key = e.ukey[b0 + gslot];
+                nx_prev = gslot ? e.ukey[b0 + gslot - 1] : 0u;
+                nx_a = e.uk[b0 + gslot];
+                nx_b = (uint32_t)lane < NP ? e.uit[(size_t)(b0 + gslot) * NP + lane] : 0u;
+            }
+            if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
+            ++barriers;
+        }
+
         // ------------------------------------------------ USER PHASE
         float loss_acc = 0.0f;
+        double loss_acc_d = 0.0;  // adaptive hinge: the columns' hinge terms (k_adaptive_select sums them in double)
         for (uint32_t p = b0 + gslot; p < b1 && !(e.debug & 1); p += gstride) {
             const bool first = p == b0;
             const bool pre = p == b0 + gslot;  // this position's list entries were prefetched
             const uint32_t key = pre ? nx_key : e.ukey[p];
             const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ukey[p - 1]);
             // pair: (positive item, negative item).  explicit: (item, index of the interaction's rating)
-            uint32_t ip = pre ? nx_a : e.uit[NP * (size_t)p], in = pre ? nx_b : (EXPL ? e.uk[p] : e.uit[2 * (size_t)p + 1]);
+            uint32_t ip = 0u, in = 0u;
+            if (!ADP) {
+                ip = pre ? nx_a : e.uit[NP * (size_t)p];
+                in = pre ? nx_b : (EXPL ? e.uk[p] : e.uit[2 * (size_t)p + 1]);
+            }
             if (!first && prev == key) continue;  // not the head of its user's run
             const uint32_t user = key & e.umask;
             const size_t uoff = (size_t)user * D + d0;
@@ -292,9 +365,9 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (HAS_S1) bus1 = slk_vload_coh<1>(e.S1[2] + user);
                 if (HAS_S2) bus2 = slk_vload_coh<1>(e.S2[2] + user);
             }
-            slk_vec<VEC> vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
-            slk_vec<VEC> vj = (on && !EXPL) ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
-            float bi = slk_ld_coh(e.P[3] + ip), bj = EXPL ? 0.0f : slk_ld_coh(e.P[3] + in);
+            slk_vec<VEC> vi = (on && !ADP) ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
+            slk_vec<VEC> vj = (on && MODE == SLK_EMODE_PAIR) ? slk_vload_coh<VEC>(e.P[1] + (size_t)in * D + d0) : zero;
+            float bi = ADP ? 0.0f : slk_ld_coh(e.P[3] + ip), bj = MODE == SLK_EMODE_PAIR ? slk_ld_coh(e.P[3] + in) : 0.0f;
             float rating = EXPL ? e.ratings[in] : 0.0f;  // an input of the call: plain load
             // The user's run is summed as the launch path sums it (slk_bilinear.hip, k_user_pass<ULONG> + k_user_stitch): in
             // occurrence order -- unless it is LONG, i.e. wholly covers an aligned tile of SLK_USER_TILE positions of the
@@ -308,7 +381,70 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             uint32_t q = p;
             for (;;) {
                 if (on) slk_vstore_coh<VEC>(e.snap + (size_t)(q - b0) * e.RS + d0, u);
-                if (EXPL) {
+                if (ADP) {
+                    // dL/dscore of this interaction's 1 + n pairs.  Pair 0 (the positive) belongs to column kc of the
+                    // minibatch's [n, B] candidate matrix; draw j is entry f = kc * n + j of the flat n * B draws, which the
+                    // reference's view(n, B) puts in row f / B of column f % B (implicit.py:266-275).  Lane s evaluates the
+                    // column of pair s as k_adaptive_select does -- the positive's score, the n candidates, first maximum wins,
+                    // x = best - positive + 1, g = 1/B where x >= 0 -- and keeps the pair's share: -g for the positive, g for
+                    // the selected draw, 0 for the others.  Column kc's hinge term is counted here, once.
+                    const bool qpre = pre && q == p;
+                    const uint32_t kc = (qpre ? nx_a : e.uk[q]) - b0, bm = b1 - b0, nn = NP - 1u;
+                    for (uint32_t s0 = 0; s0 < NP; s0 += (uint32_t)G) {
+                        const uint32_t s = s0 + (uint32_t)lane;
+                        // the pair's item id (lane s), issued with the scores: the rows of the live pairs follow at once
+                        const uint32_t it_l = (qpre && s0 == 0u) ? nx_b : (s < NP ? e.uit[(size_t)q * NP + s] : 0u);
+                        float gs = 0.0f;
+                        if (s < NP) {
+                            const uint32_t f = s == 0u ? 0u : kc * nn + (s - 1u);
+                            const uint32_t col = s == 0u ? kc : f % bm, row = s == 0u ? 0u : f / bm;
+                            const float sp = slk_ld_coh(e.sk + (size_t)(b0 + col) * NP);
+                            float best = 0.0f;
+                            uint32_t best_r = 0u;
+                            for (uint32_t r = 0; r < nn; ++r) {
+                                const uint32_t fr = r * bm + col;
+                                const float sc = slk_ld_coh(e.sk + (size_t)(b0 + fr / nn) * NP + 1u + fr % nn);
+                                if (r == 0u || sc > best) {
+                                    best = sc;
+                                    best_r = r;
+                                }
+                            }
+                            const float x = best - sp + 1.0f;
+                            const float g = x >= 0.0f ? inv_b : 0.0f;
+                            if (s == 0u) {
+                                gs = -g;
+                                loss_acc_d += (double)(x > 0.0f ? x : 0.0f);
+                            } else {
+                                gs = best_r == row ? g : 0.0f;
+                            }
+                            slk_st_coh(e.gsn + (size_t)(q - b0) * NP + s, gs);
+                        }
+                        // the live pairs (the positive and the selected draws), in pair order as the launch path's user pass adds
+                        // them, two rows in flight
+                        unsigned long long live = slk_group_or<G>(gs != 0.0f ? 1ull << lane : 0ull);
+                        while (live) {
+                            const int j0 = __builtin_ctzll(live);
+                            live &= live - 1ull;
+                            const bool two = live != 0ull;
+                            const int j1 = two ? __builtin_ctzll(live) : j0;
+                            if (two) live &= live - 1ull;
+                            const uint32_t i0 = __shfl(it_l, j0, G), i1 = __shfl(it_l, j1, G);
+                            const float g0 = __shfl(gs, j0, G), g1 = __shfl(gs, j1, G);
+                            const slk_vec<VEC> v0 = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)i0 * D + d0) : zero;
+                            const slk_vec<VEC> v1 = (on && two) ? slk_vload_coh<VEC>(e.P[1] + (size_t)i1 * D + d0) : zero;
+                            slk_vaxpy<VEC>(gu, g0, v0);
+                            gbu += g0;
+                            slk_vaxpy<VEC>(tu, g0, v0);
+                            tbu += g0;
+                            if (two) {
+                                slk_vaxpy<VEC>(gu, g1, v1);
+                                gbu += g1;
+                                slk_vaxpy<VEC>(tu, g1, v1);
+                                tbu += g1;
+                            }
+                        }
+                    }
+                } else if (EXPL) {
                     const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bi;
                     float l, g;
                     slk_explicit_loss(e.loss_kind, sc, rating, inv_b, b1 - b0, l, g);
@@ -363,6 +499,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                     }
                 }
                 if (!(q < b1 && e.ukey[q] == key)) break;
+                if (ADP) continue;
                 ip = e.uit[NP * (size_t)q];  // further occurrences of the same user in this minibatch
                 vi = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)ip * D + d0) : zero;
                 bi = slk_ld_coh(e.P[3] + ip);
@@ -403,7 +540,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             nx_a = e.ipay[ib0 + gslot];
         }
         {   // the workgroup's loss sum: waves by shuffle, the four wave sums by thread 0 on its way into the barrier
-            double x = (double)loss_acc;
+            double x = ADP ? loss_acc_d : (double)loss_acc;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
             if ((threadIdx.x & 63) == 0) s_wave_sums[threadIdx.x >> 6] = x;
@@ -433,7 +570,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (HAS_S2) bis2 = slk_vload_coh<1>(e.S2[3] + item);
             }
             float g = slk_ld_coh(e.gsn + (pay - ib0));
-            slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
+            slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : (ADP ? pay / NP : pay >> 1)) - b0) * e.RS + d0) : zero;
             // The run is summed as the launch path sums it (slk_kernels.h, k_item_pass + k_item_stitch): in occurrence order --
             // unless it is LONG, i.e. wholly covers one of the launch path's (full) tiles of TT positions of the minibatch's
             // occurrence list: then tile by tile (in occurrence order inside a tile), the tiles' sums added in order.
@@ -478,7 +615,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
                 if (run_ends) break;
                 pay = e.ipay[k];
                 g = slk_ld_coh(e.gsn + (pay - ib0));
-                uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : pay >> 1) - b0) * e.RS + d0) : zero;
+                uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)((EXPL ? pay : (ADP ? pay / NP : pay >> 1)) - b0) * e.RS + d0) : zero;
             }
             if (!is_long) {
                 gv = sq;
@@ -506,7 +643,8 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
             }
         }
         // this row group's first position of the next minibatch's user phase
-        if (mb + 1 < e.n_mb && b1 + gslot < e.nc && gslot < e.bsz) {
+        if (ADP && mb + 1 < e.n_mb) score_prefetch(b1, (e.nc - b1 < e.bsz) ? e.nc : b1 + e.bsz);
+        if (!ADP && mb + 1 < e.n_mb && b1 + gslot < e.nc && gslot < e.bsz) {
             nx_key = e.ukey[b1 + gslot];
             nx_prev = gslot ? e.ukey[b1 + gslot - 1] : 0u;
             nx_a = e.uit[NP * (size_t)(b1 + gslot)];
@@ -540,27 +678,35 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*slk_epoch_fn)(slk_epoch_args);
 
-template <int VEC, int G, bool EXPL>
+template <int VEC, int G, int MODE>
 static slk_epoch_fn epoch_fn_of(int upd) {
     switch (upd) {
-        case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD, EXPL>;
-        case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM, EXPL>;
-        case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE, EXPL>;
-        case SLK_EUPD_SGD: return k_bilinear_epoch<VEC, G, SLK_EUPD_SGD, EXPL>;
-        default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE, EXPL>;
+        case SLK_EUPD_ADAGRAD: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD, MODE>;
+        case SLK_EUPD_SPARSE_ADAM: return k_bilinear_epoch<VEC, G, SLK_EUPD_SPARSE_ADAM, MODE>;
+        case SLK_EUPD_ADAM_DENSE: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAM_DENSE, MODE>;
+        case SLK_EUPD_SGD: return k_bilinear_epoch<VEC, G, SLK_EUPD_SGD, MODE>;
+        default: return k_bilinear_epoch<VEC, G, SLK_EUPD_ADAGRAD_DENSE, MODE>;
     }
 }
 template <int VEC, int G>
-static slk_epoch_fn epoch_fn(int upd, bool expl) {
-    return expl ? epoch_fn_of<VEC, G, true>(upd) : epoch_fn_of<VEC, G, false>(upd);
+static slk_epoch_fn epoch_fn(int upd, int mode) {
+    if (mode == SLK_EMODE_EXPLICIT) return epoch_fn_of<VEC, G, SLK_EMODE_EXPLICIT>(upd);
+    if (mode == SLK_EMODE_ADAPTIVE) return epoch_fn_of<VEC, G, SLK_EMODE_ADAPTIVE>(upd);
+    return epoch_fn_of<VEC, G, SLK_EMODE_PAIR>(upd);
+}
+static int epoch_mode_of(int loss) {
+    return loss >= SLK_LOSS_REGRESSION ? SLK_EMODE_EXPLICIT : (loss == SLK_LOSS_ADAPTIVE_HINGE ? SLK_EMODE_ADAPTIVE : SLK_EMODE_PAIR);
 }
 
 // Whether a slk_bilinear_train call takes the persistent route (option "epoch_kernel": 0 never, 1 when eligible).
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss,
                         bool bloom) {
     if (!ctx->opt_epoch_kernel || ctx->epoch_refused || bloom) return false;
-    // one-negative pair losses and the explicit-feedback losses (adaptive hinge needs its score / select passes first)
-    if (loss == SLK_LOSS_ADAPTIVE_HINGE) return false;
+    // one-negative pair losses, the explicit-feedback losses, adaptive hinge over ALL 1 + n occurrences (the chunk-sorted item
+    // list; the launch path's per-minibatch live lists start at adaptive_late_min_batch, far above epoch_max_batch)
+    if (loss == SLK_LOSS_ADAPTIVE_HINGE &&
+        (!ctx->opt_epoch_adaptive || bsz > ctx->opt_epoch_adaptive_max_batch || bsz >= ctx->opt_adaptive_late_min_batch))
+        return false;
     if (bsz > ctx->opt_epoch_max_batch) return false;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     // the dense optimizers rewrite every row every minibatch: in one launch of at most one workgroup per CU that
@@ -585,9 +731,8 @@ static int epoch_upd_of(const slk_optim *optim) {
 // one workgroup per CU, and never more than the device can hold RESIDENT at once for this kernel (occupancy query x CUs: the
 // grid barrier needs every workgroup running; on gfx950 one 64-thread workgroup per CU always fits an idle device, the
 // query guards a build whose register / LDS footprint says otherwise).
-static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, bool expl, int g,
+static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, unsigned np, int g,
                            slk_epoch_fn fn, size_t lds) {
-    const unsigned np = expl ? 1u : 2u;
     const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
     unsigned grid = (unsigned)((np * bsz + gpb - 1) / gpb);
     if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
@@ -608,9 +753,9 @@ static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_opt
     return grid;
 }
 
-static slk_epoch_fn epoch_pick_fn(int vec, int g, int upd, bool expl) {
+static slk_epoch_fn epoch_pick_fn(int vec, int g, int upd, int mode) {
     slk_epoch_fn fn = nullptr;
-#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd, expl)
+#define SLK_PICK_EPOCH(V_, G_) fn = epoch_fn<V_, G_>(upd, mode)
     SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
 #undef SLK_PICK_EPOCH
     return fn;
@@ -620,10 +765,11 @@ static const size_t kEpochLds = 4 * sizeof(double) + 16;
 
 // Scratch of the persistent route for chunks of up to n_mb minibatches: called by slk_bilinear_reserve (so that the training
 // call allocates nothing) and again, idempotently, by every slk_epoch_run_chunk.
-int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, bool expl) {
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP) {
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
-    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, expl, g, epoch_pick_fn(vec, g, epoch_upd_of(optim), expl), kEpochLds);
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, (unsigned)NP, g,
+                                     epoch_pick_fn(vec, g, epoch_upd_of(optim), epoch_mode_of(loss)), kEpochLds);
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 2048))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * (grid ? grid : 1) * 8))) return rc;
@@ -649,22 +795,24 @@ int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *o
 
 // All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one persistent launch.
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
-                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int RS, float *snap, float *gsn,
+                        int64_t bsz, unsigned ubits, unsigned ibits, int loss, int NP, int RS, float *snap, float *gsn,
                         float *d_mb_loss, const float *d_ratings, hipStream_t s) {
-    const bool expl = loss >= SLK_LOSS_REGRESSION;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+    const int mode = epoch_mode_of(loss);
+    const bool expl = mode == SLK_EMODE_EXPLICIT;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+    const bool adp = mode == SLK_EMODE_ADAPTIVE;   // NP = 1 + negatives per interaction (pair losses 2, explicit 1)
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
     const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
     const int upd = epoch_upd_of(optim);
-    slk_epoch_fn fn = epoch_pick_fn(vec, g, upd, expl);
+    slk_epoch_fn fn = epoch_pick_fn(vec, g, upd, mode);
     const size_t lds = kEpochLds;
-    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, expl, g, fn, lds);
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, (unsigned)NP, g, fn, lds);
     if (grid == 0) {  // the occupancy query says no workgroup of this kernel fits a CU: nothing ran, take the launch path
         slk_fail(ctx, SLK_EIO, "k_bilinear_epoch cannot be resident on this device (occupancy 0)");
         ctx->epoch_refused = true;
         return SLK_EAGAIN_EPOCH;
     }
-    if ((rc = slk_epoch_reserve(ctx, tables, optim, n_mb, bsz, expl))) return rc;
+    if ((rc = slk_epoch_reserve(ctx, tables, optim, n_mb, bsz, loss, NP))) return rc;
 
     // per-step coefficients, in double like torch (slk_set_opt_coeffs / slk_dense_sweeps)
     const int cb = ctx->coef_flip;
@@ -712,8 +860,11 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.bsz = (uint32_t)bsz;
     e.n_mb = n_mb;
     e.ukey = (const uint32_t *)pb.ukey[1].p;
-    e.uit = expl ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
-    e.uk = expl ? (const uint32_t *)pb.uval[1].p : nullptr;
+    e.uit = (expl || adp) ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
+    e.uk = (expl || adp) ? (const uint32_t *)pb.uval[1].p : nullptr;
+    e.NP = NP;
+    e.sk = adp ? (float *)ctx->sk.p : nullptr;
+    ctx->epoch_bars_per_mb = adp ? 3 : 2;
     e.ratings = d_ratings;
     e.umask = (uint32_t)((1ull << ubits) - 1);
     e.ikey = (const uint32_t *)pb.ikey[1].p;

@@ -418,7 +418,7 @@ static int rng_read_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
                             "workgroup never arrived -- the device is shared or the grid was not resident.  Minibatches before it "
                             "are applied in full, that one in part: re-initialise the model.  This ctx now uses the per-minibatch "
                             "launches (as with option epoch_kernel=0)",
-                            (int)h.epoch_abort, (int)((h.epoch_abort - 1) / 2));
+                            (int)h.epoch_abort, (int)((h.epoch_abort - 1) / (ctx->epoch_bars_per_mb > 0 ? ctx->epoch_bars_per_mb : 2)));
         }
         return slk_fail(ctx, SLK_EIO, "sampler ran out of generated words (rejection tail > 12 sigma)");
     }

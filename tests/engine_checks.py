@@ -1325,7 +1325,7 @@ def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41):
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------
 def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, B=256, seed=31, chunk=None, epochs=2,
-                                        max_grid=None, barrier=-1, cooperative=0):
+                                        max_grid=None, barrier=-1, cooperative=0, nn=None):
     """The persistent route (option epoch_kernel = 1: every minibatch of a chunk in one cooperative launch) performs the
     launch path's arithmetic in the launch path's order: losses to fp32 summation-order noise, negatives, RNG state and
     EVERY table / optimizer-state tensor bit for bit -- including the dense optimizers, whose full-table sweep the
@@ -1343,10 +1343,13 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
     # the loss against a rating, no negatives
     explicit = loss in ('regression', 'poisson', 'logistic')
     ratings = _ratings_for(rs, loss, N) if explicit else None
+    # adaptive hinge (implicit.py:266-275): nn draws per interaction, the persistent route's score phase + in-phase selection
+    nn = (nn or 5) if loss == 'adaptive_hinge' else 1
     results = []
     for route in (0, 1):
         eng.set_option('epoch_kernel', route)
         eng.set_option('epoch_max_batch', 1 << 20)      # the persistent route for every size / optimizer under test,
+        eng.set_option('epoch_adaptive_max_batch', 1 << 20)
         eng.set_option('epoch_dense_elems', 1 << 40)     # not only where it is the default
         if chunk:
             eng.set_option('chunk_interactions', chunk)
@@ -1360,7 +1363,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
             d_users, d_items = be.alloc(users), be.alloc(items)
             d_ratings = be.alloc(ratings) if explicit else None
             losses = []
-            neg_out = be.alloc(np.full(N, -1, dtype=np.int64))
+            neg_out = be.alloc(np.full(N * nn, -1, dtype=np.int64))
             eng.profile_reset()
             eng.profile_enable(True)
             for _ in range(epochs):
@@ -1369,7 +1372,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
                     eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), N,
                                                 B, loss, be.ptr(mb_loss), stream=be.stream)
                 else:
-                    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
+                    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
                                        be.ptr(mb_loss), d_neg_out=be.ptr(neg_out), stream=be.stream)
                 losses.append(be.get(mb_loss).copy())
             eng.profile_enable(False)
@@ -1386,6 +1389,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         finally:
             eng.set_option('epoch_kernel', 1)
             eng.set_option('epoch_max_batch', 1024)
+            eng.set_option('epoch_adaptive_max_batch', 512)
             eng.set_option('epoch_dense_elems', 1 << 18)
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('epoch_max_grid', 256)

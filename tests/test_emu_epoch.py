@@ -28,6 +28,22 @@ def test_epoch_kernel_explicit_feedback_bit_identical_to_launch_path(be, loss, o
     ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 8)
 
 
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_adaptive_hinge_bit_identical_to_launch_path(be, opt):
+    """adaptive hinge (implicit.py:266-275; 5 draws per interaction, the reference's default) inside the persistent launch:
+    score phase, the view(n, B) selection inside the user phase, the item phase over all 1 + n occurrences"""
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', opt, 8)
+
+
+def test_epoch_kernel_adaptive_hinge_layouts_duplicates_chunks(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 32, U=23, I=31, N=307, B=100, nn=3)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adam_dense', 3, U=23, I=31, N=199, B=64, epochs=1, nn=1)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'sparse_adam', 8, U=1, I=2, N=130, B=64, nn=7)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 64, U=40, I=30, N=300, B=70, nn=20)  # more pairs than lanes
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'sgd', 16, N=1500, B=128, chunk=256, nn=5)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 8, U=40, I=30, N=300, B=64, max_grid=1, nn=4)
+
+
 def test_epoch_kernel_explicit_feedback_layouts_duplicates_chunks(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'regression', 'adagrad', 32, U=23, I=31, N=307, B=100)
     ec.check_epoch_kernel_is_bit_identical(be, 'logistic', 'adam_dense', 3, U=23, I=31, N=199, B=64, epochs=1)
@@ -67,5 +83,7 @@ def test_epoch_kernel_wider_cooperative_grid(monkeypatch):
         # two-level barrier: 12 workgroups in 8 groups of 1-2, and 5 workgroups (fewer than groups)
         ec.check_epoch_kernel_is_bit_identical(b, 'bpr', 'sparse_adam', 32, U=500, I=300, N=1300, B=512, epochs=1, barrier=1)
         ec.check_epoch_kernel_is_bit_identical(b, 'hinge', 'adagrad', 16, U=90, I=70, N=700, B=200, epochs=1, max_grid=5, barrier=1)
+        ec.check_epoch_kernel_is_bit_identical(b, 'adaptive_hinge', 'adagrad', 32, U=500, I=300, N=1300, B=512, epochs=1)
+        ec.check_epoch_kernel_is_bit_identical(b, 'adaptive_hinge', 'adam_dense', 16, U=90, I=70, N=700, B=200, epochs=1, max_grid=5, barrier=1, nn=3)
     finally:
         b.close()

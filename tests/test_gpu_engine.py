@@ -307,6 +307,21 @@ def test_epoch_kernel_explicit_feedback_bit_identical_to_launch_path(be, loss, o
     ec.check_epoch_kernel_is_bit_identical(be, loss, opt, 32, U=943, I=1682, N=20000, B=256, epochs=2)
 
 
+@pytest.mark.parametrize('opt', ec.ALL_OPTS)
+def test_epoch_kernel_adaptive_hinge_bit_identical_to_launch_path(be, opt):
+    """adaptive hinge with the reference's default of 5 draws (implicit.py:72) at its MovieLens-100K test shape: score phase,
+    the selection inside the user phase (scores written by other workgroups, read through sc1 loads), three barriers per minibatch"""
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', opt, 32, U=943, I=1682, N=20000, B=256, epochs=2)
+
+
+def test_epoch_kernel_adaptive_hinge_sizes_and_layouts(be):
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 64, U=100000, I=50000, N=40000, B=4096, epochs=1, nn=3)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'sparse_adam', 64, U=3000, I=1000, N=9000, B=256, epochs=1, nn=20, barrier=1)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 20, U=5, I=3, N=5000, B=512, epochs=1, nn=2)
+    ec.check_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad', 32, U=943, I=1682, N=51200, B=256, epochs=1, chunk=12800)
+
+
 def test_epoch_kernel_two_level_barrier(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=20000, B=1024, epochs=2, barrier=1)
     ec.check_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 64, U=3000, I=1000, N=9000, B=256, epochs=1, barrier=1)
