@@ -125,6 +125,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while chunk c trains (what this
  *                         package's fit() sets for its epochs: +1.5..4 % in the steady state of a run of training calls);
  *                         2: only the negatives; 0 (default of a bare ctx): everything in order on the caller's stream
+ *   "first_chunk"         with overlap_prep: minibatches in the first chunk of a call (its prep is the one nothing hides); 0 = a
+ *                         full chunk
  *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
  *   "chunk_ramp"          1: with overlap_prep the first chunks of a call ramp up from ~2^20 interactions (default 0:
  *                         measured slower at every call length, profiles/r03_c_*)
@@ -133,7 +135,7 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
  *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
  *   "epoch_adaptive"      1 (default): adaptive hinge takes the persistent kernel too (score phase + in-phase selection),
- *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 512)
+ *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 1024)
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
  *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
  *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)

@@ -247,6 +247,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_explicit_fused = (int)value;
     } else if (!strcmp(name, "epoch_kernel") && (value == 0 || value == 1)) {
         ctx->opt_epoch_kernel = (int)value;
+    } else if (!strcmp(name, "first_chunk") && value >= 0 && value <= ((int64_t)1 << 20)) {
+        ctx->opt_first_chunk = value;
     } else if (!strcmp(name, "epoch_adaptive") && (value == 0 || value == 1)) {
         ctx->opt_epoch_adaptive = (int)value;
     } else if (!strcmp(name, "epoch_adaptive_max_batch") && value >= 1 && value <= ((int64_t)1 << 20)) {

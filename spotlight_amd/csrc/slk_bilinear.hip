@@ -989,6 +989,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         int64_t ramp = ((int64_t)1 << 20) / bsz;
         if (ramp < 1) ramp = 1;
         if (!ctx->opt_overlap_prep || !ctx->opt_chunk_ramp || bsz < ctx->opt_overlap_min_batch) ramp = mb_per_chunk;
+        // option "first_chunk": overlapped, the FIRST chunk's prep is the one nothing hides (1.2 ms of an 8-minibatch chunk at the
+        // C2 shape); a first chunk of a few minibatches exposes a quarter of that and its passes still cover the prep of the
+        // full-sized chunk behind it
+        const bool ov = ctx->opt_overlap_prep && bsz >= ctx->opt_overlap_min_batch;
+        if (ov && !ctx->opt_chunk_ramp && ctx->opt_first_chunk > 0 && ctx->opt_first_chunk < mb_per_chunk &&
+            n > ctx->opt_first_chunk * bsz)
+            cb.push_back(ctx->opt_first_chunk * bsz);
         while (cb.back() < n) {
             if (ramp > mb_per_chunk) ramp = mb_per_chunk;
             const int64_t next = cb.back() + ramp * bsz;

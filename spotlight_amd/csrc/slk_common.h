@@ -116,6 +116,7 @@ struct slk_ctx {
     // adaptive hinge, plain item table: smallest minibatch whose item side is re-sorted per minibatch after the selection
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
+    int64_t opt_first_chunk = 0;   // overlapped prep: minibatches in the first chunk of a call (0: a full chunk); see slk_bilinear.hip
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
     int64_t opt_user_lat_max_batch = (int64_t)1 << 14;  // (measured, profiles/r03_c_*: user pass 9.2 -> 8.1 us at 2048, 11.6 -> 10.3 at
                                    // 8192, but 29.3 -> 31.3 at 65 536)  // minibatches up to this size take the latency-bound form of the pair-mode
@@ -130,7 +131,7 @@ struct slk_ctx {
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
     int opt_epoch_adaptive = 1;    // adaptive hinge on the persistent route (score phase + the selection inside the user phase)
-    int64_t opt_epoch_adaptive_max_batch = 512;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
+    int64_t opt_epoch_adaptive_max_batch = 1024;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
                                    // interaction: same-box A/B in profiles/r03_u_*, r03_v_*)
     int epoch_bars_per_mb = 2;     // grid barriers per minibatch of the last persistent launch (the time-out report names the minibatch)
     int opt_epoch_barrier = -1;    // grid barrier of the persistent launch: 0 one arrival counter, 1 two levels (8 sub-counters), -1 by grid size

@@ -902,7 +902,7 @@ BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_defa
 
 
 def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1000, nn=5, user_bloom=0, item_bloom=0,
-                                  chunk=4096, overlap=1, seed=21, nt=None):
+                                  chunk=4096, overlap=1, seed=21, nt=None, first_chunk=0):
     """The engine is deterministic (sorted ownership, no atomics), and chunking / the prep pipeline
     only change WHEN value-independent work happens: one big chunk on one stream and many small
     chunks with prep on the second stream must agree bit for bit -- losses, negatives, every table,
@@ -920,6 +920,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
         eng.set_option('chunk_interactions', chunk_i)
         eng.set_option('overlap_prep', overlap_i)
         eng.set_option('overlap_min_batch', 0)  # (by default only minibatches >= 2^16 overlap their prep)
+        eng.set_option('first_chunk', first_chunk if chunk_i == chunk else 0)  # a short first chunk in the pipelined run
         if nt is not None and chunk_i == chunk:  # the second run also uses another cache policy
             eng.set_option('nt', nt)
         try:
@@ -938,6 +939,7 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('overlap_prep', 0)
             eng.set_option('overlap_min_batch', 1 << 16)
+            eng.set_option('first_chunk', 0)
             if nt is not None:
                 eng.set_option('nt', 3)
     for k, (a, b) in enumerate(zip(*results)):
@@ -1389,7 +1391,7 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         finally:
             eng.set_option('epoch_kernel', 1)
             eng.set_option('epoch_max_batch', 1024)
-            eng.set_option('epoch_adaptive_max_batch', 512)
+            eng.set_option('epoch_adaptive_max_batch', 1024)
             eng.set_option('epoch_dense_elems', 1 << 18)
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('epoch_max_grid', 256)

@@ -165,6 +165,8 @@ def test_pipelined_chunks_match_oracle(be):
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 0)
         eng.set_option('overlap_min_batch', 1 << 16)
+    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, first_chunk=1)
+    ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'adagrad', 32, N=20000, B=512, first_chunk=3)
     for overlap in (0, 1, 2):
         ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=overlap)
