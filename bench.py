@@ -245,7 +245,8 @@ def bench_c4(args):
     prof = eng.profile_read()
     ts = K * B * L
     alg = 32 * D + 40
-    kern = {k: {'launches': prof[k][0], 'avg_ms': prof[k][1] / max(prof[k][0], 1)} for k in ('seq_pass', 'item_pass')}
+    kern = {k: {'launches': prof[k][0], 'avg_ms': prof[k][1] / max(prof[k][0], 1)} for k in ('seq_pass', 'item_pass', 'epoch')
+            if prof[k][0] or k != 'epoch'}  # 'epoch': minibatches of a few thousand timesteps run inside k_poolnet_epoch, one launch per chunk
     out = {'metric': 'training (sequence, timestep) pairs/sec, PoolNet BPR dim=%d' % D, 'value': ts / elapsed,
            'unit': 'timesteps/s', 'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
            'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic',

@@ -134,6 +134,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
  *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
+ *   "epoch_seq", "epoch_seq_max_timesteps"  slk_poolnet_train on a persistent kernel of its own (k_poolnet_epoch; default 0:
+ *                         bit-identical to the launches but measured slower, profiles/r03_x_*)
  *   "epoch_adaptive"      1 (default): adaptive hinge takes the persistent kernel too (score phase + in-phase selection),
  *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 1024)
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)

@@ -130,6 +130,11 @@ struct slk_ctx {
     int opt_epoch_kernel = 1;
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
+    int opt_epoch_seq = 0;         // PoolNet on the persistent route (k_poolnet_epoch).  OFF: bit-identical to the launches, but measured
+                                   // slower at every shape (profiles/r03_x_*: 256 sequences x 10 timesteps 26.8 vs 22.2 us per minibatch,
+                                   // x 32: 63 vs 26) -- one wavefront per sequence walks the scans' 256 / G chunks in turns and the item
+                                   // phase takes its 5 K occurrences five dependent round trips deep ...
+    int64_t opt_epoch_seq_max_timesteps = 4096;  // ... for minibatches of up to this many timesteps (256 sequences x 16)
     int opt_epoch_adaptive = 1;    // adaptive hinge on the persistent route (score phase + the selection inside the user phase)
     int64_t opt_epoch_adaptive_max_batch = 1024;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
                                    // interaction: same-box A/B in profiles/r03_u_*, r03_v_*)
@@ -250,10 +255,20 @@ int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32
                       uint32_t *nseg_out, hipStream_t s);
 // slk_epoch.hip: the persistent route of slk_bilinear_train
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss, bool bloom);
-int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP);
+// PoolNet on the persistent route (slk_seq.hip -> k_poolnet_epoch): the chunk's sequences, draws and mask counts
+struct slk_epoch_seq {
+    const int64_t *seqs;
+    const uint32_t *neg32, *mcount;
+    int L, C;
+    uint32_t pad_item;
+};
+bool slk_epoch_seq_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int64_t L, bool bloom,
+                            size_t lds_bytes);
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP,
+                      const slk_epoch_seq *seq = nullptr);
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
                         int64_t bsz, unsigned ubits, unsigned ibits, int loss, int NP, int RS, float *snap, float *gsn,
-                        float *d_mb_loss, const float *d_ratings, hipStream_t s);
+                        float *d_mb_loss, const float *d_ratings, hipStream_t s, const slk_epoch_seq *seq = nullptr);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
