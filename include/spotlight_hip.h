@@ -144,6 +144,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "item_long_gate"      1 (default): minibatches in which no item row's occurrences fill a whole 64-position tile of the
  *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results).
  *                         The same switch gates the user pass's long-run form (hot users: runs that fill a 32-position tile).
+ *   "item_lat_max_tiles"  item pass launches of up to this many 64-occurrence tiles (default 2048; PoolNet: a quarter) load every
+ *                         head's row + state with the record gather (k_item_pass<..., NPRE 4>: -10..-19 % on minibatches of
+ *                         4096-65 536, profiles/r03_y_*); 0: never
  *   "user_lat_max_batch"  minibatches up to this size (default 2^14) take the latency-bound form of the pair-mode user pass
  *   "prep_cus", "prep_priority"  with overlap_prep: CU-mask partition of the chip between the prep stream and the passes /
  *                         a high-priority prep stream (measured, profiles/r03_a_*: the masks slow the passes by more than

@@ -249,6 +249,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_kernel = (int)value;
     } else if (!strcmp(name, "first_chunk") && value >= 0 && value <= ((int64_t)1 << 20)) {
         ctx->opt_first_chunk = value;
+    } else if (!strcmp(name, "item_lat_max_tiles") && value >= 0) {
+        ctx->opt_item_lat_max_tiles = value;
     } else if (!strcmp(name, "epoch_seq") && (value == 0 || value == 1)) {
         ctx->opt_epoch_seq = (int)value;
     } else if (!strcmp(name, "epoch_seq_max_timesteps") && value >= 1 && value <= ((int64_t)1 << 24)) {

@@ -121,6 +121,10 @@ struct slk_ctx {
     int64_t opt_user_lat_max_batch = (int64_t)1 << 14;  // (measured, profiles/r03_c_*: user pass 9.2 -> 8.1 us at 2048, 11.6 -> 10.3 at
                                    // 8192, but 29.3 -> 31.3 at 65 536)  // minibatches up to this size take the latency-bound form of the pair-mode
                                    // user pass (k_user_pass<..., LAT>): two round trips per position instead of four
+    int64_t opt_item_lat_max_tiles = 2048;  // item pass: launches of up to this many 64-occurrence tiles take the form with every head's
+                                   // row loaded early (k_item_pass<..., NPRE 4>); 0: never.  Same-box A/B (profiles/r03_y_*): item pass
+                                   // 16.1 -> 13.5 us at minibatch 4096, 20.5 -> 16.5 at 16 384, 42.2 -> 38.0 at 65 536 (2048 tiles);
+                                   // PoolNet 256 x 10 15.1 -> 13.4, but 256 x 200 (1600 tiles) 31.9 -> 34.2: a quarter of the limit there
     int opt_item_long_gate = 1;    // 1: minibatches without a long run (k_item_long_flags) take the plain item pass; 0: every item
                                    // pass is the partial-writing one + k_item_stitch (same results; a test / measurement switch)
     int opt_explicit_fused = 1;    // explicit feedback: 1 = score + loss inside the user pass, 0 = score pass + loss kernel first

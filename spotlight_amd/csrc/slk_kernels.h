@@ -413,12 +413,16 @@ __device__ __forceinline__ void slk_item_apply(const slk_pass_args &a, uint32_t 
 
 // LONG = false: for a minibatch in which NO run wholly covers a tile (the host knows: k_item_long_flags) -- no run is long,
 // nothing is looked up or written for the partial scheme, no stitch kernel follows; results are those of LONG = true.
-template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH, bool LONG = true>
-__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(SLK_ITEM_WAVES) void k_item_pass(slk_pass_args a) {
+// NPRE_: heads per group whose row + state loads ride along with the record gather.  SLK_ITEM_NPRE (1) is the bandwidth-bound
+// form (C2 minibatches: occupancy 7 matters more than the dependent round trip of a group's second head); 4 = every head a
+// group can own, for launches of so few tiles that each workgroup takes ONE and the pass is that tile's chain of dependent
+// round trips (minibatches up to ~10^5 occurrences, PoolNet's default 256 sequences): the occupancy cap is lifted.
+template <int VEC, int G, int UPD, int MODE, int PART = SLK_PART_BOTH, bool LONG = true, int NPRE_ = SLK_ITEM_NPRE>
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : SLK_ITEM_WAVES) void k_item_pass(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr int T = 4 * GPB;
     constexpr int DL = G * VEC;  // LDS row length (>= D)
-    constexpr int NPRE = SLK_ITEM_NPRE;  // heads per group whose rows are loaded early
+    constexpr int NPRE = NPRE_;  // heads per group whose rows are loaded early
     __shared__ double red[256];
     __shared__ uint32_t s_key[T + 1 + (LONG ? 1 : 0)];  // s_key[i] = key of position tb - 1 + i (LONG: i = tn + 1 = the next tile's first key)
     __shared__ uint32_t s_far[3];      // key of the previous tile's first position, of the next (full) tile's last position
@@ -912,28 +916,35 @@ static __global__ __launch_bounds__(256) void k_item_long_flags(const uint32_t *
 // the item pass and the stitch kernel that goes behind it (slk_launch_item_pass)
 struct slk_item_fns {
     slk_pass_fn pass, stitch, pass_short;  // pass_short: k_item_pass<..., LONG = false>
+    slk_pass_fn pass_lat;                  // ... with every head's row loaded early (launches of few tiles)
 };
 
 template <int VEC, int G, int MODE, int PART = SLK_PART_BOTH>
 static slk_item_fns slk_item_pass_fn(int upd) {
     if (upd == SLK_UPD_ADAGRAD)
         return {k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_ADAGRAD, PART>,
-                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART, false>};
+                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART, false>,
+                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, MODE, PART, false, 4>};
     if (upd == SLK_UPD_SPARSE_ADAM)
         return {k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_SPARSE_ADAM, PART>,
-                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART, false>};
+                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART, false>,
+                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, MODE, PART, false, 4>};
     if (upd == SLK_UPD_SGD)
         return {k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_SGD, PART>,
-                k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART, false>};
+                k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART, false>,
+                k_item_pass<VEC, G, SLK_UPD_SGD, MODE, PART, false, 4>};
     return {k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART>, k_item_stitch<VEC, G, SLK_UPD_GRAD_ONLY, PART>,
-            k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART, false>};
+            k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART, false>,
+                k_item_pass<VEC, G, SLK_UPD_GRAD_ONLY, MODE, PART, false, 4>};
 }
 
 // Launches the item pass over a.ibegin .. a.iend and the stitch kernel behind it (partials in ctx scratch).
 // may_have_long = false: the caller KNOWS (k_item_long_flags, read back once per chunk) that no run of this window wholly
 // covers a tile -- the plain pass alone.
+// lat_div: the every-head-early form (pass_lat) is taken up to opt_item_lat_max_tiles / lat_div tiles (PoolNet's records are twice
+// as long and its form stops paying earlier: measured, profiles/r03_y_*)
 static inline int slk_launch_item_pass(slk_ctx *ctx, const slk_item_fns &fns, slk_pass_args &a, int g, hipStream_t s,
-                                       const char *what, bool may_have_long = true) {
+                                       const char *what, bool may_have_long = true, int lat_div = 1) {
     const unsigned gpb = 256u / (unsigned)g, T = 4u * gpb;
     const size_t n = (size_t)(a.iend - a.ibegin);
     if (n == 0) return SLK_OK;
@@ -942,7 +953,8 @@ static inline int slk_launch_item_pass(slk_ctx *ctx, const slk_item_fns &fns, sl
         a.ipart = nullptr;
         a.ipart_meta = nullptr;
         a.ipart_count = nullptr;
-        hipLaunchKernelGGL(fns.pass_short, dim3(slk_grid_for(ctx, n, T, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
+        const bool lat = fns.pass_lat && (int64_t)ntiles * lat_div <= ctx->opt_item_lat_max_tiles;
+        hipLaunchKernelGGL(lat ? fns.pass_lat : fns.pass_short, dim3(slk_grid_for(ctx, n, T, ctx->opt_item_grid_mult)), dim3(256), 0, s, a);
         SLK_LAUNCH_CHECK(ctx, what);
         return SLK_OK;
     }

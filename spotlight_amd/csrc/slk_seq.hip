@@ -843,10 +843,10 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             const bool may_long = !ctx->opt_item_long_gate || fb.h_lflags[mb] != 0;
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>", may_long))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<SEQ>", may_long, 4))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
-                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<SEQ,BIAS>", may_long))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<SEQ,BIAS>", may_long, 4))) return rc;
                 // ... while every occurrence feeds the n_hash hashed rows of the compressed table
                 slk_pass_args r = a;
                 r.mb_loss_out = nullptr;

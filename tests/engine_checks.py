@@ -600,7 +600,8 @@ def check_seq_train_matches_oracle(be, loss, opt, D, I=31, N=40, L=9, B=16, nn=3
     assert rel_inf(be.get(out), po.predict(seqs[1], some)) < 1e-5
 
 
-def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=32, nn=3, chunk=2048, overlap=1, bloom=0, seed=17):
+def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=32, nn=3, chunk=2048, overlap=1, bloom=0, seed=17,
+                                      option=None):
     """PoolNet training in ONE prep chunk against the same call cut into several chunks of `chunk` timesteps with the prep of
     chunk c + 1 (negatives, occurrence sort, flags) on the second stream while chunk c trains (slk_seq.hip: the pipeline of
     slk_bilinear_train): losses, negatives, RNG state, tables and optimizer state bit for bit."""
@@ -614,10 +615,12 @@ def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=3
     n_mb = (N + B - 1) // B
     n_draw = N * L * (nn if loss == 'adaptive_hinge' else 1)
     results = []
-    for chunk_i, overlap_i in ((1 << 23, 0), (chunk, overlap)):
+    for run_i, (chunk_i, overlap_i) in enumerate(((1 << 23, 0), (chunk, overlap))):
         eng.set_option('chunk_interactions', chunk_i)
         eng.set_option('overlap_prep', overlap_i)
         eng.set_option('overlap_min_batch', 0)
+        if option:  # (name, value of the first run, value of the second run, default): an option that must not change results
+            eng.set_option(option[0], option[1 + run_i])
         try:
             dev = be.seq_model(params, opt=opt, item_bloom=desc, lr=0.05)
             eng.rng_set_state(state)
@@ -633,6 +636,8 @@ def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=3
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('overlap_prep', 0)
             eng.set_option('overlap_min_batch', 1 << 16)
+            if option:
+                eng.set_option(option[0], option[3])
     for k, (a, b) in enumerate(zip(*results)):
         assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined chunks' % k)
 
@@ -1346,7 +1351,7 @@ def check_explicit_routes_agree(be, loss, opt, D, U=37, I=29, N=300, B=64, seed=
     assert np.allclose(runs[0][2], runs[1][2], rtol=1e-6)
 
 
-def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41):
+def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41, option='item_long_gate', values=(1, 0), default=1, nn=1):
     """The plain item pass (minibatches in which no run wholly covers a tile, chosen per chunk from k_item_long_flags) against
     the partial-writing pass + k_item_stitch for every minibatch: every table and state tensor bit for bit."""
     eng = be.engine
@@ -1359,19 +1364,19 @@ def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41):
     state = np.random.RandomState(seed + 1).get_state()
     n_mb = (N + B - 1) // B
     results = []
-    for gate in (1, 0):
-        eng.set_option('item_long_gate', gate)
+    for gate in values:  # (any option that must not change results: `option`, its two `values`, its `default`)
+        eng.set_option(option, gate)
         eng.set_option('epoch_kernel', 0)  # the launch path under test
         try:
             dev = be.model(params, opt=opt, **hp)
             eng.rng_set_state(state)
             d_users, d_items = be.alloc(users), be.alloc(items)
             mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
-            eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1, be.ptr(mb_loss),
+            eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn, be.ptr(mb_loss),
                                stream=be.stream)
             results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
         finally:
-            eng.set_option('item_long_gate', 1)
+            eng.set_option(option, default)
             eng.set_option('epoch_kernel', 1)
     for k, (a, b) in enumerate(zip(*results)):
         if k == 0:  # the minibatch losses: the two forms of the user pass hand positions to row groups differently, so the fp32

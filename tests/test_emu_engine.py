@@ -112,6 +112,17 @@ def test_argument_errors(be):
         _native.Engine(7, lib=eng._lib)  # no such device
 
 
+@pytest.mark.parametrize('loss,opt,nn', [('bpr', 'adagrad', 1), ('hinge', 'sparse_adam', 1), ('pointwise', 'adam_dense', 1),
+                                         ('adaptive_hinge', 'adagrad', 4), ('bpr', 'sgd', 1)])
+def test_item_pass_with_every_head_early_is_bit_neutral(be, loss, opt, nn):
+    """launches of few tiles take k_item_pass<..., NPRE 4> (every head's row + state loaded with the record gather, option
+    item_lat_max_tiles); the default form (one head early) must give the same bits"""
+    ec.check_item_long_gate_is_bit_neutral(be, loss, opt, 8, U=60, I=45, N=900, B=128, option='item_lat_max_tiles', values=(2048, 0),
+                                           default=2048, nn=nn)
+    ec.check_item_long_gate_is_bit_neutral(be, loss, opt, 32, U=5, I=3, N=700, B=256, option='item_lat_max_tiles', values=(2048, 0),
+                                           default=2048, nn=nn)  # three items: spilled and long runs
+
+
 def test_pipelined_chunks_match_single_chunk(be):
     """chunk_interactions small => several prep chunks per call: the double-buffered prep pipeline
     (negatives + sorts of chunk c+1 on the prep stream while chunk c trains) must give the same

@@ -91,6 +91,12 @@ def test_poolnet_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
     ec.check_seq_epoch_kernel_is_bit_identical(be, loss, opt, 8, I=300 if opt.endswith('dense') else 2000)
 
 
+def test_seq_item_pass_with_every_head_early_is_bit_neutral(be):
+    for loss, opt in (('bpr', 'adagrad'), ('adaptive_hinge', 'sparse_adam'), ('pointwise', 'adam_dense')):
+        ec.check_seq_chunking_is_bit_neutral(be, loss, opt, 16, chunk=1 << 23, overlap=0, option=('item_lat_max_tiles', 2048, 0, 2048))
+    ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 16, bloom=3, chunk=1 << 23, overlap=0, option=('item_lat_max_tiles', 2048, 0, 2048))
+
+
 def test_poolnet_epoch_kernel_layouts_padding_chunks(be):
     ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, L=37, N=200, B=32)          # chunks of 2 timesteps, a ragged last one
     ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'sgd', 64, L=5, N=300, B=100)             # fewer timesteps than chunks

@@ -279,6 +279,23 @@ def test_item_long_gate_is_bit_neutral(be, D, U, I, N, B):
     ec.check_item_long_gate_is_bit_neutral(be, 'bpr', 'adagrad', D, U, I, N, B)
 
 
+@pytest.mark.parametrize('loss,opt,nn', [('bpr', 'adagrad', 1), ('hinge', 'sparse_adam', 1), ('pointwise', 'adam_dense', 1),
+                                         ('adaptive_hinge', 'adagrad', 5)])
+def test_item_pass_with_every_head_early_is_bit_neutral(be, loss, opt, nn):
+    """k_item_pass<..., NPRE 4> (launches of up to item_lat_max_tiles tiles) against the default form, minibatches of 4096-65 536"""
+    ec.check_item_long_gate_is_bit_neutral(be, loss, opt, 64, U=200000, I=50000, N=200000, B=65536, option='item_lat_max_tiles',
+                                           values=(1 << 30, 0), default=2048, nn=nn)
+    ec.check_item_long_gate_is_bit_neutral(be, loss, opt, 32, U=943, I=1682, N=20000, B=4096, option='item_lat_max_tiles',
+                                           values=(1 << 30, 0), default=2048, nn=nn)
+
+
+def test_seq_item_pass_with_every_head_early_is_bit_neutral(be):
+    ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, I=20000, N=2000, L=10, B=256, chunk=1 << 23, overlap=0,
+                                         option=('item_lat_max_tiles', 1 << 30, 0, 2048))
+    ec.check_seq_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, chunk=1 << 23, overlap=0,
+                                         option=('item_lat_max_tiles', 1 << 30, 0, 2048))
+
+
 # ---- persistent epoch kernel (csrc/slk_epoch.hip): one cooperative launch per chunk of minibatches ----
 @pytest.mark.parametrize('loss', ['pointwise', 'bpr', 'hinge'])
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
