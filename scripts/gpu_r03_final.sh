@@ -23,4 +23,10 @@ python bench.py --user-zipf 1.0 --item-zipf 1.0 --steps 16 --warmup 8 --no-cpu-b
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 tables, users and positive items Zipf(1.0): %.3f G interactions/s, user pass %.3f ms, item pass %.3f ms' % (d['value']/1e9, r['kernels']['user_pass']['avg_ms'], r['kernels']['item_pass']['avg_ms']))"
 for opt in sparse_adam; do python bench.py --opt $opt --steps 16 --warmup 4 --no-cpu-baseline --no-probes --no-sharded-check --no-fit 2>/dev/null | tee $OUT/bench_$opt.json | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('C2 $opt: %.3f G interactions/s, %.4f ms, step frac %.3f' % (d['value']/1e9, d['ms_per_step'], r['step_frac_of_peak']))"; done
+timeout 200 python scripts/bench_adaptive_small.py --routes 2>/dev/null | grep '^{' > $OUT/adaptive_small_routes.jsonl; python -c "
+import json
+for l in open('$OUT/adaptive_small_routes.jsonl'):
+    d = json.loads(l); print('adaptive hinge', d['shape'], d['batch'], d['route'], '%.1f us per minibatch' % d['us_per_minibatch'])"
+timeout 200 python bench.py --workload c4 --batch 256 --seq-len 10 --items 100000 --steps 400 --warmup 16 2>/dev/null | tee $OUT/bench_poolnet_256x10.json | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('PoolNet 256 sequences x 10: %.1f us per minibatch' % (d['ms_per_step']*1e3))"
 bash scripts/pmc_run.sh ${1:-r03_final}_pmc --no-probes --no-sharded-check --no-overlapped > $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log 2>&1; tail -5 $GRAFT_REPO_ROOT/gpurun_out/${1:-r03_final}/pmc.log
