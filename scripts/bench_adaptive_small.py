@@ -23,6 +23,8 @@ for shape, U, I, D in (('c1', 943, 1682, 32), ('mid', 1_000_000, 100_000, 64)):
     for B in ((256, 512, 1024, 2048) if routes else (256, 1024, 4096, 16384, 65536)):
         for late_min in ((-1, -2) if routes else (0, 1 << 40)):
             eng = _native.Engine(0)
+            for kv in [x[len('--set='):] for x in sys.argv if x.startswith('--set=')]:  # e.g. --set=epoch_debug=8 (anatomy runs)
+                eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
             if routes:
                 eng.set_option('adaptive_late_min_batch', 1 << 40)
                 eng.set_option('epoch_kernel', 1 if late_min == -1 else 0)

@@ -267,7 +267,7 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_epoch_barrier = (int)value;
     } else if (!strcmp(name, "epoch_cooperative") && (value == 0 || value == 1)) {
         ctx->opt_epoch_cooperative = (int)value;
-    } else if (!strcmp(name, "epoch_debug") && value >= 0 && value <= 7) {
+    } else if (!strcmp(name, "epoch_debug") && value >= 0 && value <= 63) {
         ctx->opt_epoch_debug = (int)value;
     } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
         ctx->opt_epoch_dense_elems = value;

@@ -91,7 +91,8 @@ struct slk_epoch_args {
     int loss_kind;
     float eps, omb1, omb2, beta2, wd;
     int bar_kind;                  // 0: one arrival counter, 1: 8 sub-counters + a top counter
-    int debug;                     // measurement only (option "epoch_debug"): 1 skip the phases' work, 2 do not wait at barriers, 4 no drain
+    int debug;                     // measurement only (option "epoch_debug"): 1 skip the phases' work, 2 do not wait at barriers, 4 no drain,
+                                   // 8 / 16 / 32 skip the user (sequence) / item / score phase alone
 };
 
 // ---- the grid barrier -------------------------------------------------------------------------------------------------
@@ -248,6 +249,12 @@ __device__ __forceinline__ void slk_epoch_sweep_untouched(const slk_epoch_args &
 // timestep's history gradient, padding_idx rows are nobody's).  b0: first position (timestep) of the minibatch.
 enum { SLK_EI_PAIR = 0, SLK_EI_EXPL = 1, SLK_EI_ADP = 2, SLK_EI_SEQ = 3 };
 
+#ifndef SLK_EPOCH_ITEM_BATCH
+#define SLK_EPOCH_ITEM_BATCH 4  // positions of a row group (gstride apart) whose ids, then whose heads' rows + first records, are fetched
+                                // together: a minibatch with more occurrences than the grid has row groups (adaptive hinge, PoolNet,
+                                // pair losses at 1024) is otherwise one dependent chain of round trips per position
+#endif
+
 template <int VEC, int G, int UPD, int IMODE>
 __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, const slk_step_coef &c, uint32_t b0, uint32_t ib0,
                                                      uint32_t ib1, uint32_t NP, uint32_t gslot, uint32_t gstride, int D, int d0,
@@ -255,98 +262,160 @@ __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, co
     constexpr bool SEQ = IMODE == SLK_EI_SEQ;
     constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
     constexpr bool HAS_S1 = slk_epoch_has_s1<UPD>();
+    constexpr int NB = SLK_EPOCH_ITEM_BATCH;
     const slk_vec<VEC> zero = slk_vzero<VEC>();
     const slk_vec<1> zero1 = slk_vzero<1>();
     (void)NP;
-    for (uint32_t r = ib0 + gslot; r < ib1 && !(e.debug & 1); r += gstride) {
-        const bool first = r == ib0;
-        const bool pre = r == ib0 + gslot;
-        const uint32_t key = pre ? nx_key : e.ikey[r];
-        const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ikey[r - 1]);
-        uint32_t pay = pre ? nx_a : e.ipay[r];
-        if (!first && prev == key) continue;
-        const uint32_t item = key & e.imask;
-        if (SEQ && item == e.pad_item) continue;  // padding_idx rows receive no gradient (the launch path never makes them heads)
-        const size_t voff = (size_t)item * D + d0;
-        const slk_vec<VEC> v = on ? slk_vload_coh<VEC>(e.P[1] + voff) : zero;
-        const slk_vec<VEC> sv1 = (on && HAS_S1) ? slk_vload_coh<VEC>(e.S1[1] + voff) : zero;
-        const slk_vec<VEC> sv2 = (on && HAS_S2) ? slk_vload_coh<VEC>(e.S2[1] + voff) : zero;
-        const float bi = slk_ld_coh(e.P[3] + item);
-        slk_vec<1> bis1 = zero1, bis2 = zero1;
-        if (lane == 0) {
-            if (HAS_S1) bis1 = slk_vload_coh<1>(e.S1[3] + item);
-            if (HAS_S2) bis2 = slk_vload_coh<1>(e.S2[3] + item);
-        }
-        float g = slk_ld_coh(e.gsn + (pay - ib0));
-        uint32_t pos = IMODE == SLK_EI_EXPL ? pay : (IMODE == SLK_EI_PAIR ? pay >> 1 : pay / NP);
-        slk_vec<VEC> uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0) : zero;
-        // PoolNet: the sequence's own item (pair 0) also receives the history gradient of its timestep (second half of the record)
-        bool own = SEQ && pay - pos * NP == 0u;
-        slk_vec<VEC> hg = (own && on) ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + D + d0) : zero;
-        // The run is summed as the launch path sums it (slk_kernels.h, k_item_pass + k_item_stitch): in occurrence order --
-        // unless it is LONG, i.e. wholly covers one of the launch path's (full) tiles of TT positions of the minibatch's
-        // occurrence list: then tile by tile (in occurrence order inside a tile), the tiles' sums added in order.
-        // Both sums are kept; which one applies is known when the run ends.
-        constexpr uint32_t TT = 4u * (256u / (uint32_t)G);
-        slk_vec<VEC> sq = zero, gv = zero, tv = zero;
-        float sqb = 0.0f, gb = 0.0f, tb = 0.0f;
-        bool any = false, first_tile = true, is_long = false;
-        const uint32_t p0 = r - ib0;
-        uint32_t k = r;
-        for (;;) {
-            if (SEQ || g != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum; PoolNet: all do
+    auto pos_of = [&](uint32_t pay) -> uint32_t {
+        return IMODE == SLK_EI_EXPL ? pay : (IMODE == SLK_EI_PAIR ? pay >> 1 : pay / NP);
+    };
+    for (uint32_t r0 = ib0 + gslot; r0 < ib1 && !(e.debug & 1); r0 += (uint32_t)NB * gstride) {
+        // (1) the ids of the batch's positions; which of them are heads of their item's run
+        uint32_t key[NB], pay[NB];
+        bool head[NB];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    float cc = g * uo.v[i];
-                    if (own) cc += hg.v[i];
-                    sq.v[i] += cc;
-                    tv.v[i] += cc;
-                }
-                sqb += g;
-                tb += g;
-                any = true;
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t r = r0 + (uint32_t)i * gstride;
+            key[i] = pay[i] = 0u;
+            head[i] = false;
+            if (r < ib1) {
+                const bool first = r == ib0;
+                const bool pre = i == 0 && r0 == ib0 + gslot;  // this position's list entries were prefetched
+                key[i] = pre ? nx_key : e.ikey[r];
+                const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ikey[r - 1]);
+                pay[i] = pre ? nx_a : e.ipay[r];
+                // padding_idx rows receive no gradient (the launch path never makes them heads)
+                head[i] = (first || prev != key[i]) && !(SEQ && (key[i] & e.imask) == e.pad_item);
             }
-            ++k;
-            const bool run_ends = !(k < ib1 && e.ikey[k] == key);
-            const uint32_t rel = k - ib0;
-            const bool boundary = rel % TT == 0u;
-            if (run_ends || boundary) {  // the tile [tile_start, rel) is done: its sum joins the run's
-                const uint32_t tile_start = (rel - 1u) / TT * TT;
-                is_long = is_long || (tile_start >= p0 && boundary);  // a FULL tile covered from its first to its last position
-                if (first_tile) {
-                    gv = tv;
-                    gb = tb;
-                    first_tile = false;
-                } else {
+        }
+        // (2) every head's row, optimizer state, bias and first record -- and the ids of the occurrence behind it -- in ONE round trip
+        slk_vec<VEC> v[NB], sv1[NB], sv2[NB], uo[NB], hg[NB];
+        slk_vec<1> bis1[NB], bis2[NB];
+        float bi[NB], g[NB];
+        uint32_t nkey[NB], npay[NB];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) gv.v[i] += tv.v[i];
-                    gb += tb;
+        for (int i = 0; i < NB; ++i) {
+            v[i] = sv1[i] = sv2[i] = uo[i] = hg[i] = zero;
+            bis1[i] = bis2[i] = zero1;
+            bi[i] = g[i] = 0.0f;
+            nkey[i] = ~key[i];
+            npay[i] = 0u;
+            if (head[i]) {
+                const uint32_t r = r0 + (uint32_t)i * gstride;
+                const uint32_t item = key[i] & e.imask;
+                const size_t voff = (size_t)item * D + d0;
+                if (on) v[i] = slk_vload_coh<VEC>(e.P[1] + voff);
+                if (on && HAS_S1) sv1[i] = slk_vload_coh<VEC>(e.S1[1] + voff);
+                if (on && HAS_S2) sv2[i] = slk_vload_coh<VEC>(e.S2[1] + voff);
+                bi[i] = slk_ld_coh(e.P[3] + item);
+                if (lane == 0) {
+                    if (HAS_S1) bis1[i] = slk_vload_coh<1>(e.S1[3] + item);
+                    if (HAS_S2) bis2[i] = slk_vload_coh<1>(e.S2[3] + item);
                 }
-                tv = zero;
-                tb = 0.0f;
+                g[i] = slk_ld_coh(e.gsn + (pay[i] - ib0));
+                const uint32_t pos = pos_of(pay[i]);
+                if (on) uo[i] = slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0);
+                // PoolNet: the sequence's own item (pair 0) also receives the history gradient of its timestep (second half of the record)
+                if (SEQ && on && pay[i] - pos * NP == 0u) hg[i] = slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + D + d0);
+                if (r + 1u < ib1) {
+                    nkey[i] = e.ikey[r + 1u];
+                    npay[i] = e.ipay[r + 1u];
+                }
             }
-            if (run_ends) break;
-            pay = e.ipay[k];
-            g = slk_ld_coh(e.gsn + (pay - ib0));
-            pos = IMODE == SLK_EI_EXPL ? pay : (IMODE == SLK_EI_PAIR ? pay >> 1 : pay / NP);
-            uo = on ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0) : zero;
-            own = SEQ && pay - pos * NP == 0u;
-            if (SEQ) hg = (own && on) ? slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + D + d0) : zero;
         }
-        if (!is_long) {
-            gv = sq;
-            gb = sqb;
-        }
+        // (3) the runs, one after the other
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (!head[i]) continue;
+            const uint32_t r = r0 + (uint32_t)i * gstride;
+            const uint32_t kkey = key[i], item = kkey & e.imask;
+            const size_t voff = (size_t)item * D + d0;
+            // The run is summed as the launch path sums it (slk_kernels.h, k_item_pass + k_item_stitch): in occurrence order --
+            // unless it is LONG, i.e. wholly covers one of the launch path's (full) tiles of TT positions of the minibatch's
+            // occurrence list: then tile by tile (in occurrence order inside a tile), the tiles' sums added in order.
+            // Both sums are kept; which one applies is known when the run ends.
+            constexpr uint32_t TT = 4u * (256u / (uint32_t)G);
+            slk_vec<VEC> sq = zero, gv = zero, tv = zero;
+            float sqb = 0.0f, gb = 0.0f, tb = 0.0f;
+            bool any = false, first_tile = true, is_long = false;
+            const uint32_t p0 = r - ib0;
+            uint32_t k = r;
+            float gc = g[i];
+            slk_vec<VEC> uoc = uo[i], hgc = hg[i];
+            bool own = SEQ && pay[i] - pos_of(pay[i]) * NP == 0u;
+            uint32_t nk = nkey[i], np_ = npay[i];  // key and payload of occurrence k + 1 (~key: there is none)
+            for (;;) {
+                // the next occurrence's record is requested before this one is added; its ids arrived with this one's record
+                const bool cont = nk == kkey;
+                float gn = 0.0f;
+                slk_vec<VEC> uon = zero, hgn = zero;
+                bool ownn = false;
+                uint32_t nk2 = ~kkey, np2 = 0u;
+                if (cont) {
+                    const uint32_t posn = pos_of(np_);
+                    gn = slk_ld_coh(e.gsn + (np_ - ib0));
+                    if (on) uon = slk_vload_coh<VEC>(e.snap + (size_t)(posn - b0) * e.RS + d0);
+                    ownn = SEQ && np_ - posn * NP == 0u;
+                    if (ownn && on) hgn = slk_vload_coh<VEC>(e.snap + (size_t)(posn - b0) * e.RS + D + d0);
+                    if (k + 2u < ib1) {
+                        nk2 = e.ikey[k + 2u];
+                        np2 = e.ipay[k + 2u];
+                    }
+                }
+                if (SEQ || gc != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum; PoolNet: all do
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float cc = gc * uoc.v[q];
+                        if (own) cc += hgc.v[q];
+                        sq.v[q] += cc;
+                        tv.v[q] += cc;
+                    }
+                    sqb += gc;
+                    tb += gc;
+                    any = true;
+                }
+                ++k;
+                const bool run_ends = !cont;
+                const uint32_t rel = k - ib0;
+                const bool boundary = rel % TT == 0u;
+                if (run_ends || boundary) {  // the tile [tile_start, rel) is done: its sum joins the run's
+                    const uint32_t tile_start = (rel - 1u) / TT * TT;
+                    is_long = is_long || (tile_start >= p0 && boundary);  // a FULL tile covered from its first to its last position
+                    if (first_tile) {
+                        gv = tv;
+                        gb = tb;
+                        first_tile = false;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) gv.v[q] += tv.v[q];
+                        gb += tb;
+                    }
+                    tv = zero;
+                    tb = 0.0f;
+                }
+                if (run_ends) break;
+                gc = gn;
+                uoc = uon;
+                hgc = hgn;
+                own = ownn;
+                nk = nk2;
+                np_ = np2;
+            }
+            if (!is_long) {
+                gv = sq;
+                gb = sqb;
+            }
 
-        // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
-        // row; the dense optimizers update every row anyway
-        if (!(SLK_EUPD_ZERO_IS_NOOP(UPD) && !any)) {
-            if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v, sv1, sv2, gv);
-            if (lane == 0 && !(SLK_EUPD_ZERO_IS_NOOP(UPD) && gb == 0.0f)) {
-                slk_vec<1> bp, bg;
-                bp.v[0] = bi;
-                bg.v[0] = gb;
-                slk_epoch_update<1, UPD>(e, c, 3, item, bp, bis1, bis2, bg);
+            // Adagrad: a run without any gradient is an exact no-op; SparseAdam decays the moments of every looked-up
+            // row; the dense optimizers update every row anyway
+            if (!(SLK_EUPD_ZERO_IS_NOOP(UPD) && !any)) {
+                if (on) slk_epoch_update<VEC, UPD>(e, c, 1, voff, v[i], sv1[i], sv2[i], gv);
+                if (lane == 0 && !(SLK_EUPD_ZERO_IS_NOOP(UPD) && gb == 0.0f)) {
+                    slk_vec<1> bp, bg;
+                    bp.v[0] = bi[i];
+                    bg.v[0] = gb;
+                    slk_epoch_update<1, UPD>(e, c, 3, item, bp, bis1[i], bis2[i], bg);
+                }
             }
         }
     }
@@ -416,7 +485,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         // ------------------------------------------------ SCORE PHASE (adaptive hinge): k_score_pass's arithmetic
         if (ADP) {
             const uint32_t n_units = (b1 - b0) * nch;
-            for (uint32_t unit = gslot; unit < n_units && !(e.debug & 1); unit += gstride) {
+            for (uint32_t unit = gslot; unit < n_units && !(e.debug & (1 | 32)); unit += gstride) {
                 const bool pre = unit == gslot;
                 const uint32_t p = b0 + unit / nch, s0 = (unit % nch) * SB;
                 const uint32_t user = (pre ? sc_key : e.ukey[p]) & e.umask;
@@ -457,7 +526,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         // ------------------------------------------------ USER PHASE
         float loss_acc = 0.0f;
         double loss_acc_d = 0.0;  // adaptive hinge: the columns' hinge terms (k_adaptive_select sums them in double)
-        for (uint32_t p = b0 + gslot; p < b1 && !(e.debug & 1); p += gstride) {
+        for (uint32_t p = b0 + gslot; p < b1 && !(e.debug & (1 | 8)); p += gstride) {
             const bool first = p == b0;
             const bool pre = p == b0 + gslot;  // this position's list entries were prefetched
             const uint32_t key = pre ? nx_key : e.ukey[p];
@@ -667,7 +736,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
         ++barriers;
 
         // ------------------------------------------------ ITEM PHASE
-        if (!(e.debug & 1))
+        if (!(e.debug & (1 | 16)))
             slk_epoch_item_phase<VEC, G, UPD, EXPL ? SLK_EI_EXPL : (ADP ? SLK_EI_ADP : SLK_EI_PAIR)>(
                 e, c, b0, ib0, ib1, NP, gslot, gstride, D, d0, on, lane, nx_key, nx_prev, nx_a);
         if (DENSE) {
@@ -757,7 +826,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_poolnet_epoch(slk_epoch_args e
         double loss_acc = 0.0;
 
         // ------------------------------------------------ SEQUENCE PHASE
-        for (uint32_t sq = s0 + blockIdx.x; sq < s1 && !(e.debug & 1); sq += gridDim.x) {
+        for (uint32_t sq = s0 + blockIdx.x; sq < s1 && !(e.debug & (1 | 8)); sq += gridDim.x) {
             const int64_t *seq = e.seqs + (size_t)sq * L;
             const uint32_t bl = sq - s0;
             float *recs = e.snap + (size_t)bl * L * e.RS;
@@ -949,7 +1018,7 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_poolnet_epoch(slk_epoch_args e
         ++barriers;
 
         // ------------------------------------------------ ITEM PHASE
-        if (!(e.debug & 1))
+        if (!(e.debug & (1 | 16)))
             slk_epoch_item_phase<VEC, G, UPD, SLK_EI_SEQ>(e, c, t_b0, ib0, ib1, NP, gslot, gstride, D, d0, on, lane, nx_key, nx_prev,
                                                           nx_a);
         if (DENSE) slk_epoch_sweep_untouched<VEC, UPD>(e, c, 1, 3, e.touch_i, mb + 1u, e.n_items, gslot, gstride, D, d0, on, lane);
