@@ -9,12 +9,17 @@ gpurun_out/calib_*: a 1 GiB streaming copy reports FETCH 0.5 GiB / WRITE 1.0 GiB
 row gather reports 0.73 of its bytes), so 2 x FETCH is an upper bound for the random-row part."""
 import json
 import os
+import re
 import sqlite3
 import sys
 
 
 def cls(name):
-    for key in ('k_user_pass', 'k_item_pass', 'k_seq_pass', 'k_shard_user_pass', 'k_mt_generate', 'onesweep_iteration'):
+    if 'k_item_pass' in name:  # BloomEmbedding tables: the rows pass (PART 1) and the bias pass (PART 2) are different kernels
+        m = re.search(r'k_item_pass<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name)
+        part = m.group(1) if m else '0'
+        return 'k_item_pass' if part == '0' else 'k_item_pass<PART %s>' % part
+    for key in ('k_user_pass', 'k_score_pass', 'k_adaptive_select', 'k_seq_pass', 'k_shard_user_pass', 'k_mt_generate', 'onesweep_iteration'):
         if key in name:
             return key
     return None
