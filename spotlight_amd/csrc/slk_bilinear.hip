@@ -193,19 +193,43 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     gbu += g;
                 }
             } else {
+                // dL/dscore of the interaction's 1 + n pairs, one per lane (one round trip for all of them, with the pairs' item
+                // ids), then the rows of the LIVE pairs -- adaptive hinge: the positive and the selected draw -- two at a time,
+                // added in pair order (the order the one-pair-at-a-time loop this replaces added them in: same bits; a pair per
+                // iteration cost a dependent dL/dscore -> id -> row chain each)
                 const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
-                for (int s = 0; s < a.NP; ++s) {
-                    const float g = a.gk[kb + s];
-                    if (lane == 0) a.gsn[(size_t)(q - a.begin) * a.NP + s] = g;
-                    if (g != 0.0f) {
-                        const uint32_t it = a.uit[qb + s];
-                        slk_vec<VEC> v;
-                        if (BLOOM)
-                            v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
-                        else
-                            v = on ? slk_vload<VEC>(a.P[1] + (size_t)it * D + d0) : slk_vzero<VEC>();
-                        slk_vaxpy<VEC>(gu, g, v);
-                        gbu += g;
+                for (int s0 = 0; s0 < a.NP; s0 += G) {
+                    const int s = s0 + lane;
+                    float gs = 0.0f;
+                    uint32_t it_l = 0u;
+                    if (s < a.NP) {
+                        gs = a.gk[kb + s];
+                        it_l = a.uit[qb + s];
+                        a.gsn[(size_t)(q - a.begin) * a.NP + s] = gs;
+                    }
+                    unsigned long long live = slk_group_or<G>(gs != 0.0f ? 1ull << lane : 0ull);
+                    while (live) {
+                        const int j0 = __builtin_ctzll(live);
+                        live &= live - 1ull;
+                        const bool two = live != 0ull;
+                        const int j1 = two ? __builtin_ctzll(live) : j0;
+                        if (two) live &= live - 1ull;
+                        const uint32_t i0 = __shfl(it_l, j0, G), i1 = __shfl(it_l, j1, G);
+                        const float g0 = __shfl(gs, j0, G), g1 = __shfl(gs, j1, G);
+                        slk_vec<VEC> v0, v1 = slk_vzero<VEC>();
+                        if (BLOOM) {
+                            v0 = slk_emb_vec<VEC>(a.P[1], a.ib, i0, D, d0, on);
+                            if (two) v1 = slk_emb_vec<VEC>(a.P[1], a.ib, i1, D, d0, on);
+                        } else {
+                            v0 = on ? slk_vload<VEC>(a.P[1] + (size_t)i0 * D + d0) : slk_vzero<VEC>();
+                            if (two && on) v1 = slk_vload<VEC>(a.P[1] + (size_t)i1 * D + d0);
+                        }
+                        slk_vaxpy<VEC>(gu, g0, v0);
+                        gbu += g0;
+                        if (two) {
+                            slk_vaxpy<VEC>(gu, g1, v1);
+                            gbu += g1;
+                        }
                     }
                 }
             }
@@ -428,11 +452,25 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
         const slk_vec<VEC> u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         const float bu = a.P[2][user];
         const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
-        for (int s = 0; s < a.NP; ++s) {
-            const uint32_t it = a.uit[qb + s];
-            const slk_vec<VEC> v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
-            const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v)) + bu + a.P[3][it];
-            if (lane == 0) a.sk[kb + s] = sc;
+        constexpr int SB = 3;  // candidates whose rows are in flight together (1 + 5 draws: two batches)
+        for (int s0 = 0; s0 < a.NP; s0 += SB) {
+            slk_vec<VEC> v[SB];
+            float bi[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                v[j] = slk_vzero<VEC>();
+                bi[j] = 0.0f;
+                if (s0 + j < a.NP) {
+                    const uint32_t it = a.uit[qb + s0 + j];
+                    v[j] = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
+                    bi[j] = a.P[3][it];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v[j])) + bu + bi[j];
+                if (lane == 0 && s0 + j < a.NP) a.sk[kb + s0 + j] = sc;
+            }
         }
     }
 }
