@@ -1355,7 +1355,6 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             // of the eight per CU are left to the prep stream's kernels (measured, profiles/r03_a_*: 8 -> 6 costs the pass
             // nothing by itself and gives the overlap 2 % more)
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb, nsets == 2 && ctx->opt_user_grid_mult > 6 ? 6 : 0);
-            const unsigned igrid = slk_grid_for(ctx, late ? (size_t)bm * 2 : (size_t)bm * NP, 4 * gpb, ctx->opt_item_grid_mult);
 
             if (expl && ctx->opt_explicit_fused) {
                 // the user pass forms score, loss and dL/dscore itself (one pair per interaction)

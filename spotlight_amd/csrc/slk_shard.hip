@@ -635,7 +635,6 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
 #define SLK_PICK(V_, G_) ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_BLK>(upd)
         SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
-        const unsigned gpb = 256u / (unsigned)g;
         slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
         if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass<BLK>"))) return rc;
         slk_prof_end(ctx, s);
