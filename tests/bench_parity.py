@@ -333,7 +333,7 @@ def poolnet_minibatch_parity(engine, dev, stream, I, D, B, L, loss='bpr', nn=1, 
                 **{'elements_beyond_1e-5_but_within_conditioned_bound': cond})
 
 
-def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2, expect_route=None):
+def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2, expect_route=None, loss='bpr', n_neg=1):
     """One slk_bilinear_train call over n_full * B + tail interactions (more than one prep chunk), bpr + Adagrad:
       * every negative of the call and the RNG state afterwards: bit-exact against numpy (one contiguous stream);
       * for every k in `check_at`: minibatch k is checked against the oracle by teacher forcing -- a second run
@@ -356,7 +356,8 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
     rs.set_state(rng0)
     n_mb = n_full + (1 if tail else 0)
     sizes = [B] * n_full + ([tail] if tail else [])
-    want_neg = np.concatenate([rs.randint(0, I, m, dtype=np.int64) for m in sizes])  # one randint per minibatch
+    nn = n_neg if loss == 'adaptive_hinge' else 1  # adaptive hinge: n draws per interaction (implicit.py:266-275)
+    want_neg = np.concatenate([rs.randint(0, I, m * nn, dtype=np.int64) for m in sizes])  # one randint per minibatch
     want_rng = rs.get_state()
 
     def run(n_inter):
@@ -366,9 +367,9 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
         op = _native.make_optim('adagrad', [x.data_ptr() for x in s], None, lr=lr)
         k = (n_inter + B - 1) // B
         mb = torch.zeros(k, device=dev)
-        neg = torch.full((n_inter,), -1, device=dev, dtype=torch.int64)
+        neg = torch.full((n_inter * nn,), -1, device=dev, dtype=torch.int64)
         engine.rng_set_state(rng0)
-        engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), n_inter, B, 'bpr', 1, mb.data_ptr(),
+        engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), n_inter, B, loss, nn, mb.data_ptr(),
                               d_neg_out=neg.data_ptr(), stream=stream)
         return t, s, _np(mb), neg, engine.rng_get_state(), op.step
 
@@ -392,7 +393,7 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
         tA, sA, lossA, _, _, _ = run(lo)          # tables before minibatch k
         tB, sB, lossB, _, _, _ = run(hi)          # ... and after it
         assert np.array_equal(lossA, lossF[:k]) and np.array_equal(lossB, lossF[:k + 1]), 'a prefix run is not bit-identical'
-        h_u, h_i, h_n = _np(users[lo:hi]), _np(items[lo:hi]), want_neg[lo:hi]
+        h_u, h_i, h_n = _np(users[lo:hi]), _np(items[lo:hi]), want_neg[lo * nn:hi * nn]
         uu, uinv = np.unique(h_u, return_inverse=True)
         iu, iinv = np.unique(np.concatenate([h_i, h_n]), return_inverse=True)
         d_uu, d_iu = torch.from_numpy(uu).to(dev), torch.from_numpy(iu).to(dev)
@@ -400,7 +401,7 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
         pre_p = [_rows(tA[t], idxs[t]) for t in range(4)]
         pre_s = [_rows(sA[t], idxs[t]) for t in range(4)]
         ora = BilinearOracle(*pre_p, opt='adagrad', lr=lr, sparse_grads=True, state1=pre_s)
-        want_loss, want_g = ora.step(uinv, iinv[:hi - lo], iinv[hi - lo:], loss='bpr', want_grads=True)
+        want_loss, want_g = ora.step(uinv, iinv[:hi - lo], iinv[hi - lo:], loss=loss, n_neg=nn, want_grads=True)
         assert abs(float(lossF[k]) - want_loss) <= TOL * abs(want_loss), (k, float(lossF[k]), want_loss)
         bscale = max(np.abs(want_g[2]).max(), np.abs(want_g[3]).max())
         gscale = [np.abs(want_g[0]).max(), np.abs(want_g[1]).max(), bscale, bscale]

@@ -119,6 +119,21 @@ def test_c2_tables_small_and_mid_minibatches(hip, B, route):
     print('C2 tables, minibatch', B, route, out)
 
 
+@pytest.mark.parametrize('B,route', [(256, 'epoch'), (1024, 'epoch'), (1024, 'launch')])
+def test_c2_tables_adaptive_hinge_small_minibatches(hip, B, route):
+    """adaptive hinge with the reference's default of 5 draws per interaction (implicit.py:72) at its default batch size on the
+    10M x 1M tables: through the persistent kernel (score phase, the view(n, B) selection inside the user phase) and through the
+    launches; negatives + RNG state of the whole call bit-exact, two minibatches against the oracle by teacher forcing."""
+    eng, dev, stream = hip
+    eng.set_option('epoch_kernel', 1 if route == 'epoch' else 0)
+    try:
+        out = bp.multi_chunk_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, B, n_full=40, tail=B // 3 + 1, check_at=(20, 40),
+                                    seed=7 + B, expect_route=route, loss='adaptive_hinge', n_neg=5)
+    finally:
+        eng.set_option('epoch_kernel', 1)
+    print('C2 tables, adaptive hinge, minibatch', B, route, out)
+
+
 def test_c5_shard_sharded_world1_vs_fused(hip):
     """One C5-shard step (12.5M users x 125M items, dim 64, minibatch 2^20) through the row-sharded exchange path at world
     1, compared row by row with the fused path over the whole tables."""
