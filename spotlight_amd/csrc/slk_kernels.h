@@ -339,7 +339,8 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 #endif
 
 #ifndef SLK_SPILL_BATCH
-#define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD)
+#define SLK_SPILL_BATCH 2  // occurrences of a spilled run in flight per row group (4 spills VGPRs at 6 waves/SIMD; measured again in round 3
+                           // at 7: C3 1.78 -> 1.81 ms, C4 0.55 -> 0.61, C2 item pass 0.296 -> 0.310, profiles/r03_zf_*)
 #endif
 
 // Row update with the parameter / first-state elements already in registers (loaded early, see
