@@ -135,9 +135,9 @@ struct slk_ctx {
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
     int opt_epoch_seq = 0;         // PoolNet on the persistent route (k_poolnet_epoch).  OFF: bit-identical to the launches, but measured
-                                   // slower at every shape (profiles/r03_x_*: 256 sequences x 10 timesteps 26.8 vs 22.2 us per minibatch,
-                                   // x 32: 63 vs 26) -- one wavefront per sequence walks the scans' 256 / G chunks in turns and the item
-                                   // phase takes its 5 K occurrences five dependent round trips deep ...
+                                   // slower at every shape (profiles/r03_x_*, r03_za_*: 256 sequences x 10 timesteps 26.8 vs 22.2 us per
+                                   // minibatch -- two barriers ~9 us, sequence phase 11.5 (one wavefront per sequence walks the scans'
+                                   // 256 / G chunks in turns), item phase 11.2 against the launches' 10 + 13 us kernels; x 32: 63 vs 26) ...
     int64_t opt_epoch_seq_max_timesteps = 4096;  // ... for minibatches of up to this many timesteps (256 sequences x 16)
     int opt_epoch_adaptive = 1;    // adaptive hinge on the persistent route (score phase + the selection inside the user phase)
     int64_t opt_epoch_adaptive_max_batch = 1024;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
