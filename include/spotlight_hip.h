@@ -429,6 +429,18 @@ int slk_probe_step_ceiling(slk_ctx *ctx, const slk_tables *tables, const slk_opt
 int slk_probe_random_rows(slk_ctx *ctx, float *d_buf, int64_t rows, int32_t dim, int32_t layout, int32_t order,
                           int32_t rmw, int64_t n_access, int32_t iters, double *avg_ms, void *stream);
 
+/*  slk_probe_sort          the engine's stable LSD radix sort (csrc/slk_sort.hip) on caller-owned device arrays, for tests
+ *                          and measurement: n (key, payload) pairs sorted by the key bits [0, bits); kind 0 = uint32 keys
+ *                          + uint32 payloads, 1 = uint32 + uint64, 2 = uint64 + uint32 (+ 8: the input arrays may be overwritten --
+ *                          they serve as the sort's second buffer pair, as in the training prep; iters must be 0); seg_len > 0: every run of seg_len
+ *                          pairs is sorted on its own (the training prep's one-segment-per-minibatch form; the key bits at and
+ *                          above `bits` are carried, not sorted).  iters > 0: the call is repeated and *avg_ms receives the
+ *                          average duration from hipEvents on the stream (it synchronises); the inputs are left intact.
+ *                          Replaces the sparse-gradient coalesce's sort inside `loss.backward(); optimizer.step()`
+ *                          (spotlight/factorization/implicit.py:242-243). */
+int slk_probe_sort(slk_ctx *ctx, int32_t kind, const void *d_keys_in, void *d_keys_out, const void *d_vals_in,
+                   void *d_vals_out, int64_t n, int64_t seg_len, int32_t bits, int32_t iters, double *avg_ms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,8 @@ _PROTOTYPES = {
                                    C.POINTER(C.c_double), C.c_void_p]),
     'slk_probe_random_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                         C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    'slk_probe_sort': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                 C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     'slk_probe_step_ceiling': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int32,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p]),
 }
@@ -372,6 +374,14 @@ class Engine(object):
         ms = C.c_double()
         self._check(self._lib.slk_probe_random_rows(self._ctx, d_buf, int(rows), int(dim), int(layout), int(order), int(rmw),
                                                     int(n_access), int(iters), C.byref(ms), stream))
+        return float(ms.value)
+
+    def probe_sort(self, kind, d_keys_in, d_keys_out, d_vals_in, d_vals_out, n, bits, seg_len=0, iters=0, stream=0):
+        """The engine's stable radix sort on caller-owned device arrays (kind 0: u32 + u32, 1: u32 + u64, 2: u64 + u32);
+        returns the average ms of `iters` repeats (0.0 when iters == 0)."""
+        ms = C.c_double()
+        self._check(self._lib.slk_probe_sort(self._ctx, int(kind), d_keys_in, d_keys_out, d_vals_in, d_vals_out, int(n),
+                                             int(seg_len), int(bits), int(iters), C.byref(ms), stream))
         return float(ms.value)
 
     def probe_step_ceiling(self, tables, optim, batch, iters=10, stream=0):

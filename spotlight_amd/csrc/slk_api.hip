@@ -130,7 +130,7 @@ int slk_prep_stream_init(slk_ctx *ctx) {
     // reserve / first-use path, not in a timed call
     for (hipStream_t st : {ctx->prep_stream, ctx->pass_stream}) {
         if (!st) continue;
-        SLK_HIP(ctx, hipMemsetAsync(&ctx->d_rng->pad_, 0, sizeof(int32_t), st));
+        SLK_HIP(ctx, hipMemsetAsync(&ctx->d_rng->sort_abort, 0, sizeof(int32_t), st));
         SLK_HIP(ctx, hipStreamSynchronize(st));
     }
     ctx->prep_stream_cus = ctx->opt_prep_cus;
@@ -237,6 +237,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_prep_cus = (int)value;
     } else if (!strcmp(name, "prep_priority") && (value == 0 || value == 1)) {
         ctx->opt_prep_priority = (int)value;
+    } else if (!strcmp(name, "sort_cfg") && (value == 0 || value == 1)) {
+        ctx->opt_sort_cfg = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {

@@ -599,21 +599,6 @@ __global__ __launch_bounds__(256) void k_u32_to_i64(const uint32_t *in, int64_t 
         out[i] = (int64_t)in[i];
 }
 
-// key = (minibatch-in-chunk << ubits) | user.  FAT (one negative): value = (neg << 32) | pos so
-// the sorted values ARE the user pass's item pairs; otherwise value = interaction index.
-template <bool FAT>
-__global__ __launch_bounds__(256) void k_build_user_keys(const int64_t *users, const int64_t *items,
-                                                         const uint32_t *neg32, uint32_t nc, uint32_t bsz,
-                                                         unsigned ubits, uint32_t *key, void *val) {
-    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nc; k += gridDim.x * 256) {
-        key[k] = ((k / bsz) << ubits) | (uint32_t)users[k];
-        if (FAT)
-            ((uint64_t *)val)[k] = ((uint64_t)neg32[k] << 32) | (uint64_t)(uint32_t)items[k];
-        else
-            ((uint32_t *)val)[k] = k;
-    }
-}
-
 __global__ __launch_bounds__(256) void k_pack_items(const uint32_t *uk, const int64_t *items,
                                                     const uint32_t *neg32, uint32_t nc, int nn, uint32_t *uit) {
     const int NP = nn + 1;
@@ -621,16 +606,6 @@ __global__ __launch_bounds__(256) void k_pack_items(const uint32_t *uk, const in
         const uint32_t k = uk[q];
         uit[(size_t)q * NP] = (uint32_t)items[k];
         for (int r = 0; r < nn; ++r) uit[(size_t)q * NP + 1 + r] = neg32[(size_t)k * nn + r];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_build_item_keys(const uint32_t *uit, uint32_t nocc, int NP,
-                                                         uint32_t bsz, unsigned ibits, uint32_t *key,
-                                                         uint32_t *val) {
-    for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < nocc; r += gridDim.x * 256) {
-        const uint32_t q = r / (uint32_t)NP;
-        key[r] = ((q / bsz) << ibits) | uit[r];
-        val[r] = r;
     }
 }
 
@@ -1214,21 +1189,15 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const unsigned mbbits = slk_bits_for((uint64_t)((nc - 1) / (uint32_t)bsz));
         uint32_t *ukey_in = (uint32_t *)pb.ukey[0].p, *ukey = (uint32_t *)pb.ukey[1].p;
         const uint32_t *uit, *uk = nullptr;
+        uint32_t *const ukeys[2] = {ukey_in, ukey};
         if (!pre) {
-            hipLaunchKernelGGL((k_build_user_keys<true>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
-                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
-            SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
-            if ((rc = slk_sort_pairs_u32_u64(ctx, ukey_in, ukey, (const uint64_t *)pb.uval[0].p,
-                                             (uint64_t *)pb.uval[1].p, nc, ubits + mbbits, s)))
-                return rc;
+            // (keys and the fat (positive, negative) payload are formed by the sort's first pass from the id arrays)
+            uint64_t *const uvals[2] = {(uint64_t *)pb.uval[0].p, (uint64_t *)pb.uval[1].p};
+            if ((rc = slk_sort_user_fat(ctx, cu, ci, (const uint32_t *)neg32, nc, (size_t)bsz, ubits, mbbits, ukeys, uvals, s))) return rc;
             uit = (const uint32_t *)pb.uval[1].p;  // little-endian (pos, neg) pairs
         } else {
-            hipLaunchKernelGGL((k_build_user_keys<false>), dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, cu, ci,
-                               (const uint32_t *)neg32, nc, (uint32_t)bsz, ubits, ukey_in, pb.uval[0].p);
-            SLK_LAUNCH_CHECK(ctx, "k_build_user_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, ukey_in, ukey, (const uint32_t *)pb.uval[0].p,
-                                             (uint32_t *)pb.uval[1].p, nc, ubits + mbbits, s)))
-                return rc;
+            uint32_t *const uvals[2] = {(uint32_t *)pb.uval[0].p, (uint32_t *)pb.uval[1].p};
+            if ((rc = slk_sort_user_idx(ctx, cu, nc, (size_t)bsz, ubits, mbbits, ukeys, uvals, s))) return rc;
             uk = (const uint32_t *)pb.uval[1].p;
             hipLaunchKernelGGL(k_pack_items, dim3(slk_grid_for(ctx, nc, 256)), dim3(256), 0, s, uk, ci,
                                (const uint32_t *)neg32, nc, nn, (uint32_t *)pb.uit.p);
@@ -1240,13 +1209,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                (uint32_t *)pb.ipay[0].p);
             SLK_LAUNCH_CHECK(ctx, "k_invert_perm");
         } else {
-            hipLaunchKernelGGL(k_build_item_keys, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, uit, nocc, NP,
-                               (uint32_t)bsz, ibits, (uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ipay[0].p);
-            SLK_LAUNCH_CHECK(ctx, "k_build_item_keys");
-            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p,
-                                             (const uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p, nocc,
-                                             ibits + mbbits, s)))
-                return rc;
+            uint32_t *const ikeys[2] = {(uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p};
+            uint32_t *const ivals[2] = {(uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p};
+            if ((rc = slk_sort_item_occ(ctx, uit, nocc, (size_t)bsz, NP, ibits, mbbits, ikeys, ivals, s))) return rc;
         }
         // which minibatches hold a LONG run (an item run that wholly covers a tile of the item pass, [0, n_mb); a user run that
         // wholly covers a tile of the user pass, [n_mb, 2 n_mb)): ids only, so the answer is fetched once per chunk and the usual
@@ -1281,7 +1246,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.bik[0].p,
                                              (uint32_t *)pb.bik[1].p,
                                              (const uint32_t *)pb.bip[0].p,
-                                             (uint32_t *)pb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+                                             (uint32_t *)pb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s, true)))
                 return rc;
         }
         if (Hu) {
@@ -1292,7 +1257,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)pb.buk[0].p,
                                              (uint32_t *)pb.buk[1].p,
                                              (const uint32_t *)pb.bup[0].p,
-                                             (uint32_t *)pb.bup[1].p, (size_t)nc * Hu, ucbits + mbbits, s)))
+                                             (uint32_t *)pb.bup[1].p, (size_t)nc * Hu, ucbits + mbbits, s, true)))
                 return rc;
         }
         slk_prof_end(ctx, s);
@@ -1394,7 +1359,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                     if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[BL_LATE_SORT], (const uint32_t *)ctx->extra[BL_LK0].p,
                                                      (uint32_t *)ctx->extra[BL_LK1].p,
                                                      (const uint32_t *)ctx->extra[BL_LV0].p,
-                                                     (uint32_t *)ctx->extra[BL_LV1].p, nl, ibits + 1, s)))  // + the dead entries' bit
+                                                     (uint32_t *)ctx->extra[BL_LV1].p, nl, ibits + 1, s, true)))  // + the dead entries' bit
                         return rc;
                     slk_prof_end(ctx, s);
                     a.ikey = (const uint32_t *)ctx->extra[BL_LK1].p;
@@ -1468,7 +1433,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                     if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[BL_LATE_SORT], (const uint32_t *)ctx->extra[BL_LK0].p,
                                                      (uint32_t *)ctx->extra[BL_LK1].p,
                                                      (const uint32_t *)ctx->extra[BL_LV0].p,
-                                                     (uint32_t *)ctx->extra[BL_LV1].p, nlh, icbits + 1, s)))
+                                                     (uint32_t *)ctx->extra[BL_LV1].p, nlh, icbits + 1, s, true)))
                         return rc;
                     r.ikey = (const uint32_t *)ctx->extra[BL_LK1].p;
                     r.ipay = (const uint32_t *)ctx->extra[BL_LV1].p;

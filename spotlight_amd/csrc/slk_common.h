@@ -56,7 +56,7 @@ struct slk_rng_dev {
     unsigned long long t_last;  // stream index of the word that produced the last output
     unsigned long long accepted;
     int32_t epoch_abort;      // sticky: the persistent epoch kernel abandoned a launch (grid barrier time-out)
-    int32_t pad_;
+    int32_t sort_abort;       // sticky: a radix-sort look-back gave up waiting for the tile before it (slk_sort.hip)
 };
 
 #define SLK_EXTRA_BUFS 48
@@ -110,6 +110,7 @@ struct slk_ctx {
     int opt_prep_cus = 0;
     int opt_prep_priority = 0;
     int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
+    int opt_sort_cfg = 1;          // radix sort: 1 = sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys, 0 = always 256 x 16
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
@@ -237,15 +238,26 @@ const uint32_t *slk_mt_jump_table(slk_ctx *ctx);  // slk_mtjump.hip (host)
 int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,
                    hipStream_t s);
 
-// sort wrapper (slk_sort.hip)
+// the engine's stable LSD radix sort (slk_sort.hip).  Pairs sorted by the key bits [0, end_bit); `clobber`: the input arrays
+// may be overwritten (they serve as the second buffer pair; otherwise one is taken from the scratch)
 int slk_sort_pairs_u32_u32(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                           uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+                           uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
 int slk_sort_pairs_u32_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
 int slk_sort_pairs_u64_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
-                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+                              uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
-                           uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s);
+                           uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
+int slk_sort_pairs_any(slk_ctx *ctx, int kind, const void *kin, void *kout, const void *vin, void *vout, size_t n, size_t seg_len,
+                       unsigned bits, hipStream_t s, bool clobber);
+// the training prep's sorts: keys built by the first pass from the id arrays, one segment per minibatch of `bsz` interactions;
+// result in (key[1], val[1]), (key[0], val[0]) is the second buffer pair
+int slk_sort_user_fat(slk_ctx *ctx, const int64_t *users, const int64_t *items, const uint32_t *neg32, size_t nc, size_t bsz,
+                      unsigned ubits, unsigned mbbits, uint32_t *const key[2], uint64_t *const val[2], hipStream_t s);
+int slk_sort_user_idx(slk_ctx *ctx, const int64_t *users, size_t nc, size_t bsz, unsigned ubits, unsigned mbbits,
+                      uint32_t *const key[2], uint32_t *const val[2], hipStream_t s);
+int slk_sort_item_occ(slk_ctx *ctx, const uint32_t *uit, size_t nocc, size_t bsz, int NP, unsigned ibits, unsigned mbbits,
+                      uint32_t *const key[2], uint32_t *const val[2], hipStream_t s);
 
 // shared host helpers (slk_bilinear.hip)
 int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g);

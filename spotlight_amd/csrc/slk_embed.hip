@@ -186,7 +186,7 @@ SLK_EXPORT int slk_embedding_backward_plan(slk_ctx *ctx, int64_t rows, int32_t d
     SLK_LAUNCH_CHECK(ctx, "k_emb_keys");
     unsigned bits = 0;
     for (uint64_t r = (uint64_t)rows; r; r >>= 1) ++bits;  // keys go up to `rows` inclusive
-    if ((rc = slk_sort_pairs_u32_u32_in(ctx, E[EM_SORT], k0, k1, p0, p1, occ, bits, s))) return rc;
+    if ((rc = slk_sort_pairs_u32_u32_in(ctx, E[EM_SORT], k0, k1, p0, p1, occ, bits, s, true))) return rc;
     if (num_rows_out) {
         if ((rc = slk_ensure(ctx, E[EM_HEADS], (occ + 1) * 4))) return rc;
         uint32_t nseg = 0, last = 0;

@@ -328,3 +328,39 @@ SLK_EXPORT int slk_probe_random_rows(slk_ctx *ctx, float *d_buf, int64_t rows, i
     });
 #undef SLK_PROBE_R
 }
+
+SLK_EXPORT int slk_probe_sort(slk_ctx *ctx, int32_t kind, const void *d_keys_in, void *d_keys_out, const void *d_vals_in,
+                              void *d_vals_out, int64_t n, int64_t seg_len, int32_t bits, int32_t iters, double *avg_ms,
+                              void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    const bool clobber = (kind & 8) != 0;  // the inputs may be overwritten (they serve as the second buffer pair): iters must be 0
+    kind &= 7;
+    if (clobber && iters > 0) return slk_fail(ctx, SLK_EINVAL, "slk_probe_sort: a clobbering sort cannot be repeated");
+    if (n < 0 || seg_len < 0 || bits < 1 || kind < 0 || kind > 2 || (n > 0 && (!d_keys_in || !d_keys_out || !d_vals_in || !d_vals_out)))
+        return slk_fail(ctx, SLK_EINVAL, "slk_probe_sort: bad arguments");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    int rc;
+    if ((rc = slk_sort_pairs_any(ctx, kind, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, (size_t)seg_len, (unsigned)bits,
+                                 s, clobber)))
+        return rc;
+    if (iters > 0 && avg_ms) {
+        hipEvent_t e0, e1;
+        SLK_HIP(ctx, hipEventCreate(&e0));
+        SLK_HIP(ctx, hipEventCreate(&e1));
+        SLK_HIP(ctx, hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i)
+            if ((rc = slk_sort_pairs_any(ctx, kind, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, (size_t)seg_len,
+                                         (unsigned)bits, s, false)))
+                return rc;
+        SLK_HIP(ctx, hipEventRecord(e1, s));
+        SLK_HIP(ctx, hipEventSynchronize(e1));
+        float ms = 0.0f;
+        SLK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = (double)ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return SLK_OK;
+}

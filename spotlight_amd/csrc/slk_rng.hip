@@ -403,14 +403,19 @@ static int rng_read_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos) {
     hipStream_t cs = slk_copy_stream(ctx);
     SLK_HIP(ctx, hipMemcpyAsync(&h, ctx->d_rng, sizeof(h), hipMemcpyDeviceToHost, cs));
     SLK_HIP(ctx, hipStreamSynchronize(cs));
-    if (h.insufficient || h.epoch_abort) {
+    if (h.insufficient || h.epoch_abort || h.sort_abort) {
         // Reported ONCE: the flags are cleared on the device (they used to stay raised until the next slk_rng_set_state, which
         // a pipelined fit() never issues on its training ctx -- every later epoch then failed).  A barrier time-out also
         // retires the persistent route on this ctx: the per-minibatch launches need no co-residency.
         const int32_t zero2[2] = {0, 0};
         SLK_HIP(ctx, hipMemcpyAsync(&ctx->d_rng->insufficient, zero2, 4, hipMemcpyHostToDevice, cs));
         SLK_HIP(ctx, hipMemcpyAsync(&ctx->d_rng->epoch_abort, zero2 + 1, 4, hipMemcpyHostToDevice, cs));
+        SLK_HIP(ctx, hipMemcpyAsync(&ctx->d_rng->sort_abort, zero2, 4, hipMemcpyHostToDevice, cs));
         SLK_HIP(ctx, hipStreamSynchronize(cs));
+        if (h.sort_abort)
+            return slk_fail(ctx, SLK_EIO,
+                            "radix sort abandoned a look-back: a tile never published its digit counts (the device is shared or a "
+                            "workgroup was lost).  The tables may hold partial updates: re-initialise the model");
         if (h.epoch_abort) {
             ctx->epoch_refused = true;
             return slk_fail(ctx, SLK_EIO,

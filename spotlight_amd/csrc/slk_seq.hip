@@ -741,7 +741,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         SLK_LAUNCH_CHECK(ctx, "k_seq_item_keys");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)fb.ikey[0].p, (uint32_t *)fb.ikey[1].p,
                                          (const uint32_t *)fb.ipay[0].p, (uint32_t *)fb.ipay[1].p, nocc,
-                                         ibits + mbbits, s)))
+                                         ibits + mbbits, s, true)))
             return rc;
         // which minibatches hold a LONG run of the plain occurrence list (slk_kernels.h, k_item_long_flags): fetched once
         // per chunk; the usual minibatch (none) gets the plain item pass with no stitch kernel behind it
@@ -764,7 +764,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)fb.bik[0].p,
                                              (uint32_t *)fb.bik[1].p,
                                              (const uint32_t *)fb.bip[0].p,
-                                             (uint32_t *)fb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s)))
+                                             (uint32_t *)fb.bip[1].p, (size_t)nocc * Hi, icbits + mbbits, s, true)))
                 return rc;
         }
         slk_prof_end(ctx, s);

@@ -316,7 +316,7 @@ SLK_EXPORT int slk_to_sequence_plan(slk_ctx *ctx, const int64_t *d_users, const 
         SLK_LAUNCH_CHECK(ctx, "k_ts_rebase");
         if (tbits == 0)
             order1 = idx;  // all timestamps equal: lexsort keeps the input order
-        else if ((rc = slk_sort_pairs_u32_u32_in(ctx, E[TS_SORT], k32, k32o, idx, order1, N, tbits, s)))
+        else if ((rc = slk_sort_pairs_u32_u32_in(ctx, E[TS_SORT], k32, k32o, idx, order1, N, tbits, s, true)))
             return rc;
     } else {
         if ((rc = slk_ensure(ctx, E[TS_T2], N * 8))) return rc;
@@ -325,7 +325,7 @@ SLK_EXPORT int slk_to_sequence_plan(slk_ctx *ctx, const int64_t *d_users, const 
         hipLaunchKernelGGL(k_ts_rebase, dim3(ts_grid(ctx, N)), dim3(256), 0, s, d_timestamps, (int)ts_kind, N, mm[0],
                            (uint32_t *)nullptr, k64, idx);
         SLK_LAUNCH_CHECK(ctx, "k_ts_rebase");
-        if ((rc = slk_sort_pairs_u64_u32_in(ctx, E[TS_SORT], (const uint64_t *)k64, (uint64_t *)k64o, idx, order1, N, tbits, s)))
+        if ((rc = slk_sort_pairs_u64_u32_in(ctx, E[TS_SORT], (const uint64_t *)k64, (uint64_t *)k64o, idx, order1, N, tbits, s, true)))
             return rc;
     }
 

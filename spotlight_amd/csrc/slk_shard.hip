@@ -355,7 +355,7 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
         SLK_LAUNCH_CHECK(ctx, "k_shard_user_keys");
         if ((rc = slk_sort_pairs_u32_u64(ctx, (const uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->ukey[1].p,
                                          (const uint64_t *)ctx->uval[0].p, (uint64_t *)ctx->uval[1].p, nn,
-                                         ubits + slk_bits_for((uint64_t)T - 1), s)))
+                                         ubits + slk_bits_for((uint64_t)T - 1), s, true)))
             return rc;
         const uint32_t *uit = (const uint32_t *)ctx->uval[1].p;
         hipLaunchKernelGGL(k_shard_owner_keys, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s, uit,
@@ -365,7 +365,7 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[SH_OKEY0].p,
                                          (uint32_t *)ctx->extra[SH_OKEY1].p,
                                          (const uint32_t *)ctx->extra[SH_OVAL0].p,
-                                         (uint32_t *)ctx->extra[SH_OVAL1].p, nl, slk_bits_for((uint64_t)bins - 1), s)))
+                                         (uint32_t *)ctx->extra[SH_OVAL1].p, nl, slk_bits_for((uint64_t)bins - 1), s, true)))
             return rc;
         slk_prof_end(ctx, s);
     }
@@ -475,7 +475,7 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
         SLK_LAUNCH_CHECK(ctx, "k_shard_regroup");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ikey[0].p, (uint32_t *)ctx->ikey[1].p,
                                          (const uint32_t *)ctx->ipay[0].p, (uint32_t *)ctx->ipay[1].p, (size_t)nr,
-                                         ibits + slk_bits_for((uint64_t)M - 1), s)))
+                                         ibits + slk_bits_for((uint64_t)M - 1), s, true)))
             return rc;
         slk_prof_end(ctx, s);
     }

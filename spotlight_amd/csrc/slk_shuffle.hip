@@ -701,7 +701,7 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     hipLaunchKernelGGL(k_fy_keys, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)J, N, key0, val0);
     SLK_LAUNCH_CHECK(ctx, "k_fy_keys");
     // own temporary storage: the shuffle may be prepared on another stream than the training passes
-    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[FY_SORT], key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s)))
+    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[FY_SORT], key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s, true)))
         return rc;
     uint32_t *R[2] = {key0, val0};  // the sort's inputs are free again
     hipLaunchKernelGGL(k_fy_iota, dim3(fy_grid(ctx, N)), dim3(256), 0, s, R[0], N);

@@ -28,8 +28,7 @@ def build(force=False):
 def _build(force):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
     deps = srcs + [os.path.join(CSRC, 'slk_common.h'), os.path.join(CSRC, 'slk_kernels.h'), os.path.join(ROOT, 'include', 'spotlight_hip.h'),
-                   os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h'),
-                   os.path.join(HERE, 'rocprim', 'rocprim.hpp')]
+                   os.path.join(HERE, 'emu_runtime.cpp'), os.path.join(HERE, 'hip', 'hip_runtime.h')]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     objs, procs = [], []

@@ -124,6 +124,23 @@ unsigned long long shfl_exchange(unsigned long long v, int src, int width) {
     return w.slot[lw][my & 1][src];
 }
 
+unsigned long long ballot_exchange(bool pred) {
+    const unsigned lane = cur->linear & 63u;
+    WaveSync &w = blk().waves[cur->linear >> 6];
+    const int lw = 6, seg = 0;
+    const unsigned my = w.gen[lw][seg];
+    w.slot[lw][my & 1][lane] = pred ? 1ull : 0ull;
+    if (++w.arrived[lw][seg] == 64u) {
+        w.arrived[lw][seg] = 0;
+        ++w.gen[lw][seg];
+    } else {
+        while (w.gen[lw][seg] == my) yield_to_scheduler();
+    }
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64u; ++l) m |= (w.slot[lw][my & 1][l] & 1ull) << l;
+    return m;
+}
+
 static void init_block(Block &b, uint3_ idx, dim3 block, unsigned nthreads, size_t shmem, char *stacks, size_t stack_bytes) {
     b.idx = idx;
     b.fibers.resize(nthreads);

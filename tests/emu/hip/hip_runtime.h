@@ -78,6 +78,7 @@ void next_launch_resident();   // SLK_RESIDENT_GRID_LAUNCH(): the next plain lau
 bool take_resident_flag();
 void syncthreads();
 unsigned long long shfl_exchange(unsigned long long v, int src_lane_in_wave, int width);
+unsigned long long ballot_exchange(bool pred);
 }  // namespace emu
 
 #define threadIdx (::emu::cur->tid)
@@ -178,6 +179,10 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+// wave-wide vote: every lane of the wave must call it (as for the shuffles)
+static inline unsigned long long __ballot(int pred) { return emu::ballot_exchange(pred != 0); }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 template <class T>
 static inline T __ldg(const T *p) { return *p; }
