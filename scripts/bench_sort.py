@@ -19,6 +19,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default='')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--cases', default='', help='comma-separated case indices (default: all)')
+    ap.add_argument('--cfgs', default='1,0', help='sort_cfg values to time')
+    ap.add_argument('--xcds', default='1', help='sort_xcd values to time')
+    ap.add_argument('--debug-sweep', action='store_true', help='also time the measurement-only forms (sort_debug 1, 2, 3: wrong results)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     eng = _native.Engine(0)
@@ -35,10 +39,14 @@ def main():
         ('4096 pairs (single tile), 20 bits', 0, 4096, 20, 0),
     ]
     out = open(args.out, 'a') if args.out else None
-    for cfg in (1, 0):
+    if args.cases:
+        cases = [cases[int(i)] for i in args.cases.split(',')]
+    for cfg, dbg, xcd in [(int(c), 0, int(x)) for x in args.xcds.split(',') for c in args.cfgs.split(',')] + ([(1, 1, 1), (1, 2, 1), (1, 3, 1)] if args.debug_sweep else []):
         eng.set_option('sort_cfg', cfg)
+        eng.set_option('sort_xcd', xcd)
+        eng.set_option('sort_debug', dbg)
         for label, kind, n, bits, seg in cases:
-            if cfg == 0 and n < (1 << 20):
+            if (cfg == 0 or dbg) and n < (1 << 20):
                 continue
             kt = torch.int64 if kind == 2 else torch.int32
             vt = torch.int64 if kind == 1 else torch.int32
@@ -50,11 +58,12 @@ def main():
             passes = (bits + 7) // 8
             pair = keys.element_size() + vals.element_size()
             traffic = n * (passes * 2 * pair + keys.element_size())
-            rec = {'case': label, 'sort_cfg': cfg, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
+            rec = {'case': label, 'sort_cfg': cfg, 'sort_debug': dbg, 'sort_xcd': xcd, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
                    'gpairs_per_s': round(n / ms / 1e6, 3), 'tb_per_s_own_traffic': round(traffic / ms / 1e9, 3)}
             print(json.dumps(rec), flush=True)
             if out:
                 out.write(json.dumps(rec) + '\n')
+    eng.set_option('sort_debug', 0)
     eng.close()
 
 

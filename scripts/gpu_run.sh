@@ -36,7 +36,7 @@ for st in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
     sort)
       timeout 600 python -m pytest tests/test_gpu_sort.py -m gpu -q -x -p no:cacheprovider > $OUT/pytest_sort.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_sort.log; tail -6 $OUT/pytest_sort.log
-      timeout 300 python scripts/bench_sort.py --out $OUT/bench_sort.jsonl 2> $OUT/bench_sort.err | cut -c1-230; tail -3 $OUT/bench_sort.err ;;
+      timeout 300 python scripts/bench_sort.py ${SORT_ARGS:-} --out $OUT/bench_sort.jsonl 2> $OUT/bench_sort.err | cut -c1-230; tail -3 $OUT/bench_sort.err ;;
     bench)
       timeout 900 python bench.py "${args[@]}" > $OUT/bench_$sfx.json 2> $OUT/bench_$sfx.err; echo "bench ${args[*]:-} exit $?"; cut -c1-1500 $OUT/bench_$sfx.json; tail -3 $OUT/bench_$sfx.err ;;
     prof)
@@ -58,6 +58,14 @@ for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); print('%-34s %s  %s' % (d['label'], ['%.4f' % x for x in d.get('ms_per_step_all', [])], {k: round(v, 4) for k, v in d.get('class_ms_per_step', {}).items()}))"
       tail -3 $OUT/sweep_$sname.err ;;
+    trace)   # trace:<label>:<script>[:args]  -- rocprofv3 kernel trace of python scripts/<script>
+      label=${args[0]}; script=${args[1]}; rest=("${args[@]:2}")
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_$label -o t -- python $ROOT/scripts/$script "${rest[@]}" > $OUT/trace_$label.out 2> $OUT/trace_$label.err)
+      echo "trace $label exit $?"; python scripts/summarize_any.py $OUT/trace_$label > $OUT/trace_$label.md; rm -rf $OUT/trace_$label; head -30 $OUT/trace_$label.md | cut -c1-200 ;;
+    pmcx)    # pmcx:<label>:<counters, space separated>:<script>[:args]  -- one rocprofv3 --pmc pass of python scripts/<script>
+      label=${args[0]}; ctrs=${args[1]}; script=${args[2]}; rest=("${args[@]:3}")
+      (cd /tmp && timeout 900 rocprofv3 --pmc $ctrs -d $OUT/pmcx_$label -o t -- python $ROOT/scripts/$script "${rest[@]}" > $OUT/pmcx_$label.out 2> $OUT/pmcx_$label.err)
+      echo "pmcx $label exit $?"; python scripts/summarize_any.py $OUT/pmcx_$label > $OUT/pmcx_$label.md; rm -rf $OUT/pmcx_$label; head -40 $OUT/pmcx_$label.md | cut -c1-200 ;;
     py)
       script=${args[0]}; rest=("${args[@]:1}")
       timeout 900 python scripts/$script "${rest[@]}" > $OUT/py_$(basename $script .py)_$sfx.log 2>&1; echo "$script exit $?"; tail -25 $OUT/py_$(basename $script .py)_$sfx.log | cut -c1-300 ;;

@@ -5,7 +5,7 @@ import sys
 
 
 def short(n):
-    n = n.replace('void ', '')
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '')
     if 'radix_sort_onesweep_iteration' in n:
         return 'rocprim radix_sort onesweep_iteration <%s>' % (
             'u32,u64' if 'unsigned long const*, unsigned long*' in n else 'u32,u32')

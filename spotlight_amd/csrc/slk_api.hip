@@ -194,7 +194,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta};
+                       &ctx->ipart_meta, &ctx->upart_meta};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -239,6 +239,10 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_prep_priority = (int)value;
     } else if (!strcmp(name, "sort_cfg") && (value == 0 || value == 1)) {
         ctx->opt_sort_cfg = (int)value;
+    } else if (!strcmp(name, "sort_xcd") && (value == 0 || value == 1)) {
+        ctx->opt_sort_xcd = (int)value;
+    } else if (!strcmp(name, "sort_debug") && value >= 0 && value <= 3) {
+        ctx->opt_sort_debug = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
         ctx->opt_item_grid_mult = (int)value;
     } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {

@@ -1036,7 +1036,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
         if ((rc = slk_ensure(ctx, pb.lflags, 2 * (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk: items, users
     }
-    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_UPART_META, BL_LATE_SORT };  // ctx->extra slots
+    enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_LATE_SORT = 38 };  // ctx->extra slots (24, 25: slk_eval.hip; the user-partial metas, which keep launch stamps across calls, have a buffer of their own: ctx->upart_meta)
     const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * 4))) return rc;  // dL/dscore per (position, pair)
@@ -1060,9 +1060,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (!bloom) {
         if ((rc = slk_ensure(ctx, ctx->extra[BL_UPART], 2 * utiles * (size_t)UPS * 4))) return rc;
         const size_t meta_bytes = 2 * utiles * 8 + 64;
-        if (meta_bytes > ctx->extra[BL_UPART_META].cap) {
-            if ((rc = slk_ensure(ctx, ctx->extra[BL_UPART_META], meta_bytes))) return rc;
-            SLK_HIP(ctx, hipMemsetAsync(ctx->extra[BL_UPART_META].p, 0, ctx->extra[BL_UPART_META].cap, s));  // stamp 0 is never used
+        if (meta_bytes > ctx->upart_meta.cap) {
+            if ((rc = slk_ensure(ctx, ctx->upart_meta, meta_bytes))) return rc;
+            SLK_HIP(ctx, hipMemsetAsync(ctx->upart_meta.p, 0, ctx->upart_meta.cap, s));  // stamp 0 is never used
         }
     }
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
@@ -1388,12 +1388,12 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             const bool lat = upass_lat && (int64_t)bm <= ctx->opt_user_lat_max_batch;
             if (user_may_long) {
                 if (ctx->upart_gen >= 0x0ffffffeu) {  // the 28-bit stamp wraps: forget every old partial
-                    SLK_HIP(ctx, hipMemsetAsync(ctx->extra[BL_UPART_META].p, 0, ctx->extra[BL_UPART_META].cap, s));
+                    SLK_HIP(ctx, hipMemsetAsync(ctx->upart_meta.p, 0, ctx->upart_meta.cap, s));
                     ctx->upart_gen = 0u;
                 }
                 ++ctx->upart_gen;
                 a.upart = (float *)ctx->extra[BL_UPART].p;
-                a.upart_meta = (uint32_t *)ctx->extra[BL_UPART_META].p;
+                a.upart_meta = (uint32_t *)ctx->upart_meta.p;
                 a.upart_count = a.upart_meta + 4 * utiles;
                 a.upart_gen = ctx->upart_gen;
                 a.UPS = UPS;

@@ -88,7 +88,7 @@ struct slk_ctx {
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
-        sort_tmp, dgrad[4], ipart, ipart_meta;
+        sort_tmp, dgrad[4], ipart, ipart_meta, upart_meta;  // (the *_meta buffers keep launch stamps ACROSS calls: never shared)
     size_t dgrad_elems[4] = {0, 0, 0, 0};
     // tuning (slk_ctx_set_option)
     int64_t opt_chunk_interactions = (int64_t)1 << 23;  // interactions per prep chunk
@@ -111,6 +111,8 @@ struct slk_ctx {
     int opt_prep_priority = 0;
     int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
     int opt_sort_cfg = 1;          // radix sort: 1 = sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys, 0 = always 256 x 16
+    int opt_sort_xcd = 1;          // segmented sorts: 1 = a segment's tiles run on one XCD (slk_sort.hip), 0 = tiles in grid order
+    int opt_sort_debug = 0;        // measurement only: 1 the sort skips its look-back walks, 2 ranks from LDS atomics (results are wrong)
     int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged

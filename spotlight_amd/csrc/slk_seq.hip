@@ -22,7 +22,7 @@
 
 #include "slk_kernels.h"
 
-enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1, SQ_GSN = 23, SQ_MCOUNT_B = 30 };  // (24, 25: slk_bilinear.hip, whose slot 24 keeps stamps across calls)  // ctx->extra slots (0..10 belong to slk_shard.hip, 16 to slk_bilinear.hip)
+enum { SQ_MCOUNT = 12, SQ_REP, SQ_BIK0, SQ_BIK1, SQ_BIP0, SQ_BIP1, SQ_GSN = 23, SQ_MCOUNT_B = 30 };  // ctx->extra slots (24, 25: slk_eval.hip; 0..10 belong to slk_shard.hip, 16..23 and 38 to slk_bilinear.hip)
 
 struct slk_seq_args {
     const float *E;         // item_embeddings

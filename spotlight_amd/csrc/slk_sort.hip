@@ -29,7 +29,8 @@ constexpr int RS_RADIX = 1 << RS_RB;
 constexpr uint32_t RS_VAL_MASK = (1u << 30) - 1u;  // status word: flag << 30 | count (segments hold < 2^30 pairs)
 constexpr uint32_t RS_AGG = 1u, RS_INC = 2u;
 constexpr int RS_MAX_PASS = 8;
-constexpr int RS_HIST_KEYS = 16384;       // keys per histogram workgroup
+constexpr int RS_HIST_KEYS = 8192;        // keys per histogram workgroup
+constexpr int RS_LBW = 16;                // look-back: status words in flight per digit and round trip
 constexpr uint32_t RS_MAX_SPINS = 1u << 22;  // x (s_sleep + one fabric round trip): seconds; then the sort gives up (sticky flag)
 
 enum { RS_LOAD_PLAIN = 0, RS_LOAD_USER_FAT, RS_LOAD_USER_IDX, RS_LOAD_ITEM_OCC };
@@ -49,6 +50,9 @@ struct rs_args {
     uint32_t *ticket;        // [pass]
     uint32_t *status;        // this pass: [tile][1 << width]
     int32_t *abort_flag;     // sticky (slk_rng_dev::sort_abort): a look-back gave up
+    int xcd;                 // 1: a segment's tiles are taken by the workgroups of ONE XCD (segment s -> XCD s % 8)
+    uint32_t nseg;
+    int debug;               // measurement only (option "sort_debug"): 1 no look-back walk, 2 ranks from LDS atomics
 };
 
 template <class KeyT>
@@ -96,10 +100,20 @@ __global__ __launch_bounds__(256) void k_rs_hist(rs_args a) {
     const uint32_t b1 = (b0 >= s1 || s1 - b0 < (uint32_t)RS_HIST_KEYS) ? s1 : b0 + (uint32_t)RS_HIST_KEYS;  // (a short last segment)
     for (int i = threadIdx.x; i < a.npass * RS_RADIX; i += 256) sh[i] = 0u;
     __syncthreads();
-    for (uint32_t gi = b0 + threadIdx.x; gi < b1; gi += 256) {
-        const KeyT k = rs_load_key<KeyT, LOADER>(a, gi, seg);
-        for (int p = 0; p < a.npass; ++p)
-            atomicAdd(&sh[p * RS_RADIX + rs_digit<KeyT>(k, a.shift[p], (1u << a.width[p]) - 1u)], 1u);
+    // eight keys per thread in flight (the kernel is otherwise one dependent load -> LDS-atomics chain per key)
+    for (uint32_t g0 = b0 + threadIdx.x; g0 < b1; g0 += 8u * 256u) {
+        KeyT k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t gi = g0 + (uint32_t)u * 256u;
+            k[u] = gi < b1 ? rs_load_key<KeyT, LOADER>(a, gi, seg) : (KeyT)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (g0 + (uint32_t)u * 256u >= b1) continue;
+            for (int p = 0; p < a.npass; ++p)
+                atomicAdd(&sh[p * RS_RADIX + rs_digit<KeyT>(k[u], a.shift[p], (1u << a.width[p]) - 1u)], 1u);
+        }
     }
     __syncthreads();
     uint32_t *gh = a.hist + (size_t)seg * a.npass * RS_RADIX;
@@ -137,6 +151,15 @@ __global__ __launch_bounds__(256) void k_rs_scan(rs_args a) {
     a.base[o] = seg * a.seg_len + rs_block_excl_scan<256>(c, s_wsum);
 }
 
+// the XCD this workgroup runs on (0..7)
+__device__ __forceinline__ uint32_t rs_xcc_id() {
+#if defined(__HIPCC__)
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
+#else
+    return blockIdx.x & 7u;
+#endif
+}
+
 // lanes of the wave that hold the same digit as this one (valid lanes only)
 __device__ __forceinline__ unsigned long long rs_match(uint32_t d, int nbits, bool valid) {
     unsigned long long m = __ballot(valid);
@@ -164,10 +187,30 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int shift = a.shift[a.pass], nbits = a.width[a.pass];
     const uint32_t radix = 1u << nbits, dmask = radix - 1u;
-    if (!SINGLE && threadIdx.x == 0) s_tile = atomicAdd(a.ticket + a.pass, 1u);
+    if (!SINGLE && threadIdx.x == 0) {
+        if (a.xcd) {
+            // Segment s belongs to XCD s % 8: its tiles' runs meet in ONE L2 (adjacent tiles complete each other's partial lines
+            // before they are written back) and its look-back words never cross the fabric.  A workgroup whose XCD has run out
+            // of tiles takes one of the next XCD's (the grid has exactly one workgroup per tile, so every tile is taken); the
+            // order of the tickets of one XCD is still the order of the dependency chain of its segments.
+            const uint32_t x0 = rs_xcc_id();
+            uint32_t t = 0xffffffffu;
+            for (uint32_t i = 0; i < 8u && t == 0xffffffffu; ++i) {
+                const uint32_t x = (x0 + i) & 7u;
+                const uint32_t nsx = a.nseg > x ? (a.nseg - x + 7u) / 8u : 0u;
+                if (!nsx) continue;
+                const uint32_t k = atomicAdd(a.ticket + 8 + a.pass * 8 + x, 1u);
+                if (k < nsx * a.tps) t = (x + 8u * (k / a.tps)) * a.tps + k % a.tps;
+            }
+            s_tile = t;
+        } else {
+            s_tile = atomicAdd(a.ticket + a.pass, 1u);
+        }
+    }
     for (int i = threadIdx.x; i < WAVES * RS_RADIX; i += THREADS) s_cnt[i] = 0u;
     __syncthreads();
     const uint32_t tile = SINGLE ? 0u : s_tile;
+    if (tile == 0xffffffffu) return;  // (cannot happen: one workgroup per tile)
     const uint32_t seg = tile / a.tps, tis = tile - seg * a.tps;
     const uint32_t s0 = seg * a.seg_len;
     const uint32_t s1 = (a.n - s0 < a.seg_len) ? a.n : s0 + a.seg_len;
@@ -178,12 +221,79 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
     ValT val[KPT];
     uint32_t pos2[KPT / 2];  // tile positions (< 2^16), two per register
     const uint32_t e0 = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
+    // every key load first, then every payload load: the keys are waited for alone, the payloads land behind the ranking
+    if (LOADER == RS_LOAD_PLAIN) {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const uint32_t e = e0 + (uint32_t)j * 64u;
-        key[j] = 0;
-        val[j] = 0;
-        if (e < cnt) rs_load<KeyT, ValT, LOADER>(a, t0 + e, seg, key[j], val[j]);
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t e = e0 + (uint32_t)j * 64u;
+            key[j] = e < cnt ? ((const KeyT *)a.kin)[t0 + e] : (KeyT)0;
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t e = e0 + (uint32_t)j * 64u;
+            val[j] = e < cnt ? ((const ValT *)a.vin)[t0 + e] : (ValT)0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t e = e0 + (uint32_t)j * 64u;
+            key[j] = 0;
+            val[j] = 0;
+            if (e < cnt) rs_load<KeyT, ValT, LOADER>(a, t0 + e, seg, key[j], val[j]);
+        }
+    }
+    // the tile's digit counts, published BEFORE the ranking: the tiles behind this one add them up while it ranks
+    const uint32_t d = threadIdx.x;
+    uint32_t tcount = 0, before = 0;
+    if (!SINGLE) {
+        if (d < radix) s_lbase[d] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if (e0 + (uint32_t)j * 64u < cnt) atomicAdd(&s_lbase[rs_digit<KeyT>(key[j], shift, dmask)], 1u);
+        __syncthreads();
+        if (d < radix) {
+            tcount = s_lbase[d];
+            __hip_atomic_store(a.status + (size_t)tile * radix + d, ((tis == 0 ? RS_INC : RS_AGG) << 30) | tcount, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            // The digit owners (the first `radix` threads) walk back NOW, before they rank: the workgroup's other waves -- and the
+            // other workgroups of the CU -- rank meanwhile, so the walk's round trips are not idle time of the SIMDs.
+            if (tis != 0 && !(a.debug & 1)) {
+                // look-back: the counts of the segment's tiles before this one, RS_LBW status words per round trip, back to the
+                // nearest tile that knows its own inclusive count
+                const uint32_t *row0 = a.status + (size_t)(tile - tis) * radix + d;
+                int32_t t = (int32_t)tis - 1;
+                uint32_t spins = 0;
+                bool done = false;
+                while (!done) {
+                    uint32_t v[RS_LBW];
+#pragma unroll
+                    for (int i = 0; i < RS_LBW; ++i) {
+                        const int32_t ti = t - i;
+                        v[i] = ti >= 0 ? __hip_atomic_load(row0 + (size_t)ti * radix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    }
+                    int consumed = 0;
+#pragma unroll
+                    for (int i = 0; i < RS_LBW; ++i) {
+                        const uint32_t f = v[i] >> 30;
+                        if (done || f == 0u || consumed != i) continue;
+                        before += v[i] & RS_VAL_MASK;
+                        ++consumed;
+                        if (f == RS_INC) done = true;
+                    }
+                    t -= consumed;
+                    if (!done && consumed == 0) {
+                        if (++spins > RS_MAX_SPINS) {  // a tile before this one never published: give up, loudly
+                            *a.abort_flag = 1;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __hip_atomic_store(a.status + (size_t)tile * radix + d, (RS_INC << 30) | ((before + tcount) & RS_VAL_MASK),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     // ranks inside the wave's 64 * KPT elements, in element order (round j, then lane)
     uint32_t *wcnt = s_cnt + wave * RS_RADIX;
@@ -192,59 +302,35 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
         if ((j & 1) == 0) pos2[j / 2] = 0u;
         if ((uint32_t)wave * 64u * KPT + (uint32_t)j * 64u >= cnt) continue;  // (wave-uniform: a round past the tile's end)
         const bool valid = e0 + (uint32_t)j * 64u < cnt;
-        const uint32_t d = rs_digit<KeyT>(key[j], shift, dmask);
-        const unsigned long long m = rs_match(d, nbits, valid);
-        const int leader = m ? __ffsll((long long)m) - 1 : lane;
-        uint32_t first = 0;
-        if (m && lane == leader) first = atomicAdd(&wcnt[d], (uint32_t)__popcll(m));
-        first = __shfl(first, leader);
-        const uint32_t r = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t dj = rs_digit<KeyT>(key[j], shift, dmask);
+        uint32_t r;
+        if (a.debug & 2) {  // measurement only: ranks from LDS atomics (unstable order)
+            r = valid ? atomicAdd(&wcnt[dj], 1u) : 0u;
+        } else {
+            const unsigned long long m = rs_match(dj, nbits, valid);
+            const int leader = m ? __ffsll((long long)m) - 1 : lane;
+            uint32_t first = 0;
+            if (m && lane == leader) first = atomicAdd(&wcnt[dj], (uint32_t)__popcll(m));
+            first = __shfl(first, leader);
+            r = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
         pos2[j / 2] = (j & 1) ? (pos2[j / 2] | (r << 16)) : r;
     }
     __syncthreads();
-    // per digit: waves' counts -> the wave's first rank; the tile's count; the counts of the tiles before it
-    const uint32_t d = threadIdx.x;
-    uint32_t tcount = 0;
+    // per digit: waves' counts -> the wave's first rank in the tile's bucket
     if (d < radix) {
+        uint32_t run = 0;
         for (int w = 0; w < WAVES; ++w) {
             const uint32_t c = s_cnt[w * RS_RADIX + d];
-            s_cnt[w * RS_RADIX + d] = tcount;
-            tcount += c;
+            s_cnt[w * RS_RADIX + d] = run;
+            run += c;
         }
+        if (SINGLE) tcount = run;
     }
     const uint32_t lb = rs_block_excl_scan<THREADS>(tcount, s_wsum);
     if (d < radix) {
-        uint32_t before = 0, gbase = s0;
-        if (!SINGLE) {
-            gbase = a.base[((size_t)seg * a.npass + a.pass) * RS_RADIX + d];
-            uint32_t *st = a.status + (size_t)tile * radix + d;
-            if (tis == 0) {
-                __hip_atomic_store(st, (RS_INC << 30) | tcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(st, (RS_AGG << 30) | tcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t *q = st - radix;
-                uint32_t spins = 0;
-                for (;;) {
-                    const uint32_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t f = v >> 30;
-                    if (!f) {
-                        if (++spins > RS_MAX_SPINS) {  // a tile before this one never published: give up, loudly
-                            *a.abort_flag = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
-                    before += v & RS_VAL_MASK;
-                    if (f == RS_INC) break;
-                    q -= radix;
-                }
-                __hip_atomic_store(st, (RS_INC << 30) | ((before + tcount) & RS_VAL_MASK), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            gbase = lb;
-        }
+        uint32_t gbase = lb;
+        if (!SINGLE) gbase = a.base[((size_t)seg * a.npass + a.pass) * RS_RADIX + d];
         s_lbase[d] = lb;
         s_goff[d] = gbase + before - lb;
     }
@@ -316,7 +402,7 @@ static void rs_make_plan(rs_plan &pl, size_t n, size_t seg_len, unsigned bits, u
     rs_split_bits(bits, &pl.npass, pl.shift, pl.width);
     size_t o = (size_t)pl.nseg * pl.npass * RS_RADIX * 4;  // hist
     pl.off_ticket = o;
-    o += 64;
+    o += 512;  // [0, 8): one ticket per pass; [8 + 8 p, 16 + 8 p): pass p's tickets per XCD
     for (int p = 0; p < pl.npass; ++p) {
         pl.off_status[p] = o;
         o += (size_t)pl.ntiles * ((size_t)1 << pl.width[p]) * 4;
@@ -390,6 +476,9 @@ static int rs_sort(slk_ctx *ctx, slk_buf &scratch, rs_args a, size_t n, size_t s
     a.base = (uint32_t *)(base + pl.off_base);
     a.ticket = (uint32_t *)(base + pl.off_ticket);
     a.abort_flag = &ctx->d_rng->sort_abort;
+    a.debug = ctx->opt_sort_debug;
+    a.nseg = pl.nseg;
+    a.xcd = (ctx->opt_sort_xcd && pl.nseg >= 2) ? 1 : 0;
     void *kfinal = a.kout, *vfinal = a.vout;
     if (!single) {
         SLK_HIP(ctx, hipMemsetAsync(base, 0, pl.zero_bytes, s));
