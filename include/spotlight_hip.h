@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 6
+#define SLK_ABI_VERSION 7
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -308,6 +308,21 @@ int slk_rank_targets(slk_ctx *ctx, float *d_scores, int64_t n_rows, int64_t num_
                      const int64_t *d_exc_rows, const int64_t *d_exc_items, int64_t n_exc,
                      const int64_t *d_tgt_rows, const int64_t *d_tgt_items, int64_t n_tgt,
                      double *d_rank_out, void *stream);
+/* Fused ranking (ABI 7): the ranks WITHOUT a score matrix -- what mrr_score / sequence_mrr_score need of
+ * `predictions = -model.predict(u); predictions[train items] = FLOAT_MAX; rankdata(predictions)[test items]`
+ * (spotlight/evaluation.py:39-52, 88-106).  A GROUP is one user (slk_bilinear_rank: d_group_users[n_groups]) or one
+ * sequence (slk_poolnet_rank: d_group_sequences[n_groups][seq_len]); a ROW is one held-out item of a group: its group
+ * d_row_group[r] and the item d_row_target[r].  d_exc_off[n_groups + 1] / d_exc_items: per group the items pushed to the end
+ * of its ranking (CSR; every item at most once per group; NULL: none).  d_rank_out[r] = the 'average' rank of the row's
+ * target (1 = best).  The scores are the ones slk_bilinear_predict / slk_poolnet_predict return, bit for bit: the item
+ * table streams ONCE per 64 rows through the matrix cores (exact-fp32 MFMA) and every score is compared with its row's
+ * target score as it leaves the accumulators. */
+int slk_bilinear_rank(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_group_users, int64_t n_groups,
+                      const int64_t *d_row_group, const int64_t *d_row_target, int64_t n_rows,
+                      const int64_t *d_exc_off, const int64_t *d_exc_items, double *d_rank_out, void *stream);
+int slk_poolnet_rank(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_group_sequences, int64_t n_groups,
+                     int64_t seq_len, const int64_t *d_row_group, const int64_t *d_row_target, int64_t n_rows,
+                     const int64_t *d_exc_off, const int64_t *d_exc_items, double *d_rank_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row-sharded BilinearNet training (the reference has no multi-GPU code, the

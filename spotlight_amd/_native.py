@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 6
+SLK_ABI_VERSION = 7
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -86,6 +86,10 @@ _PROTOTYPES = {
     'slk_bilinear_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_poolnet_scores': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_void_p]),
+    'slk_bilinear_rank': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_poolnet_rank': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_rank_targets': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shard_buffer_floats': (C.c_int64, [C.c_int32, C.c_int64]),
@@ -312,6 +316,17 @@ class Engine(object):
     def poolnet_scores(self, tables, d_sequences, n_seq, seq_len, d_out, stream=0):
         self._check(self._lib.slk_poolnet_scores(self._ctx, C.byref(tables), d_sequences, int(n_seq), int(seq_len),
                                                  d_out, stream))
+
+    def bilinear_rank(self, tables, d_group_users, n_groups, d_row_group, d_row_target, n_rows, d_exc_off, d_exc_items,
+                      d_rank_out, stream=0):
+        self._check(self._lib.slk_bilinear_rank(self._ctx, C.byref(tables), d_group_users, int(n_groups), d_row_group,
+                                                d_row_target, int(n_rows), d_exc_off, d_exc_items, d_rank_out, stream))
+
+    def poolnet_rank(self, tables, d_group_sequences, n_groups, seq_len, d_row_group, d_row_target, n_rows, d_exc_off,
+                     d_exc_items, d_rank_out, stream=0):
+        self._check(self._lib.slk_poolnet_rank(self._ctx, C.byref(tables), d_group_sequences, int(n_groups), int(seq_len),
+                                               d_row_group, d_row_target, int(n_rows), d_exc_off, d_exc_items, d_rank_out,
+                                               stream))
 
     def rank_targets(self, d_scores, n_rows, num_items, d_exc_rows, d_exc_items, n_exc, d_tgt_rows, d_tgt_items,
                      n_tgt, d_rank_out, stream=0):

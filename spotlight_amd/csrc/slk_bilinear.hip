@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_predict(const float *U, const float *V,
         const int64_t i = items ? items[k] : k;
         const slk_vec<VEC> a = slk_emb_vec<VEC>(U, ub, (uint32_t)u, D, d0, on);
         const slk_vec<VEC> b = slk_emb_vec<VEC>(V, ib, (uint32_t)i, D, d0, on);
-        const float s = slk_group_sum<G>(slk_vdot<VEC>(a, b)) + bu[u] + bi[i];
+        const float s = (slk_chain_dot<VEC, G>(a, b) + bu[u]) + bi[i];  // the score's definition: slk_kernels.h, slk_eval.hip
         if (lane == 0) out[k] = s;
     }
 }
@@ -863,6 +863,18 @@ SLK_EXPORT int slk_bilinear_predict(slk_ctx *ctx, const slk_tables *tables, cons
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
     slk_prof_begin(ctx, SLK_K_SCORE, s);
+    if (n_users == 1 && !d_items) {
+        // one user against EVERY item: the item table streams through the matrix cores (slk_eval.hip), same scores bit for bit
+        if (n != tables->num_items)
+            return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_predict: d_items == NULL scores all %lld items, n is %lld",
+                            (long long)tables->num_items, (long long)n);
+        const float *rep, *rbias;
+        const int64_t *gmap;
+        if ((rc = slk_eval_user_rep(ctx, tables, vec, g, d_users, &rep, &rbias, &gmap, s))) return rc;
+        rc = slk_eval_predict_all(ctx, tables, rep, rbias, gmap, d_out, s);
+        slk_prof_end(ctx, s);
+        return rc;
+    }
 #define SLK_PREDICT(V_, G_)                                                                          \
     hipLaunchKernelGGL((k_predict<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, \
                        (const float *)tables->d_param[0], (const float *)tables->d_param[1],          \

@@ -112,8 +112,13 @@ struct slk_ctx {
     int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
     int opt_sort_cfg = 1;          // radix sort: 1 = sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys, 0 = always 256 x 16
     int opt_sort_xcd = 1;          // segmented sorts: 1 = a segment's tiles run on one XCD (slk_sort.hip), 0 = tiles in grid order
+    int opt_eval_wg_per_cu = 2;    // the scoring sweep's resident workgroups per CU (by LDS footprint; 0: what its registers allow, 3).
+                                   // Measured, 4096 x 10^6 scores: 2 -> 7.06 ms, 3 -> 8.31 ms (profiles/r04_h_*): the third workgroup's blocks
+                                   // push the other two's out of the L2
     int opt_sort_debug = 0;        // measurement only: 1 the sort skips its look-back walks, 2 ranks from LDS atomics (results are wrong)
-    int opt_item_grid_mult = 64;   // item pass: at most this many workgroups per CU
+    int opt_item_grid_mult = 128;  // item pass: at most this many workgroups per CU (128 = one tile per workgroup at the C2 size, the
+                                   // hardware balances the tail: item pass -2 % at C2 and the C5 shard, neutral at C3 / C4 / 65 536:
+                                   // profiles/r04_g_*, r04_h_*)
     int opt_user_grid_mult = 8;    // user pass / other row passes
     int opt_seq_variant = 1;       // PoolNet: 1 = register-resident sequence pass when it fits, 0 = LDS-staged
     // adaptive hinge, plain item table: smallest minibatch whose item side is re-sorted per minibatch after the selection
@@ -260,6 +265,12 @@ int slk_sort_user_idx(slk_ctx *ctx, const int64_t *users, size_t nc, size_t bsz,
                       uint32_t *const key[2], uint32_t *const val[2], hipStream_t s);
 int slk_sort_item_occ(slk_ctx *ctx, const uint32_t *uit, size_t nocc, size_t bsz, int NP, unsigned ibits, unsigned mbbits,
                       uint32_t *const key[2], uint32_t *const val[2], hipStream_t s);
+
+// slk_eval.hip: one representation against every item through the GEMM sweep (predict with d_items == NULL)
+int slk_eval_predict_all(slk_ctx *ctx, const slk_tables *tables, const float *rep, const float *rbias, const int64_t *gmap,
+                         float *d_out, hipStream_t s);
+int slk_eval_user_rep(slk_ctx *ctx, const slk_tables *tables, int vec, int g, const int64_t *d_user, const float **rep,
+                      const float **rbias, const int64_t **gmap, hipStream_t s);
 
 // shared host helpers (slk_bilinear.hip)
 int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g);

@@ -62,6 +62,27 @@ __device__ __forceinline__ slk_vec<VEC> slk_emb_vec(const float *T, const slk_bl
     return v;
 }
 
+// THE score's dot product (predict / ranking; slk_eval.hip): the d-ordered chain acc = fmaf(a_d, b_d, acc) from acc = 0, which
+// is bit for bit what v_mfma_f32_32x32x2_f32 computes when the scores are formed as a GEMM on the matrix cores.  Here on
+// the vector unit for one (row, item) pair held by a row group: lane s continues the chain of lane s - 1 over its own VEC
+// elements (G dependent steps: this form serves explicit pairs, whose cost is the row gathers).  Every lane gets the result.
+template <int VEC, int G>
+__device__ __forceinline__ float slk_chain_dot(const slk_vec<VEC> &a, const slk_vec<VEC> &b) {
+    const int lane = threadIdx.x % G;
+    float acc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+        const float in = __shfl(acc, s > 0 ? s - 1 : 0, G);
+        if (lane == s) {
+            float c = s > 0 ? in : 0.0f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) c = fmaf(a.v[i], b.v[i], c);
+            acc = c;
+        }
+    }
+    return __shfl(acc, G - 1, G);
+}
+
 static inline void slk_bloom_to_dev(const slk_bloom *b, slk_bloom_dev *out) {
     memset(out, 0, sizeof(*out));
     out->pad_id = 0xffffffffu;

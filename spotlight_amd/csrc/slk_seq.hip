@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_seq_predict(const float *rep, const flo
     for (int64_t k = (int64_t)blockIdx.x * GPB + grp; k < n; k += (int64_t)gridDim.x * GPB) {
         const int64_t i = items ? items[k] : k;
         const slk_vec<VEC> b = slk_emb_vec<VEC>(V, ib, (uint32_t)i, D, d0, on);
-        const float s = bi[i] + slk_group_sum<G>(slk_vdot<VEC>(r, b));
+        const float s = bi[i] + slk_chain_dot<VEC, G>(r, b);  // the score's definition: slk_kernels.h, slk_eval.hip
         if (lane == 0) out[k] = s;
     }
 }
@@ -940,6 +940,21 @@ SLK_EXPORT int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const
                            (const float *)rep, (const float *)tables->d_param[1],                                \
                            (const float *)tables->d_param[3], ibd, (int)tables->dim, d_items, n, d_out);         \
     } while (0)
+    if (!d_items) {
+        // every item: the representation, then the item table through the matrix cores (slk_eval.hip)
+        if (n != tables->num_items)
+            return slk_fail(ctx, SLK_EINVAL, "slk_poolnet_predict: d_items == NULL scores all %lld items, n is %lld",
+                            (long long)tables->num_items, (long long)n);
+#define SLK_SEQ_REP(V_, G_)                                                                                      \
+        hipLaunchKernelGGL((k_seq_final_repr<V_, G_>), dim3(1), dim3(64), 0, s, (const float *)tables->d_param[1], \
+                           ibd, (int)tables->dim, d_sequence, (int)seq_len, rep)
+        SLK_FOR_LAYOUT(vec, g, SLK_SEQ_REP);
+#undef SLK_SEQ_REP
+        SLK_LAUNCH_CHECK(ctx, "k_seq_final_repr");
+        rc = slk_eval_predict_all(ctx, tables, rep, nullptr, nullptr, d_out, s);
+        slk_prof_end(ctx, s);
+        return rc;
+    }
     SLK_FOR_LAYOUT(vec, g, SLK_SEQ_PREDICT);
 #undef SLK_SEQ_PREDICT
     SLK_LAUNCH_CHECK(ctx, "k_seq_predict");

@@ -2,9 +2,11 @@
 semantics of spotlight/evaluation.py:9-244.
 
 mrr_score and sequence_mrr_score have a fast path for this package's models: instead of one
-predict() (a full pass over the item table) and one host scipy.stats.rankdata per user, users are
-scored a tile at a time on the GPU and the rank of every held-out item is counted there
-(csrc/slk_eval.hip: slk_bilinear_scores / slk_poolnet_scores / slk_rank_targets).  Any other model
+predict() (a full pass over the item table) and one host scipy.stats.rankdata per user, the item
+table streams through the matrix cores once per 64 held-out items (exact-fp32 MFMA: the same
+scores as predict(), bit for bit) and every score is compared with its row's target score as it is
+formed -- no score matrix (csrc/slk_eval.hip: slk_bilinear_rank / slk_poolnet_rank; models without
+that route are scored a tile of rows at a time: slk_*_scores + slk_rank_targets).  Any other model
 object (anything with the reference's predict()) takes the generic per-user route, which is also
 what the tests compare the fast path with.
 """
@@ -28,6 +30,22 @@ def _device_ranks(model, keys, num_items, exclude, targets):
             x = np.asarray(x)
             if x.size and (x.min() < 0 or x.max() >= num_items):  # numpy's error on predictions[indices]
                 raise IndexError('index {} is out of bounds for axis 0 with size {}'.format(int(x.max()), num_items))
+    fused = getattr(model, '_fused_ranks', None)
+    if fused is not None:
+        # one ROW per held-out item; per group the DISTINCT excluded items (predictions[ids] = FLOAT_MAX is idempotent)
+        tl = [np.asarray(x).reshape(-1).astype(np.int64) for x in targets]
+        el = [np.unique(np.asarray(x).reshape(-1).astype(np.int64)) for x in exclude]
+        row_group = np.repeat(np.arange(len(keys), dtype=np.int64), [len(x) for x in tl])
+        row_target = np.concatenate(tl) if tl else np.zeros(0, np.int64)
+        if any(len(x) for x in el):
+            exc_off = np.concatenate([[0], np.cumsum([len(x) for x in el])]).astype(np.int64)
+            exc_items = np.concatenate(el)
+        else:
+            exc_off = exc_items = None
+        ranks = fused(keys, row_group, row_target, exc_off, exc_items) if len(row_group) else np.zeros(0)
+        if ranks is not None:
+            bounds = np.concatenate([[0], np.cumsum([len(x) for x in tl])])
+            return [ranks[bounds[k]:bounds[k + 1]] for k in range(len(keys))]
     out = []
     for lo in range(0, len(keys), per_tile):
         hi = min(lo + per_tile, len(keys))
@@ -50,7 +68,7 @@ def _device_ranks(model, keys, num_items, exclude, targets):
 
 
 def _has_fast_path(model):
-    return getattr(model, '_batch_scores', None) is not None
+    return getattr(model, '_batch_scores', None) is not None or getattr(model, '_fused_ranks', None) is not None
 
 
 def mrr_score(model, test, train=None):

@@ -173,3 +173,4 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
     # evaluation.mrr_score's device fast path ranks raw scores; predicted ratings (exp / sigmoid of them)
     # take the generic predict() route, as in the reference (evaluation.py:9-56)
     _batch_scores = None
+    _fused_ranks = None

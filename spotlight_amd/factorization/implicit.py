@@ -296,6 +296,7 @@ class ImplicitFactorizationModel(object):
                               sparse=self._sparse)
         if not isinstance(net, BilinearNet):
             self._autograd_route = True  # an arbitrary module: the reference's loop through autograd (see the class docstring)
+            self._fused_ranks = None
             self._batch_scores = None    # (evaluation's whole-table fast path needs BilinearNet's tables; predict() serves it)
         else:
             for layer in (net.user_embeddings, net.item_embeddings):
@@ -540,6 +541,22 @@ class ImplicitFactorizationModel(object):
                                 d_items.data_ptr() if d_items is not None else None, n,
                                 out.data_ptr(), _stream_for(device))
         return out.cpu().numpy().flatten()
+
+    def _fused_ranks(self, user_ids, row_group, row_target, exc_off, exc_items):
+        """Average ranks of the rows' target items (evaluation.mrr_score's fast path): one counting sweep of the item table
+        per 64 rows on the matrix cores, no score matrix (csrc/slk_eval.hip, slk_bilinear_rank)."""
+        users = np.ascontiguousarray(np.asarray(user_ids).reshape(-1), dtype=np.int64)
+        self._check_input(users, None, allow_items_none=True)
+        self._net.train(False)
+        device = self._net.tables()[0].device
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int64))).to(device)
+        d_users, d_rg, d_rt = dev(users), dev(row_group), dev(row_target)
+        d_eo, d_ei = (dev(exc_off), dev(exc_items)) if exc_off is not None else (None, None)
+        ranks = torch.empty(len(row_group), dtype=torch.float64, device=device)
+        _engine_for(device).bilinear_rank(self._slk_tables(), d_users.data_ptr(), users.size, d_rg.data_ptr(), d_rt.data_ptr(),
+                                          len(row_group), d_eo.data_ptr() if d_eo is not None else None,
+                                          d_ei.data_ptr() if d_ei is not None else None, ranks.data_ptr(), _stream_for(device))
+        return ranks.cpu().numpy()
 
     def _batch_scores(self, user_ids):
         """[len(user_ids), num_items] device tensor: row r == predict(user_ids[r]) (bit-identical), a

@@ -153,6 +153,10 @@ class ShardedBilinearTrainer(object):
         self.last_exchange_rows = 2 * n - sc_peer[self.rank]  # lookups that crossed xGMI
         self.exchange_rows += self.last_exchange_rows
         loss_out = torch.zeros(m_n, dtype=torch.float32, device=self.device)
+        # world 1: every lookup's owner is this rank, so an all_to_all_single would be a device-local copy of the whole buffer
+        # (rcclGenericKernel: 2 x 0.43 ms per C2 minibatch, profiles/r02_o_*): the requester side reads the owner side's
+        # buffers in place.  (At world > 1 the collective moves the local segment itself.)
+        alias = w == 1
         for m in range(m_n):
             units = range(m * s_n, (m + 1) * s_n)
             # owners: the rows of every slice's requests; rows travel back (async)
@@ -160,6 +164,10 @@ class ShardedBilinearTrainer(object):
             for k, t in enumerate(units):
                 rows_send = self._buf('rows_send%d' % k, n_recv[t], torch.float32)
                 eng.shard_gather(self._tables, t, rows_send.data_ptr(), stream=st)
+                if alias:
+                    rows_recv.append(rows_send)
+                    h_rows.append(None)
+                    continue
                 rr = self._buf('rows_recv%d' % k, n_send[t], torch.float32)
                 rows_recv.append(rr)
                 h_rows.append(dist.all_to_all_single(rr, rows_send, sc_unit[t], rc_unit[t], group=self.group,
@@ -169,13 +177,15 @@ class ShardedBilinearTrainer(object):
             grad_recv = self._buf('grad_recv', sum(n_recv[t] for t in units), torch.float32)
             h_grad, off = [], 0
             for k, t in enumerate(units):
-                h_rows[k].wait()
-                grad_send = self._buf('grad_send%d' % k, n_send[t], torch.float32)
+                if h_rows[k] is not None:
+                    h_rows[k].wait()
+                grad_send = grad_recv[off:off + n_recv[t]] if alias else self._buf('grad_send%d' % k, n_send[t], torch.float32)
                 eng.shard_user_pass(self._tables, self.optim, self._shard, t, global_batches[m], loss,
                                     rows_recv[k].data_ptr(), grad_send.data_ptr(), loss_out[m:].data_ptr(),
                                     accumulate=k > 0, stream=st)
-                h_grad.append(dist.all_to_all_single(grad_recv[off:off + n_recv[t]], grad_send, rc_unit[t],
-                                                     sc_unit[t], group=self.group, async_op=True))
+                if not alias:
+                    h_grad.append(dist.all_to_all_single(grad_recv[off:off + n_recv[t]], grad_send, rc_unit[t],
+                                                         sc_unit[t], group=self.group, async_op=True))
                 off += n_recv[t]
             for h in h_grad:
                 h.wait()
@@ -244,6 +254,7 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
     # evaluation.mrr_score's one-device fast path scores against whole tables; this model's are local shards
     # indexed by local rows, so ranking goes through predict() (rows assembled from their owners)
     _batch_scores = None
+    _fused_ranks = None
 
     def __init__(self, *args, **kwargs):
         self._group = kwargs.pop('group', None)

@@ -301,6 +301,7 @@ class ImplicitSequenceModel(object):
 
         sequences = np.atleast_2d(sequences)
 
+        all_items = item_ids is None
         if item_ids is None:
             item_ids = np.arange(self._num_items).reshape(-1, 1)
 
@@ -316,11 +317,32 @@ class ImplicitSequenceModel(object):
         device = self._net.tables()[0].device
         engine = _host._engine_for(device)
         d_seq = torch.from_numpy(seq).to(device)
-        d_items = torch.from_numpy(items).to(device)
+        d_items = None if all_items else torch.from_numpy(items).to(device)  # None: every item, in id order
         out = torch.empty(items.size, dtype=torch.float32, device=device)
-        engine.poolnet_predict(self._slk_tables(), d_seq.data_ptr(), seq.size, d_items.data_ptr(), items.size,
-                               out.data_ptr(), _host._stream_for(device))
+        engine.poolnet_predict(self._slk_tables(), d_seq.data_ptr(), seq.size, d_items.data_ptr() if d_items is not None else None,
+                               items.size, out.data_ptr(), _host._stream_for(device))
         return out.cpu().numpy().flatten()
+
+    def _fused_ranks(self, sequences, row_group, row_target, exc_off, exc_items):
+        """Average ranks of the rows' target items (evaluation.sequence_mrr_score's fast path): one counting sweep of the item
+        table per 64 rows on the matrix cores, no score matrix (csrc/slk_eval.hip, slk_poolnet_rank).  None when the
+        representation is not this package's PoolNet (the caller then ranks predict()'s rows)."""
+        if not isinstance(self._net, PoolNet):
+            return None
+        self._net.train(False)
+        sequences = np.atleast_2d(sequences)
+        self._check_input(sequences)
+        device = self._net.tables()[0].device
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(np.int64))).to(device)
+        d_seqs, d_rg, d_rt = dev(sequences), dev(row_group), dev(row_target)
+        d_eo, d_ei = (dev(exc_off), dev(exc_items)) if exc_off is not None else (None, None)
+        ranks = torch.empty(len(row_group), dtype=torch.float64, device=device)
+        _host._engine_for(device).poolnet_rank(self._slk_tables(), d_seqs.data_ptr(), sequences.shape[0], sequences.shape[1],
+                                               d_rg.data_ptr(), d_rt.data_ptr(), len(row_group),
+                                               d_eo.data_ptr() if d_eo is not None else None,
+                                               d_ei.data_ptr() if d_ei is not None else None, ranks.data_ptr(),
+                                               _host._stream_for(device))
+        return ranks.cpu().numpy()
 
     def _batch_scores(self, sequences):
         """[n_sequences, num_items] device tensor: row r == predict(sequences[r]) (bit-identical), a tile

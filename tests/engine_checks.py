@@ -1466,3 +1466,83 @@ def check_epoch_kernel_is_bit_identical(be, loss, opt, D, U=300, I=170, N=2500, 
         assert np.array_equal(a, b), ('tensor %d differs between the persistent kernel and the launch path' % k,
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
 
+
+
+def f32_chain_dot(a, b):
+    """The package's score dot product in numpy: acc = fmaf(a_d, b_d, acc) over d ascending, in float32 (an fma = the
+    exactly rounded float64 product-sum of float32 operands: 24 + 24-bit products and a 24-bit addend fit a double)."""
+    acc = np.zeros(np.broadcast(a[..., 0], b[..., 0]).shape, np.float32)
+    for d in range(a.shape[-1]):
+        acc = (a[..., d].astype(np.float64) * b[..., d].astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+    return acc
+
+
+def check_scores_are_the_fma_chain(be, D, U=70, I=700, seed=3):
+    """predict(user) over EVERY item (the matrix-core sweep, csrc/slk_eval.hip), predict over explicit pairs (the vector-unit
+    chain) and the numpy chain give the same bits; the batched score rows too."""
+    rng = np.random.RandomState(seed)
+    params = [rng.randn(U, D).astype(np.float32), rng.randn(I, D).astype(np.float32), rng.randn(U).astype(np.float32),
+              rng.randn(I).astype(np.float32)]
+    dev = be.model(params)
+    eng = be.engine
+    users = np.array([0, U - 1, U // 2], dtype=np.int64)
+    want = {int(u): ((f32_chain_dot(params[0][u][None, :], params[1]) + params[2][u]) + params[3]).astype(np.float32) for u in users}
+    for u in users:
+        out = be.alloc(np.empty(I, dtype=np.float32))
+        d_u = be.alloc(np.array([u], dtype=np.int64))
+        eng.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, I, be.ptr(out), be.stream)
+        got_all = be.get(out).copy()
+        d_pu, d_pi = be.alloc(np.full(I, u, dtype=np.int64)), be.alloc(np.arange(I, dtype=np.int64))
+        eng.bilinear_predict(dev.tables, be.ptr(d_pu), I, be.ptr(d_pi), I, be.ptr(out), be.stream)
+        got_pairs = be.get(out).copy()
+        assert np.array_equal(got_all, got_pairs), (D, int(u), np.abs(got_all - got_pairs).max())
+        assert np.array_equal(got_all, want[int(u)]), (D, int(u), np.abs(got_all - want[int(u)]).max())
+    rows = be.alloc(np.empty((len(users), I), dtype=np.float32))
+    d_users = be.alloc(users)
+    eng.bilinear_scores(dev.tables, be.ptr(d_users), len(users), be.ptr(rows), be.stream)
+    for r, u in enumerate(users):
+        assert np.array_equal(be.get(rows)[r], want[int(u)])
+
+
+def check_fused_ranks(be, D=24, U=90, I=333, n_rows=150, seed=5, ties=True):
+    """slk_bilinear_rank against scipy-style average ranks of the chain scores: targets on and off their group's exclusion
+    list, exact ties (duplicated item rows), groups without exclusions, several rows per group."""
+    rng = np.random.RandomState(seed)
+    V = rng.randn(I, D).astype(np.float32)
+    bi = rng.randn(I).astype(np.float32)
+    if ties:
+        V[5] = V[6] = V[7]
+        bi[5] = bi[6] = bi[7]
+    params = [rng.randn(U, D).astype(np.float32), V, rng.randn(U).astype(np.float32), bi]
+    dev = be.model(params)
+    groups = rng.choice(U, size=40, replace=False).astype(np.int64)
+    row_group = np.sort(rng.randint(0, len(groups), n_rows)).astype(np.int64)
+    row_target = rng.randint(0, I, n_rows).astype(np.int64)
+    row_target[:6] = [5, 6, 7, 5, 6, 7]
+    exc = [np.unique(rng.randint(0, I, rng.randint(0, 30))) if g % 3 else np.zeros(0, np.int64) for g in range(len(groups))]
+    for r in range(0, n_rows, 7):  # some targets are excluded themselves
+        g = row_group[r]
+        if len(exc[g]):
+            exc[g] = np.unique(np.append(exc[g], row_target[r]))
+    exc_off = np.concatenate([[0], np.cumsum([len(x) for x in exc])]).astype(np.int64)
+    exc_items = np.concatenate(exc).astype(np.int64)
+    ranks = be.alloc(np.zeros(n_rows, dtype=np.float64))
+    d_g, d_rg, d_rt, d_eo, d_ei = be.alloc(groups), be.alloc(row_group), be.alloc(row_target), be.alloc(exc_off), be.alloc(exc_items)
+    be.engine.bilinear_rank(dev.tables, be.ptr(d_g), len(groups), be.ptr(d_rg), be.ptr(d_rt), n_rows, be.ptr(d_eo), be.ptr(d_ei),
+                            be.ptr(ranks), be.stream)
+    got = be.get(ranks)
+    for r in range(n_rows):
+        u = groups[row_group[r]]
+        s = ((f32_chain_dot(params[0][u][None, :], V) + params[2][u]) + bi).astype(np.float32)
+        s[exc[row_group[r]]] = -np.finfo(np.float32).max
+        t = s[row_target[r]]
+        want = float((s > t).sum()) + (float((s == t).sum()) + 1.0) * 0.5
+        assert got[r] == want, (r, got[r], want)
+    # no exclusion lists at all
+    be.engine.bilinear_rank(dev.tables, be.ptr(d_g), len(groups), be.ptr(d_rg), be.ptr(d_rt), n_rows, None, None, be.ptr(ranks), be.stream)
+    got = be.get(ranks)
+    for r in range(0, n_rows, 5):
+        u = groups[row_group[r]]
+        s = ((f32_chain_dot(params[0][u][None, :], V) + params[2][u]) + bi).astype(np.float32)
+        t = s[row_target[r]]
+        assert got[r] == float((s > t).sum()) + (float((s == t).sum()) + 1.0) * 0.5

@@ -276,3 +276,13 @@ def test_user_long_gate_is_bit_neutral(be, D, U, I, N, B, opt):
     """the plain user pass for minibatches without a long user run (k_user_long_flags) against the partial-writing form +
     k_user_stitch for every minibatch: same bits (short runs are walked identically; long ones take the long form either way)"""
     ec.check_item_long_gate_is_bit_neutral(be, 'bpr', opt, D, U, I, N, B)
+
+
+@pytest.mark.parametrize('D', [4, 16, 31, 64, 100, 128, 256])
+def test_scores_are_the_fma_chain(be, D):
+    ec.check_scores_are_the_fma_chain(be, D)
+
+
+def test_fused_ranks(be):
+    ec.check_fused_ranks(be)
+    ec.check_fused_ranks(be, D=64, U=200, I=1500, n_rows=300, seed=9)

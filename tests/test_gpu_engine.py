@@ -396,3 +396,13 @@ def test_hot_users_closed_loop(be, loss, opt):
 @pytest.mark.parametrize('D,U,I,N,B,opt', [(64, 3, 50000, 200000, 65536, 'adagrad'), (32, 40, 500, 100000, 30000, 'sparse_adam')])
 def test_user_long_gate_is_bit_neutral(be, D, U, I, N, B, opt):
     ec.check_item_long_gate_is_bit_neutral(be, 'bpr', opt, D, U, I, N, B)
+
+
+@pytest.mark.parametrize('D', [4, 16, 31, 64, 100, 128, 256])
+def test_scores_are_the_fma_chain(be, D):
+    ec.check_scores_are_the_fma_chain(be, D)
+
+
+def test_fused_ranks(be):
+    ec.check_fused_ranks(be)
+    ec.check_fused_ranks(be, D=64, U=200, I=1500, n_rows=300, seed=9)
