@@ -120,22 +120,18 @@ int slk_ctx_create(slk_ctx **out, int device_id);
 void slk_ctx_destroy(slk_ctx *ctx);
 const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create error */
 
-/* Tuning knobs (none changes results):
+/* Tuning knobs (none changes results).  Round 4 removed the ones whose A/Bs lost everywhere in round 3 ("first_chunk",
+ * "chunk_ramp", "prep_cus", "prep_priority", "epoch_seq" with its PoolNet persistent kernel): the numbers are in
+ * profiles/r03_a_*, r03_c_*, r03_w_*, r03_x_*.
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
  *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while chunk c trains (what this
  *                         package's fit() sets for its epochs: +1.5..4 % in the steady state of a run of training calls);
  *                         2: only the negatives; 0 (default of a bare ctx): everything in order on the caller's stream
- *   "first_chunk"         with overlap_prep: minibatches in the first chunk of a call (its prep is the one nothing hides); 0 = a
- *                         full chunk
  *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
- *   "chunk_ramp"          1: with overlap_prep the first chunks of a call ramp up from ~2^20 interactions (default 0:
- *                         measured slower at every call length, profiles/r03_c_*)
- *   "item_grid_mult"      item pass: workgroups per CU (default 64)
+ *   "item_grid_mult"      item pass: workgroups per CU (default 128)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
  *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
- *   "epoch_seq", "epoch_seq_max_timesteps"  slk_poolnet_train on a persistent kernel of its own (k_poolnet_epoch; default 0:
- *                         bit-identical to the launches but measured slower, profiles/r03_x_*)
  *   "epoch_adaptive"      1 (default): adaptive hinge takes the persistent kernel too (score phase + in-phase selection),
  *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 1024)
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
@@ -148,9 +144,10 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         head's row + state with the record gather (k_item_pass<..., NPRE 4>: -10..-19 % on minibatches of
  *                         4096-65 536, profiles/r03_y_*); 0: never
  *   "user_lat_max_batch"  minibatches up to this size (default 2^14) take the latency-bound form of the pair-mode user pass
- *   "prep_cus", "prep_priority"  with overlap_prep: CU-mask partition of the chip between the prep stream and the passes /
- *                         a high-priority prep stream (measured, profiles/r03_a_*: the masks slow the passes by more than
- *                         the prep they hide; defaults 0)
+ *   "sort_cfg"            radix sort (csrc/slk_sort.hip): 1 (default) sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys,
+ *                         0 always 256 x 16;  "sort_xcd": 1 (default) a segment's tiles run on one XCD
+ *   "eval_wg_per_cu"      resident workgroups per CU of the scoring sweep (csrc/slk_eval.hip; default 2, 0 = what its registers
+ *                         allow)
  *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */

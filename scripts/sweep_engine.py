@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from spotlight_amd import _native  # noqa: E402
 
-DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 0, 'first_chunk': 0, 'chunk_ramp': 0, 'overlap_min_batch': 1 << 16, 'item_grid_mult': 128,
-            'user_grid_mult': 8, 'prep_cus': 0, 'prep_priority': 0, 'nt': 3, 'user_lat_max_batch': 1 << 14, 'item_long_gate': 1, 'item_lat_max_tiles': 2048, 'sort_cfg': 1}
+DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 0, 'overlap_min_batch': 1 << 16, 'item_grid_mult': 128,
+            'user_grid_mult': 8, 'nt': 3, 'user_lat_max_batch': 1 << 14, 'item_long_gate': 1, 'item_lat_max_tiles': 2048, 'sort_cfg': 1}
 
 
 def main():

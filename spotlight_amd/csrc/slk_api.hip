@@ -90,53 +90,17 @@ int slk_prof_drain(slk_ctx *ctx) {
     return SLK_OK;
 }
 
-// A CU mask with `n` of the device's CUs (take = true) or all the others (take = false).  The mask's bits are dealt to the
-// XCDs first and to the shader engines next (bit b -> XCD b mod 8), so the lowest n bits are n CUs spread evenly over the chip.
-static void slk_cu_mask(const slk_ctx *ctx, int n, bool take, uint32_t *words, uint32_t nwords) {
-    for (uint32_t w = 0; w < nwords; ++w) words[w] = 0u;
-    for (int b = 0; b < ctx->num_cus && b < (int)nwords * 32; ++b)
-        if ((b < n) == take) words[b >> 5] |= 1u << (b & 31);
-}
-
 int slk_prep_stream_init(slk_ctx *ctx) {
-    if (ctx->prep_stream && ctx->prep_stream_cus == ctx->opt_prep_cus && ctx->prep_stream_prio == ctx->opt_prep_priority)
-        return SLK_OK;
-    if (ctx->prep_stream) {  // the partition options changed: both streams are re-created (idle: every call ends joined)
-        SLK_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
-        SLK_HIP(ctx, hipStreamDestroy(ctx->prep_stream));
-        ctx->prep_stream = nullptr;
-        if (ctx->pass_stream) {
-            SLK_HIP(ctx, hipStreamSynchronize(ctx->pass_stream));
-            SLK_HIP(ctx, hipStreamDestroy(ctx->pass_stream));
-            ctx->pass_stream = nullptr;
-        }
-    }
-    const int n = ctx->opt_prep_cus;
-    if (n > 0 && n < ctx->num_cus) {
-        uint32_t mask[32];
-        slk_cu_mask(ctx, n, true, mask, 32);
-        SLK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->prep_stream, 32, mask));
-        slk_cu_mask(ctx, n, false, mask, 32);
-        SLK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->pass_stream, 32, mask));
-    } else if (ctx->opt_prep_priority) {
-        int lo = 0, hi = 0;
-        SLK_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SLK_HIP(ctx, hipStreamCreateWithPriority(&ctx->prep_stream, hipStreamNonBlocking, hi));
-    } else {
-        SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
-    }
+    if (ctx->prep_stream) return SLK_OK;
+    // (CU-masked and high-priority prep streams were measured in round 3 and lost: a masked pass loses far more than its
+    // share of CUs, a priority stream gains nothing beyond the plain one -- profiles/r03_a_*)
+    SLK_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
     // the runtime sets a stream's hardware queue up at its first launch (measured: ~2 ms, once per stream -- the first
     // overlapped training call of a process ran 0.86 instead of 0.75 ms per step, profiles/r03_e_*): done here, in the
     // reserve / first-use path, not in a timed call
-    for (hipStream_t st : {ctx->prep_stream, ctx->pass_stream}) {
-        if (!st) continue;
-        SLK_HIP(ctx, hipMemsetAsync(&ctx->d_rng->sort_abort, 0, sizeof(int32_t), st));
-        SLK_HIP(ctx, hipStreamSynchronize(st));
-    }
-    ctx->prep_stream_cus = ctx->opt_prep_cus;
-    ctx->prep_stream_prio = ctx->opt_prep_priority;
-    for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1], &ctx->ev_pass_in,
-                          &ctx->ev_pass_out})
+    SLK_HIP(ctx, hipMemsetAsync(&ctx->d_rng->sort_abort, 0, sizeof(int32_t), ctx->prep_stream));
+    SLK_HIP(ctx, hipStreamSynchronize(ctx->prep_stream));
+    for (hipEvent_t *e : {&ctx->ev_start, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_done[0], &ctx->ev_done[1]})
         if (!*e) SLK_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SLK_OK;
 }
@@ -209,12 +173,11 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         if (pb.h_lflags) (void)hipHostFree(pb.h_lflags);
     }
     for (hipEvent_t e : {ctx->ev_start, ctx->ev_prep[0], ctx->ev_prep[1], ctx->ev_done[0], ctx->ev_done[1], ctx->ev_coef[0], ctx->ev_coef[1],
-                         ctx->ev_pass_in, ctx->ev_pass_out, ctx->ev_sampled})
+                         ctx->ev_sampled})
         if (e) (void)hipEventDestroy(e);
     for (void *h : ctx->h_coef)
         if (h) (void)hipHostFree(h);
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
-    if (ctx->pass_stream) (void)hipStreamDestroy(ctx->pass_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
     if (ctx->d_jump) (void)hipFree(ctx->d_jump);
@@ -231,12 +194,6 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_overlap_prep = (int)value;
     } else if (!strcmp(name, "overlap_min_batch") && value >= 0) {
         ctx->opt_overlap_min_batch = value;
-    } else if (!strcmp(name, "chunk_ramp") && (value == 0 || value == 1)) {
-        ctx->opt_chunk_ramp = (int)value;
-    } else if (!strcmp(name, "prep_cus") && value >= 0 && value <= 1024) {
-        ctx->opt_prep_cus = (int)value;
-    } else if (!strcmp(name, "prep_priority") && (value == 0 || value == 1)) {
-        ctx->opt_prep_priority = (int)value;
     } else if (!strcmp(name, "sort_cfg") && (value == 0 || value == 1)) {
         ctx->opt_sort_cfg = (int)value;
     } else if (!strcmp(name, "eval_wg_per_cu") && value >= 0 && value <= 8) {
@@ -255,14 +212,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_explicit_fused = (int)value;
     } else if (!strcmp(name, "epoch_kernel") && (value == 0 || value == 1)) {
         ctx->opt_epoch_kernel = (int)value;
-    } else if (!strcmp(name, "first_chunk") && value >= 0 && value <= ((int64_t)1 << 20)) {
-        ctx->opt_first_chunk = value;
     } else if (!strcmp(name, "item_lat_max_tiles") && value >= 0) {
         ctx->opt_item_lat_max_tiles = value;
-    } else if (!strcmp(name, "epoch_seq") && (value == 0 || value == 1)) {
-        ctx->opt_epoch_seq = (int)value;
-    } else if (!strcmp(name, "epoch_seq_max_timesteps") && value >= 1 && value <= ((int64_t)1 << 24)) {
-        ctx->opt_epoch_seq_max_timesteps = value;
     } else if (!strcmp(name, "epoch_adaptive") && (value == 0 || value == 1)) {
         ctx->opt_epoch_adaptive = (int)value;
     } else if (!strcmp(name, "epoch_adaptive_max_batch") && value >= 1 && value <= ((int64_t)1 << 20)) {

@@ -118,11 +118,17 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
         // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
         // fetching early there only lengthens register lifetimes)
-        constexpr bool EARLY_STATE = (EXPL || LAT) && !BLOOM && UPD == SLK_UPD_ADAGRAD;
-        slk_vec<VEC> su = slk_vzero<VEC>();
+        // SparseAdam (round 4): both moment rows (and the bias's moments) with the row in every mode -- its update otherwise
+        // starts with a dependent round trip of TWO more rows per user behind the loss (the pass ran at 0.45 of the roofline
+        // against Adagrad's 0.63, profiles/r03_final_bench_sparse_adam.json)
+        constexpr bool EARLY_ADAM = !BLOOM && UPD == SLK_UPD_SPARSE_ADAM && !ULONG;
+        constexpr bool EARLY_STATE = ((EXPL || LAT) && !BLOOM && UPD == SLK_UPD_ADAGRAD) || EARLY_ADAM;
+        slk_vec<VEC> su = slk_vzero<VEC>(), su2 = slk_vzero<VEC>();
         if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
-        float sbu = 0.0f;
+        if (EARLY_ADAM && on) su2 = slk_vload_if_nt<VEC>(a.S2[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
+        float sbu = 0.0f, sbu2 = 0.0f;
         if (EARLY_STATE) sbu = a.S1[2][user];
+        if (EARLY_ADAM) sbu2 = a.S2[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
         uint32_t q = p;
@@ -261,12 +267,23 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         if (BLOOM && a.ub.n_hash) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
-            if (EARLY_STATE)
+            if (EARLY_ADAM)
+                slk_apply_vec_pre<VEC, UPD, true>(a, 0, uoff, u, su, gu, &su2, (SLK_NT_OF(a) & 1) != 0);
+            else if (EARLY_STATE)
                 slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (SLK_NT_OF(a) & 1) != 0);
             else
                 slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
         }
-        if (EARLY_STATE) {
+        if (EARLY_ADAM) {
+            if (lane == 0) {  // (SparseAdam decays the moments of a looked-up row whatever its gradient is)
+                slk_vec<1> bpv, bsv, bsv2, gbv;
+                bpv.v[0] = bu;
+                bsv.v[0] = sbu;
+                bsv2.v[0] = sbu2;
+                gbv.v[0] = gbu;
+                slk_apply_vec_pre<1, UPD, true>(a, 2, user, bpv, bsv, gbv, &bsv2);
+            }
+        } else if (EARLY_STATE) {
             if (lane == 0 && gbu != 0.0f) {  // gbu == 0 is an exact no-op for Adagrad (slk_apply_bias)
                 slk_vec<1> bpv, bsv, gbv;
                 bpv.v[0] = bu;
@@ -1004,29 +1021,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // two of the user pass's eight workgroups per CU left to the prep stream the steady state of a run of training calls gains
     // 1.5-4 %; round 1 had measured no gain with the pass holding every wave slot); off on a bare ctx (slk_common.h).
     const size_t nc_max = (size_t)(chunk_cap < n ? chunk_cap : n);
-    // chunk boundaries.  In order on one stream: chunks of chunk_cap.  Overlapped (prep of chunk c+1 beside the passes of
-    // chunk c): the first chunk's prep is the one nothing hides, so the chunks ramp up -- ~2^20 interactions, then doubling to
-    // chunk_cap (the small sorts of the first chunks are less efficient, but they run beside passes).  Chunking is
-    // value-neutral: the negatives of a call are one contiguous draw however it is cut.
+    // chunk boundaries: chunks of chunk_cap.  Chunking is value-neutral: the negatives of a call are one contiguous draw however
+    // it is cut.  (Ramped chunks and a short first chunk for the overlapped prep were measured in round 3 and lost at every
+    // call length -- small chunks pay the sampler's jump-ahead and the sorts' fixed costs again: profiles/r03_c_*, r03_w_*.)
     std::vector<int64_t> cb;
     cb.push_back(0);
-    {
-        int64_t ramp = ((int64_t)1 << 20) / bsz;
-        if (ramp < 1) ramp = 1;
-        if (!ctx->opt_overlap_prep || !ctx->opt_chunk_ramp || bsz < ctx->opt_overlap_min_batch) ramp = mb_per_chunk;
-        // option "first_chunk": overlapped, the FIRST chunk's prep is the one nothing hides (1.2 ms of an 8-minibatch chunk at the
-        // C2 shape); a first chunk of a few minibatches exposes a quarter of that and its passes still cover the prep of the
-        // full-sized chunk behind it
-        const bool ov = ctx->opt_overlap_prep && bsz >= ctx->opt_overlap_min_batch;
-        if (ov && !ctx->opt_chunk_ramp && ctx->opt_first_chunk > 0 && ctx->opt_first_chunk < mb_per_chunk &&
-            n > ctx->opt_first_chunk * bsz)
-            cb.push_back(ctx->opt_first_chunk * bsz);
-        while (cb.back() < n) {
-            if (ramp > mb_per_chunk) ramp = mb_per_chunk;
-            const int64_t next = cb.back() + ramp * bsz;
-            cb.push_back(next < n ? next : n);
-            ramp *= 2;
-        }
+    while (cb.back() < n) {
+        const int64_t next = cb.back() + mb_per_chunk * bsz;
+        cb.push_back(next < n ? next : n);
     }
     const size_t n_chunks = cb.size() - 1;
     const int nsets = (ctx->opt_overlap_prep && n_chunks > 1 && bsz >= ctx->opt_overlap_min_batch) ? 2 : 1;
@@ -1516,13 +1518,6 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     hipStream_t ps = ctx->prep_stream;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
     SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
-    // option "prep_cus": the chip is split between the two -- the passes run on the ctx's stream masked to the CUs the prep
-    // stream does not use, between two events on the caller's stream (`s` is what every launch below goes to)
-    hipStream_t caller = s;
-    if (ctx->pass_stream) {
-        SLK_HIP(ctx, hipStreamWaitEvent(ctx->pass_stream, ctx->ev_start, 0));
-        s = ctx->pass_stream;
-    }
     if ((rc = do_sample(0, ctx->pb[0], ps))) return rc;
     if (sort_ahead && (rc = do_sort(0, ctx->pb[0], ps))) return rc;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
@@ -1540,10 +1535,6 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = do_chunk(ck, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }
-    if (s != caller) {
-        SLK_HIP(ctx, hipEventRecord(ctx->ev_pass_out, s));
-        SLK_HIP(ctx, hipStreamWaitEvent(caller, ctx->ev_pass_out, 0));
-    }
-    ctx->last_stream = caller;  // every prep is ordered before the tail of the caller's stream
+    ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
     return SLK_OK;
 }

@@ -97,19 +97,8 @@ struct slk_ctx {
                                    // steady state of a run of training calls it gains 1.5-4 % (profiles/r03_*); a lone call of a few
                                    // chunks gains nothing, every pass runs ~10 % longer beside the sorts, and kernel timings under a
                                    // tracer stop agreeing with the untraced ones -- so a bare ctx keeps everything on one stream
-    // Partition of the chip between the prep of chunk c+1 and the passes of chunk c (only with overlap_prep).  The row passes
-    // are grid-stride kernels that keep every wave slot of every CU for their whole run, so a second stream's kernels
-    // otherwise only run in the gaps: prep_cus > 0 gives the prep stream a CU mask of that many CUs (spread over the XCDs and
-    // shader engines) and runs the passes on a ctx-owned stream masked to the other CUs (ordered against the caller's
-    // stream by events); prep_priority = 1 creates the (unmasked) prep stream with the highest priority instead.
-    int opt_chunk_ramp = 0;        // overlapped prep: 1 = the first chunks of a call ramp up from ~2^20 interactions.  Measured
-                                   // (profiles/r03_c_*): worse at every call length (0.797 vs 0.758 ms per step at 20 minibatches per call,
-                                   // 0.765 vs 0.751 at 64) -- small chunks pay the sampler's jump-ahead and the sorts' fixed costs again
     int64_t opt_overlap_min_batch = (int64_t)1 << 16;  // the prep overlaps the passes only for minibatches of at least this size
                                    // (measured: +3 % at 8192, where the passes are short latency-bound kernels; -1..-3 % at 65 536)
-    int opt_prep_cus = 0;
-    int opt_prep_priority = 0;
-    int prep_stream_cus = -1, prep_stream_prio = -1;  // the settings ctx->prep_stream / pass_stream were created with
     int opt_sort_cfg = 1;          // radix sort: 1 = sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys, 0 = always 256 x 16
     int opt_sort_xcd = 1;          // segmented sorts: 1 = a segment's tiles run on one XCD (slk_sort.hip), 0 = tiles in grid order
     int opt_eval_wg_per_cu = 2;    // the scoring sweep's resident workgroups per CU (by LDS footprint; 0: what its registers allow, 3).
@@ -124,7 +113,6 @@ struct slk_ctx {
     // adaptive hinge, plain item table: smallest minibatch whose item side is re-sorted per minibatch after the selection
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
-    int64_t opt_first_chunk = 0;   // overlapped prep: minibatches in the first chunk of a call (0: a full chunk); see slk_bilinear.hip
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
     int64_t opt_user_lat_max_batch = (int64_t)1 << 14;  // (measured, profiles/r03_c_*: user pass 9.2 -> 8.1 us at 2048, 11.6 -> 10.3 at
                                    // 8192, but 29.3 -> 31.3 at 65 536)  // minibatches up to this size take the latency-bound form of the pair-mode
@@ -142,11 +130,6 @@ struct slk_ctx {
     int opt_epoch_kernel = 1;
     int64_t opt_epoch_max_batch = 1024;
     bool epoch_refused = false;    // a cooperative launch was refused on this device: stay on the launch path
-    int opt_epoch_seq = 0;         // PoolNet on the persistent route (k_poolnet_epoch).  OFF: bit-identical to the launches, but measured
-                                   // slower at every shape (profiles/r03_x_*, r03_za_*: 256 sequences x 10 timesteps 26.8 vs 22.2 us per
-                                   // minibatch -- two barriers ~9 us, sequence phase 11.5 (one wavefront per sequence walks the scans'
-                                   // 256 / G chunks in turns), item phase 11.2 against the launches' 10 + 13 us kernels; x 32: 63 vs 26) ...
-    int64_t opt_epoch_seq_max_timesteps = 4096;  // ... for minibatches of up to this many timesteps (256 sequences x 16)
     int opt_epoch_adaptive = 1;    // adaptive hinge on the persistent route (score phase + the selection inside the user phase)
     int64_t opt_epoch_adaptive_max_batch = 1024;  // ... for minibatches up to this size (three barriers and 1 + n occurrences per
                                    // interaction: same-box A/B in profiles/r03_u_*, r03_v_*)
@@ -168,8 +151,6 @@ struct slk_ctx {
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
     bool prep_warmed = false;           // the one-off tiny prep on the prep stream has run (slk_bilinear_reserve)
-    hipStream_t pass_stream = nullptr;  // prep_cus > 0: the passes' stream, masked to the CUs the prep stream does not use
-    hipEvent_t ev_pass_in = nullptr, ev_pass_out = nullptr;
     hipEvent_t ev_sampled = nullptr;    // behind the last draw of negatives (slk_sample_u32): slk_rng_get_state_sampled
     bool sampled_valid = false;         //   false after slk_rng_set_state / a shuffle (whose end only the stream sync knows)
     hipStream_t copy_stream = nullptr;  // small state copies (slk_rng_{set,get}_state): never the null stream
@@ -284,20 +265,10 @@ int slk_compact_heads(slk_ctx *ctx, const uint32_t *d_sorted, uint32_t n, uint32
                       uint32_t *nseg_out, hipStream_t s);
 // slk_epoch.hip: the persistent route of slk_bilinear_train
 bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int loss, bool bloom);
-// PoolNet on the persistent route (slk_seq.hip -> k_poolnet_epoch): the chunk's sequences, draws and mask counts
-struct slk_epoch_seq {
-    const int64_t *seqs;
-    const uint32_t *neg32, *mcount;
-    int L, C;
-    uint32_t pad_item;
-};
-bool slk_epoch_seq_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int64_t L, bool bloom,
-                            size_t lds_bytes);
-int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP,
-                      const slk_epoch_seq *seq = nullptr);
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP);
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
                         int64_t bsz, unsigned ubits, unsigned ibits, int loss, int NP, int RS, float *snap, float *gsn,
-                        float *d_mb_loss, const float *d_ratings, hipStream_t s, const slk_epoch_seq *seq = nullptr);
+                        float *d_mb_loss, const float *d_ratings, hipStream_t s);
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);

@@ -68,12 +68,6 @@ struct slk_epoch_args {
     const uint32_t *ukey, *uit;    // (minibatch << ubits) | user, sorted; [2 * position] = (pos item, neg item)
     const uint32_t *uk;            // explicit feedback: uit[position] = item, uk[position] = the interaction's index in
     const float *ratings;          //   ratings[] (chunk-local)
-    // PoolNet (k_poolnet_epoch): the chunk's sequences [n_seq][L], its draws (sequence/implicit.py:266-286 order), mask.sum() per
-    // minibatch, timesteps per row-group chunk of the launch path's scans, the padding_idx row
-    const int64_t *seqs;
-    const uint32_t *neg32, *mcount;
-    int L, C;
-    uint32_t pad_item;
     int NP;                        // adaptive hinge: uit[NP * position + s] = the positive (s = 0) and the n draws of the interaction
     float *sk;                     //   uk[position] (chunk-local); sk[NP * interaction + s] = their scores (score phase)
     uint32_t umask;
@@ -243,11 +237,11 @@ __device__ __forceinline__ void slk_epoch_sweep_untouched(const slk_epoch_args &
     }
 }
 
-// ---- the item phase of one minibatch: shared by k_bilinear_epoch and k_poolnet_epoch ----------------------------------------
+// ---- the item phase of one minibatch ------------------------------------------------------------------------------------
 // IMODE: how a payload names its record -- pair losses (occurrence = 2 * position + pair), explicit feedback (= position),
 // adaptive hinge (NP * position + pair), PoolNet (NP * timestep + pair; every occurrence is live, pair 0 also carries the
 // timestep's history gradient, padding_idx rows are nobody's).  b0: first position (timestep) of the minibatch.
-enum { SLK_EI_PAIR = 0, SLK_EI_EXPL = 1, SLK_EI_ADP = 2, SLK_EI_SEQ = 3 };
+enum { SLK_EI_PAIR = 0, SLK_EI_EXPL = 1, SLK_EI_ADP = 2 };
 
 #ifndef SLK_EPOCH_ITEM_BATCH
 #define SLK_EPOCH_ITEM_BATCH 4  // positions of a row group (gstride apart) whose ids, then whose heads' rows + first records, are fetched
@@ -259,7 +253,6 @@ template <int VEC, int G, int UPD, int IMODE>
 __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, const slk_step_coef &c, uint32_t b0, uint32_t ib0,
                                                      uint32_t ib1, uint32_t NP, uint32_t gslot, uint32_t gstride, int D, int d0,
                                                      bool on, int lane, uint32_t nx_key, uint32_t nx_prev, uint32_t nx_a) {
-    constexpr bool SEQ = IMODE == SLK_EI_SEQ;
     constexpr bool HAS_S2 = slk_epoch_has_s2<UPD>();
     constexpr bool HAS_S1 = slk_epoch_has_s1<UPD>();
     constexpr int NB = SLK_EPOCH_ITEM_BATCH;
@@ -285,17 +278,17 @@ __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, co
                 const uint32_t prev = pre ? nx_prev : (first ? 0u : e.ikey[r - 1]);
                 pay[i] = pre ? nx_a : e.ipay[r];
                 // padding_idx rows receive no gradient (the launch path never makes them heads)
-                head[i] = (first || prev != key[i]) && !(SEQ && (key[i] & e.imask) == e.pad_item);
+                head[i] = first || prev != key[i];
             }
         }
         // (2) every head's row, optimizer state, bias and first record -- and the ids of the occurrence behind it -- in ONE round trip
-        slk_vec<VEC> v[NB], sv1[NB], sv2[NB], uo[NB], hg[NB];
+        slk_vec<VEC> v[NB], sv1[NB], sv2[NB], uo[NB];
         slk_vec<1> bis1[NB], bis2[NB];
         float bi[NB], g[NB];
         uint32_t nkey[NB], npay[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            v[i] = sv1[i] = sv2[i] = uo[i] = hg[i] = zero;
+            v[i] = sv1[i] = sv2[i] = uo[i] = zero;
             bis1[i] = bis2[i] = zero1;
             bi[i] = g[i] = 0.0f;
             nkey[i] = ~key[i];
@@ -315,8 +308,6 @@ __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, co
                 g[i] = slk_ld_coh(e.gsn + (pay[i] - ib0));
                 const uint32_t pos = pos_of(pay[i]);
                 if (on) uo[i] = slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + d0);
-                // PoolNet: the sequence's own item (pair 0) also receives the history gradient of its timestep (second half of the record)
-                if (SEQ && on && pay[i] - pos * NP == 0u) hg[i] = slk_vload_coh<VEC>(e.snap + (size_t)(pos - b0) * e.RS + D + d0);
                 if (r + 1u < ib1) {
                     nkey[i] = e.ikey[r + 1u];
                     npay[i] = e.ipay[r + 1u];
@@ -341,32 +332,27 @@ __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, co
             const uint32_t p0 = r - ib0;
             uint32_t k = r;
             float gc = g[i];
-            slk_vec<VEC> uoc = uo[i], hgc = hg[i];
-            bool own = SEQ && pay[i] - pos_of(pay[i]) * NP == 0u;
+            slk_vec<VEC> uoc = uo[i];
             uint32_t nk = nkey[i], np_ = npay[i];  // key and payload of occurrence k + 1 (~key: there is none)
             for (;;) {
                 // the next occurrence's record is requested before this one is added; its ids arrived with this one's record
                 const bool cont = nk == kkey;
                 float gn = 0.0f;
-                slk_vec<VEC> uon = zero, hgn = zero;
-                bool ownn = false;
+                slk_vec<VEC> uon = zero;
                 uint32_t nk2 = ~kkey, np2 = 0u;
                 if (cont) {
                     const uint32_t posn = pos_of(np_);
                     gn = slk_ld_coh(e.gsn + (np_ - ib0));
                     if (on) uon = slk_vload_coh<VEC>(e.snap + (size_t)(posn - b0) * e.RS + d0);
-                    ownn = SEQ && np_ - posn * NP == 0u;
-                    if (ownn && on) hgn = slk_vload_coh<VEC>(e.snap + (size_t)(posn - b0) * e.RS + D + d0);
                     if (k + 2u < ib1) {
                         nk2 = e.ikey[k + 2u];
                         np2 = e.ipay[k + 2u];
                     }
                 }
-                if (SEQ || gc != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum; PoolNet: all do
+                if (gc != 0.0f) {  // occurrences without a gradient (inactive hinge) do not touch the sum
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
-                        float cc = gc * uoc.v[q];
-                        if (own) cc += hgc.v[q];
+                        const float cc = gc * uoc.v[q];
                         sq.v[q] += cc;
                         tv.v[q] += cc;
                     }
@@ -396,8 +382,6 @@ __device__ __forceinline__ void slk_epoch_item_phase(const slk_epoch_args &e, co
                 if (run_ends) break;
                 gc = gn;
                 uoc = uon;
-                hgc = hgn;
-                own = ownn;
                 nk = nk2;
                 np_ = np2;
             }
@@ -779,272 +763,6 @@ __global__ __launch_bounds__(SLK_EPOCH_TB) void k_bilinear_epoch(slk_epoch_args 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// PoolNet (ImplicitSequenceModel.fit with representation='pooling', sequence/implicit.py:225-255; batch_size 256 by default,
-// :85-97): every minibatch of a prepared chunk inside one persistent launch.
-//
-//   SEQUENCE PHASE  one workgroup (one wavefront) per sequence: k_seq_pass's arithmetic (slk_seq.hip) -- the running,
-//                   padding-aware average, the scores of the sequence's own item and of the draws, the masked loss, dL/dscore,
-//                   the cumsum's reverse scan -- in k_seq_pass's order: its 256 / G row groups each own a chunk of C
-//                   consecutive timesteps and the chunks' sums are added front to back (back to front for the reverse scan);
-//                   here the wavefront's 64 / G row groups take those chunks in turns, so every sum associates the same way.
-//                   Item rows and biases through sc1 loads, records and dL/dscore through sc1 stores.
-//   -- grid barrier --
-//   ITEM PHASE      slk_epoch_item_phase<SLK_EI_SEQ>
-//   -- grid barrier --
-// ---------------------------------------------------------------------------------------------------------------------
-template <int VEC, int G, int UPD, bool ADAPT>
-__global__ __launch_bounds__(SLK_EPOCH_TB) void k_poolnet_epoch(slk_epoch_args e) {
-    HIP_DYNAMIC_SHARED(double, s_wave_sums)  // [4] wave loss sums, the barrier's two flag words (bytes 32..40), from byte 64: the scans' rows
-    int *s_flags = reinterpret_cast<int *>(s_wave_sums + 4);
-    float *lds = reinterpret_cast<float *>(s_wave_sums + 8);
-    if (threadIdx.x < 4) s_wave_sums[threadIdx.x] = 0.0;
-    constexpr int TB = SLK_EPOCH_TB;
-    constexpr int NGP = TB / G;   // row groups of this workgroup
-    constexpr int NG = 256 / G;   // row groups of k_seq_pass: the chunks of its scans
-    constexpr int DL = G * VEC;
-    constexpr bool DENSE = slk_epoch_dense<UPD>();
-    const int lane = threadIdx.x % G, grp = threadIdx.x / G;
-    const int D = e.D, d0 = lane * VEC, L = e.L, C = e.C;
-    const bool on = d0 < D;
-    const uint32_t gslot = blockIdx.x * NGP + grp, gstride = gridDim.x * NGP;
-    const slk_vec<VEC> zero = slk_vzero<VEC>();
-    const uint32_t NP = (uint32_t)e.NP;
-    const int nn = e.NP - 1;
-    float *sE = lds;                   // [L][DL]  item rows, later dL/d(prefix sum)
-    float *sT = lds + (size_t)L * DL;  // [NG][DL] per-chunk sums
-    float *sC = sT + NG * DL;          // [NG][DL] per-chunk non-zero counts
-    unsigned barriers = 0;
-
-    for (uint32_t mb = 0; mb < e.n_mb; ++mb) {
-        const uint32_t s0 = mb * e.bsz, s1 = (e.nc - s0 < e.bsz) ? e.nc : s0 + e.bsz;  // nc: sequences of the chunk
-        const uint32_t Bs = s1 - s0;
-        const slk_step_coef c = e.coef[mb];
-        const float M = (float)e.mcount[mb];
-        const uint32_t *neg = e.neg32 + (size_t)s0 * nn * L;
-        const uint32_t t_b0 = s0 * (uint32_t)L, t_b1 = s1 * (uint32_t)L;  // the minibatch's timesteps (chunk-local)
-        const uint32_t ib0 = NP * t_b0, ib1 = NP * t_b1;
-        double loss_acc = 0.0;
-
-        // ------------------------------------------------ SEQUENCE PHASE
-        for (uint32_t sq = s0 + blockIdx.x; sq < s1 && !(e.debug & (1 | 8)); sq += gridDim.x) {
-            const int64_t *seq = e.seqs + (size_t)sq * L;
-            const uint32_t bl = sq - s0;
-            float *recs = e.snap + (size_t)bl * L * e.RS;
-            __syncthreads();  // LDS of the previous sequence no longer in use
-            // (A) stage the sequence's item rows
-            for (int t = grp; t < L; t += NGP) {
-                const slk_vec<VEC> ev = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)(uint32_t)seq[t] * D + d0) : zero;
-                slk_vstore<VEC>(sE + t * DL + d0, ev);
-            }
-            __syncthreads();
-            // (B1) per-chunk sum and non-zero count
-            for (int vg = grp; vg < NG; vg += NGP) {
-                const int t0 = vg * C < L ? vg * C : L, t1 = t0 + C < L ? t0 + C : L;
-                slk_vec<VEC> sum = zero, cnt = zero;
-                for (int t = t0; t < t1; ++t) {
-                    const slk_vec<VEC> ev = slk_vload<VEC>(sE + t * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        sum.v[i] += ev.v[i];
-                        cnt.v[i] += (ev.v[i] != 0.0f) ? 1.0f : 0.0f;
-                    }
-                }
-                slk_vstore<VEC>(sT + vg * DL + d0, sum);
-                slk_vstore<VEC>(sC + vg * DL + d0, cnt);
-            }
-            __syncthreads();
-            // (B2) exclusive prefix -> representation -> scores -> loss -> dL/d(prefix sum)
-            for (int vg = grp; vg < NG; vg += NGP) {
-                const int t0 = vg * C < L ? vg * C : L, t1 = t0 + C < L ? t0 + C : L;
-                if (t0 >= t1) continue;
-                slk_vec<VEC> S = zero, Cn = zero;
-                for (int gq = 0; gq < vg; ++gq) {
-                    const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0), y = slk_vload<VEC>(sC + gq * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        S.v[i] += x.v[i];
-                        Cn.v[i] += y.v[i];
-                    }
-                }
-                for (int tb = t0; tb < t1; tb += 4) {
-                    uint32_t it[4], nid[4];
-                    slk_vec<VEC> nrow[4];
-                    float pb[4], nb[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int t = tb + k;
-                        it[k] = nid[k] = 0;
-                        pb[k] = nb[k] = 0.0f;
-                        nrow[k] = zero;
-                        if (t < t1) {
-                            it[k] = (uint32_t)seq[t];
-                            pb[k] = slk_ld_coh(e.P[3] + it[k]);
-                            if (!ADAPT) {
-                                nid[k] = neg[(size_t)bl * L + t];
-                                nrow[k] = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)nid[k] * D + d0) : zero;
-                                nb[k] = slk_ld_coh(e.P[3] + nid[k]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int t = tb + k;
-                        if (t >= t1) break;
-                        const slk_vec<VEC> ev = slk_vload<VEC>(sE + t * DL + d0);
-                        slk_vec<VEC> rep, c1;
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            c1.v[i] = Cn.v[i] + 1.0f;
-                            rep.v[i] = S.v[i] / c1.v[i];
-                        }
-                        const float sp = pb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, ev));
-                        float sn;
-                        int chosen = 0;
-                        slk_vec<VEC> nr = nrow[k];
-                        if (!ADAPT) {
-                            sn = nb[k] + slk_group_sum<G>(slk_vdot<VEC>(rep, nr));
-                        } else {
-                            // losses.py:164-166: the highest-scoring of the n candidates drawn for this (sequence, timestep);
-                            // row (r*B + b) of the (n*B, L) draw; first maximum wins
-                            sn = 0.0f;
-                            for (int rb = 0; rb < nn; rb += 4) {
-                                slk_vec<VEC> cr[4];
-                                float cbv[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    cr[j] = zero;
-                                    cbv[j] = 0.0f;
-                                    if (rb + j < nn) {
-                                        const uint32_t cid = neg[((size_t)(rb + j) * Bs + bl) * L + t];
-                                        cr[j] = on ? slk_vload_coh<VEC>(e.P[1] + (size_t)cid * D + d0) : zero;
-                                        cbv[j] = slk_ld_coh(e.P[3] + cid);
-                                    }
-                                }
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    if (rb + j < nn) {
-                                        const float sc = cbv[j] + slk_group_sum<G>(slk_vdot<VEC>(rep, cr[j]));
-                                        if (rb + j == 0 || sc > sn) {
-                                            sn = sc;
-                                            chosen = rb + j;
-                                            nr = cr[j];
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        float l, gp, gn;
-                        slk_pair_loss(e.loss_kind, sp, sn, 1.0f, l, gp, gn);
-                        const float mask = it[k] != 0u ? 1.0f : 0.0f;
-                        const float w = mask / M;  // d(sum(loss*mask)/sum(mask)) / d loss
-                        gp = gp * w;
-                        gn = gn * w;
-                        float *rec = recs + (size_t)t * e.RS;
-                        if (on) slk_vstore_coh<VEC>(rec + d0, rep);
-                        if (lane == 0) {
-                            loss_acc += (double)(l * mask);
-                            const uint32_t gi = (bl * (uint32_t)L + (uint32_t)t) * NP;
-                            slk_st_coh(e.gsn + gi, gp);
-                            if (!ADAPT) {
-                                slk_st_coh(e.gsn + gi + 1, gn);
-                            } else {
-                                for (int j = 0; j < nn; ++j) slk_st_coh(e.gsn + gi + 1 + j, (j == chosen) ? gn : 0.0f);
-                            }
-                        }
-                        // advance the running sums, then overwrite the staged row by dL/d(prefix sum)
-                        slk_vec<VEC> gs;
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            gs.v[i] = (gp * ev.v[i] + gn * nr.v[i]) / c1.v[i];
-                            S.v[i] += ev.v[i];
-                            Cn.v[i] += (ev.v[i] != 0.0f) ? 1.0f : 0.0f;
-                        }
-                        slk_vstore<VEC>(sE + t * DL + d0, gs);
-                    }
-                }
-            }
-            __syncthreads();  // every chunk's owner has consumed the chunk sums
-            // (C) cumsum backward: row j receives the sum of dL/d(prefix sum) over t > j
-            for (int vg = grp; vg < NG; vg += NGP) {
-                const int t0 = vg * C < L ? vg * C : L, t1 = t0 + C < L ? t0 + C : L;
-                slk_vec<VEC> sum = zero;
-                for (int t = t0; t < t1; ++t) {
-                    const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) sum.v[i] += x.v[i];
-                }
-                slk_vstore<VEC>(sT + vg * DL + d0, sum);
-            }
-            __syncthreads();
-            for (int vg = grp; vg < NG; vg += NGP) {
-                const int t0 = vg * C < L ? vg * C : L, t1 = t0 + C < L ? t0 + C : L;
-                if (t0 >= t1) continue;
-                slk_vec<VEC> suf = zero;
-                for (int gq = NG - 1; gq > vg; --gq) {
-                    const slk_vec<VEC> x = slk_vload<VEC>(sT + gq * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
-                }
-                for (int t = t1 - 1; t >= t0; --t) {
-                    if (on) slk_vstore_coh<VEC>(recs + (size_t)t * e.RS + D + d0, suf);
-                    const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
-                }
-            }
-        }
-        if (DENSE && lane == 0) {  // the item rows this minibatch touches (padding_idx rows are nobody's: the sweep takes them)
-            for (uint32_t r = ib0 + gslot; r < ib1; r += gstride) {
-                const uint32_t item = e.ikey[r] & e.imask;
-                if (item != e.pad_item) __hip_atomic_store(e.touch_i + item, mb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // this row group's first position of the item phase
-        uint32_t nx_key = 0, nx_prev = 0, nx_a = 0;
-        if (ib0 + gslot < ib1) {
-            nx_key = e.ikey[ib0 + gslot];
-            nx_prev = gslot ? e.ikey[ib0 + gslot - 1] : 0u;
-            nx_a = e.ipay[ib0 + gslot];
-        }
-        {   // the workgroup's share of the minibatch loss (k_seq_pass: the block's sum / mask.sum())
-            double x = loss_acc;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-            if ((threadIdx.x & 63) == 0) s_wave_sums[threadIdx.x >> 6] = x / (double)M;
-        }
-        if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums,
-                               e.partial + (size_t)mb * gridDim.x + blockIdx.x))
-            return;
-        ++barriers;
-
-        // ------------------------------------------------ ITEM PHASE
-        if (!(e.debug & (1 | 16)))
-            slk_epoch_item_phase<VEC, G, UPD, SLK_EI_SEQ>(e, c, t_b0, ib0, ib1, NP, gslot, gstride, D, d0, on, lane, nx_key, nx_prev,
-                                                          nx_a);
-        if (DENSE) slk_epoch_sweep_untouched<VEC, UPD>(e, c, 1, 3, e.touch_i, mb + 1u, e.n_items, gslot, gstride, D, d0, on, lane);
-        if (!slk_epoch_barrier(e, barriers + 1, s_flags + (barriers & 1u), s_wave_sums, nullptr)) return;
-        ++barriers;
-    }
-
-    // loss.item() of every minibatch: the workgroups' shares, published on the way into each sequence-phase barrier
-    constexpr int NW = TB / 64;
-    for (uint32_t mb = blockIdx.x * NW + (threadIdx.x >> 6); mb < e.n_mb; mb += gridDim.x * NW) {
-        double x = 0.0;
-        for (unsigned i = threadIdx.x & 63u; i < gridDim.x; i += 64) {
-            const unsigned long long bits = __hip_atomic_load(
-                reinterpret_cast<const unsigned long long *>(e.partial + (size_t)mb * gridDim.x + i), __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-            double d;
-            memcpy(&d, &bits, 8);
-            x += d;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-        if ((threadIdx.x & 63) == 0) e.mb_loss[mb] = (float)x;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 typedef void (*slk_epoch_fn)(slk_epoch_args);
@@ -1086,18 +804,6 @@ bool slk_epoch_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_
     return true;
 }
 
-// PoolNet (slk_poolnet_train): plain item table, minibatches of up to "epoch_seq_max_timesteps" timesteps (the reference's
-// default is 256 sequences; a workgroup of the persistent launch is ONE wavefront walking a whole sequence, so long sequences
-// belong to the 256-thread sequence pass of the launch path)
-bool slk_epoch_seq_eligible(const slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, int64_t L,
-                            bool bloom, size_t lds_bytes) {
-    if (!ctx->opt_epoch_kernel || !ctx->opt_epoch_seq || ctx->epoch_refused || bloom) return false;
-    if (bsz * L > ctx->opt_epoch_seq_max_timesteps || lds_bytes + 64 > 60 * 1024) return false;
-    const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
-    if (dense && tables->num_items * (int64_t)(tables->dim + 1) > ctx->opt_epoch_dense_elems) return false;
-    return true;
-}
-
 enum { EP_COEF = 40, EP_BAR, EP_PARTIAL, EP_TOUCH };  // ctx->extra slots
 
 static int epoch_upd_of(const slk_optim *optim) {
@@ -1115,12 +821,12 @@ static int epoch_upd_of(const slk_optim *optim) {
 // grid barrier needs every workgroup running; on gfx950 one 64-thread workgroup per CU always fits an idle device, the
 // query guards a build whose register / LDS footprint says otherwise).
 static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t bsz, unsigned np, int g,
-                           slk_epoch_fn fn, size_t lds, bool seq = false) {
+                           slk_epoch_fn fn, size_t lds) {
     const unsigned gpb = (unsigned)SLK_EPOCH_TB / (unsigned)g;
     unsigned grid = (unsigned)((np * bsz + gpb - 1) / gpb);
     if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
         // the dense optimizers also sweep every row of the larger table once per phase: one row per row group if the chip allows
-        const int64_t rows = (!seq && tables->num_users > tables->num_items) ? tables->num_users : tables->num_items;
+        const int64_t rows = tables->num_users > tables->num_items ? tables->num_users : tables->num_items;
         const unsigned by_rows = (unsigned)((rows + gpb - 1) / gpb);
         if (by_rows > grid) grid = by_rows;
     }
@@ -1146,47 +852,18 @@ static slk_epoch_fn epoch_pick_fn(int vec, int g, int upd, int mode) {
 
 static const size_t kEpochLds = 4 * sizeof(double) + 16;
 
-template <int VEC, int G>
-static slk_epoch_fn poolnet_epoch_fn(int upd, bool adaptive) {
-#define SLK_PN(U_) (adaptive ? (slk_epoch_fn)k_poolnet_epoch<VEC, G, U_, true> : (slk_epoch_fn)k_poolnet_epoch<VEC, G, U_, false>)
-    switch (upd) {
-        case SLK_EUPD_ADAGRAD: return SLK_PN(SLK_EUPD_ADAGRAD);
-        case SLK_EUPD_SPARSE_ADAM: return SLK_PN(SLK_EUPD_SPARSE_ADAM);
-        case SLK_EUPD_ADAM_DENSE: return SLK_PN(SLK_EUPD_ADAM_DENSE);
-        case SLK_EUPD_SGD: return SLK_PN(SLK_EUPD_SGD);
-        default: return SLK_PN(SLK_EUPD_ADAGRAD_DENSE);
-    }
-#undef SLK_PN
-}
-static slk_epoch_fn poolnet_pick_fn(int vec, int g, int upd, bool adaptive) {
-    slk_epoch_fn fn = nullptr;
-#define SLK_PICK_EPOCH(V_, G_) fn = poolnet_epoch_fn<V_, G_>(upd, adaptive)
-    SLK_FOR_LAYOUT(vec, g, SLK_PICK_EPOCH);
-#undef SLK_PICK_EPOCH
-    return fn;
-}
-// dynamic LDS of k_poolnet_epoch: 64 B (loss sums, barrier flags) + the staged sequence + the chunk sums / counts
-static size_t poolnet_epoch_lds(int vec, int g, int L) {
-    const size_t DL = (size_t)g * vec, NG = 256 / (size_t)g;
-    return 64 + ((size_t)L * DL + 2 * NG * DL) * 4;
-}
-
 // Scratch of the persistent route for chunks of up to n_mb minibatches: called by slk_bilinear_reserve (so that the training
 // call allocates nothing) and again, idempotently, by every slk_epoch_run_chunk.
-int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP,
-                      const slk_epoch_seq *seq) {
+int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, uint32_t n_mb, int64_t bsz, int loss, int NP) {
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
-    const unsigned grid =
-        seq ? epoch_grid(ctx, tables, optim, bsz, (unsigned)NP * (unsigned)seq->L, g,
-                         poolnet_pick_fn(vec, g, epoch_upd_of(optim), loss == SLK_LOSS_ADAPTIVE_HINGE), poolnet_epoch_lds(vec, g, seq->L), true)
-            : epoch_grid(ctx, tables, optim, bsz, (unsigned)NP, g, epoch_pick_fn(vec, g, epoch_upd_of(optim), epoch_mode_of(loss)),
-                         kEpochLds);
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, (unsigned)NP, g, epoch_pick_fn(vec, g, epoch_upd_of(optim), epoch_mode_of(loss)),
+                                     kEpochLds);
     if ((rc = slk_ensure(ctx, ctx->extra[EP_COEF], (size_t)n_mb * sizeof(slk_step_coef)))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_BAR], 2048))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[EP_PARTIAL], (size_t)n_mb * (grid ? grid : 1) * 8))) return rc;
     if (optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE) {
-        const size_t rows = (seq ? 0 : (size_t)tables->num_users) + (size_t)tables->num_items;
+        const size_t rows = (size_t)tables->num_users + (size_t)tables->num_items;
         if ((rc = slk_ensure(ctx, ctx->extra[EP_TOUCH], rows * 4))) return rc;
     }
     // pinned, double-buffered host staging of the per-minibatch coefficients (an asynchronous copy from pageable memory may
@@ -1208,25 +885,23 @@ int slk_epoch_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *o
 // All minibatches of one prepared chunk (sorted lists in pb, see slk_bilinear.hip) in one persistent launch.
 int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim, const slk_prep_bufs &pb, uint32_t nc,
                         int64_t bsz, unsigned ubits, unsigned ibits, int loss, int NP, int RS, float *snap, float *gsn,
-                        float *d_mb_loss, const float *d_ratings, hipStream_t s, const slk_epoch_seq *seq) {
-    // seq: PoolNet -- nc sequences of seq->L timesteps in minibatches of bsz sequences, k_poolnet_epoch
+                        float *d_mb_loss, const float *d_ratings, hipStream_t s) {
     const int mode = epoch_mode_of(loss);
-    const bool expl = !seq && mode == SLK_EMODE_EXPLICIT;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
-    const bool adp = !seq && mode == SLK_EMODE_ADAPTIVE;   // NP = 1 + negatives per interaction (pair losses 2, explicit 1)
+    const bool expl = mode == SLK_EMODE_EXPLICIT;  // d_ratings: the chunk's ratings, indexed by pb.uval[1] (see do_sort)
+    const bool adp = mode == SLK_EMODE_ADAPTIVE;   // NP = 1 + negatives per interaction (pair losses 2, explicit 1)
     int vec, g, rc;
     if (!slk_pick_layout(tables->dim, &vec, &g)) return slk_fail(ctx, SLK_EINVAL, "embedding dim %d unsupported", tables->dim);
     const uint32_t n_mb = (uint32_t)((nc + bsz - 1) / bsz);
     const int upd = epoch_upd_of(optim);
-    slk_epoch_fn fn = seq ? poolnet_pick_fn(vec, g, upd, loss == SLK_LOSS_ADAPTIVE_HINGE) : epoch_pick_fn(vec, g, upd, mode);
-    const size_t lds = seq ? poolnet_epoch_lds(vec, g, seq->L) : kEpochLds;
-    if (lds > 48 * 1024) SLK_HIP(ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, seq ? (unsigned)NP * (unsigned)seq->L : (unsigned)NP, g, fn, lds, seq != nullptr);
+    slk_epoch_fn fn = epoch_pick_fn(vec, g, upd, mode);
+    const size_t lds = kEpochLds;
+    const unsigned grid = epoch_grid(ctx, tables, optim, bsz, (unsigned)NP, g, fn, lds);
     if (grid == 0) {  // the occupancy query says no workgroup of this kernel fits a CU: nothing ran, take the launch path
         slk_fail(ctx, SLK_EIO, "k_bilinear_epoch cannot be resident on this device (occupancy 0)");
         ctx->epoch_refused = true;
         return SLK_EAGAIN_EPOCH;
     }
-    if ((rc = slk_epoch_reserve(ctx, tables, optim, n_mb, bsz, loss, NP, seq))) return rc;
+    if ((rc = slk_epoch_reserve(ctx, tables, optim, n_mb, bsz, loss, NP))) return rc;
 
     // per-step coefficients, in double like torch (slk_set_opt_coeffs / slk_dense_sweeps)
     const int cb = ctx->coef_flip;
@@ -1256,7 +931,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_BAR].p, 0, 2048, s));
     const bool dense_opt = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (dense_opt) {
-        const size_t rows = (seq ? 0 : (size_t)tables->num_users) + (size_t)tables->num_items;
+        const size_t rows = (size_t)tables->num_users + (size_t)tables->num_items;
         SLK_HIP(ctx, hipMemsetAsync(ctx->extra[EP_TOUCH].p, 0, rows * 4, s));
     }
 
@@ -1268,23 +943,14 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
         e.S2[t] = optim->d_state2[t];
     }
     e.D = tables->dim;
-    e.n_users = seq ? 0u : (uint32_t)tables->num_users;
+    e.n_users = (uint32_t)tables->num_users;
     e.n_items = (uint32_t)tables->num_items;
     e.nc = nc;
     e.bsz = (uint32_t)bsz;
     e.n_mb = n_mb;
-    if (!seq) {
-        e.ukey = (const uint32_t *)pb.ukey[1].p;
-        e.uit = (expl || adp) ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
-        e.uk = (expl || adp) ? (const uint32_t *)pb.uval[1].p : nullptr;
-    } else {
-        e.seqs = seq->seqs;
-        e.neg32 = seq->neg32;
-        e.mcount = seq->mcount;
-        e.L = seq->L;
-        e.C = seq->C;
-        e.pad_item = seq->pad_item;
-    }
+    e.ukey = (const uint32_t *)pb.ukey[1].p;
+    e.uit = (expl || adp) ? (const uint32_t *)pb.uit.p : (const uint32_t *)pb.uval[1].p;
+    e.uk = (expl || adp) ? (const uint32_t *)pb.uval[1].p : nullptr;
     e.NP = NP;
     e.sk = adp ? (float *)ctx->sk.p : nullptr;
     ctx->epoch_bars_per_mb = adp ? 3 : 2;
@@ -1300,7 +966,7 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
     e.mb_loss = d_mb_loss;
     e.coef = (const slk_step_coef *)ctx->extra[EP_COEF].p;
     e.touch_u = dense_opt ? (uint32_t *)ctx->extra[EP_TOUCH].p : nullptr;
-    e.touch_i = dense_opt ? e.touch_u + (seq ? 0 : tables->num_users) : nullptr;
+    e.touch_i = dense_opt ? e.touch_u + tables->num_users : nullptr;
     e.bar = (unsigned *)ctx->extra[EP_BAR].p;
     e.status = &ctx->d_rng->epoch_abort;
     e.loss_kind = loss;

@@ -619,10 +619,6 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
     const int64_t occ_mult = (int64_t)NP * (Hi ? Hi : 1);
     while (mb_per_chunk > 1 && mb_per_chunk * bsz * L * occ_mult >= ((int64_t)1 << 31)) mb_per_chunk >>= 1;
     if (mb_per_chunk < 1) mb_per_chunk = 1;
-    // minibatches of a few thousand timesteps (the reference's default: 256 sequences): every minibatch of a chunk inside ONE
-    // persistent launch (slk_epoch.hip, k_poolnet_epoch); at most 2^13 minibatches per launch (loss partials, barrier count)
-    bool epoch_route = slk_epoch_seq_eligible(ctx, tables, optim, bsz, L, Hi > 0, lds_bytes);
-    if (epoch_route && mb_per_chunk > ((int64_t)1 << 13)) mb_per_chunk = (int64_t)1 << 13;
     const int64_t chunk_seqs = mb_per_chunk * bsz;
     const size_t ns_max = (size_t)(chunk_seqs < n_seq ? chunk_seqs : n_seq);
     const size_t nts_max = ns_max * L;
@@ -690,10 +686,6 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             if ((rc = slk_ensure_lflags_host(ctx, pb, (size_t)mb_per_chunk))) return rc;
             pb.h_lflags_n = 0;
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
-        }
-        if (epoch_route) {
-            slk_epoch_seq sq = {nullptr, nullptr, nullptr, (int)L, (int)((L + NG - 1) / NG), 0u};
-            if ((rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((ns_max + bsz - 1) / bsz), bsz, (int)loss, NP, &sq))) return rc;
         }
         // sampler and sort scratch of the largest chunk, so that the training call allocates nothing
         if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nts_max * nn))) return rc;
@@ -865,27 +857,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
         return SLK_OK;
     };
 
-    // one prepared chunk: the persistent launch, or (not eligible / launch refused: nothing ran) the per-minibatch launches
-    auto do_chunk = [&](int64_t c0, int set) -> int {
-        if (!epoch_route) return do_passes(c0, set);
-        slk_prep_bufs &fb = ctx->pb[set];
-        const uint32_t ns = (uint32_t)((n_seq - c0 < chunk_seqs) ? (n_seq - c0) : chunk_seqs);
-        slk_epoch_seq sq;
-        sq.seqs = d_sequences + c0 * L;
-        sq.neg32 = (const uint32_t *)fb.neg32.p;
-        sq.mcount = (const uint32_t *)ctx->extra[set ? SQ_MCOUNT_B : SQ_MCOUNT].p;
-        sq.L = (int)L;
-        sq.C = (int)((L + NG - 1) / NG);
-        sq.pad_item = padding_idx < 0 ? 0xffffffffu : (uint32_t)padding_idx;
-        int rc = slk_epoch_run_chunk(ctx, tables, optim, fb, ns, bsz, 0u, ibits, (int)loss, NP, RS, (float *)ctx->snap.p,
-                                     (float *)ctx->extra[SQ_GSN].p, d_mb_loss + mb_global, nullptr, s, &sq);
-        if (rc == SLK_EAGAIN_EPOCH) {
-            epoch_route = false;
-            return do_passes(c0, set);
-        }
-        mb_global += (ns + bsz - 1) / bsz;
-        return rc;
-    };
+    auto do_chunk = [&](int64_t c0, int set) -> int { return do_passes(c0, set); };
 
     if (nsets == 1) {
         for (int64_t c0 = 0; c0 < n_seq; c0 += chunk_seqs) {

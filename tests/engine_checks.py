@@ -642,64 +642,6 @@ def check_seq_chunking_is_bit_neutral(be, loss, opt, D, I=2000, N=300, L=24, B=3
         assert np.array_equal(a, b), ('tensor %d differs between one chunk and the pipelined chunks' % k)
 
 
-def check_seq_epoch_kernel_is_bit_identical(be, loss, opt, D, I=2000, N=600, L=10, B=64, nn=3, seed=19, chunk=None, epochs=2,
-                                            max_grid=None, barrier=-1, pad_ratio=0.3, padding_idx=0):
-    """PoolNet on the persistent route (k_poolnet_epoch: sequence phase + item phase per minibatch inside one launch per chunk)
-    against the per-minibatch launches (k_seq_pass / k_seq_pass_reg + item pass + dense sweep): minibatch losses to the order
-    of their double sums, negatives, RNG state, the item tables and every optimizer-state tensor bit for bit."""
-    eng = be.engine
-    rs = np.random.RandomState(seed)
-    seqs = make_sequences(rs, N, L, I, pad_ratio)
-    params = _seq_params(rs, I, D)
-    state = np.random.RandomState(seed + 1).get_state()
-    n_mb = (N + B - 1) // B
-    n_draw = N * L * (nn if loss == 'adaptive_hinge' else 1)
-    results = []
-    for route in (0, 1):
-        eng.set_option('epoch_seq', route)
-        eng.set_option('epoch_seq_max_timesteps', 1 << 24)
-        eng.set_option('epoch_dense_elems', 1 << 40)
-        if chunk:
-            eng.set_option('chunk_interactions', chunk)
-        if max_grid:
-            eng.set_option('epoch_max_grid', max_grid)
-        eng.set_option('epoch_barrier', barrier)
-        try:
-            dev = be.seq_model(params, opt=opt, lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
-            eng.rng_set_state(state)
-            d_seqs = be.alloc(seqs)
-            neg_out = be.alloc(np.full(n_draw, -1, dtype=np.int64))
-            losses = []
-            eng.profile_reset()
-            eng.profile_enable(True)
-            for _ in range(epochs):
-                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
-                eng.poolnet_train(dev.tables, dev.optim, padding_idx, be.ptr(d_seqs), N, L, B, loss, nn, be.ptr(mb_loss),
-                                  d_neg_out=be.ptr(neg_out), stream=be.stream)
-                losses.append(be.get(mb_loss).copy())
-            eng.profile_enable(False)
-            prof = eng.profile_read()
-            if route:  # the route under test really ran
-                assert prof['epoch'][0] >= epochs and prof['seq_pass'][0] == 0, prof
-            else:
-                assert prof['epoch'][0] == 0 and prof['seq_pass'][0] == epochs * n_mb, prof
-            st = eng.rng_get_state()
-            assert dev.optim.step == epochs * n_mb
-            results.append((np.concatenate(losses), [be.get(neg_out), st[1], np.array(st[2])] + [be.get(x) for x in dev.p + dev.s1 + dev.s2]))
-        finally:
-            eng.set_option('epoch_seq', 0)  # (the default: measured slower than the launches, slk_common.h)
-            eng.set_option('epoch_seq_max_timesteps', 4096)
-            eng.set_option('epoch_dense_elems', 1 << 18)
-            eng.set_option('chunk_interactions', 1 << 23)
-            eng.set_option('epoch_max_grid', 256)
-            eng.set_option('epoch_barrier', -1)
-    (la, ta), (lb, tb) = results
-    assert np.isfinite(la).all() and np.abs(la - lb).max() <= 2e-6 * np.abs(la).max(), (la, lb)
-    for k, (x, y) in enumerate(zip(ta, tb)):
-        assert np.array_equal(x, y), ('tensor %d differs between the persistent kernel and the launch path' % k,
-                                      float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
-
-
 def check_seq_single_step_gradients(be, loss, D, I=40, B=24, L=11, nn=3, seed=11, bloom=0, ratio=0.4, tol=1e-5):
     """Identical minibatch and parameters: loss within 1e-5 rel, summed gradients within 1e-5 of
     each table's inf-norm; read back through ADAM_DENSE with lr = 0, beta1 = 0."""
@@ -965,7 +907,7 @@ BLOOM_FIXTURES = ['bloom_item_bpr_adagrad', 'bloom_item_adaptive_hinge_adam_defa
 
 
 def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1000, nn=5, user_bloom=0, item_bloom=0,
-                                  chunk=4096, overlap=1, seed=21, nt=None, first_chunk=0):
+                                  chunk=4096, overlap=1, seed=21, nt=None):
     """The engine is deterministic (sorted ownership, no atomics), and chunking / the prep pipeline
     only change WHEN value-independent work happens: one big chunk on one stream and many small
     chunks with prep on the second stream must agree bit for bit -- losses, negatives, every table,
@@ -983,7 +925,6 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
         eng.set_option('chunk_interactions', chunk_i)
         eng.set_option('overlap_prep', overlap_i)
         eng.set_option('overlap_min_batch', 0)  # (by default only minibatches >= 2^16 overlap their prep)
-        eng.set_option('first_chunk', first_chunk if chunk_i == chunk else 0)  # a short first chunk in the pipelined run
         if nt is not None and chunk_i == chunk:  # the second run also uses another cache policy
             eng.set_option('nt', nt)
         try:
@@ -1002,7 +943,6 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
             eng.set_option('chunk_interactions', 1 << 23)
             eng.set_option('overlap_prep', 0)
             eng.set_option('overlap_min_batch', 1 << 16)
-            eng.set_option('first_chunk', 0)
             if nt is not None:
                 eng.set_option('nt', 3)
     for k, (a, b) in enumerate(zip(*results)):

@@ -144,14 +144,10 @@ def test_pipelined_chunks_match_single_chunk(be):
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 0)
         eng.set_option('overlap_min_batch', 1 << 16)
-        eng.set_option('item_grid_mult', 64)
+        eng.set_option('item_grid_mult', 128)
         eng.set_option('user_grid_mult', 8)
     ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100)
     ec.check_chunking_is_bit_neutral(be, 'hinge', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100, overlap=2)
-    # a short first chunk (option first_chunk: 1 and 2 minibatches in front of chunks of 3)
-    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 8, U=40, I=30, N=500, B=32, chunk=100, first_chunk=1)
-    ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'adagrad', 8, U=40, I=30, N=500, B=32, nn=3, chunk=100, first_chunk=2)
-    ec.check_chunking_is_bit_neutral(be, 'bpr', 'sparse_adam', 8, U=40, I=30, N=90, B=32, chunk=1 << 20, first_chunk=2)  # [2, 1]
     ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 8, U=40, I=30, N=300, B=32, nn=3, chunk=64,
                                      overlap=0)
     ec.check_chunking_is_bit_neutral(be, 'pointwise', 'adam_dense', 8, U=40, I=50, N=300, B=32, chunk=64,

@@ -83,29 +83,10 @@ def test_seq_argument_errors(be):
 
 
 
-@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
-@pytest.mark.parametrize('opt', ec.ALL_OPTS)
-def test_poolnet_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
-    """PoolNet's minibatch loop (sequence/implicit.py:225-255) inside the persistent launch (k_poolnet_epoch): one wavefront
-    per sequence takes the 256-thread sequence pass's chunks in turns -- same sums in the same order"""
-    ec.check_seq_epoch_kernel_is_bit_identical(be, loss, opt, 8, I=300 if opt.endswith('dense') else 2000)
-
-
 def test_seq_item_pass_with_every_head_early_is_bit_neutral(be):
     for loss, opt in (('bpr', 'adagrad'), ('adaptive_hinge', 'sparse_adam'), ('pointwise', 'adam_dense')):
         ec.check_seq_chunking_is_bit_neutral(be, loss, opt, 16, chunk=1 << 23, overlap=0, option=('item_lat_max_tiles', 2048, 0, 2048))
     ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 16, bloom=3, chunk=1 << 23, overlap=0, option=('item_lat_max_tiles', 2048, 0, 2048))
-
-
-def test_poolnet_epoch_kernel_layouts_padding_chunks(be):
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, L=37, N=200, B=32)          # chunks of 2 timesteps, a ragged last one
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'sgd', 64, L=5, N=300, B=100)             # fewer timesteps than chunks
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'adagrad_dense', 16, I=300, nn=5)
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 8, I=3, N=300, B=64)             # three items: long runs, tile-wise sums
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 20, L=70, N=100, B=16, padding_idx=-1)
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'hinge', 'adam_dense', 3, I=50, L=9, N=100, B=16, pad_ratio=0.8)
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 16, N=700, B=64, chunk=64 * 10 * 3)  # launches of 3 minibatches
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'pointwise', 'sparse_adam', 8, max_grid=1)
 
 
 @pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('pointwise', 'adam_dense', 0),

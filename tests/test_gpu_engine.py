@@ -165,8 +165,6 @@ def test_pipelined_chunks_match_oracle(be):
         eng.set_option('chunk_interactions', 1 << 23)
         eng.set_option('overlap_prep', 0)
         eng.set_option('overlap_min_batch', 1 << 16)
-    ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, first_chunk=1)
-    ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'adagrad', 32, N=20000, B=512, first_chunk=3)
     for overlap in (0, 1, 2):
         ec.check_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, overlap=overlap)
         ec.check_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, overlap=overlap)
@@ -351,22 +349,6 @@ def test_epoch_kernel_many_minibatches_and_chunks(be):
     ec.check_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, U=943, I=1682, N=102400, B=256, epochs=1, chunk=25600)
 
 
-
-
-@pytest.mark.parametrize('loss', ec.ALL_LOSSES)
-@pytest.mark.parametrize('opt', ec.ALL_OPTS)
-def test_poolnet_epoch_kernel_bit_identical_to_launch_path(be, loss, opt):
-    """PoolNet at the reference's default batch size (256 sequences, sequence/implicit.py:85-97) and max_sequence_length 10 on a
-    MovieLens-100K-sized item table: k_poolnet_epoch against k_seq_pass_reg + item pass (+ dense sweep)"""
-    ec.check_seq_epoch_kernel_is_bit_identical(be, loss, opt, 32, I=1682, N=4000, L=10, B=256)
-
-
-def test_poolnet_epoch_kernel_sizes_and_layouts(be):
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 64, I=100000, N=3000, L=16, B=256)
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 64, I=50000, N=600, L=200, B=64, epochs=1)   # LDS-staged 200 timesteps
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'adaptive_hinge', 'sparse_adam', 128, I=5000, N=2000, L=10, B=256, nn=5, barrier=1)
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'hinge', 'adagrad', 20, I=7, N=3000, L=10, B=512, epochs=1)   # seven items: long runs
-    ec.check_seq_epoch_kernel_is_bit_identical(be, 'bpr', 'adagrad', 32, I=1682, N=25600, L=10, B=256, epochs=1, chunk=2560 * 20)
 
 
 @pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('pointwise', 'adam_dense', 0),
