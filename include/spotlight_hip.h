@@ -166,8 +166,11 @@ int slk_rng_get_state(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
  * instead of the whole stream: a training call draws a chunk's negatives ahead of its passes, so the position the next
  * epoch's `shuffle` continues from (spotlight/factorization/implicit.py:213-216 -> torch_utils.py:46-47) is known while the
  * epoch's last passes are still running -- fit() draws that shuffle on a second ctx / stream beside them.  Falls back to
- * slk_rng_get_state when nothing was drawn since slk_rng_set_state / slk_shuffle_perm.  Failures of kernels that are still
- * running are reported by the next slk_rng_get_state. */
+ * slk_rng_get_state when nothing was drawn since slk_rng_set_state / slk_shuffle_perm.  Error flags: both calls REPORT AND
+ * CLEAR the ctx's sticky device-side flags (sampler ran out of words, abandoned persistent launch, abandoned sort look-back)
+ * -- each is reported exactly once, by whichever of the two calls reads it first; a flag raised by a kernel that is still
+ * running when slk_rng_get_state_sampled returns is reported by the next slk_rng_get_state (this package's fit() calls it,
+ * via check(), behind every epoch's loss read-back). */
 int slk_rng_get_state_sampled(slk_ctx *ctx, uint32_t *h_key, int32_t *pos);
 
 /* spotlight/sampling.py:8-36 sample_items(num_items, shape, random_state): `count` uniform

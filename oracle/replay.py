@@ -35,8 +35,13 @@ def rel_inf(a, b):
 
 
 def frac_outside(a, b, tol=2e-4):
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float((np.abs(a - b) > tol * max(np.abs(b).max(), 1e-30)).mean())
+    """Open-loop DRIFT of a table after a multi-epoch replay: ||a - b||_2 / ||b||_2.  (Round 4: the former "fraction of the
+    elements outside 2e-4" -- an outlier quota -- is gone; several epochs from zero accumulators are chaotic element by
+    element, torch's own dense and sparse paths end 6e-4 apart, so the quota-free statement is a norm: a handful of
+    sign-flipped lr-sized steps are invisible in it, a wrong update rule or a missed row is not.  The element-wise statements
+    are the first-step gradients at 1e-5 here and the closed-loop engine tests, tests/engine_checks.py.)"""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
 def replay_with_oracle(case, rec, tol=1e-5):
@@ -99,8 +104,9 @@ def replay_with_oracle(case, rec, tol=1e-5):
         ref = rec['final_%d' % t]
         got = o.p[t].reshape(ref.shape)
         if t >= 2:
-            bscale = max(np.abs(rec['final_2']).max(), np.abs(rec['final_3']).max(), 1e-30)
-            fr['final_%d' % t] = float((np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)) > 2e-4 * bscale).mean())
+            # (both bias tables against their JOINT norm, like their gradients above)
+            bnorm = max(np.sqrt(np.linalg.norm(np.asarray(rec['final_2'], np.float64)) ** 2 + np.linalg.norm(np.asarray(rec['final_3'], np.float64)) ** 2), 1e-30)
+            fr['final_%d' % t] = float(np.linalg.norm(np.asarray(got, np.float64).ravel() - np.asarray(ref, np.float64).ravel()) / bnorm)
         else:
             fr['final_%d' % t] = frac_outside(got, ref)
     errs['predict_all'] = rel_inf(o.predict(3), rec['predict_user3_all'])

@@ -402,31 +402,39 @@ class ImplicitFactorizationModel(object):
             device_epoch_shuffle(prep, self._random_state, n, d_perm, sources, prep_stream)
             return prep.rng_get_state()
 
-        state = shuffle_into(0, self._random_state.get_state())
-        for epoch_num in range(self._n_iter):
-            d_users, d_items = bufs[epoch_num % len(bufs)]
-            engine.rng_set_state(state)  # behind shuffle(e): the negatives of this epoch continue from here
-            ostruct = binding.as_struct()
-            engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
-                                  self._batch_size, self._loss, self._num_negative_samples,
-                                  mb_loss.data_ptr(), stream=stream)
-            binding.store_steps(ostruct.step)
-            state_after_epoch = engine.rng_get_state_sampled()  # waits for the epoch's last draw, not for its passes
-            if epoch_num + 1 < self._n_iter:
-                state = shuffle_into((epoch_num + 1) % 2, state_after_epoch)  # beside the last passes of this epoch
+        if self._n_iter <= 0:  # nothing to train: no shuffle is drawn, the RandomState stays where it is (as in the reference)
+            upload.result()
+            return
+        # self._random_state runs AHEAD of training (it sits behind the shuffle prepared for the next epoch); `consumed` is the
+        # state the reference would hold at this point -- restored on every way out, the normal one included
+        consumed = self._random_state.get_state()
+        try:
+            state = shuffle_into(0, consumed)
+            for epoch_num in range(self._n_iter):
+                d_users, d_items = bufs[epoch_num % len(bufs)]
+                engine.rng_set_state(state)  # behind shuffle(e): the negatives of this epoch continue from here
+                ostruct = binding.as_struct()
+                engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
+                                      self._batch_size, self._loss, self._num_negative_samples,
+                                      mb_loss.data_ptr(), stream=stream)
+                binding.store_steps(ostruct.step)
+                consumed = engine.rng_get_state_sampled()  # waits for the epoch's last draw, not for its passes
+                if epoch_num + 1 < self._n_iter:
+                    state = shuffle_into((epoch_num + 1) % 2, consumed)  # beside the last passes of this epoch
 
-            # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
-            epoch_loss = float(mb_loss.double().mean().item())
-            engine.check()  # errors the training kernels can only report through the ctx
+                # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
+                epoch_loss = float(mb_loss.double().mean().item())
+                engine.check()  # errors the training kernels can only report through the ctx
 
-            if verbose:
-                print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
+                if verbose:
+                    print('Epoch {}: loss {}'.format(epoch_num, epoch_loss))
 
-            if np.isnan(epoch_loss) or epoch_loss == 0.0:
-                # the reference stops here having consumed the stream up to this epoch's negatives only
-                self._random_state.set_state(state_after_epoch)
-                raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
-        self._random_state.set_state(state_after_epoch)
+                if np.isnan(epoch_loss) or epoch_loss == 0.0:
+                    # the reference stops here having consumed the stream up to this epoch's negatives only
+                    raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
+        finally:
+            upload.result()  # (joins the upload thread on the exceptional paths too)
+            self._random_state.set_state(consumed)
 
     def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):
         """The epoch loop for datasets of the reference's own scale (MovieLens-100K: 80 000 interactions per epoch): there an

@@ -283,6 +283,25 @@ def test_pipelined_fit_is_value_neutral(emu_device):
     check_pipelined_fit_is_value_neutral()
 
 
+def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(emu_device):
+    """n_iter = 0 is a no-op on both epoch loops (the large-epoch loop raised UnboundLocalError); a degenerate epoch
+    leaves the RandomState behind that epoch's negatives -- not behind the shuffle already prepared for the next one."""
+    rs = np.random.RandomState(12)
+    inter = Interactions(rs.randint(0, 90, 2000).astype(np.int32), rs.randint(0, 60, 2000).astype(np.int32), num_users=90, num_items=60)
+    for limit in (host._PIPELINE_MAX_DRAWS, 0):
+        old = host._PIPELINE_MAX_DRAWS
+        host._PIPELINE_MAX_DRAWS = limit
+        try:
+            model = ImplicitFactorizationModel(loss='bpr', embedding_dim=8, n_iter=0, batch_size=256, optimizer_func=_adagrad,
+                                               random_state=np.random.RandomState(7))
+            before = model._random_state.get_state()
+            model.fit(inter)
+            after = model._random_state.get_state()
+            assert np.array_equal(before[1], after[1]) and before[2] == after[2]
+        finally:
+            host._PIPELINE_MAX_DRAWS = old
+
+
 
 class _TwoTower(torch.nn.Module):
     """A representation that is NOT BilinearNet (the reference accepts any module with forward(user_ids, item_ids),

@@ -11,6 +11,17 @@ from oracle.replay import (case_from_rec, replay_bloom_with_oracle, replay_expli
                            replay_with_oracle)
 
 
+# Open-loop drift of the final tables after the recorded multi-epoch runs, as a NORM (||oracle - reference||_2 / ||reference||_2;
+# oracle/replay.py::frac_outside): no outlier quota.  Bounds = the engine tests' (tests/engine_checks.py); measured over the
+# fixtures: embedding tables <= 2.6e-4, bias tables <= 6.7e-2 (a PoolNet bias table of a few hundred near-zero elements).
+DRIFT_ROWS, DRIFT_BIAS = 5e-3, 0.2
+
+
+def assert_drift(drift, bias_keys=('final_2', 'final_3')):
+    for k, v in drift.items():
+        assert v <= (DRIFT_BIAS if k in bias_keys else DRIFT_ROWS), (k, v, drift)
+
+
 @pytest.mark.parametrize('name', golden_names())
 def test_oracle_replays_reference_run(name):
     rec = np.load(os.path.join(GOLDEN, name + '.npz'))
@@ -21,7 +32,7 @@ def test_oracle_replays_reference_run(name):
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss')
     assert step < 1e-5, errs          # north-star tolerance on identical minibatches
     assert errs['loss'] < 1e-4
-    assert max(frac.values()) <= 0.02, frac
+    assert_drift(frac)
 
 
 @pytest.mark.parametrize('name', golden_names('seq'))
@@ -33,7 +44,7 @@ def test_oracle_replays_reference_sequence_run(name):
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
     assert step < 1e-5, errs
     assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_some'] < 1e-5
-    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
+    assert_drift(frac, bias_keys=('final_1',))
 
 
 @pytest.mark.parametrize('name', golden_names('bloom'))
@@ -45,7 +56,7 @@ def test_oracle_replays_reference_bloom_run(name):
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
     assert step < 1e-5, errs
     assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_pairs'] < 1e-5
-    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
+    assert_drift(frac)
 
 
 @pytest.mark.parametrize('seed', [0, 42, 2 ** 31 + 5])
@@ -92,4 +103,4 @@ def test_oracle_replays_reference_explicit_run(name):
     step = max(v for k, v in errs.items() if k.startswith('grad0') or k == 'loss0')
     assert step < 1e-5, errs
     assert errs['loss'] < 1e-3 and errs['predict_all'] < 1e-5 and errs['predict_pairs'] < 1e-5
-    assert max(frac.values()) <= float(case.get('frac_tol', 0.05)), frac
+    assert_drift(frac)
