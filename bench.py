@@ -455,13 +455,67 @@ class Backend(object):
         self.side = None
 
     def init_dist(self, rank, world, local_rank):
+        """Process group + a self-check of everything the first multi-GPU run could trip over, BEFORE any table is allocated:
+        every failure names the rank, the device and the variable to look at, and exits non-zero within the time-out instead of
+        hanging (the driver's 8-GPU run is the first hardware run of this path: it must not be lost to a launcher problem)."""
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29400')
-        if self.kind == 'hip':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+        who = 'bench.py rank %d/%d (local rank %d)' % (rank, world, local_rank)
+
+        def die(code, msg):
+            sys.stderr.write('%s: %s\n' % (who, msg))
+            sys.stderr.flush()
+            os._exit(code)
+        timeout = datetime.timedelta(seconds=int(os.environ.get('SLK_BENCH_DIST_TIMEOUT', '180')))
+        try:
+            if self.kind == 'hip':
+                if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') != '0':
+                    die(4, 'HSA_ENABLE_IPC_MODE_LEGACY=%s: this host driver only supports dmabuf IPC; RCCL needs it unset or 0'
+                        % os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])
+                if torch.cuda.device_count() <= local_rank:
+                    die(4, 'LOCAL_RANK %d but only %d HIP device(s) visible (HIP_VISIBLE_DEVICES=%s)'
+                        % (local_rank, torch.cuda.device_count(), os.environ.get('HIP_VISIBLE_DEVICES')))
+                os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')  # a failed collective raises instead of hanging
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
+                                        timeout=timeout)
+            else:
+                dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 -- rendezvous / RCCL initialisation
+            die(4, 'init_process_group failed: %r (MASTER_ADDR=%s MASTER_PORT=%s WORLD_SIZE=%s)'
+                % (e, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'), os.environ.get('WORLD_SIZE')))
+        try:
+            # (1) every rank sits on its own device
+            ident = 'cpu:%d' % rank
+            if self.kind == 'hip':
+                props = torch.cuda.get_device_properties(local_rank)
+                ident = '%s/%s' % (getattr(props, 'uuid', None) or props.name, local_rank)
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            if self.kind == 'hip' and len(set(idents)) != world:
+                die(5, 'two ranks share a device: %s' % idents)
+            # (2) the collectives the sharded path issues, at their smallest: all_reduce, all_to_all_single with uneven splits
+            x = torch.full((4,), float(rank + 1), device=self.dev)
+            dist.all_reduce(x)
+            want = world * (world + 1) / 2.0
+            if abs(float(x[0].item()) - want) > 1e-3:
+                die(5, 'all_reduce returned %r, expected %r' % (float(x[0].item()), want))
+            send_counts = [(rank + p) % 3 + 1 for p in range(world)]
+            recv_counts = [(p + rank) % 3 + 1 for p in range(world)]
+            send = torch.cat([torch.full((c,), float(rank * 100 + p), device=self.dev) for p, c in enumerate(send_counts)])
+            recv = torch.empty(sum(recv_counts), device=self.dev)
+            dist.all_to_all_single(recv, send, recv_counts, send_counts)
+            got = recv.cpu().tolist()
+            exp = [float(p * 100 + rank) for p, c in enumerate(recv_counts) for _ in range(c)]
+            if got != exp:
+                die(5, 'all_to_all_single with uneven splits returned %r, expected %r' % (got, exp))
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            die(5, 'collective self-check failed: %r' % (e,))
         return dist
 
     def generator(self, seed):
