@@ -46,7 +46,7 @@ def main():
         eng.set_option('sort_xcd', xcd)
         eng.set_option('sort_debug', dbg)
         for label, kind, n, bits, seg in cases:
-            if (cfg == 0 or dbg) and n < (1 << 20):
+            if (cfg != 1 or dbg) and n < (1 << 20):
                 continue
             kt = torch.int64 if kind == 2 else torch.int32
             vt = torch.int64 if kind == 1 else torch.int32
@@ -64,6 +64,7 @@ def main():
             if out:
                 out.write(json.dumps(rec) + '\n')
     eng.set_option('sort_debug', 0)
+    eng.set_option('sort_cfg', 1)
     eng.close()
 
 

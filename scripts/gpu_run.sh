@@ -62,6 +62,12 @@ for l in sys.stdin:
       label=${args[0]}; script=${args[1]}; rest=("${args[@]:2}")
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace_$label -o t -- python $ROOT/scripts/$script "${rest[@]}" > $OUT/trace_$label.out 2> $OUT/trace_$label.err)
       echo "trace $label exit $?"; python scripts/summarize_any.py $OUT/trace_$label > $OUT/trace_$label.md; rm -rf $OUT/trace_$label; head -30 $OUT/trace_$label.md | cut -c1-200 ;;
+    fittrace)   # fittrace[:n[:epochs]]  -- kernel trace of the drop-in fit() + per-epoch anatomy
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $OUT/fittrace -o t -- python $ROOT/scripts/trace_fit_epochs.py "${args[@]}" > $OUT/fittrace.out 2> $OUT/fittrace.err)
+      echo "fittrace exit $?"; tail -1 $OUT/fittrace.out
+      db=$(find $OUT/fittrace -name "*.db" | head -1)
+      [ -n "$db" ] && python scripts/fit_epoch_breakdown.py "$db" > $OUT/fit_epoch_breakdown.txt 2>&1 && python scripts/timeline_gaps.py "$db" 100 >> $OUT/fit_epoch_breakdown.txt 2>&1
+      rm -rf $OUT/fittrace; head -60 $OUT/fit_epoch_breakdown.txt | cut -c1-200 ;;
     pmcx)    # pmcx:<label>:<counters, space separated>:<script>[:args]  -- one rocprofv3 --pmc pass of python scripts/<script>
       label=${args[0]}; ctrs=${args[1]}; script=${args[2]}; rest=("${args[@]:3}")
       (cd /tmp && timeout 900 rocprofv3 --pmc $ctrs -d $OUT/pmcx_$label -o t -- python $ROOT/scripts/$script "${rest[@]}" > $OUT/pmcx_$label.out 2> $OUT/pmcx_$label.err)

@@ -172,19 +172,59 @@ __device__ __forceinline__ unsigned long long rs_match(uint32_t d, int nbits, bo
 }
 
 // ---- one pass: tile -> ranks -> look-back -> LDS exchange -> scatter ----------------------------------------------------------
-// SINGLE: the whole input is one tile (no histogram, no look-back: bucket bases are the tile's own scan)
+// The counts of the segment's tiles before this one, for digit d: RS_LBW status words per round trip, back to the nearest tile
+// that knows its own inclusive count.  Returns false when a tile never published (the sort gives up: sticky flag).
+__device__ __forceinline__ bool rs_walk(const rs_args &a, const uint32_t *row0, uint32_t radix, uint32_t tis, uint32_t &before) {
+    int32_t t = (int32_t)tis - 1;
+    uint32_t spins = 0;
+    bool done = false;
+    while (!done) {
+        uint32_t v[RS_LBW];
+#pragma unroll
+        for (int i = 0; i < RS_LBW; ++i) {
+            const int32_t ti = t - i;
+            v[i] = ti >= 0 ? __hip_atomic_load(row0 + (size_t)ti * radix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+        int consumed = 0;
+#pragma unroll
+        for (int i = 0; i < RS_LBW; ++i) {
+            const uint32_t f = v[i] >> 30;
+            if (done || f == 0u || consumed != i) continue;
+            before += v[i] & RS_VAL_MASK;
+            ++consumed;
+            if (f == RS_INC) done = true;
+        }
+        t -= consumed;
+        if (!done && consumed == 0) {
+            if (++spins > RS_MAX_SPINS) {  // a tile before this one never published: give up, loudly
+                *a.abort_flag = 1;
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return true;
+}
+
+// SINGLE: the whole input is one tile (no histogram, no look-back: bucket bases are the tile's own scan).
+// (A dedicated WALKER wave -- the workgroup's last wave holds no keys, publishes the counts, walks back with four digits per
+// lane and forms the bucket offsets while the other seven rank -- was built and measured in round 4: 0.235 / 0.314 ms against
+// 0.227 / 0.304 ms for the C2 user / item sorts without it, profiles/r04_l_*.  The walk of the FIRST wave of tiles is a chain
+// through the tiles before them whoever walks it; the tiles behind find inclusive counts at once.  Removed.)
 template <class KeyT, class ValT, int THREADS, int KPT, int LOADER, bool SINGLE>
-__global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_args a) {
-    constexpr int WAVES = THREADS / 64, TILE = THREADS * KPT;
+__global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU_RANGE(4, 6) void k_rs_scatter(rs_args a) {
+    constexpr int WAVES = THREADS / 64, KW = WAVES, TILE = KW * 64 * KPT;
+    constexpr int OPT = (TILE + THREADS - 1) / THREADS;  // output positions per thread
     constexpr int XB = sizeof(KeyT) > sizeof(ValT) ? sizeof(KeyT) : sizeof(ValT);
-    __shared__ uint32_t s_cnt[WAVES * RS_RADIX];  // per wave: running digit counts, then the wave's first rank in the tile's bucket
-    __shared__ uint32_t s_lbase[RS_RADIX];        // first position of the bucket in the tile's sorted order
+    __shared__ uint32_t s_cnt[KW * RS_RADIX];     // per key wave: running digit counts, then the wave's first rank in the tile's bucket
+    __shared__ uint32_t s_lbase[RS_RADIX];        // the tile's digit counts, then the first position of the bucket in the tile's sorted order
     __shared__ uint32_t s_goff[RS_RADIX];         // output index of the bucket's element at tile position i = s_goff + i
     __shared__ uint32_t s_wsum[WAVES];
     __shared__ uint32_t s_tile;
     __shared__ __attribute__((aligned(16))) unsigned char s_x[(size_t)TILE * XB];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr bool is_key = true;  // (every wave holds keys)
     const int shift = a.shift[a.pass], nbits = a.width[a.pass];
     const uint32_t radix = 1u << nbits, dmask = radix - 1u;
     if (!SINGLE && threadIdx.x == 0) {
@@ -207,7 +247,8 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
             s_tile = atomicAdd(a.ticket + a.pass, 1u);
         }
     }
-    for (int i = threadIdx.x; i < WAVES * RS_RADIX; i += THREADS) s_cnt[i] = 0u;
+    for (int i = threadIdx.x; i < KW * RS_RADIX; i += THREADS) s_cnt[i] = 0u;
+    if (threadIdx.x < RS_RADIX) s_lbase[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t tile = SINGLE ? 0u : s_tile;
     if (tile == 0xffffffffu) return;  // (cannot happen: one workgroup per tile)
@@ -221,135 +262,119 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
     ValT val[KPT];
     uint32_t pos2[KPT / 2];  // tile positions (< 2^16), two per register
     const uint32_t e0 = (uint32_t)wave * 64u * KPT + (uint32_t)lane;
-    // every key load first, then every payload load: the keys are waited for alone, the payloads land behind the ranking
-    if (LOADER == RS_LOAD_PLAIN) {
+    if (is_key) {
+        // every key load first, then every payload load: the keys are waited for alone, the payloads land behind the ranking
+        if (LOADER == RS_LOAD_PLAIN) {
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t e = e0 + (uint32_t)j * 64u;
-            key[j] = e < cnt ? ((const KeyT *)a.kin)[t0 + e] : (KeyT)0;
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t e = e0 + (uint32_t)j * 64u;
+                key[j] = e < cnt ? ((const KeyT *)a.kin)[t0 + e] : (KeyT)0;
+            }
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t e = e0 + (uint32_t)j * 64u;
+                val[j] = e < cnt ? ((const ValT *)a.vin)[t0 + e] : (ValT)0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t e = e0 + (uint32_t)j * 64u;
+                key[j] = 0;
+                val[j] = 0;
+                if (e < cnt) rs_load<KeyT, ValT, LOADER>(a, t0 + e, seg, key[j], val[j]);
+            }
         }
+        // the tile's digit counts: published BEFORE the ranking, so the tiles behind this one add them up while it ranks
+        if (!SINGLE) {
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t e = e0 + (uint32_t)j * 64u;
-            val[j] = e < cnt ? ((const ValT *)a.vin)[t0 + e] : (ValT)0;
+            for (int j = 0; j < KPT; ++j)
+                if (e0 + (uint32_t)j * 64u < cnt) atomicAdd(&s_lbase[rs_digit<KeyT>(key[j], shift, dmask)], 1u);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const uint32_t e = e0 + (uint32_t)j * 64u;
             key[j] = 0;
             val[j] = 0;
-            if (e < cnt) rs_load<KeyT, ValT, LOADER>(a, t0 + e, seg, key[j], val[j]);
         }
     }
-    // the tile's digit counts, published BEFORE the ranking: the tiles behind this one add them up while it ranks
-    const uint32_t d = threadIdx.x;
+    if (!SINGLE) __syncthreads();
+
     uint32_t tcount = 0, before = 0;
-    if (!SINGLE) {
-        if (d < radix) s_lbase[d] = 0u;
-        __syncthreads();
+    uint32_t *wcnt = s_cnt + (is_key ? wave : 0) * RS_RADIX;
+    auto rank_keys = [&]() {
+        // ranks inside the wave's 64 * KPT elements, in element order (round j, then lane)
 #pragma unroll
-        for (int j = 0; j < KPT; ++j)
-            if (e0 + (uint32_t)j * 64u < cnt) atomicAdd(&s_lbase[rs_digit<KeyT>(key[j], shift, dmask)], 1u);
-        __syncthreads();
-        if (d < radix) {
+        for (int j = 0; j < KPT; ++j) {
+            if ((j & 1) == 0) pos2[j / 2] = 0u;
+            if ((uint32_t)wave * 64u * KPT + (uint32_t)j * 64u >= cnt) continue;  // (wave-uniform: a round past the tile's end)
+            const bool valid = e0 + (uint32_t)j * 64u < cnt;
+            const uint32_t dj = rs_digit<KeyT>(key[j], shift, dmask);
+            uint32_t r;
+            if (a.debug & 2) {  // measurement only: ranks from LDS atomics (unstable order)
+                r = valid ? atomicAdd(&wcnt[dj], 1u) : 0u;
+            } else {
+                const unsigned long long m = rs_match(dj, nbits, valid);
+                const int leader = m ? __ffsll((long long)m) - 1 : lane;
+                uint32_t first = 0;
+                if (m && lane == leader) first = atomicAdd(&wcnt[dj], (uint32_t)__popcll(m));
+                first = __shfl(first, leader);
+                r = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            }
+            pos2[j / 2] = (j & 1) ? (pos2[j / 2] | (r << 16)) : r;
+        }
+    };
+    {
+        const uint32_t d = threadIdx.x;
+        if (!SINGLE && d < radix) {
             tcount = s_lbase[d];
             __hip_atomic_store(a.status + (size_t)tile * radix + d, ((tis == 0 ? RS_INC : RS_AGG) << 30) | tcount, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-            // The digit owners (the first `radix` threads) walk back NOW, before they rank: the workgroup's other waves -- and the
-            // other workgroups of the CU -- rank meanwhile, so the walk's round trips are not idle time of the SIMDs.
+            // the digit owners (the first `radix` threads) walk back NOW, before they rank: the workgroup's other waves -- and
+            // the other workgroups of the CU -- rank meanwhile
             if (tis != 0 && !(a.debug & 1)) {
-                // look-back: the counts of the segment's tiles before this one, RS_LBW status words per round trip, back to the
-                // nearest tile that knows its own inclusive count
-                const uint32_t *row0 = a.status + (size_t)(tile - tis) * radix + d;
-                int32_t t = (int32_t)tis - 1;
-                uint32_t spins = 0;
-                bool done = false;
-                while (!done) {
-                    uint32_t v[RS_LBW];
+                rs_walk(a, a.status + (size_t)(tile - tis) * radix + d, radix, tis, before);
+                __hip_atomic_store(a.status + (size_t)tile * radix + d, (RS_INC << 30) | ((before + tcount) & RS_VAL_MASK), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        rank_keys();
+        __syncthreads();
+        // per digit: waves' counts -> the wave's first rank in the tile's bucket
+        if (d < radix) {
+            uint32_t run = 0;
+            for (int w = 0; w < KW; ++w) {
+                const uint32_t c = s_cnt[w * RS_RADIX + d];
+                s_cnt[w * RS_RADIX + d] = run;
+                run += c;
+            }
+            if (SINGLE) tcount = run;
+        }
+        const uint32_t lb = rs_block_excl_scan<THREADS>(tcount, s_wsum);
+        if (d < radix) {
+            uint32_t gbase = lb;
+            if (!SINGLE) gbase = a.base[((size_t)seg * a.npass + a.pass) * RS_RADIX + d];
+            s_lbase[d] = lb;
+            s_goff[d] = gbase + before - lb;
+        }
+    }
+    __syncthreads();
+    // keys through LDS into the tile's sorted order, then out: thread i takes tile positions i, i + THREADS, ...
+    KeyT *xk = reinterpret_cast<KeyT *>(s_x);
+    if (is_key) {
 #pragma unroll
-                    for (int i = 0; i < RS_LBW; ++i) {
-                        const int32_t ti = t - i;
-                        v[i] = ti >= 0 ? __hip_atomic_load(row0 + (size_t)ti * radix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    }
-                    int consumed = 0;
-#pragma unroll
-                    for (int i = 0; i < RS_LBW; ++i) {
-                        const uint32_t f = v[i] >> 30;
-                        if (done || f == 0u || consumed != i) continue;
-                        before += v[i] & RS_VAL_MASK;
-                        ++consumed;
-                        if (f == RS_INC) done = true;
-                    }
-                    t -= consumed;
-                    if (!done && consumed == 0) {
-                        if (++spins > RS_MAX_SPINS) {  // a tile before this one never published: give up, loudly
-                            *a.abort_flag = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-                __hip_atomic_store(a.status + (size_t)tile * radix + d, (RS_INC << 30) | ((before + tcount) & RS_VAL_MASK),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < KPT; ++j) {
+            if (e0 + (uint32_t)j * 64u < cnt) {
+                const uint32_t dj = rs_digit<KeyT>(key[j], shift, dmask);
+                const uint32_t pj = ((pos2[j / 2] >> ((j & 1) * 16)) & 0xffffu) + s_lbase[dj] + wcnt[dj];
+                pos2[j / 2] = (j & 1) ? ((pos2[j / 2] & 0xffffu) | (pj << 16)) : ((pos2[j / 2] & 0xffff0000u) | pj);
+                xk[pj] = key[j];
             }
         }
     }
-    // ranks inside the wave's 64 * KPT elements, in element order (round j, then lane)
-    uint32_t *wcnt = s_cnt + wave * RS_RADIX;
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        if ((j & 1) == 0) pos2[j / 2] = 0u;
-        if ((uint32_t)wave * 64u * KPT + (uint32_t)j * 64u >= cnt) continue;  // (wave-uniform: a round past the tile's end)
-        const bool valid = e0 + (uint32_t)j * 64u < cnt;
-        const uint32_t dj = rs_digit<KeyT>(key[j], shift, dmask);
-        uint32_t r;
-        if (a.debug & 2) {  // measurement only: ranks from LDS atomics (unstable order)
-            r = valid ? atomicAdd(&wcnt[dj], 1u) : 0u;
-        } else {
-            const unsigned long long m = rs_match(dj, nbits, valid);
-            const int leader = m ? __ffsll((long long)m) - 1 : lane;
-            uint32_t first = 0;
-            if (m && lane == leader) first = atomicAdd(&wcnt[dj], (uint32_t)__popcll(m));
-            first = __shfl(first, leader);
-            r = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        }
-        pos2[j / 2] = (j & 1) ? (pos2[j / 2] | (r << 16)) : r;
-    }
     __syncthreads();
-    // per digit: waves' counts -> the wave's first rank in the tile's bucket
-    if (d < radix) {
-        uint32_t run = 0;
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = s_cnt[w * RS_RADIX + d];
-            s_cnt[w * RS_RADIX + d] = run;
-            run += c;
-        }
-        if (SINGLE) tcount = run;
-    }
-    const uint32_t lb = rs_block_excl_scan<THREADS>(tcount, s_wsum);
-    if (d < radix) {
-        uint32_t gbase = lb;
-        if (!SINGLE) gbase = a.base[((size_t)seg * a.npass + a.pass) * RS_RADIX + d];
-        s_lbase[d] = lb;
-        s_goff[d] = gbase + before - lb;
-    }
-    __syncthreads();
-    // keys through LDS into the tile's sorted order, then out: lane i takes tile position i
-    KeyT *xk = reinterpret_cast<KeyT *>(s_x);
+    uint32_t gidx[OPT];
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        if (e0 + (uint32_t)j * 64u < cnt) {
-            const uint32_t dj = rs_digit<KeyT>(key[j], shift, dmask);
-            const uint32_t pj = ((pos2[j / 2] >> ((j & 1) * 16)) & 0xffffu) + s_lbase[dj] + wcnt[dj];
-            pos2[j / 2] = (j & 1) ? ((pos2[j / 2] & 0xffffu) | (pj << 16)) : ((pos2[j / 2] & 0xffff0000u) | pj);
-            xk[pj] = key[j];
-        }
-    }
-    __syncthreads();
-    uint32_t gidx[KPT];
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
+    for (int j = 0; j < OPT; ++j) {
         const uint32_t i = (uint32_t)j * THREADS + threadIdx.x;
         gidx[j] = 0;
         if (i < cnt) {
@@ -360,12 +385,14 @@ __global__ __launch_bounds__(THREADS) SLK_WAVES_PER_EU(4) void k_rs_scatter(rs_a
     }
     __syncthreads();
     ValT *xv = reinterpret_cast<ValT *>(s_x);
+    if (is_key) {
 #pragma unroll
-    for (int j = 0; j < KPT; ++j)
-        if (e0 + (uint32_t)j * 64u < cnt) xv[(pos2[j / 2] >> ((j & 1) * 16)) & 0xffffu] = val[j];
+        for (int j = 0; j < KPT; ++j)
+            if (e0 + (uint32_t)j * 64u < cnt) xv[(pos2[j / 2] >> ((j & 1) * 16)) & 0xffffu] = val[j];
+    }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
+    for (int j = 0; j < OPT; ++j) {
         const uint32_t i = (uint32_t)j * THREADS + threadIdx.x;
         if (i < cnt) ((ValT *)a.vout)[gidx[j]] = xv[i];
     }
@@ -441,7 +468,7 @@ static int rs_sort(slk_ctx *ctx, slk_buf &scratch, rs_args a, size_t n, size_t s
     if (bits > 8 * sizeof(KeyT)) bits = 8 * sizeof(KeyT);
     if (bits < 1) bits = 1;
     const bool single = LOADER == RS_LOAD_PLAIN && n <= 4096;
-    const int cfg = (!single && n >= ((size_t)1 << 20) && ctx->opt_sort_cfg != 0) ? 1 : 0;
+    const int cfg = (!single && n >= (size_t)ctx->opt_sort_big_min && ctx->opt_sort_cfg) ? 1 : 0;
     const unsigned tile = rs_tile_of(cfg);
     rs_plan pl;
     rs_make_plan(pl, n, single ? 0 : seg_len, bits, tile);

@@ -72,3 +72,19 @@ def test_sort_clobbering_input(be, n, bits):
     # even and odd pass counts with the input as the second buffer pair (the shuffle's and the bloom lists' sorts)
     check_sort(be, 0, n, bits, seed=n, clobber=True)
     check_sort(be, 1, n, bits, seed=n + 1, clobber=True)
+
+
+@pytest.mark.parametrize('cfg', [0, 1])
+def test_sort_big_tile_shapes_at_small_sizes(be, cfg):
+    """The large sorts' tile shapes (512 x 16) forced onto sizes the emulator can hold:
+    several tiles with look-back, segments, a short last tile, skewed digits, both payload widths."""
+    be.engine.set_option('sort_big_min', 1)
+    try:
+        check_sort(be, 0, 20000, 20, seed=21, cfg=cfg)
+        check_sort(be, 1, 3 * 9000 + 55, 13, seg_len=9000, seed=22, cfg=cfg)
+        check_sort(be, 0, 16000, 24, seed=23, skew=True, cfg=cfg)
+        check_sort(be, 2, 8000, 40, seed=24, cfg=cfg)
+        check_sort(be, 1, 15000, 32, seed=25, cfg=cfg, clobber=True)
+    finally:
+        be.engine.set_option('sort_big_min', 1 << 20)
+        be.engine.set_option('sort_cfg', 1)
