@@ -154,7 +154,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
  * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once),
- * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created). */
+ * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created),
+ * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
 
 /* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference
@@ -209,6 +210,18 @@ int slk_bilinear_train_explicit(slk_ctx *ctx, const slk_tables *tables, slk_opti
                                 const int64_t *d_users, const int64_t *d_items, const float *d_ratings,
                                 int64_t n, int64_t batch_size, int32_t loss, float *d_mb_loss, void *stream);
 
+/* The FIRST chunk of the next slk_bilinear_train call with these very arguments, prepared NOW (ABI 7): its negatives and
+ * sorts run on the ctx's second stream beside whatever `stream` still holds -- in this package's fit() the last passes of the
+ * epoch before, as soon as the next epoch's shuffled ids exist (spotlight/factorization/implicit.py:212-221 is the loop being
+ * pipelined; the draws are the ones `sample_items` would make first, sampling.py:34).  h_key (uint32[624]) / pos: optional --
+ * the MT19937 state the call's draws start from, written without waiting for the ctx's stream (the caller has waited for the
+ * last draw: slk_rng_get_state_sampled).  The next slk_bilinear_train must be that call (same ids, n, batch_size, loss,
+ * n_neg, no d_neg_in): anything else is refused -- the prepared draws are consumed -- until slk_rng_set_state.  A no-op for
+ * calls that would not pipeline their prep (one chunk, minibatches below "overlap_min_batch", the persistent route, option
+ * "overlap_prep" 0). */
+int slk_bilinear_prefetch(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, const int64_t *d_users,
+                          const int64_t *d_items, int64_t n, int64_t batch_size, int32_t loss, int32_t n_neg,
+                          const uint32_t *h_key, int32_t pos, void *stream);
 int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n,
                          int64_t batch_size, int32_t loss, int32_t n_neg, void *stream);
 

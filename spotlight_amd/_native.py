@@ -62,6 +62,8 @@ _PROTOTYPES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_bilinear_train_explicit': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    'slk_bilinear_prefetch': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     'slk_bilinear_reserve': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int64, C.c_int64,
                                        C.c_int32, C.c_int32, C.c_void_p]),
     'slk_bilinear_predict': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_void_p, C.c_int64,
@@ -242,6 +244,18 @@ class Engine(object):
         self._check(self._lib.slk_bilinear_train_explicit(
             self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, d_ratings, int(n), int(batch_size),
             LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_mb_loss, stream))
+
+    def bilinear_prefetch(self, tables, optim, d_users, d_items, n, batch_size, loss, n_neg, state=None, stream=0):
+        """Prepares the first chunk of the next bilinear_train call with these arguments on the ctx's second stream; `state`: the
+        numpy RandomState state its draws start from (written without waiting for the ctx's stream)."""
+        key, pos = None, 0
+        if state is not None:
+            key = np.ascontiguousarray(state[1], dtype=np.uint32)
+            pos = int(state[2])
+        self._check(self._lib.slk_bilinear_prefetch(
+            self._ctx, C.byref(tables), C.byref(optim), d_users, d_items, int(n), int(batch_size),
+            LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), int(n_neg),
+            key.ctypes.data_as(C.c_void_p) if key is not None else None, pos, stream))
 
     def bilinear_reserve(self, tables, optim, n, batch_size, loss, n_neg, stream=0):
         self._check(self._lib.slk_bilinear_reserve(

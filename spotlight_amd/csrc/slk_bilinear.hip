@@ -911,7 +911,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                const int64_t *d_users, const int64_t *d_items, int64_t n,
                                int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
                                int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only,
-                               const float *d_ratings = nullptr);
+                               const float *d_ratings = nullptr, bool prefetch_only = false);
 
 SLK_EXPORT int slk_bilinear_train(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim,
                                   const int64_t *d_users, const int64_t *d_items, int64_t n,
@@ -928,6 +928,28 @@ SLK_EXPORT int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, cons
     o = *optim;
     return bilinear_train_impl(ctx, tables, &o, nullptr, nullptr, n, batch_size, loss, n_neg, nullptr, nullptr,
                                nullptr, stream, true);
+}
+
+// The FIRST chunk of the next slk_bilinear_train call with these very arguments, prepared now: its negatives and sorts go to
+// the ctx's prep stream, beside whatever the caller's stream still holds (the passes of the epoch before).  fit() calls it as
+// soon as the next epoch's shuffled ids exist; h_key / pos (optional): the MT19937 state the call's draws start from, written
+// without waiting for the ctx's stream (the caller has waited for the last draw: slk_rng_get_state_sampled).  A no-op for
+// calls that would not pipeline their prep (a single chunk, minibatches below "overlap_min_batch", the persistent route).
+SLK_EXPORT int slk_bilinear_prefetch(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, const int64_t *d_users,
+                                     const int64_t *d_items, int64_t n, int64_t batch_size, int32_t loss, int32_t n_neg,
+                                     const uint32_t *h_key, int32_t pos, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (!optim) return slk_fail(ctx, SLK_EINVAL, "optim is NULL");
+    if (h_key) {
+        if (pos < 0 || pos > 624) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_prefetch: pos %d outside [0, 624]", pos);
+        SLK_HIP(ctx, hipSetDevice(ctx->device));
+        if (ctx->sampled_valid && ctx->ev_sampled) SLK_HIP(ctx, hipEventSynchronize(ctx->ev_sampled));
+        int rc = slk_rng_write_state(ctx, h_key, pos);
+        if (rc) return rc;
+    }
+    slk_optim o = *optim;
+    return bilinear_train_impl(ctx, tables, &o, d_users, d_items, n, batch_size, loss, n_neg, nullptr, nullptr, nullptr, stream,
+                               false, nullptr, true);
 }
 
 // ExplicitFactorizationModel.fit's minibatch loop (spotlight/factorization/explicit.py:213-236): the same
@@ -947,7 +969,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                const int64_t *d_users, const int64_t *d_items, int64_t n,
                                int64_t batch_size, int32_t loss, int32_t n_neg, const int64_t *d_neg_in,
                                int64_t *d_neg_out, float *d_mb_loss, void *stream, bool reserve_only,
-                               const float *d_ratings) {
+                               const float *d_ratings, bool prefetch_only) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
@@ -966,7 +988,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int NP = nn + 1;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
     if (n == 0) return SLK_OK;
-    if (!reserve_only && (!d_users || !d_items || !d_mb_loss))
+    if (!reserve_only && (!d_users || !d_items || (!d_mb_loss && !prefetch_only)))
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: NULL id/loss pointer");
     if (batch_size * (int64_t)NP >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "batch_size * (1 + negatives) must be < 2^31");
@@ -1500,6 +1522,39 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return rc;
     };
 
+    // a chunk prepared ahead by slk_bilinear_prefetch: it must be THIS call's first chunk (its negatives are already drawn)
+    const bool have0 = !prefetch_only && ctx->pf.valid;
+    if (have0 && (nsets != 2 || epoch_route || ctx->pf.users != (const void *)d_users || ctx->pf.items != (const void *)d_items ||
+                  ctx->pf.n != n || ctx->pf.bsz != bsz || ctx->pf.loss != (int)loss || ctx->pf.nn != nn || ctx->pf.nc0 != cb[1] || d_neg_in)) {
+        ctx->pf.valid = false;
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: a chunk was prepared ahead (slk_bilinear_prefetch) for another call; its "
+                                         "draws are consumed -- set the RNG state again");
+    }
+    if (!prefetch_only) ctx->pf.valid = false;
+    if (prefetch_only) {
+        ctx->pf.valid = false;
+        if (nsets != 2 || epoch_route || d_neg_in) return SLK_OK;  // such a call prepares in line: nothing to run ahead
+        if ((rc = slk_prep_stream_init(ctx))) return rc;
+        hipStream_t ps = ctx->prep_stream;
+        // the set the call before did NOT finish on: its last reader were the passes two chunks back (ev_done of that set)
+        const int set = ctx->last_pipe_set >= 0 ? (ctx->last_pipe_set ^ 1) : 0;
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));  // inputs produced on the caller's stream
+        SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+        SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set], 0));
+        if ((rc = do_sample(0, ctx->pb[set], ps))) return rc;
+        if (ctx->opt_overlap_prep == 1 && (rc = do_sort(0, ctx->pb[set], ps))) return rc;
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set], ps));
+        ctx->pf.valid = true;
+        ctx->pf.set = set;
+        ctx->pf.users = d_users;
+        ctx->pf.items = d_items;
+        ctx->pf.n = n;
+        ctx->pf.bsz = bsz;
+        ctx->pf.nc0 = cb[1];
+        ctx->pf.loss = (int)loss;
+        ctx->pf.nn = nn;
+        return SLK_OK;
+    }
     if (nsets == 1) {
         // everything in order on the caller's stream
         for (size_t ck = 0; ck < n_chunks; ++ck) {
@@ -1508,6 +1563,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if ((rc = do_chunk(ck, ctx->pb[0]))) return rc;
         }
         ctx->last_stream = s;
+        ctx->last_pipe_set = -1;
         return SLK_OK;
     }
     // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream.
@@ -1518,16 +1574,20 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     hipStream_t ps = ctx->prep_stream;
     SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
     SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
-    if ((rc = do_sample(0, ctx->pb[0], ps))) return rc;
-    if (sort_ahead && (rc = do_sort(0, ctx->pb[0], ps))) return rc;
-    SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[0], ps));
-    int set = 0;
+    int set = have0 ? ctx->pf.set : 0;
+    if (have0) ++ctx->stat_prefetched;
+    if (!have0) {
+        if ((rc = do_sample(0, ctx->pb[set], ps))) return rc;
+        if (sort_ahead && (rc = do_sort(0, ctx->pb[set], ps))) return rc;
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set], ps));
+    }
     for (size_t ck = 0; ck < n_chunks; ++ck, set ^= 1) {
         SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
         if (!sort_ahead && (rc = do_sort(ck, ctx->pb[set], s))) return rc;
         if (ck + 1 < n_chunks) {
-            // the other buffer set was last read by the passes of the previous chunk
-            if (ck > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
+            // the other buffer set was last read by the passes of the previous chunk (with a chunk prepared ahead: by the last
+            // passes of the call before this one)
+            if (ck > 0 || have0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
             if ((rc = do_sample(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             if (sort_ahead && (rc = do_sort(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
@@ -1535,6 +1595,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if ((rc = do_chunk(ck, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
     }
+    ctx->last_pipe_set = set ^ 1;  // (the loop's last increment undone: the set of the last chunk)
     ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
     return SLK_OK;
 }

@@ -176,6 +176,17 @@ struct slk_ctx {
     int64_t em_occ = -1, em_rows = 0, em_segments = -1;
     int em_dim = 0;
 
+    // slk_bilinear_prefetch: the first chunk of the NEXT training call, prepared (negatives + sorts) on the prep stream beside
+    // the passes of the call before it
+    struct {
+        bool valid = false;
+        int set = 0;
+        const void *users = nullptr, *items = nullptr;
+        int64_t n = 0, bsz = 0, nc0 = 0;
+        int loss = 0, nn = 0;
+    } pf;
+    int64_t stat_prefetched = 0;    // chunks prepared ahead that a training call took over (slk_ctx_get_stat)
+    int last_pipe_set = -1;         // buffer set of the last chunk of the last pipelined training call (-1: none yet)
     uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)
     uint32_t upart_gen = 0;         // user pass, long runs: likewise (slk_bilinear.hip)
     int64_t stat_user_long = 0, stat_item_long = 0;  // launches of the partial-writing forms (slk_ctx_get_stat)
@@ -275,6 +286,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
+// slk_rng.hip: numpy state -> d_rng without waiting for the ctx's stream (the caller knows no draw is in flight)
+int slk_rng_write_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos);
 
 static inline unsigned slk_bits_for(uint64_t max_value) {
     unsigned b = 1;

@@ -13,6 +13,7 @@
 //   k_rng_finalize  restores (key, pos) to exactly what numpy would hold after the draw:
 //                   the state block containing the last CONSUMED word, pos = offset + 1.
 #include <math.h>
+#include <stddef.h>
 
 #include "slk_common.h"
 
@@ -360,9 +361,28 @@ SLK_EXPORT int slk_rng_set_state(slk_ctx *ctx, const uint32_t *h_key, int32_t po
     // the stream the ctx's kernels were last enqueued on -- which may be the null stream (torch's default): a null handle is
     // a stream to wait for, not "no stream" (the state copy below no longer synchronises with it implicitly)
     SLK_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    // (the stream is idle: the sticky flags and the sampler's bookkeeping start afresh, as they always did here)
     ctx->sampled_valid = false;
+    ctx->pf.valid = false;
     slk_rng_dev h;
     memset(&h, 0, sizeof(h));
+    memcpy(h.key, h_key, sizeof(h.key));
+    h.pos = pos;
+    hipStream_t cs = slk_copy_stream(ctx);
+    SLK_HIP(ctx, hipMemcpyAsync(ctx->d_rng, &h, sizeof(h), hipMemcpyHostToDevice, cs));
+    SLK_HIP(ctx, hipStreamSynchronize(cs));
+    return SLK_OK;
+}
+
+// (key, pos) only: the sticky flags are not touched -- a kernel still running may raise one
+int slk_rng_write_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos) {
+    ctx->sampled_valid = false;
+    ctx->pf.valid = false;  // a chunk prepared ahead was drawn from the stream this call replaces
+    struct {
+        uint32_t key[SLK_MT_N];
+        int32_t pos;
+    } h;
+    static_assert(offsetof(slk_rng_dev, pos) == sizeof(uint32_t) * SLK_MT_N, "slk_rng_dev layout");
     memcpy(h.key, h_key, sizeof(h.key));
     h.pos = pos;
     // stream-ordered, not a null-stream hipMemcpy: that one would wait for (and hold up) the work of every other stream of

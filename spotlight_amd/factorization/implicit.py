@@ -20,6 +20,7 @@ _ENGINES = {}
 # at 10^8 interactions the two lanes time-slice the chip (train 71 ms + prepare 38 ms alone, 100 ms together:
 # profiles/r02_m_fit_pipelined_at_1e8_no_gain.json)
 _PIPELINE_MAX_DRAWS = 1 << 22
+_PREFETCH = True  # large epochs: the next epoch's first chunk is prepared beside the last passes of this one (test switch)
 
 
 def _engine_for(device):
@@ -410,9 +411,13 @@ class ImplicitFactorizationModel(object):
         consumed = self._random_state.get_state()
         try:
             state = shuffle_into(0, consumed)
+            engine.rng_set_state(state)  # behind shuffle(0): the negatives of the first epoch continue from here
+            pending_state = None
             for epoch_num in range(self._n_iter):
                 d_users, d_items = bufs[epoch_num % len(bufs)]
-                engine.rng_set_state(state)  # behind shuffle(e): the negatives of this epoch continue from here
+                if pending_state is not None:  # (_PREFETCH off: the state is set in line, behind this ctx's stream)
+                    engine.rng_set_state(pending_state)
+                    pending_state = None
                 ostruct = binding.as_struct()
                 engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
                                       self._batch_size, self._loss, self._num_negative_samples,
@@ -421,6 +426,15 @@ class ImplicitFactorizationModel(object):
                 consumed = engine.rng_get_state_sampled()  # waits for the epoch's last draw, not for its passes
                 if epoch_num + 1 < self._n_iter:
                     state = shuffle_into((epoch_num + 1) % 2, consumed)  # beside the last passes of this epoch
+                    # ... and so do the negatives + sorts of the next epoch's FIRST chunk (the one prep nothing else hides:
+                    # 2.1 of a 30 ms epoch at 2^25 interactions, profiles/r04_j_fit_epoch_breakdown.txt); the state behind
+                    # shuffle(e + 1) is written without waiting for this epoch's passes
+                    nu, ni = bufs[(epoch_num + 1) % 2]
+                    if _PREFETCH:
+                        engine.bilinear_prefetch(tables, binding.as_struct(), nu.data_ptr(), ni.data_ptr(), n, self._batch_size,
+                                                 self._loss, self._num_negative_samples, state=state, stream=stream)
+                    else:
+                        pending_state = state
 
                 # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
                 epoch_loss = float(mb_loss.double().mean().item())

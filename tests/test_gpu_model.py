@@ -273,6 +273,16 @@ def test_pipelined_fit_is_value_neutral_on_gpu():
     check_pipelined_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
 
 
+def test_prefetched_first_chunk_is_value_neutral_on_gpu():
+    """The next epoch's first chunk prepared on the ctx's second stream beside the last passes of this epoch
+    (slk_bilinear_prefetch; real streams, real overlap): same tables and RandomState, bit for bit."""
+    import torch
+    from spotlight_amd.factorization import implicit as host
+    from test_host_model import check_prefetched_first_chunk_is_value_neutral
+    engine = host._engine_for(torch.device('cuda', 0))
+    check_prefetched_first_chunk_is_value_neutral(engine, use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
+
+
 def test_pipelined_seq_fit_is_value_neutral_on_gpu():
     from test_host_seq_model import check_pipelined_seq_fit_is_value_neutral
     check_pipelined_seq_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())

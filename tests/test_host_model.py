@@ -283,6 +283,46 @@ def test_pipelined_fit_is_value_neutral(emu_device):
     check_pipelined_fit_is_value_neutral()
 
 
+def check_prefetched_first_chunk_is_value_neutral(engine, use_cuda=False, to_numpy=lambda w: w.detach().numpy()):
+    """Large-epoch fit(): the next epoch's first chunk (negatives + sorts) prepared beside the last passes of this one
+    (slk_bilinear_prefetch) against the same loop with the state set and the chunk prepared in line: tables, optimizer steps
+    and RandomState bit for bit.  Minibatches above the persistent route's limit in chunks of two, so that every call pipelines its prep."""
+    rs = np.random.RandomState(12)
+    inter = Interactions(rs.randint(0, 90, 9000).astype(np.int32), rs.randint(0, 60, 9000).astype(np.int32), num_users=90, num_items=60)
+    results = []
+    old = host._PIPELINE_MAX_DRAWS, host._PREFETCH
+    engine.set_option('chunk_interactions', 4096)
+    engine.set_option('overlap_min_batch', 0)
+    engine.set_option('overlap_prep', 1)  # (what _engine_for sets on the product's ctx)
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        for pf in (True, False):
+            host._PREFETCH = pf
+            before = engine.get_stat('prefetched_chunks')
+            for loss, kw in (('bpr', dict(optimizer_func=_adagrad)), ('adaptive_hinge', dict(num_negative_samples=3, optimizer_func=_adagrad)),
+                             ('pointwise', dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=0.01)))):
+                model = ImplicitFactorizationModel(loss=loss, embedding_dim=16, n_iter=3, batch_size=2048, use_cuda=use_cuda,
+                                                   random_state=np.random.RandomState(7), **kw)
+                model.fit(inter)
+                model.fit(inter)
+                st = model._random_state.get_state()
+                results.append([to_numpy(w).copy() for w in model._net.tables()] + [st[1].copy(), np.array(st[2])])
+            # the route under test really ran: 2 epochs of every 3-epoch fit() take over a prepared chunk
+            assert engine.get_stat('prefetched_chunks') - before == (3 * 2 * 2 if pf else 0)
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._PREFETCH = old
+        engine.set_option('chunk_interactions', 1 << 23)
+        engine.set_option('overlap_min_batch', 1 << 16)
+    half = len(results) // 2
+    for a, b in zip(results[:half], results[half:]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_prefetched_first_chunk_is_value_neutral(emu_device):
+    check_prefetched_first_chunk_is_value_neutral(emu_device)
+
+
 def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(emu_device):
     """n_iter = 0 is a no-op on both epoch loops (the large-epoch loop raised UnboundLocalError); a degenerate epoch
     leaves the RandomState behind that epoch's negatives -- not behind the shuffle already prepared for the next one."""
