@@ -155,7 +155,9 @@ int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
  * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once),
  * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created),
- * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over). */
+ * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over),
+ * "prefetch_pending" (what the last slk_bilinear_prefetch left for the next training call: 0 nothing -- it was a no-op --,
+ * 1 the first chunk, 2 the first chunk and the negatives of the whole call). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
 
 /* numpy RandomState.set_state()/get_state() hand-over of the MT19937 stream the reference
@@ -211,7 +213,9 @@ int slk_bilinear_train_explicit(slk_ctx *ctx, const slk_tables *tables, slk_opti
                                 int64_t n, int64_t batch_size, int32_t loss, float *d_mb_loss, void *stream);
 
 /* The FIRST chunk of the next slk_bilinear_train call with these very arguments, prepared NOW (ABI 7): its negatives and
- * sorts run on the ctx's second stream beside whatever `stream` still holds -- in this package's fit() the last passes of the
+ * sorts -- and the negatives of the call's OTHER chunks too, when the call draws fewer than 2^30 of them: one contiguous draw,
+ * after which slk_rng_get_state_sampled returns the stream position behind the whole call -- run on the ctx's second stream
+ * beside whatever `stream` still holds -- in this package's fit() the last passes of the
  * epoch before, as soon as the next epoch's shuffled ids exist (spotlight/factorization/implicit.py:212-221 is the loop being
  * pipelined; the draws are the ones `sample_items` would make first, sampling.py:34).  h_key (uint32[624]) / pos: optional --
  * the MT19937 state the call's draws start from, written without waiting for the ctx's stream (the caller has waited for the

@@ -178,6 +178,10 @@ class Engine(object):
             self.set_option(name.strip(), int(value))
 
     def close(self):
+        twin = getattr(self, '_prep_twin', None)  # the test harness's second ctx (factorization/implicit.py::_prep_lane_for)
+        if twin is not None:
+            self._prep_twin = None
+            twin.close()
         if getattr(self, '_ctx', None):
             self._lib.slk_ctx_destroy(self._ctx)
             self._ctx = None

@@ -158,7 +158,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta, &ctx->upart_meta};
+                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -257,6 +257,7 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "user_long_launches")) *value = ctx->stat_user_long;
     else if (!strcmp(name, "item_long_launches")) *value = ctx->stat_item_long;
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
+    else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);
     else return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_stat: unknown statistic %s", name);
     return SLK_OK;
 }

@@ -1188,11 +1188,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     // ---- prep of one chunk into buffer set `pb` (value-independent: ids only), in two halves:
     // the negatives (ALU/latency-bound MT19937 generator), then the sorts (HBM-bound)
+    // negatives of the whole call drawn ahead by slk_bilinear_prefetch (ctx->pf_neg): the chunks read theirs from it
+    const uint32_t *neg_all = nullptr;
     auto do_sample = [&](size_t ck, slk_prep_bufs &pb, hipStream_t s) -> int {
         int rc;
         const int64_t c0 = cb[ck];
         const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         uint32_t *neg32 = (uint32_t *)pb.neg32.p;
+        if (neg_all) return SLK_OK;
 
         // ---- negatives (sampling.py:34, one randint per minibatch == one contiguous draw)
         if (nn == 0) return SLK_OK;  // explicit feedback draws none
@@ -1218,7 +1221,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         const uint32_t nc = (uint32_t)(cb[ck + 1] - c0);
         const uint32_t nocc = nc * (uint32_t)NP;
         const int64_t *cu = d_users + c0, *ci = d_items + c0;
-        uint32_t *neg32 = (uint32_t *)pb.neg32.p;
+        const uint32_t *neg32 = neg_all ? neg_all + (size_t)c0 * nn : (const uint32_t *)pb.neg32.p;
 
         // ---- prep: sort interactions by (minibatch, user), occurrences by (minibatch, item)
         slk_prof_begin(ctx, SLK_K_PREP, s);
@@ -1541,9 +1544,20 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));  // inputs produced on the caller's stream
         SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
         SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set], 0));
-        if ((rc = do_sample(0, ctx->pb[set], ps))) return rc;
+        // The negatives of the WHOLE call in one draw (it is one contiguous draw however the call is chunked): the stream
+        // position behind them -- where the NEXT epoch's shuffle starts -- is then known an epoch ahead
+        // (slk_rng_get_state_sampled), and the training call itself draws nothing.  Calls of >= 2^30 draws keep drawing by chunk.
+        const bool all = nn > 0 && (uint64_t)n * (uint64_t)nn < ((uint64_t)1 << 30);
+        if (all) {
+            if ((rc = slk_ensure(ctx, ctx->pf_neg, (size_t)n * nn * 4))) return rc;
+            if ((rc = slk_sample_u32(ctx, tables->num_items, n * (int64_t)nn, (uint32_t *)ctx->pf_neg.p, nullptr, ps))) return rc;
+            neg_all = (const uint32_t *)ctx->pf_neg.p;
+        } else if ((rc = do_sample(0, ctx->pb[set], ps))) {
+            return rc;
+        }
         if (ctx->opt_overlap_prep == 1 && (rc = do_sort(0, ctx->pb[set], ps))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set], ps));
+        ctx->pf.all = all;
         ctx->pf.valid = true;
         ctx->pf.set = set;
         ctx->pf.users = d_users;
@@ -1576,6 +1590,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
     int set = have0 ? ctx->pf.set : 0;
     if (have0) ++ctx->stat_prefetched;
+    if (have0 && ctx->pf.all) neg_all = (const uint32_t *)ctx->pf_neg.p;
     if (!have0) {
         if ((rc = do_sample(0, ctx->pb[set], ps))) return rc;
         if (sort_ahead && (rc = do_sort(0, ctx->pb[set], ps))) return rc;
@@ -1583,6 +1598,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
     for (size_t ck = 0; ck < n_chunks; ++ck, set ^= 1) {
         SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
+        if (ck == 0 && neg_all && d_neg_out) {  // the caller wants the draws: they were made ahead, as uint32
+            hipLaunchKernelGGL(k_u32_to_i64, dim3(slk_grid_for(ctx, (size_t)n * nn, 256)), dim3(256), 0, s, neg_all, d_neg_out, (size_t)n * nn);
+            SLK_LAUNCH_CHECK(ctx, "k_u32_to_i64");
+        }
         if (!sort_ahead && (rc = do_sort(ck, ctx->pb[set], s))) return rc;
         if (ck + 1 < n_chunks) {
             // the other buffer set was last read by the passes of the previous chunk (with a chunk prepared ahead: by the last

@@ -45,10 +45,14 @@ _PREP = {}
 def _prep_lane_for(device):
     """(engine, raw stream) on which the NEXT epoch's shuffle and negatives are prepared while the current epoch trains
     (fit() of small datasets, see ImplicitFactorizationModel.fit): a second slk_ctx with its own scratch and a side HIP
-    stream.  Under the GPU-less test harness (one synchronous emulator engine) it is the training engine itself."""
+    stream.  Under the GPU-less test harness it is a second ctx of the same (synchronous, single-threaded) emulator library:
+    two ctxs, as on the GPU -- what the prep lane does to its RNG state must not reach the training ctx."""
     engine = _engine_for(device)
     if _native._LIB is None or engine._lib is not _native._LIB:
-        return engine, _stream_for(device)
+        twin = getattr(engine, '_prep_twin', None)
+        if twin is None:
+            twin = engine._prep_twin = _native.Engine(0, lib=engine._lib)
+        return twin, _stream_for(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
     if index not in _PREP:
         _PREP[index] = (_native.Engine(index), torch.cuda.Stream(device))
@@ -377,16 +381,24 @@ class ImplicitFactorizationModel(object):
         if self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS:
             d_users0, d_items0 = upload.result()
             return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose)
-        # Large epochs.  The stream is consumed in the reference's order -- shuffle of epoch e, negatives of epoch e (drawn
-        # inside the training call, a chunk of minibatches ahead of its passes), shuffle of epoch e + 1 -- so the position
-        # epoch e + 1's shuffle starts from is known as soon as epoch e's LAST draw has completed, about a chunk of passes
-        # before the epoch ends (slk_rng_get_state_sampled): that shuffle and its id gathers run on the second slk_ctx / HIP
-        # stream beside those passes, into the other pair of id buffers.  Same ids, same negatives, same RandomState
-        # afterwards, bit-identical tables (tests/test_host_model.py); at 2^25 interactions per epoch the shuffle is
-        # 5 of 37 ms.
+        # Large epochs: a three-stage pipeline over epochs (round 4), every stage consuming the ONE MT19937 stream in the
+        # reference's order -- shuffle(e), negatives(e), shuffle(e + 1), ... (implicit.py:212-221, torch_utils.py:46-47,
+        # sampling.py:34):
+        #   train lane   the passes of epoch e (slk_bilinear_train; it draws nothing: its negatives exist already)
+        #   prep stream  the negatives of the WHOLE epoch e + 1 and the sorts of its first chunk (slk_bilinear_prefetch), drawn
+        #                beside the last passes of epoch e as soon as epoch e's training call has been enqueued
+        #   prep lane    the shuffle + id gathers of epoch e + 2 on the second slk_ctx / HIP stream, from the stream position
+        #                behind epoch e + 1's negatives -- known an epoch ahead (slk_rng_get_state_sampled); on a worker thread,
+        #                because the numpy-exact shuffle reads counts back and would hold the host up
+        # so that in the steady state nothing but the passes is on the critical path.  Same ids, negatives and RandomState as
+        # the serial loop, bit-identical tables (tests/test_host_model.py, tests/test_gpu_model.py).  Before: 28.9 ms per epoch
+        # at 2^25 interactions, of which 3.3 ms shuffle and 2.1 ms first-chunk prep ran with no pass beside them
+        # (profiles/r04_m_fit_epoch_breakdown.txt).
         prep, prep_stream = _prep_lane_for(device)
+        threaded = _PREFETCH and prep is not engine and engine._lib is _native._LIB  # (the test harness's emulator is single-threaded)
+        n_slots = min(self._n_iter, 3 if _PREFETCH else 2)
         bufs = [(torch.empty(n, dtype=torch.int64, device=device), torch.empty(n, dtype=torch.int64, device=device))
-                for _ in range(2 if self._n_iter > 1 else 1)]
+                for _ in range(max(n_slots, 1))]
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         d_users0 = d_items0 = None
 
@@ -398,43 +410,81 @@ class ImplicitFactorizationModel(object):
                 if d_users0 is None:
                     d_users0, d_items0 = upload.result()
                 return [(d_users0, bufs[slot][0], 1), (d_items0, bufs[slot][1], 1)]
-            self._random_state.set_state(state)  # (device_epoch_shuffle's host fall-back draws from it)
+            fallback = np.random.RandomState()  # (device_epoch_shuffle's host fall-back draws from it: private to this job)
+            fallback.set_state(state)
+            if device.type == 'cuda':
+                torch.cuda.set_device(device)
             prep.rng_set_state(state)
-            device_epoch_shuffle(prep, self._random_state, n, d_perm, sources, prep_stream)
+            device_epoch_shuffle(prep, fallback, n, d_perm, sources, prep_stream)
             return prep.rng_get_state()
+
+        class _Job(object):
+            """shuffle_into on a worker thread (or at once, under the single-threaded test harness)."""
+
+            def __init__(self, slot, state):
+                self._out, self._err, self._thread = None, None, None
+                if threaded:
+                    import threading
+                    self._thread = threading.Thread(target=self._run, args=(slot, state))
+                    self._thread.start()
+                else:
+                    self._run(slot, state)
+
+            def _run(self, slot, state):
+                try:
+                    self._out = shuffle_into(slot, state)
+                except BaseException as e:  # noqa: BLE001 -- re-raised by join()
+                    self._err = e
+
+            def join(self):
+                if self._thread is not None:
+                    self._thread.join()
+                if self._err is not None:
+                    raise self._err
+                return self._out
 
         if self._n_iter <= 0:  # nothing to train: no shuffle is drawn, the RandomState stays where it is (as in the reference)
             upload.result()
             return
-        # self._random_state runs AHEAD of training (it sits behind the shuffle prepared for the next epoch); `consumed` is the
-        # state the reference would hold at this point -- restored on every way out, the normal one included
+        # self._random_state runs AHEAD of training; `consumed` is the state the reference would hold at this point -- restored on
+        # every way out, the normal one included
         consumed = self._random_state.get_state()
+        job = None
         try:
-            state = shuffle_into(0, consumed)
-            engine.rng_set_state(state)  # behind shuffle(0): the negatives of the first epoch continue from here
-            pending_state = None
+            state = shuffle_into(0, consumed)  # the first epoch's shuffle: the one nothing hides
+            if _PREFETCH:
+                engine.bilinear_prefetch(tables, binding.as_struct(), bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), n, self._batch_size,
+                                         self._loss, self._num_negative_samples, state=state, stream=stream)
+                after_negs = engine.rng_get_state_sampled()  # behind negatives(0) -- or `state` itself if nothing was drawn ahead
+                drawn_ahead = engine.get_stat('prefetch_pending') == 2
+            else:
+                engine.rng_set_state(state)
+                after_negs, drawn_ahead = None, False
+            if drawn_ahead and self._n_iter > 1:
+                job = _Job(1 % n_slots, after_negs)  # shuffle(1) beside the passes of epoch 0
             for epoch_num in range(self._n_iter):
-                d_users, d_items = bufs[epoch_num % len(bufs)]
-                if pending_state is not None:  # (_PREFETCH off: the state is set in line, behind this ctx's stream)
-                    engine.rng_set_state(pending_state)
-                    pending_state = None
+                d_users, d_items = bufs[epoch_num % n_slots]
                 ostruct = binding.as_struct()
                 engine.bilinear_train(tables, ostruct, d_users.data_ptr(), d_items.data_ptr(), n,
                                       self._batch_size, self._loss, self._num_negative_samples,
                                       mb_loss.data_ptr(), stream=stream)
                 binding.store_steps(ostruct.step)
-                consumed = engine.rng_get_state_sampled()  # waits for the epoch's last draw, not for its passes
+                # the state the reference holds at the end of this epoch: behind its negatives
+                consumed = after_negs if drawn_ahead else engine.rng_get_state_sampled()
                 if epoch_num + 1 < self._n_iter:
-                    state = shuffle_into((epoch_num + 1) % 2, consumed)  # beside the last passes of this epoch
-                    # ... and so do the negatives + sorts of the next epoch's FIRST chunk (the one prep nothing else hides:
-                    # 2.1 of a 30 ms epoch at 2^25 interactions, profiles/r04_j_fit_epoch_breakdown.txt); the state behind
-                    # shuffle(e + 1) is written without waiting for this epoch's passes
-                    nu, ni = bufs[(epoch_num + 1) % 2]
+                    nxt = (epoch_num + 1) % n_slots
+                    # shuffle(e + 1): prepared an epoch ago on the worker -- or now, beside the last passes of this epoch
+                    state = job.join() if job is not None else shuffle_into(nxt, consumed)
+                    job = None
                     if _PREFETCH:
-                        engine.bilinear_prefetch(tables, binding.as_struct(), nu.data_ptr(), ni.data_ptr(), n, self._batch_size,
-                                                 self._loss, self._num_negative_samples, state=state, stream=stream)
+                        engine.bilinear_prefetch(tables, binding.as_struct(), bufs[nxt][0].data_ptr(), bufs[nxt][1].data_ptr(), n,
+                                                 self._batch_size, self._loss, self._num_negative_samples, state=state, stream=stream)
+                        after_negs = engine.rng_get_state_sampled()
+                        drawn_ahead = engine.get_stat('prefetch_pending') == 2
+                        if drawn_ahead and epoch_num + 2 < self._n_iter:
+                            job = _Job((epoch_num + 2) % n_slots, after_negs)
                     else:
-                        pending_state = state
+                        engine.rng_set_state(state)
 
                 # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
                 epoch_loss = float(mb_loss.double().mean().item())
@@ -447,6 +497,11 @@ class ImplicitFactorizationModel(object):
                     # the reference stops here having consumed the stream up to this epoch's negatives only
                     raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
         finally:
+            if job is not None:
+                try:
+                    job.join()
+                except BaseException:  # noqa: BLE001 -- the exception already on its way out wins
+                    pass
             upload.result()  # (joins the upload thread on the exceptional paths too)
             self._random_state.set_state(consumed)
 

@@ -307,8 +307,8 @@ def check_prefetched_first_chunk_is_value_neutral(engine, use_cuda=False, to_num
                 model.fit(inter)
                 st = model._random_state.get_state()
                 results.append([to_numpy(w).copy() for w in model._net.tables()] + [st[1].copy(), np.array(st[2])])
-            # the route under test really ran: 2 epochs of every 3-epoch fit() take over a prepared chunk
-            assert engine.get_stat('prefetched_chunks') - before == (3 * 2 * 2 if pf else 0)
+            # the route under test really ran: every epoch of every 3-epoch fit() takes over a prepared chunk
+            assert engine.get_stat("prefetched_chunks") - before == (3 * 2 * 3 if pf else 0)
     finally:
         host._PIPELINE_MAX_DRAWS, host._PREFETCH = old
         engine.set_option('chunk_interactions', 1 << 23)
