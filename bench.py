@@ -624,8 +624,19 @@ def fit_end_to_end(be, args):
     t0 = time.perf_counter()
     model.fit(inter)
     be.sync()
-    dt = (time.perf_counter() - t0) / epochs
+    t_full = time.perf_counter() - t0
+    dt = t_full / epochs
+    # the same call with 2 epochs: the difference is 8 epochs of the steady state (no id upload, no first shuffle, no drain)
+    model._n_iter = 2
+    t0 = time.perf_counter()
+    model.fit(inter)
+    be.sync()
+    t_two = time.perf_counter() - t0
+    steady = (t_full - t_two) / (epochs - 2)
     return {'interactions_per_epoch': n, 'epochs_timed': epochs, 'seconds_per_epoch': dt, 'interactions_per_s': n / dt,
+            'steady_state_seconds_per_epoch': steady, 'steady_state_interactions_per_s': n / steady,
+            'steady_state_note': '(fit of 10 epochs - fit of 2 epochs) / 8: what every further epoch costs once the three-stage '
+                                 'pipeline runs (next epoch\'s negatives + first sorts, the shuffle after next, this epoch\'s passes)',
             'first_fit_seconds': first,
             'what': 'ImplicitFactorizationModel.fit(): id upload (once per fit), per epoch the numpy-exact device shuffle + id '
                     'gathers + %d minibatches + the loss read-back; first_fit_seconds also holds table initialisation on the '
