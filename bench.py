@@ -792,12 +792,26 @@ def main():
             prof_ov = eng.profile_read()
         finally:
             eng.set_option('overlap_prep', 0)
+    # The line's value: the same K minibatches once more, in line on one stream as in the first timed call, now that the process
+    # has ~5 K steps behind it.  The FIRST K-step call of a process (elapsed, above: what rounds 1-3 reported as the value) runs
+    # 4-5 % slower than every later one -- the GPU is still leaving its idle power state; 1 s of copy kernels in front takes half
+    # of that off, more training steps all of it (profiles/r04_o_first_call_of_a_process.txt) -- and a training run is thousands
+    # of steps long.  Both figures go into the line (first_call); the bracket is the same: barrier + sync, exactly K steps, sync.
+    elapsed_first = elapsed
+    barrier()
+    xg = xgmi_rows[0]
+    t3 = time.perf_counter()
+    run(W, K)
+    be.sync()
+    elapsed = time.perf_counter() - t3
+    barrier()
+    xgmi_rows[0] = xg
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
         dist.barrier()
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_first], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_first = float(t[0].item()), float(t[1].item())
         dist.all_reduce(mb_loss)  # per-rank shares of each global minibatch loss
         # what the process group itself observed: its size and every rank's device
         seen = [None] * dist.get_world_size()
@@ -899,8 +913,8 @@ def main():
                                   'other_ms_per_step': {k: prof_ov[k][1] / K for k in ('sample', 'prep')},
                                   'note': 'the same K minibatches with option overlap_prep = 1 (what fit() sets on its ctx): the next '
                                           'chunk\'s negatives + sorts on a second stream beside the passes; second call of its kind '
-                                          '(steady state of a training run; the timed region above is the first K-minibatch call of the '
-                                          'process, on one stream).  Beside the sorts every pass runs longer, the step shorter.'}
+                                          '(the line\'s value is the same K minibatches in order on one stream).  Beside the sorts every pass runs '
+                                          'longer, the step shorter.'}
         if prof['epoch'][0]:
             roof['persistent_epoch_kernel'] = {'launches': prof['epoch'][0], 'us_per_minibatch': prof['epoch'][1] / K * 1e3,
                                                'note': 'every minibatch of a chunk inside one cooperative launch (slk_epoch.hip)'}
@@ -972,6 +986,13 @@ def main():
                           'the other slices\' compute); no replicas' % world},
                'roofline': roof,
                'ms_per_step_with_kernel_timers': elapsed_profiled / K * 1e3,
+               'timed_region': 'exactly K minibatches between barrier + device sync, negatives, sorts and passes in order on one '
+                               'stream; the LAST K-step call of the run (after the W warm-up steps, the first K-step call, the '
+                               'instrumented one and the roofline.overlapped leg): the steady state of a training run',
+               'first_call': {'ms_per_step': elapsed_first / K * 1e3, 'interactions_per_s': world * K * B / elapsed_first,
+                              'note': 'the first K-step call of the process, straight after the W warm-up steps (what rounds 1-3 '
+                                      'printed as value): the GPU is still leaving its idle power state, '
+                                      'profiles/r04_o_first_call_of_a_process.txt'},
                'final_minibatch_loss': float(losses[-1])}
         if shard_check is not None:
             out['sharded_world1_consistency'] = shard_check

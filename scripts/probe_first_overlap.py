@@ -23,7 +23,7 @@ side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev));
 stream = torch.cuda.current_stream(dev).cuda_stream if mode != 'nullstream' else 0
 def run(first, n_mb):
     eng.bilinear_train(tb, op, users[first * B:].data_ptr(), items[first * B:].data_ptr(), n_mb * B, B, 'bpr', 1, mb[first:].data_ptr(), stream=stream)
-if mode == 'inline':
+if mode in ('inline', 'busy', 'busy1s', 'w5x2', 'legsfirst', 'idle'):
     eng.set_option('overlap_prep', 0)
 eng.rng_set_state(np.random.RandomState(1).get_state())
 eng.bilinear_reserve(tb, op, K * B, B, 'bpr', 1, stream=stream)
@@ -35,6 +35,17 @@ if mode == 'tiny':      # a tiny overlapped call first: 2 chunks of one minibatc
 elif mode == 'w9':      # warm-up long enough to be overlapped itself
     run(0, 9)
 elif mode == 'w5x2':    # the same 5-minibatch warm-up twice
+    run(0, W)
+elif mode == 'busy1s':  # ~1 s of copy kernels
+    n = 1 << 28
+    bufs = [torch.empty(n, device=dev) for _ in range(3)]
+    for _ in range(30):
+        eng.probe_stream(0, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), n, iters=10, stream=stream)
+elif mode == 'legsfirst':  # bench.py's secondary legs (two overlapped K-step calls) BEFORE the timed in-line call
+    eng.set_option('overlap_prep', 1)
+    run(W, K); run(W, K)
+    torch.cuda.synchronize(dev)
+    eng.set_option('overlap_prep', 0)
     run(0, W)
 elif mode == 'busy':    # ~100 ms of copy kernels right before the timed calls (clock / power state, not the ids)
     n = 1 << 28
