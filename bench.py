@@ -602,8 +602,8 @@ def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):
 def fit_end_to_end(be, args):
     """The drop-in API around the engine, end to end: ImplicitFactorizationModel.fit() (spotlight/factorization/implicit.py:184-252)
     on the workload's shapes -- per epoch the numpy-exact device shuffle, the id gathers, every minibatch, the loss read-back; the
-    ids are uploaded once per fit() (host -> HBM, included).  One warm fit() first (table initialisation, scratch), then a timed
-    fit() of 10 epochs (the reference's default n_iter)."""
+    ids are uploaded once per fit() (host -> HBM, included).  One warm fit() of 3 epochs first (table initialisation, scratch,
+    the epoch loop's id buffers), then a timed fit() of 10 epochs (the reference's default n_iter)."""
     from spotlight_amd.factorization.implicit import ImplicitFactorizationModel
     from spotlight_amd.interactions import Interactions
     n = int(args.fit_interactions)
@@ -613,7 +613,10 @@ def fit_end_to_end(be, args):
     opts = {'adagrad': dict(sparse=True, optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2)),
             'sparse_adam': dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=1e-2)),
             'adam_dense': dict(l2=1e-6)}[args.opt]
-    model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=args.dim, n_iter=1, batch_size=args.batch, use_cuda=True,
+    # (the warm fit runs 3 epochs: the large-epoch loop rotates three pairs of id buffers, and the timed fit should find all of
+    # them in torch's caching allocator like every fit() after a process's first -- fresh HIP allocations of that size cost
+    # 15-25 ms each, profiles/r04_t_fit_first_epoch_probe.txt)
+    model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=args.dim, n_iter=3, batch_size=args.batch, use_cuda=True,
                                        random_state=np.random.RandomState(1), **opts)
     t0 = time.perf_counter()
     model.fit(inter)

@@ -4,6 +4,8 @@ Same constructor, fit(), predict(), error messages and random-state behaviour as
 reference; everything inside the epoch loop (negative sampling, both forward passes, loss,
 backward, optimizer update) is one C-ABI call into csrc/libspotlight_hip.so per epoch.
 """
+import time
+
 import numpy as np
 import torch
 import torch.optim as optim
@@ -20,6 +22,7 @@ _ENGINES = {}
 # at 10^8 interactions the two lanes time-slice the chip (train 71 ms + prepare 38 ms alone, 100 ms together:
 # profiles/r02_m_fit_pipelined_at_1e8_no_gain.json)
 _PIPELINE_MAX_DRAWS = 1 << 22
+_DEFERRED_CHECK_MIN = 1 << 22  # ids per fit() from which the id-range checks run on worker threads beside the upload
 _PREFETCH = True  # large epochs: the next epoch's first chunk is prepared beside the last passes of this one (test switch)
 
 
@@ -134,6 +137,73 @@ class IdUpload(object):
         if self._err:
             raise self._err[0]
         return self._out
+
+
+class _Background(object):
+    """fn() on a worker thread (or at once); join() returns its value or re-raises what it raised.  (Module level on purpose: a
+    class created inside fit() would form a reference cycle through its closure and keep the epoch's id buffers -- GBs at
+    bench scale -- out of the caching allocator until the cyclic collector runs; the next fit() then paid 20-50 ms of
+    hipMalloc, profiles/r04_t_fit_first_epoch_probe.txt.)"""
+
+    def __init__(self, fn, threaded):
+        self._fn, self._out, self._err, self._thread = fn, None, None, None
+        if threaded:
+            import threading
+            self._thread = threading.Thread(target=self._run, name='spotlight-epoch-shuffle')
+            self._thread.start()
+        else:
+            self._run()
+
+    def _run(self):
+        try:
+            self._out = self._fn()
+        except BaseException as e:  # noqa: BLE001 -- re-raised by join()
+            self._err = e
+        self._fn = None
+
+    def join(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+
+class _Deferred(object):
+    """Every function of `fns` now, or each on a worker thread of its own; result() joins and re-raises the first error in
+    the order of `fns` (the order the serial checks would have raised in)."""
+
+    def __init__(self, fns, threaded):
+        self.threaded = bool(threaded)
+        self._errs, self._threads = [None] * len(fns), []
+
+        def work(k):
+            try:
+                fns[k]()
+            except BaseException as e:  # noqa: BLE001 -- re-raised by result()
+                self._errs[k] = e
+        for k in range(len(fns)):
+            if self.threaded:
+                import threading
+                self._threads.append(threading.Thread(target=work, args=(k,), name='spotlight-id-check'))
+                self._threads[-1].start()
+            else:
+                work(k)
+                if self._errs[k] is not None:
+                    break
+
+    def join(self):
+        for t in self._threads:
+            t.join()
+        self._threads = []
+
+    def result(self):
+        self.join()
+        for k, e in enumerate(self._errs):
+            if e is not None:
+                self._errs = [None] * len(self._errs)
+                raise e
 
 
 def _reject_negative_ids(ids):
@@ -336,17 +406,23 @@ class ImplicitFactorizationModel(object):
             self._binding = _OptimizerBinding(self._optimizer, tables, self._sparse)
         return self._binding
 
-    def _check_input(self, user_ids, item_ids, allow_items_none=False):
+    def _check_user_ids(self, user_ids):
         user_id_max = user_ids if isinstance(user_ids, int) else user_ids.max()
         if user_id_max >= self._num_users:
             raise ValueError('Maximum user id greater than number of users in model.')
         _reject_negative_ids(user_ids)
-        if allow_items_none and item_ids is None:
-            return
+
+    def _check_item_ids(self, item_ids):
         item_id_max = item_ids if isinstance(item_ids, int) else item_ids.max()
         if item_id_max >= self._num_items:
             raise ValueError('Maximum item id greater than number of items in model.')
         _reject_negative_ids(item_ids)
+
+    def _check_input(self, user_ids, item_ids, allow_items_none=False):
+        self._check_user_ids(user_ids)
+        if allow_items_none and item_ids is None:
+            return
+        self._check_item_ids(item_ids)
 
     def _slk_tables(self):
         return self._net.slk_tables()
@@ -359,27 +435,39 @@ class ImplicitFactorizationModel(object):
         if not self._initialized:
             self._initialize(interactions)
 
-        self._check_input(user_ids, item_ids)
-
-        if getattr(self, '_autograd_route', False):
+        n = len(user_ids)
+        nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
+        autograd = getattr(self, '_autograd_route', False)
+        small = self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS
+        # the id-range checks (implicit.py:169-182): four reductions over the host arrays, 12 ms at 2^25 ids.  On the large-epoch
+        # path they run on worker threads beside the id upload and the first epoch's shuffle; their verdict is collected before
+        # the first training call is enqueued (nothing the caller can observe has changed by then: the RandomState is restored,
+        # the tables are untouched).
+        check = _Deferred([lambda: self._check_user_ids(user_ids), lambda: self._check_item_ids(item_ids)],
+                          threaded=not (autograd or small) and n >= _DEFERRED_CHECK_MIN)
+        if not check.threaded:
+            check.result()
+        # diagnostic: set model._fit_timeline = [] before fit() to collect (label, host time) marks of the large-epoch loop
+        tl = getattr(self, '_fit_timeline', None)
+        mark = (lambda label: tl.append((label, time.perf_counter()))) if tl is not None else (lambda label: None)
+        mark('checks started')
+        if autograd:
             return self._fit_autograd(user_ids, item_ids, verbose)
         binding = self._bind()
         device = self._net.tables()[0].device
         engine = _engine_for(device)
         stream = _stream_for(device)
         tables = self._slk_tables()
-        n = len(user_ids)
         n_minibatches = (n + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 
         engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss,
                                 self._num_negative_samples, stream=stream)
+        mark('scratch reserved')
         # ids go to the device once (on a worker thread: the first epoch's permutation is drawn meanwhile); every epoch's
         # permutation x[shuffle_indices] of them (torch_utils.py:35-52) is computed there, bit-exact with numpy's Fisher-Yates
-        upload = IdUpload([user_ids, item_ids], device)
-        nn = self._num_negative_samples if self._loss == 'adaptive_hinge' else 1
-        if self._n_iter > 1 and n * nn <= _PIPELINE_MAX_DRAWS:
-            d_users0, d_items0 = upload.result()
+        if small:
+            d_users0, d_items0 = IdUpload([user_ids, item_ids], device).result()
             return self._fit_pipelined(binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose)
         # Large epochs: a three-stage pipeline over epochs (round 4), every stage consuming the ONE MT19937 stream in the
         # reference's order -- shuffle(e), negatives(e), shuffle(e + 1), ... (implicit.py:212-221, torch_utils.py:46-47,
@@ -401,6 +489,10 @@ class ImplicitFactorizationModel(object):
                 for _ in range(max(n_slots, 1))]
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
         d_users0 = d_items0 = None
+        # (the upload starts AFTER the epoch buffers exist: its worker allocates from the same caching allocator, and racing it
+        # for the blocks the previous fit() left there sent this thread to hipMalloc, 15 ms per pair of buffers)
+        mark('epoch buffers')
+        upload = IdUpload([user_ids, item_ids], device)
 
         def shuffle_into(slot, state):
             """bufs[slot] = ids[numpy-exact shuffle] drawn from `state` on the prep lane; returns the state behind the shuffle
@@ -418,40 +510,23 @@ class ImplicitFactorizationModel(object):
             device_epoch_shuffle(prep, fallback, n, d_perm, sources, prep_stream)
             return prep.rng_get_state()
 
-        class _Job(object):
-            """shuffle_into on a worker thread (or at once, under the single-threaded test harness)."""
-
-            def __init__(self, slot, state):
-                self._out, self._err, self._thread = None, None, None
-                if threaded:
-                    import threading
-                    self._thread = threading.Thread(target=self._run, args=(slot, state))
-                    self._thread.start()
-                else:
-                    self._run(slot, state)
-
-            def _run(self, slot, state):
-                try:
-                    self._out = shuffle_into(slot, state)
-                except BaseException as e:  # noqa: BLE001 -- re-raised by join()
-                    self._err = e
-
-            def join(self):
-                if self._thread is not None:
-                    self._thread.join()
-                if self._err is not None:
-                    raise self._err
-                return self._out
+        def _Job(slot, state):
+            # shuffle_into on a worker thread (or at once, under the single-threaded test harness)
+            return _Background(lambda: shuffle_into(slot, state), threaded)
 
         if self._n_iter <= 0:  # nothing to train: no shuffle is drawn, the RandomState stays where it is (as in the reference)
             upload.result()
+            check.result()
             return
+        mark('loop set up')
         # self._random_state runs AHEAD of training; `consumed` is the state the reference would hold at this point -- restored on
         # every way out, the normal one included
         consumed = self._random_state.get_state()
         job = None
         try:
             state = shuffle_into(0, consumed)  # the first epoch's shuffle: the one nothing hides
+            mark('shuffle 0')
+            check.result()  # raises what _check_input raised
             if _PREFETCH:
                 engine.bilinear_prefetch(tables, binding.as_struct(), bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), n, self._batch_size,
                                          self._loss, self._num_negative_samples, state=state, stream=stream)
@@ -462,6 +537,7 @@ class ImplicitFactorizationModel(object):
                 after_negs, drawn_ahead = None, False
             if drawn_ahead and self._n_iter > 1:
                 job = _Job(1 % n_slots, after_negs)  # shuffle(1) beside the passes of epoch 0
+            mark('prefetch 0')
             for epoch_num in range(self._n_iter):
                 d_users, d_items = bufs[epoch_num % n_slots]
                 ostruct = binding.as_struct()
@@ -469,6 +545,7 @@ class ImplicitFactorizationModel(object):
                                       self._batch_size, self._loss, self._num_negative_samples,
                                       mb_loss.data_ptr(), stream=stream)
                 binding.store_steps(ostruct.step)
+                mark('train %d enqueued' % epoch_num)
                 # the state the reference holds at the end of this epoch: behind its negatives
                 consumed = after_negs if drawn_ahead else engine.rng_get_state_sampled()
                 if epoch_num + 1 < self._n_iter:
@@ -476,6 +553,7 @@ class ImplicitFactorizationModel(object):
                     # shuffle(e + 1): prepared an epoch ago on the worker -- or now, beside the last passes of this epoch
                     state = job.join() if job is not None else shuffle_into(nxt, consumed)
                     job = None
+                    mark('shuffle %d joined' % (epoch_num + 1))
                     if _PREFETCH:
                         engine.bilinear_prefetch(tables, binding.as_struct(), bufs[nxt][0].data_ptr(), bufs[nxt][1].data_ptr(), n,
                                                  self._batch_size, self._loss, self._num_negative_samples, state=state, stream=stream)
@@ -483,11 +561,13 @@ class ImplicitFactorizationModel(object):
                         drawn_ahead = engine.get_stat('prefetch_pending') == 2
                         if drawn_ahead and epoch_num + 2 < self._n_iter:
                             job = _Job((epoch_num + 2) % n_slots, after_negs)
+                        mark('prefetch %d' % (epoch_num + 1))
                     else:
                         engine.rng_set_state(state)
 
                 # mean of per-minibatch loss.item() (implicit.py:240,245): one D2H per epoch; also waits for the epoch's kernels
                 epoch_loss = float(mb_loss.double().mean().item())
+                mark('epoch %d done' % epoch_num)
                 engine.check()  # errors the training kernels can only report through the ctx
 
                 if verbose:
@@ -503,7 +583,13 @@ class ImplicitFactorizationModel(object):
                 except BaseException:  # noqa: BLE001 -- the exception already on its way out wins
                     pass
             upload.result()  # (joins the upload thread on the exceptional paths too)
+            check.join()
             self._random_state.set_state(consumed)
+            # the epoch's device buffers go back to the caching allocator NOW (closures above hold cells, not tensors, once
+            # these names are cleared): the next fit() reuses them instead of allocating
+            del bufs[:]
+            d_perm = d_users0 = d_items0 = None
+            upload._out = None
 
     def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):
         """The epoch loop for datasets of the reference's own scale (MovieLens-100K: 80 000 interactions per epoch): there an

@@ -342,6 +342,32 @@ def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(
             host._PIPELINE_MAX_DRAWS = old
 
 
+def test_id_checks_on_worker_threads_raise_like_the_serial_ones(emu_device):
+    """Large fits run the id-range checks (implicit.py:169-182) on worker threads beside the upload and the first shuffle: the
+    same exceptions in the same order, before anything is trained, RandomState and tables as they were."""
+    rs = np.random.RandomState(3)
+    users, items = rs.randint(0, 90, 3000).astype(np.int32), rs.randint(0, 60, 3000).astype(np.int32)
+    good = Interactions(users, items, num_users=90, num_items=60)
+    old = host._PIPELINE_MAX_DRAWS, host._DEFERRED_CHECK_MIN
+    host._PIPELINE_MAX_DRAWS, host._DEFERRED_CHECK_MIN = 0, 1
+    try:
+        model = ImplicitFactorizationModel(loss='bpr', embedding_dim=8, n_iter=2, batch_size=512, optimizer_func=_adagrad,
+                                           random_state=np.random.RandomState(7))
+        model.fit(good)
+        for bad_users, bad_items, exc, text in ((users + 1000, items, ValueError, 'user id'), (users, items + 1000, ValueError, 'item id'),
+                                               (users + 1000, items + 1000, ValueError, 'user id'), (users, items - 70, IndexError, 'index out of range')):
+            before = model._random_state.get_state()
+            tables = [t.detach().cpu().numpy().copy() for t in model._net.tables()]
+            with pytest.raises(exc, match=text):
+                model.fit(Interactions(bad_users, bad_items, num_users=90, num_items=60))
+            after = model._random_state.get_state()
+            assert np.array_equal(before[1], after[1]) and before[2] == after[2]
+            for a, t in zip(tables, model._net.tables()):
+                assert np.array_equal(a, t.detach().cpu().numpy())
+        model.fit(good)  # and the model still trains
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._DEFERRED_CHECK_MIN = old
+
 
 class _TwoTower(torch.nn.Module):
     """A representation that is NOT BilinearNet (the reference accepts any module with forward(user_ids, item_ids),
