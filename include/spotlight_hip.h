@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 7
+#define SLK_ABI_VERSION 8
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -273,6 +273,15 @@ int slk_poolnet_predict(slk_ctx *ctx, const slk_tables *tables, const int64_t *d
 int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, void *stream);
 int slk_gather_rows_i64(slk_ctx *ctx, const int64_t *d_src, const int64_t *d_perm, int64_t n, int64_t row_len,
                         int64_t *d_dst, void *stream);
+/* The same x[shuffle_indices] for fit()'s TWO id arrays at once (torch_utils.py:46-52 applies one permutation to every
+ * array; factorization/implicit.py:212-215 passes user_ids and item_ids): slk_pack_id_pairs narrows the ids to 32 bits and
+ * interleaves them, d_pairs[2 r] = d_users[r], d_pairs[2 r + 1] = d_items[r] (once per fit(); ids < 2^32), and
+ * slk_gather_id_pairs writes d_users_out[r] = user of pair d_perm[r], d_items_out[r] = its item -- one random 8-byte read
+ * per interaction instead of two, the permutation read once. (ABI 8) */
+int slk_pack_id_pairs(slk_ctx *ctx, const int64_t *d_users, const int64_t *d_items, int64_t n, uint32_t *d_pairs,
+                      void *stream);
+int slk_gather_id_pairs(slk_ctx *ctx, const uint32_t *d_pairs, const int64_t *d_perm, int64_t n, int64_t *d_users_out,
+                        int64_t *d_items_out, void *stream);
 
 /* Interactions.to_sequence (spotlight/interactions.py:170-266): the interactions ordered by
  * np.lexsort((timestamps, user_ids)) and cut, per user, into left-zero-padded windows of

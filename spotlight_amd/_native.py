@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 7
+SLK_ABI_VERSION = 8
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -77,6 +77,8 @@ _PROTOTYPES = {
                                       C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_shuffle_perm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'slk_gather_rows_i64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_pack_id_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'slk_gather_id_pairs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_to_sequence_plan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
                                        C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_void_p]),
     'slk_to_sequence_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -294,6 +296,14 @@ class Engine(object):
 
     def gather_rows_i64(self, d_src, d_perm, n, row_len, d_dst, stream=0):
         self._check(self._lib.slk_gather_rows_i64(self._ctx, d_src, d_perm, int(n), int(row_len), d_dst, stream))
+
+    def pack_id_pairs(self, d_users, d_items, n, d_pairs, stream=0):
+        """d_pairs[2 r], d_pairs[2 r + 1] = (uint32) d_users[r], d_items[r] (include/spotlight_hip.h: slk_pack_id_pairs)."""
+        self._check(self._lib.slk_pack_id_pairs(self._ctx, d_users, d_items, int(n), d_pairs, stream))
+
+    def gather_id_pairs(self, d_pairs, d_perm, n, d_users_out, d_items_out, stream=0):
+        """Both id arrays of fit() through one permutation (slk_gather_id_pairs)."""
+        self._check(self._lib.slk_gather_id_pairs(self._ctx, d_pairs, d_perm, int(n), d_users_out, d_items_out, stream))
 
     # -- Interactions.to_sequence on the device (include/spotlight_hip.h: slk_to_sequence_*) --
     def to_sequence_plan(self, d_users, d_items, d_timestamps, ts_kind, n, num_users, max_sequence_length,

@@ -104,7 +104,13 @@ def device_epoch_shuffle(engine, random_state, n, d_perm, arrays, stream):
         engine.rng_set_state(random_state.get_state())
     if callable(arrays):
         arrays = arrays()
-    for d_src, d_dst, row_len in arrays:
+    for entry in arrays:
+        if len(entry) == 4:  # ('pairs', d_pairs, d_users_dst, d_items_dst): both id arrays from their packed form in one pass
+            _, d_pairs, d_users_dst, d_items_dst = entry
+            engine.gather_id_pairs(d_pairs.data_ptr(), d_perm.data_ptr(), n, d_users_dst.data_ptr(), d_items_dst.data_ptr(),
+                                   stream=stream)
+            continue
+        d_src, d_dst, row_len = entry
         engine.gather_rows_i64(d_src.data_ptr(), d_perm.data_ptr(), n, row_len, d_dst.data_ptr(), stream=stream)
 
 
@@ -488,7 +494,7 @@ class ImplicitFactorizationModel(object):
         bufs = [(torch.empty(n, dtype=torch.int64, device=device), torch.empty(n, dtype=torch.int64, device=device))
                 for _ in range(max(n_slots, 1))]
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
-        d_users0 = d_items0 = None
+        d_pairs = unpacked = None
         # (the upload starts AFTER the epoch buffers exist: its worker allocates from the same caching allocator, and racing it
         # for the blocks the previous fit() left there sent this thread to hipMalloc, 15 ms per pair of buffers)
         mark('epoch buffers')
@@ -498,17 +504,25 @@ class ImplicitFactorizationModel(object):
             """bufs[slot] = ids[numpy-exact shuffle] drawn from `state` on the prep lane; returns the state behind the shuffle
             (reading it waits for the prep lane's stream: the gathers are complete)."""
             def sources():
-                nonlocal d_users0, d_items0
-                if d_users0 is None:
-                    d_users0, d_items0 = upload.result()
-                return [(d_users0, bufs[slot][0], 1), (d_items0, bufs[slot][1], 1)]
+                # the uploaded ids, packed once per fit() into (user, item) pairs of 32 bits: a shuffled interaction is then
+                # ONE random 8-byte read for both arrays (slk_gather_id_pairs)
+                nonlocal d_pairs, unpacked
+                if d_pairs is None:
+                    unpacked = upload.result()  # (kept until the prep lane has been waited for, below)
+                    upload._out = None
+                    d_pairs = torch.empty(2 * n, dtype=torch.int32, device=device)
+                    prep.pack_id_pairs(unpacked[0].data_ptr(), unpacked[1].data_ptr(), n, d_pairs.data_ptr(), stream=prep_stream)
+                return [('pairs', d_pairs, bufs[slot][0], bufs[slot][1])]
             fallback = np.random.RandomState()  # (device_epoch_shuffle's host fall-back draws from it: private to this job)
             fallback.set_state(state)
             if device.type == 'cuda':
                 torch.cuda.set_device(device)
             prep.rng_set_state(state)
+            nonlocal unpacked
             device_epoch_shuffle(prep, fallback, n, d_perm, sources, prep_stream)
-            return prep.rng_get_state()
+            after = prep.rng_get_state()
+            unpacked = None  # the 64-bit copies of the ids: packed by now
+            return after
 
         def _Job(slot, state):
             # shuffle_into on a worker thread (or at once, under the single-threaded test harness)
@@ -588,7 +602,7 @@ class ImplicitFactorizationModel(object):
             # the epoch's device buffers go back to the caching allocator NOW (closures above hold cells, not tensors, once
             # these names are cleared): the next fit() reuses them instead of allocating
             del bufs[:]
-            d_perm = d_users0 = d_items0 = None
+            d_perm = d_pairs = unpacked = None
             upload._out = None
 
     def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):

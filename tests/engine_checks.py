@@ -992,6 +992,17 @@ def _check_shuffle_matches_numpy(be, n, seed, burn, rows):
         d_src, d_dst = be.alloc(src), be.alloc(np.zeros_like(src))
         eng.gather_rows_i64(be.ptr(d_src), be.ptr(d_perm), n, rows, be.ptr(d_dst), stream=be.stream)
         assert np.array_equal(be.get(d_dst), src[want])
+    if n:
+        # both id arrays of fit() through the permutation from their packed 32-bit form (slk_pack_id_pairs / slk_gather_id_pairs)
+        ids = np.random.RandomState(seed + 1)
+        users, items = ids.randint(0, 1 << 31, n).astype(np.int64), ids.randint(0, 1 << 31, n).astype(np.int64)
+        users[0], items[-1] = (1 << 32) - 1, 0  # the whole 32-bit range survives the narrowing
+        d_u, d_i, d_pairs = be.alloc(users), be.alloc(items), be.alloc(np.zeros(2 * n, dtype=np.uint32))
+        d_uo, d_io = be.alloc(np.zeros(n, dtype=np.int64)), be.alloc(np.zeros(n, dtype=np.int64))
+        eng.pack_id_pairs(be.ptr(d_u), be.ptr(d_i), n, be.ptr(d_pairs), stream=be.stream)
+        eng.gather_id_pairs(be.ptr(d_pairs), be.ptr(d_perm), n, be.ptr(d_uo), be.ptr(d_io), stream=be.stream)
+        assert np.array_equal(be.get(d_pairs).reshape(n, 2), np.stack([users, items], 1).astype(np.uint32))
+        assert np.array_equal(be.get(d_uo), users[want]) and np.array_equal(be.get(d_io), items[want])
     # the negatives drawn next continue the same stream
     d_neg = be.alloc(np.zeros(64, dtype=np.int64))
     eng.sample_items(1000, 64, be.ptr(d_neg), stream=be.stream)
