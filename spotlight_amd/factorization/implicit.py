@@ -412,23 +412,25 @@ class ImplicitFactorizationModel(object):
             self._binding = _OptimizerBinding(self._optimizer, tables, self._sparse)
         return self._binding
 
-    def _check_user_ids(self, user_ids):
+    def _check_user_id_max(self, user_ids):
         user_id_max = user_ids if isinstance(user_ids, int) else user_ids.max()
         if user_id_max >= self._num_users:
             raise ValueError('Maximum user id greater than number of users in model.')
-        _reject_negative_ids(user_ids)
 
-    def _check_item_ids(self, item_ids):
+    def _check_item_id_max(self, item_ids):
         item_id_max = item_ids if isinstance(item_ids, int) else item_ids.max()
         if item_id_max >= self._num_items:
             raise ValueError('Maximum item id greater than number of items in model.')
-        _reject_negative_ids(item_ids)
+
+    def _id_checks(self, user_ids, item_ids):
+        """The checks of _check_input as separate functions, in the order they raise (one reduction over a host array each)."""
+        return [lambda: self._check_user_id_max(user_ids), lambda: _reject_negative_ids(user_ids),
+                lambda: self._check_item_id_max(item_ids), lambda: _reject_negative_ids(item_ids)]
 
     def _check_input(self, user_ids, item_ids, allow_items_none=False):
-        self._check_user_ids(user_ids)
-        if allow_items_none and item_ids is None:
-            return
-        self._check_item_ids(item_ids)
+        checks = self._id_checks(user_ids, item_ids)
+        for f in (checks[:2] if allow_items_none and item_ids is None else checks):
+            f()
 
     def _slk_tables(self):
         return self._net.slk_tables()
@@ -449,7 +451,7 @@ class ImplicitFactorizationModel(object):
         # path they run on worker threads beside the id upload and the first epoch's shuffle; their verdict is collected before
         # the first training call is enqueued (nothing the caller can observe has changed by then: the RandomState is restored,
         # the tables are untouched).
-        check = _Deferred([lambda: self._check_user_ids(user_ids), lambda: self._check_item_ids(item_ids)],
+        check = _Deferred(self._id_checks(user_ids, item_ids),
                           threaded=not (autograd or small) and n >= _DEFERRED_CHECK_MIN)
         if not check.threaded:
             check.result()
