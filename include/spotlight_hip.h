@@ -155,6 +155,7 @@ int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
  * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once),
  * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created),
+ * "overlapped_chunks" (chunks whose negatives + sorts ran on the ctx's second stream beside the passes of the chunk before),
  * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over),
  * "prefetch_pending" (what the last slk_bilinear_prefetch left for the next training call: 0 nothing -- it was a no-op --,
  * 1 the first chunk, 2 the first chunk and the negatives of the whole call). */

@@ -256,6 +256,7 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "epoch_refused")) *value = ctx->epoch_refused ? 1 : 0;
     else if (!strcmp(name, "user_long_launches")) *value = ctx->stat_user_long;
     else if (!strcmp(name, "item_long_launches")) *value = ctx->stat_item_long;
+    else if (!strcmp(name, "overlapped_chunks")) *value = ctx->stat_overlapped;
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
     else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);
     else return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_stat: unknown statistic %s", name);

@@ -1610,6 +1610,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if ((rc = do_sample(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             if (sort_ahead && (rc = do_sort(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
+            ++ctx->stat_overlapped;
         }
         if ((rc = do_chunk(ck, ctx->pb[set]))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));

@@ -187,6 +187,7 @@ struct slk_ctx {
         bool all = false;           // the negatives of the WHOLE call were drawn ahead (into pf_neg), not only the first chunk's
     } pf;
     slk_buf pf_neg;                 // uint32[n * negatives per interaction] of such a call
+    int64_t stat_overlapped = 0;    // chunks whose negatives + sorts ran on the prep stream beside the chunk before's passes
     int64_t stat_prefetched = 0;    // chunks prepared ahead that a training call took over (slk_ctx_get_stat)
     int last_pipe_set = -1;         // buffer set of the last chunk of the last pipelined training call (-1: none yet)
     uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)

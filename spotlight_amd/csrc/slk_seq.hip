@@ -880,6 +880,7 @@ static int poolnet_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim 
             if (c0 > 0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));  // that set's last reader: the chunk before
             if ((rc = do_prep(c0 + chunk_seqs, set ^ 1, ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
+            ++ctx->stat_overlapped;
         }
         if ((rc = do_chunk(c0, set))) return rc;
         SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));

@@ -150,3 +150,87 @@ def test_c5_shard_sharded_world1_vs_fused(hip):
         dist.destroy_process_group()
         torch.cuda.empty_cache()
     print('C5-shard sharded(world 1) vs fused', out)
+
+
+# ---- round 4: the prep of the next chunk beside the passes is what every model's fit() runs -- PoolNet and
+# explicit feedback at bench size, overlapped against in line (the in-line path is the one the oracle tests above pin)
+
+def _two_runs(eng, run, tensors):
+    """run() from the same initial tensors with overlap_prep 0 and 1; returns the two lists of resulting tensors (+ extras)."""
+    import numpy as np
+    start = [t.clone() for t in tensors]
+    outs = []
+    for overlap in (0, 1):
+        for t, s in zip(tensors, start):
+            t.copy_(s)
+        eng.set_option('overlap_prep', overlap)
+        before = eng.get_stat('overlapped_chunks')
+        try:
+            eng.rng_set_state(np.random.RandomState(31).get_state())
+            extra = run()
+            torch.cuda.synchronize()
+            st = eng.rng_get_state()
+        finally:
+            eng.set_option('overlap_prep', 0)
+        assert (eng.get_stat('overlapped_chunks') - before >= 1) == bool(overlap)  # the route that was meant ran
+        outs.append([t.clone() for t in tensors] + list(extra) + [torch.from_numpy(st[1].astype('int64')), torch.tensor([st[2]])])
+    return outs
+
+
+def test_poolnet_multi_chunk_overlapped_equals_in_line_at_bench_size(hip):
+    """C4 shape (4096 sequences x 200 timesteps per minibatch, 1M items, dim 64, bpr, Adagrad), 9 minibatches + a short one in
+    ONE call = three prep chunks: tables, accumulators, per-minibatch losses, negatives and RNG state bit-identical whether the
+    next chunk's negatives + sorts run on the second stream beside the passes or in line."""
+    from spotlight_amd import _native
+    eng, dev, stream = hip
+    I, D, B, L, n_seq = 1_000_000, 64, 4096, 200, 9 * 4096 + 1000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(41)
+    E = torch.empty(I, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen)
+    E[0] = 0
+    bias = torch.empty(I, device=dev).normal_(0, 0.1, generator=gen)
+    s_e, s_b = torch.rand(I, D, device=dev, generator=gen) * 1e-3, torch.rand(I, device=dev, generator=gen) * 1e-3
+    seqs = torch.randint(1, I, (n_seq, L), device=dev, dtype=torch.int64, generator=gen)
+    seqs[::7, :40] = 0  # some left padding
+    tb = _native.make_seq_tables(E.data_ptr(), bias.data_ptr(), I, D)
+    mb = torch.zeros((n_seq + B - 1) // B, device=dev)
+    neg = torch.zeros(n_seq * L, dtype=torch.int64, device=dev)
+
+    def run():
+        op = _native.make_optim('adagrad', [None, s_e.data_ptr(), None, s_b.data_ptr()], None, lr=1e-2)
+        eng.poolnet_train(tb, op, 0, seqs.data_ptr(), n_seq, L, B, 'bpr', 1, mb.data_ptr(), d_neg_out=neg.data_ptr(), stream=stream)
+        return [mb.clone(), neg.clone()]
+    a, b = _two_runs(eng, run, [E, bias, s_e, s_b])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(a[4].min()) > 0 and int(a[5].max()) < I
+
+
+def test_explicit_multi_chunk_overlapped_equals_in_line_at_bench_size(hip):
+    """Explicit feedback (explicit.py:213-236) on the C2 tables, regression loss, Adagrad, 10 minibatches of 2^20 + a short one in
+    one call (two prep chunks: sorts only, there are no negatives): overlapped == in line, bit for bit."""
+    from spotlight_amd import _native
+    eng, dev, stream = hip
+    U, I, D, B, n = 10_000_000, 1_000_000, 64, 1 << 20, 10 * (1 << 20) + 54_321
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(43)
+    tables = [torch.empty(U, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen), torch.empty(I, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen),
+              torch.empty(U, device=dev).normal_(0, 0.1, generator=gen), torch.empty(I, device=dev).normal_(0, 0.1, generator=gen)]
+    state = [torch.rand(t.shape, device=dev, generator=gen) * 1e-3 for t in tables]
+    users = torch.randint(0, U, (n,), device=dev, dtype=torch.int64, generator=gen)
+    items = torch.randint(0, I, (n,), device=dev, dtype=torch.int64, generator=gen)
+    ratings = torch.randint(1, 6, (n,), device=dev, generator=gen).to(torch.float32)
+    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
+    mb = torch.zeros((n + B - 1) // B, device=dev)
+
+    def run():
+        op = _native.make_optim('adagrad', [t.data_ptr() for t in state], None, lr=1e-2)
+        eng.bilinear_train_explicit(tb, op, users.data_ptr(), items.data_ptr(), ratings.data_ptr(), n, B, 'regression', mb.data_ptr(),
+                                    stream=stream)
+        return [mb.clone()]
+    a, b = _two_runs(eng, run, tables + state)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert float(a[8].min()) > 0
+    del tables, state
+    torch.cuda.empty_cache()
