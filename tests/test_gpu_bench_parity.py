@@ -178,12 +178,12 @@ def _two_runs(eng, run, tensors):
 
 
 def test_poolnet_multi_chunk_overlapped_equals_in_line_at_bench_size(hip):
-    """C4 shape (4096 sequences x 200 timesteps per minibatch, 1M items, dim 64, bpr, Adagrad), 9 minibatches + a short one in
-    ONE call = three prep chunks: tables, accumulators, per-minibatch losses, negatives and RNG state bit-identical whether the
+    """C4 shape (4096 sequences x 200 timesteps per minibatch, 1M items, dim 64, bpr, Adagrad), 25 minibatches + a short one in
+    ONE call = several prep chunks: tables, accumulators, per-minibatch losses, negatives and RNG state bit-identical whether the
     next chunk's negatives + sorts run on the second stream beside the passes or in line."""
     from spotlight_amd import _native
     eng, dev, stream = hip
-    I, D, B, L, n_seq = 1_000_000, 64, 4096, 200, 9 * 4096 + 1000
+    I, D, B, L, n_seq = 1_000_000, 64, 4096, 200, 25 * 4096 + 1000
     gen = torch.Generator(device=dev)
     gen.manual_seed(41)
     E = torch.empty(I, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen)
@@ -207,11 +207,11 @@ def test_poolnet_multi_chunk_overlapped_equals_in_line_at_bench_size(hip):
 
 
 def test_explicit_multi_chunk_overlapped_equals_in_line_at_bench_size(hip):
-    """Explicit feedback (explicit.py:213-236) on the C2 tables, regression loss, Adagrad, 10 minibatches of 2^20 + a short one in
-    one call (two prep chunks: sorts only, there are no negatives): overlapped == in line, bit for bit."""
+    """Explicit feedback (explicit.py:213-236) on the C2 tables, regression loss, Adagrad, 20 minibatches of 2^20 + a short one in
+    one call (two prep chunks of 16 M interactions: sorts only, there are no negatives): overlapped == in line, bit for bit."""
     from spotlight_amd import _native
     eng, dev, stream = hip
-    U, I, D, B, n = 10_000_000, 1_000_000, 64, 1 << 20, 10 * (1 << 20) + 54_321
+    U, I, D, B, n = 10_000_000, 1_000_000, 64, 1 << 20, 20 * (1 << 20) + 54_321
     gen = torch.Generator(device=dev)
     gen.manual_seed(43)
     tables = [torch.empty(U, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen), torch.empty(I, D, device=dev).normal_(0, 0.5 / 8.0, generator=gen),
