@@ -144,10 +144,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         head's row + state with the record gather (k_item_pass<..., NPRE 4>: -10..-19 % on minibatches of
  *                         4096-65 536, profiles/r03_y_*); 0: never
  *   "user_lat_max_batch"  minibatches up to this size (default 2^14) take the latency-bound form of the pair-mode user pass
- *   "sort_cfg"            radix sort (csrc/slk_sort.hip): 1 (default) sorts of >= 2^20 pairs use tiles of 512 threads x 16 keys,
- *                         0 always 256 x 16;  "sort_xcd": 1 (default) a segment's tiles run on one XCD
- *   "eval_wg_per_cu"      resident workgroups per CU of the scoring sweep (csrc/slk_eval.hip; default 2, 0 = what its registers
- *                         allow)
+ *   "sort_big_min"        radix sort (csrc/slk_sort.hip): sorts of at least this many pairs (default 2^20) use tiles of 512 threads x
+ *                         16 keys, smaller ones 256 x 16 (test hook: both shapes at any size);  "sort_debug": measurement only,
+ *                         1-3 skip parts of a pass (profiles/r04_b_*; the output is then not sorted)
  *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */

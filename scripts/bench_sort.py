@@ -20,8 +20,7 @@ def main():
     ap.add_argument('--out', default='')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--cases', default='', help='comma-separated case indices (default: all)')
-    ap.add_argument('--cfgs', default='1,0', help='sort_cfg values to time')
-    ap.add_argument('--xcds', default='1', help='sort_xcd values to time')
+    ap.add_argument('--cfgs', default='1,0', help='tile shapes to time: 1 = 512 threads x 16 keys (what sorts of >= 2^20 pairs use), 0 = 256 x 16')
     ap.add_argument('--debug-sweep', action='store_true', help='also time the measurement-only forms (sort_debug 1, 2, 3: wrong results)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -41,9 +40,8 @@ def main():
     out = open(args.out, 'a') if args.out else None
     if args.cases:
         cases = [cases[int(i)] for i in args.cases.split(',')]
-    for cfg, dbg, xcd in [(int(c), 0, int(x)) for x in args.xcds.split(',') for c in args.cfgs.split(',')] + ([(1, 1, 1), (1, 2, 1), (1, 3, 1)] if args.debug_sweep else []):
-        eng.set_option('sort_cfg', cfg)
-        eng.set_option('sort_xcd', xcd)
+    for cfg, dbg in [(int(c), 0) for c in args.cfgs.split(',')] + ([(1, 1), (1, 2), (1, 3)] if args.debug_sweep else []):
+        eng.set_option('sort_big_min', 1 if cfg else 1 << 62)
         eng.set_option('sort_debug', dbg)
         for label, kind, n, bits, seg in cases:
             if (cfg != 1 or dbg) and n < (1 << 20):
@@ -58,13 +56,13 @@ def main():
             passes = (bits + 7) // 8
             pair = keys.element_size() + vals.element_size()
             traffic = n * (passes * 2 * pair + keys.element_size())
-            rec = {'case': label, 'sort_cfg': cfg, 'sort_debug': dbg, 'sort_xcd': xcd, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
+            rec = {'case': label, 'big_tiles': cfg, 'sort_debug': dbg, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
                    'gpairs_per_s': round(n / ms / 1e6, 3), 'tb_per_s_own_traffic': round(traffic / ms / 1e9, 3)}
             print(json.dumps(rec), flush=True)
             if out:
                 out.write(json.dumps(rec) + '\n')
     eng.set_option('sort_debug', 0)
-    eng.set_option('sort_cfg', 1)
+    eng.set_option('sort_big_min', 1 << 20)
     eng.close()
 
 

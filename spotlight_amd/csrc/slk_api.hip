@@ -194,14 +194,8 @@ SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value)
         ctx->opt_overlap_prep = (int)value;
     } else if (!strcmp(name, "overlap_min_batch") && value >= 0) {
         ctx->opt_overlap_min_batch = value;
-    } else if (!strcmp(name, "sort_cfg") && (value == 0 || value == 1)) {
-        ctx->opt_sort_cfg = (int)value;
-    } else if (!strcmp(name, "eval_wg_per_cu") && value >= 0 && value <= 8) {
-        ctx->opt_eval_wg_per_cu = (int)value;
     } else if (!strcmp(name, "sort_big_min") && value >= 1) {
         ctx->opt_sort_big_min = value;
-    } else if (!strcmp(name, "sort_xcd") && (value == 0 || value == 1)) {
-        ctx->opt_sort_xcd = (int)value;
     } else if (!strcmp(name, "sort_debug") && value >= 0 && value <= 3) {
         ctx->opt_sort_debug = (int)value;
     } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {

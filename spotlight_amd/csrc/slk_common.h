@@ -101,12 +101,7 @@ struct slk_ctx {
                                    // tracer stop agreeing with the untraced ones -- so a bare ctx keeps everything on one stream
     int64_t opt_overlap_min_batch = (int64_t)1 << 16;  // the prep overlaps the passes only for minibatches of at least this size
                                    // (measured: +3 % at 8192, where the passes are short latency-bound kernels; -1..-3 % at 65 536)
-    int opt_sort_cfg = 1;          // radix sort, sorts of >= sort_big_min pairs: 1 = tiles of 512 threads x 16 keys, 0 = 256 x 16 like the small sorts
-    int64_t opt_sort_big_min = (int64_t)1 << 20;
-    int opt_sort_xcd = 1;          // segmented sorts: 1 = a segment's tiles run on one XCD (slk_sort.hip), 0 = tiles in grid order
-    int opt_eval_wg_per_cu = 2;    // the scoring sweep's resident workgroups per CU (by LDS footprint; 0: what its registers allow, 3).
-                                   // Measured, 4096 x 10^6 scores: 2 -> 7.06 ms, 3 -> 8.31 ms (profiles/r04_h_*): the third workgroup's blocks
-                                   // push the other two's out of the L2
+    int64_t opt_sort_big_min = (int64_t)1 << 20;  // radix sort: sorts of at least this many pairs use tiles of 512 threads x 16 keys, smaller ones 256 x 16
     int opt_sort_debug = 0;        // measurement only: 1 the sort skips its look-back walks, 2 ranks from LDS atomics (results are wrong)
     int opt_item_grid_mult = 128;  // item pass: at most this many workgroups per CU (128 = one tile per workgroup at the C2 size, the
                                    // hardware balances the tail: item pass -2 % at C2 and the C5 shard, neutral at C3 / C4 / 65 536:

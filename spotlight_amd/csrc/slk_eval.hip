@@ -421,8 +421,9 @@ static int eval_gemm(slk_ctx *ctx, const slk_tables *tables, slk_gemm_args a, bo
     const int64_t chunks = (a.I + per - 1) / per;
     if (row_tiles > 65535) return slk_fail(ctx, SLK_EINVAL, "scoring: %lld rows per call, at most %d", (long long)a.R, 65535 * 32 * mt);
     size_t lds = ((size_t)(32 * mt + SLK_GEMM_IB) * SLK_GEMM_KS + 4 * 32 * mt) * 4;
-    // option "eval_wg_per_cu" (measurement): fewer resident workgroups per CU than the registers allow, by LDS footprint
-    if (ctx->opt_eval_wg_per_cu > 0 && lds < (size_t)160 * 1024 / ctx->opt_eval_wg_per_cu - 256) lds = (size_t)160 * 1024 / ctx->opt_eval_wg_per_cu - 256;
+    // two resident workgroups per CU, by LDS footprint: the registers would allow three, and three share the LDS bandwidth and
+    // the L2 worse (4096 x 10^6: 8.3 ms against 7.06, profiles/r04_h_bench_eval_{2,3}wg.json)
+    if (lds < (size_t)160 * 1024 / 2 - 256) lds = (size_t)160 * 1024 / 2 - 256;
     gemm_fn fn = count ? gemm_kernel<true>(mt, vec4) : gemm_kernel<false>(mt, vec4);
     if (lds > 48 * 1024) SLK_HIP(ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)chunks, (unsigned)row_tiles), dim3(256), lds, s, a);

@@ -468,7 +468,7 @@ static int rs_sort(slk_ctx *ctx, slk_buf &scratch, rs_args a, size_t n, size_t s
     if (bits > 8 * sizeof(KeyT)) bits = 8 * sizeof(KeyT);
     if (bits < 1) bits = 1;
     const bool single = LOADER == RS_LOAD_PLAIN && n <= 4096;
-    const int cfg = (!single && n >= (size_t)ctx->opt_sort_big_min && ctx->opt_sort_cfg) ? 1 : 0;
+    const int cfg = (!single && n >= (size_t)ctx->opt_sort_big_min) ? 1 : 0;
     const unsigned tile = rs_tile_of(cfg);
     rs_plan pl;
     rs_make_plan(pl, n, single ? 0 : seg_len, bits, tile);
@@ -505,7 +505,7 @@ static int rs_sort(slk_ctx *ctx, slk_buf &scratch, rs_args a, size_t n, size_t s
     a.abort_flag = &ctx->d_rng->sort_abort;
     a.debug = ctx->opt_sort_debug;
     a.nseg = pl.nseg;
-    a.xcd = (ctx->opt_sort_xcd && pl.nseg >= 2) ? 1 : 0;
+    a.xcd = pl.nseg >= 2 ? 1 : 0;
     void *kfinal = a.kout, *vfinal = a.vout;
     if (!single) {
         SLK_HIP(ctx, hipMemsetAsync(base, 0, pl.zero_bytes, s));

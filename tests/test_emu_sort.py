@@ -23,8 +23,8 @@ def check_sort(be, kind, n, bits, seg_len=0, seed=0, skew=False, cfg=None, clobb
         vals = vals | (np.arange(n, dtype=np.uint64) << np.uint64(33))
     k_in, v_in = be.alloc(keys), be.alloc(vals)
     k_out, v_out = be.alloc(np.zeros(n, kt)), be.alloc(np.zeros(n, vt))
-    if cfg is not None:
-        be.engine.set_option('sort_cfg', cfg)
+    if cfg is not None:  # 1: the large sorts' tiles (512 threads x 16 keys) whatever the size, 0: the small sorts' (256 x 16)
+        be.engine.set_option('sort_big_min', 1 if cfg else 1 << 62)
     be.engine.probe_sort(kind + (8 if clobber else 0), be.ptr(k_in), be.ptr(k_out), be.ptr(v_in), be.ptr(v_out), n, bits, seg_len=seg_len)
     mask = kt(top if bits >= 8 * keys.itemsize else (1 << bits) - 1)
     got_k, got_v = be.get(k_out), be.get(v_out)
@@ -78,7 +78,6 @@ def test_sort_clobbering_input(be, n, bits):
 def test_sort_big_tile_shapes_at_small_sizes(be, cfg):
     """The large sorts' tile shapes (512 x 16) forced onto sizes the emulator can hold:
     several tiles with look-back, segments, a short last tile, skewed digits, both payload widths."""
-    be.engine.set_option('sort_big_min', 1)
     try:
         check_sort(be, 0, 20000, 20, seed=21, cfg=cfg)
         check_sort(be, 1, 3 * 9000 + 55, 13, seg_len=9000, seed=22, cfg=cfg)
@@ -87,4 +86,3 @@ def test_sort_big_tile_shapes_at_small_sizes(be, cfg):
         check_sort(be, 1, 15000, 32, seed=25, cfg=cfg, clobber=True)
     finally:
         be.engine.set_option('sort_big_min', 1 << 20)
-        be.engine.set_option('sort_cfg', 1)

@@ -28,7 +28,7 @@ def test_sort_matches_numpy(be, kind, n, bits):
 def test_sort_segmented_chunk(be, kind, bits, cfg):
     # the training prep's shape: 8 minibatches of 2^20 pairs (the last one short), sorted on the id bits only
     check_sort(be, kind, 7 * (1 << 20) + 300001, bits, seg_len=1 << 20, seed=11, cfg=cfg)
-    be.engine.set_option('sort_cfg', 1)
+    be.engine.set_option('sort_big_min', 1 << 20)
 
 
 @pytest.mark.parametrize('cfg', [0, 1])
@@ -36,7 +36,7 @@ def test_sort_large_skewed(be, cfg):
     # 80 % of the keys equal: every tile's look-back meets runs of aggregates
     check_sort(be, 0, 5 * (1 << 20) + 17, 23, seed=12, skew=True, cfg=cfg)
     check_sort(be, 1, 3 * (1 << 20), 27, seg_len=1 << 20, seed=13, skew=True, cfg=cfg)
-    be.engine.set_option('sort_cfg', 1)
+    be.engine.set_option('sort_big_min', 1 << 20)
 
 
 @pytest.mark.parametrize('n,bits', [(4096, 13), (9000, 16), (1 << 21, 22), (1 << 21, 32)])
