@@ -242,7 +242,7 @@ def bench_scoring(args):
                'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'dtype': 'f32',
                'data': 'synthetic', 'vs_baseline': None,
                'config': {'workload': 'predict: one user against %d items, dim %d (C2 item table)' % (I, D)},
-               'roofline': {'bound': 'hbm', 'kernel': 'k_score_gemm<1, WRITE>', 'alg_bytes_per_call': alg, 'device_ms_per_call': dev_ms,
+               'roofline': {'bound': 'hbm', 'kernel': 'k_score_rows<1>', 'alg_bytes_per_call': alg, 'device_ms_per_call': dev_ms,
                             'achieved': alg / dev_ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / dev_ms / 1e6 / HBM_PEAK_GBS,
                             'calls_per_s_at_peak': HBM_PEAK_GBS * 1e9 / alg, 'traffic': None}}
     else:

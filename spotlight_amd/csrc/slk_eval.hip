@@ -281,6 +281,98 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(3) void k_score_gemm(slk_gemm
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A handful of rows against every item (predict(user): ONE row; implicit.py:277-311 with item_ids = None): a GEMV, bound by the
+// one pass over the item table -- 32 rows of matrix-core tile around a single live row buy nothing.  k_score_rows streams the
+// table in blocks of 256 item rows through registers into LDS (the next block's 64 KB are in flight while the current one is
+// used; two workgroups per CU = 128 KB per CU in flight) and every thread walks the score chain of ONE item against the NR
+// rows: acc[r] = fmaf(a_r[k], b[k], acc[r]), k ascending -- the chain of slk_chain_dot and of the MFMA, so the scores are the
+// same bits whichever kernel forms them.  Plain tables with dim % 4 == 0 (anything else takes k_score_gemm's general loader).
+// ---------------------------------------------------------------------------------------------------------------------------
+#define SLK_ROWS_IB 256  // items per block: one per thread
+
+template <int NR>
+__global__ __launch_bounds__(256) void k_score_rows(slk_gemm_args a) {
+    constexpr int IB = SLK_ROWS_IB, KC = SLK_GEMM_KC, KS = SLK_GEMM_KS;
+    constexpr int BREG = IB * KC / 256;  // staged floats per thread
+    HIP_DYNAMIC_SHARED(float, lds)
+    float *sB = lds;              // [IB][KS]
+    float *sA = sB + IB * KS;     // [NR][KC]
+    float *s_rb = sA + NR * KC;   // [NR]
+    const int tid = threadIdx.x;
+    const int D = a.D;
+    const int64_t i_begin = (int64_t)blockIdx.x * a.items_per_wg;
+    const int64_t i_end = (a.I - i_begin < a.items_per_wg) ? a.I : i_begin + a.items_per_wg;
+    if (i_begin >= i_end) return;
+    const int nkc = (D + KC - 1) / KC;
+    auto group_of = [&](int r) -> int64_t {
+        int64_t g = a.rowmap ? a.rowmap[r] : r;
+        return a.gmap ? a.gmap[g] : g;
+    };
+    if (tid < NR) s_rb[tid] = (tid < a.R && a.rbias) ? a.rbias[group_of(tid)] : 0.0f;
+    auto stage_a = [&](int kc) {
+        for (int e = tid; e < NR * KC; e += 256) {
+            const int row = e / KC, k = e - row * KC;
+            sA[e] = (row < a.R && kc + k < D) ? a.rep[(size_t)group_of(row) * D + kc + k] : 0.0f;
+        }
+    };
+    float breg[BREG];
+    auto fetch_b = [&](int64_t i0, int kc) {
+#pragma unroll
+        for (int u = 0; u < BREG / 4; ++u) {
+            const int q = tid + 256 * u, item = q / (KC / 4), k = (q - item * (KC / 4)) * 4;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (i0 + item < i_end && kc + k < D) v = *reinterpret_cast<const float4 *>(a.V + (size_t)(i0 + item) * D + kc + k);
+            breg[4 * u] = v.x;
+            breg[4 * u + 1] = v.y;
+            breg[4 * u + 2] = v.z;
+            breg[4 * u + 3] = v.w;
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int u = 0; u < BREG / 4; ++u) {
+            const int q = tid + 256 * u, item = q / (KC / 4), k = (q - item * (KC / 4)) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sB[item * KS + k + c] = breg[4 * u + c];
+        }
+    };
+    if (nkc == 1) stage_a(0);
+    fetch_b(i_begin, 0);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += IB) {
+        float acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = 0.0f;
+        for (int c = 0; c < nkc; ++c) {
+            const int kc = c * KC;
+            __syncthreads();  // the previous chunk's operands have been read
+            if (nkc > 1) stage_a(kc);
+            store_b();
+            __syncthreads();
+            {
+                const bool more_k = c + 1 < nkc;
+                const int64_t ni = more_k ? i0 : i0 + IB;
+                if (ni < i_end) fetch_b(ni, more_k ? kc + KC : 0);
+            }
+            const int kw = (D - kc < KC) ? D - kc : KC;
+            const float *pb = sB + tid * KS;
+#pragma unroll 8
+            for (int k = 0; k < kw; ++k) {
+                const float b = pb[k];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r] = fmaf(sA[r * KC + k], b, acc[r]);
+            }
+        }
+        const int64_t item = i0 + tid;
+        if (item < i_end) {
+            const float bias = a.bi[item];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (r < a.R) a.out[(size_t)r * a.I + item] = a.rbias ? (acc[r] + s_rb[r]) + bias : bias + acc[r];
+        }
+    }
+}
+
 // st[r] = score(representation of row r, its target item) on the vector unit (the same chain); a target that is on its own
 // group's exclusion list scores -FLT_MAX, as the reference's `predictions[excluded] = FLOAT_MAX` makes it
 template <int VEC, int G>
@@ -402,6 +494,19 @@ static int eval_gemm(slk_ctx *ctx, const slk_tables *tables, slk_gemm_args a, bo
     a.D = tables->dim;
     a.I = tables->num_items;
     if (a.R <= 0 || a.I <= 0) return SLK_OK;
+    if (!count && a.R <= 8 && a.ib.n_hash == 0 && a.D % 4 == 0) {
+        // a handful of rows: the streaming form (k_score_rows), two workgroups per CU each sweeping whole blocks of 256 items
+        int64_t per = (a.I + 2 * (int64_t)ctx->num_cus - 1) / (2 * (int64_t)ctx->num_cus);
+        per = (per + SLK_ROWS_IB - 1) / SLK_ROWS_IB * SLK_ROWS_IB;
+        a.items_per_wg = per;
+        const int nr = a.R == 1 ? 1 : (a.R == 2 ? 2 : (a.R <= 4 ? 4 : 8));
+        const size_t lds = ((size_t)SLK_ROWS_IB * SLK_GEMM_KS + (size_t)nr * SLK_GEMM_KC + nr) * 4;
+        gemm_fn fn = nr == 1 ? k_score_rows<1> : (nr == 2 ? k_score_rows<2> : (nr == 4 ? k_score_rows<4> : k_score_rows<8>));
+        SLK_HIP(ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3((unsigned)((a.I + per - 1) / per)), dim3(256), lds, s, a);
+        SLK_LAUNCH_CHECK(ctx, "k_score_rows");
+        return SLK_OK;
+    }
     // rows per workgroup: 64 (the item rows are streamed once per row tile; a 128-row tile was measured out: its four
     // accumulator tiles + the staged block leave no room for three workgroups per CU, and the sweep is bound by how many
     // blocks the CU has in flight), 32 for a handful (predict: one row -- a 32-row tile keeps the matrix-core time below the

@@ -1453,6 +1453,16 @@ def check_scores_are_the_fma_chain(be, D, U=70, I=700, seed=3):
     eng.bilinear_scores(dev.tables, be.ptr(d_users), len(users), be.ptr(rows), be.stream)
     for r, u in enumerate(users):
         assert np.array_equal(be.get(rows)[r], want[int(u)])
+    # every row count's kernel: the streaming form for a handful of rows (1, 2, <= 4, <= 8), one and two matrix-core tiles above
+    for n_rows in (2, 5, 8, 9, 40):
+        batch = rng.randint(0, U, n_rows).astype(np.int64)
+        rows = be.alloc(np.full((n_rows, I), np.nan, dtype=np.float32))
+        d_batch = be.alloc(batch)
+        eng.bilinear_scores(dev.tables, be.ptr(d_batch), n_rows, be.ptr(rows), be.stream)
+        got = be.get(rows)
+        for r, u in enumerate(batch):
+            w = ((f32_chain_dot(params[0][u][None, :], params[1]) + params[2][u]) + params[3]).astype(np.float32)
+            assert np.array_equal(got[r], w), (D, n_rows, r)
 
 
 def check_fused_ranks(be, D=24, U=90, I=333, n_rows=150, seed=5, ties=True):
