@@ -112,8 +112,8 @@ __device__ __forceinline__ float slk_gemm_item_elem(const float *V, const slk_bl
     return v;
 }
 
-template <int MT, bool COUNT, bool VEC4>
-__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(3) void k_score_gemm(slk_gemm_args a) {
+template <int MT, bool COUNT, bool VEC4, bool AREG>
+__global__ __launch_bounds__(256) SLK_WAVES_PER_EU(2) void k_score_gemm(slk_gemm_args a) {  // (two workgroups per CU by LDS footprint, eval_gemm: 2 waves per SIMD)
     constexpr int RT = 32 * MT, IB = SLK_GEMM_IB, KC = SLK_GEMM_KC, KS = SLK_GEMM_KS;
     constexpr int BREG = VEC4 ? IB * KC / 256 : 1;  // staged floats per thread (plain tables of dim % 4 == 0)
     HIP_DYNAMIC_SHARED(float, lds)
@@ -198,6 +198,16 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(3) void k_score_gemm(slk_gemm
     }
     if (nkc == 1) stage_a(0);
     fetch_b(i_begin, 0);
+#if defined(__HIPCC__)
+    float areg[AREG ? MT * (KC / 2) : 1];
+    if (AREG) {
+        __syncthreads();  // sA is complete (zero beyond D: the chain adds +0 for the padded depth)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < KC; k += 2) areg[m * (KC / 2) + k / 2] = sA[(m * 32 + (lane & 31)) * KS + (lane >> 5) + k];
+    }
+#endif
     for (int64_t i0 = i_begin; i0 < i_end; i0 += IB) {
         slk_f32x16 acc[MT];
 #pragma unroll
@@ -220,11 +230,22 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(3) void k_score_gemm(slk_gemm
 #if defined(__HIPCC__)
             const float *pa = sA + (lane & 31) * KS + (lane >> 5);
             const float *pb = sB + (wave * 32 + (lane & 31)) * KS + (lane >> 5);
-#pragma unroll 2
-            for (int k = 0; k < kw; k += 2) {
-                const float b = pb[k];
+            if (AREG) {
+                // the representations' operand lives in registers for the whole sweep (dim <= 64: one chunk): one LDS read per
+                // two matrix instructions instead of three
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m * 32 * KS + k], b, acc[m], 0, 0, 0);
+                for (int k = 0; k < KC; k += 2) {
+                    const float b = pb[k];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[m * (KC / 2) + k / 2], b, acc[m], 0, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int k = 0; k < kw; k += 2) {
+                    const float b = pb[k];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[m * 32 * KS + k], b, acc[m], 0, 0, 0);
+                }
             }
 #else
             // the test harness's host build: the same k-ordered fmaf chain per accumulator element, operands from LDS
@@ -480,10 +501,12 @@ enum { EV_ST = 37, EV_CNT = 39 };  // ctx->extra slots of the fused ranking (24,
 
 typedef void (*gemm_fn)(slk_gemm_args);
 
+// areg: the representations' operand in registers for the whole sweep (plain tables of dim <= 64)
 template <bool COUNT>
-static gemm_fn gemm_kernel(int mt, bool vec4) {
-    if (mt == 1) return vec4 ? k_score_gemm<1, COUNT, true> : k_score_gemm<1, COUNT, false>;
-    return vec4 ? k_score_gemm<2, COUNT, true> : k_score_gemm<2, COUNT, false>;
+static gemm_fn gemm_kernel(int mt, bool vec4, bool areg) {
+    if (areg) return mt == 1 ? k_score_gemm<1, COUNT, true, true> : k_score_gemm<2, COUNT, true, true>;
+    if (mt == 1) return vec4 ? k_score_gemm<1, COUNT, true, false> : k_score_gemm<1, COUNT, false, false>;
+    return vec4 ? k_score_gemm<2, COUNT, true, false> : k_score_gemm<2, COUNT, false, false>;
 }
 
 // one sweep of the item table per tile of 32 * mt rows.  `count`: compare with a.st and add into a.gt / a.eq, else store a.out
@@ -529,7 +552,8 @@ static int eval_gemm(slk_ctx *ctx, const slk_tables *tables, slk_gemm_args a, bo
     // two resident workgroups per CU, by LDS footprint: the registers would allow three, and three share the LDS bandwidth and
     // the L2 worse (4096 x 10^6: 8.3 ms against 7.06, profiles/r04_h_bench_eval_{2,3}wg.json)
     if (lds < (size_t)160 * 1024 / 2 - 256) lds = (size_t)160 * 1024 / 2 - 256;
-    gemm_fn fn = count ? gemm_kernel<true>(mt, vec4) : gemm_kernel<false>(mt, vec4);
+    const bool areg = vec4 && a.D <= SLK_GEMM_KC;
+    gemm_fn fn = count ? gemm_kernel<true>(mt, vec4, areg) : gemm_kernel<false>(mt, vec4, areg);
     if (lds > 48 * 1024) SLK_HIP(ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)chunks, (unsigned)row_tiles), dim3(256), lds, s, a);
     SLK_LAUNCH_CHECK(ctx, "k_score_gemm");
