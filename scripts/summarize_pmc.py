@@ -50,6 +50,11 @@ def main():
         out[k]['launches'] = max(v[1] for v in cs.values())
         if 'FETCH_SIZE' in out[k] and 'WRITE_SIZE' in out[k]:
             out[k]['hbm_bytes_per_launch'] = (2.0 * out[k]['FETCH_SIZE'] + out[k]['WRITE_SIZE']) * 1024.0
+        # derived: how long a request of the L2 to the memory side stays outstanding (Little: level / requests, in L2 clocks)
+        for kind in ('RD', 'WR'):
+            req, lvl = out[k].get('TCC_EA0_%sREQ_sum' % kind), out[k].get('TCC_EA0_%sREQ_LEVEL_sum' % kind)
+            if req and lvl:
+                out[k]['derived_%s_request_latency_clocks' % kind.lower()] = lvl / req
     with open(dst + '.json', 'w') as f:
         json.dump(out, f, indent=1, sort_keys=True)
     with open(dst + '.md', 'w') as f:
