@@ -1,7 +1,9 @@
 """Ranking / accuracy metrics -- the callers on the far side of predict(), with the signatures and
 semantics of spotlight/evaluation.py:9-244.
 
-mrr_score and sequence_mrr_score have a fast path for this package's models: instead of one
+precision_recall_score / sequence_precision_recall_score take their top-k sets from score rows formed on the GPU a tile of
+users at a time (torch.topk; a tie across a k boundary falls back to the reference's own per-user route, whose argsort
+breaks it in its own way).  mrr_score and sequence_mrr_score have a fast path for this package's models: instead of one
 predict() (a full pass over the item table) and one host scipy.stats.rankdata per user, the item
 table streams through the matrix cores once per 64 held-out items (exact-fp32 MFMA: the same
 scores as predict(), bit for bit) and every score is compared with its row's target score as it is
@@ -16,6 +18,7 @@ import scipy.stats as st
 FLOAT_MAX = np.finfo(np.float32).max
 
 _SCORE_BYTES = 256 << 20  # device memory for one tile of score rows
+_STATS = {'topk_device': 0, 'topk_reference_route': 0}  # keys whose top-k sets came from the device / fell back (tests read it)
 
 
 def _device_ranks(model, keys, num_items, exclude, targets):
@@ -64,6 +67,37 @@ def _device_ranks(model, keys, num_items, exclude, targets):
         ranks = ranks.cpu().numpy()
         bounds = np.cumsum([0] + [len(np.asarray(x).reshape(-1)) for x in targets[lo:hi]])
         out.extend(ranks[bounds[k]:bounds[k + 1]] for k in range(hi - lo))
+    return out
+
+
+def _device_topk_sets(model, keys, num_items, exclude, ks):
+    """For every key (user or sequence) and every k of `ks`: the SET of its k best items, train / preceding items pushed to
+    the end -- what `predictions.argsort()[:k]` of the reference holds (evaluation.py:150-155, 212-217; precision and recall
+    depend on the set only) -- from score rows formed on the GPU a tile of keys at a time (model._batch_scores: the bits of
+    predict()) and torch.topk.  Returns a list of (order, ok): `order` the kmax best items, best first; `ok` False where a
+    tie crosses one of the k boundaries (numpy's argsort breaks such ties in an unspecified way: the caller takes the
+    reference's own route for that key)."""
+    import torch
+    kmax = int(max(ks))
+    per_tile = max(1, _SCORE_BYTES // (4 * num_items))
+    out = []
+    for lo in range(0, len(keys), per_tile):
+        hi = min(lo + per_tile, len(keys))
+        scores = model._batch_scores(keys[lo:hi])
+        ex = [np.asarray(x).reshape(-1).astype(np.int64) for x in exclude[lo:hi]]
+        for x in ex:
+            if x.size and (x.min() < 0 or x.max() >= num_items):  # numpy's error on predictions[indices]
+                raise IndexError('index {} is out of bounds for axis 0 with size {}'.format(int(x.max()), num_items))
+        if any(x.size for x in ex):
+            er = torch.from_numpy(np.repeat(np.arange(hi - lo), [x.size for x in ex]).astype(np.int64)).to(scores.device)
+            ei = torch.from_numpy(np.concatenate(ex)).to(scores.device)
+            scores[er, ei] = -float(FLOAT_MAX)  # predictions = -scores; predictions[excluded] = FLOAT_MAX
+        vals, idx = torch.topk(scores, kmax + 1, dim=1, largest=True, sorted=True)
+        vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+        for r in range(hi - lo):
+            ok = all(vals[r, int(k) - 1] != vals[r, int(k)] for k in ks) and not np.isnan(vals[r]).any()
+            _STATS['topk_device' if ok else 'topk_reference_route'] += 1
+            out.append((idx[r, :kmax], ok))
     return out
 
 
@@ -121,8 +155,15 @@ def sequence_precision_recall_score(model, test, k=10, exclude_preceding=False):
     elements before them (evaluation.py:112-162)."""
     sequences = test.sequences[:, :-k]
     targets = test.sequences[:, -k:]
+    fast = None
+    if getattr(model, '_batch_scores', None) is not None and len(sequences) and 0 < k < model._num_items:
+        exclude = [sequences[i] if exclude_preceding else np.zeros(0, np.int64) for i in range(len(sequences))]
+        fast = _device_topk_sets(model, sequences, model._num_items, exclude, [k])
     pairs = []
     for i in range(len(sequences)):
+        if fast is not None and fast[i][1]:
+            pairs.append(_get_precision_recall(fast[i][0], targets[i], k))
+            continue
         predictions = -model.predict(sequences[i])
         if exclude_preceding:
             predictions[sequences[i]] = FLOAT_MAX
@@ -138,8 +179,20 @@ def precision_recall_score(model, test, train=None, k=10):
     train = train.tocsr() if train is not None else None
     ks = np.array([k]) if np.isscalar(k) else k
     precision, recall = [], []
+    fast = {}
+    if getattr(model, '_batch_scores', None) is not None and len(ks) and 0 < int(min(ks)) and int(max(ks)) < model._num_items:
+        users = np.array([u for u in range(test.shape[0]) if test.indptr[u + 1] > test.indptr[u]], dtype=np.int64)
+        if len(users):
+            exclude = [train[u].indices if train is not None else np.zeros(0, np.int64) for u in users]
+            fast = dict(zip(users.tolist(), _device_topk_sets(model, users, model._num_items, exclude, [int(x) for x in ks])))
     for user_id, row in enumerate(test):
         if not len(row.indices):
+            continue
+        order, ok = fast.get(user_id, (None, False))
+        if ok:
+            p, r = zip(*[_get_precision_recall(order, row.indices, x) for x in ks])
+            precision.append(p)
+            recall.append(r)
             continue
         predictions = -model.predict(user_id)
         if train is not None:

@@ -126,6 +126,16 @@ def check_factorization_fast_path(bloom=False, **kw):
         fast = ev.mrr_score(model, te, train=train)
         slow = ev.mrr_score(OnlyPredict(model), te, train=train)
         assert fast.shape == slow.shape and np.allclose(fast, slow, rtol=1e-12, atol=0)
+        # precision / recall at k: the top-k SETS from the score rows on the device == the per-user argsort route (rows 5 and 6
+        # tie: a boundary that cuts between them sends that user down the reference's own route)
+        before = dict(ev._STATS)
+        for k in (1, 5, np.array([1, 3, 10, 69])):
+            fp, fr = ev.precision_recall_score(model, te, train=train, k=k)
+            sp, sr = ev.precision_recall_score(OnlyPredict(model), te, train=train, k=k)
+            assert fp.shape == sp.shape and np.array_equal(fp, sp) and np.array_equal(fr, sr), k
+        assert ev._STATS['topk_device'] > before['topk_device']  # the device route was taken ...
+        if train is not None:
+            assert ev._STATS['topk_reference_route'] > before['topk_reference_route']  # ... and k = 69 of 70 cuts through the excluded tail
     return model
 
 
@@ -145,6 +155,10 @@ def check_sequence_fast_path(bloom=False, **kw):
         fast = ev.sequence_mrr_score(model, seq, exclude_preceding=excl)
         slow = ev.sequence_mrr_score(OnlyPredict(model), seq, exclude_preceding=excl)
         assert fast.shape == slow.shape and np.allclose(fast, slow, rtol=1e-12, atol=0)
+        for k in (1, 2, 3):
+            fp, fr = ev.sequence_precision_recall_score(model, seq, k=k, exclude_preceding=excl)
+            sp, sr = ev.sequence_precision_recall_score(OnlyPredict(model), seq, k=k, exclude_preceding=excl)
+            assert np.array_equal(fp, sp) and np.array_equal(fr, sr), (k, excl)
     return model
 
 
