@@ -1125,7 +1125,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         }
         if (nsets == 2 && !ctx->prep_warmed && nn > 0 && nc_max >= 4096) {
             // One tiny prep on the prep stream, ordered against the caller's stream by the pipeline's own events: whatever the
-            // runtime sets up the first time these kernels (sampler, rocPRIM sorts) run on a stream and the first time two
+            // runtime sets up the first time these kernels (sampler, sorts) run on a stream and the first time two
             // streams wait for each other's events then happens here and not inside the first overlapped training call
             // (measured: that call ran 0.81-0.87 instead of 0.75-0.77 ms per step; a prior overlapped call of two minibatches
             // removes it, profiles/r03_p_*).  The RNG state is put back afterwards.
