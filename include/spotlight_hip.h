@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 8
+#define SLK_ABI_VERSION 9
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -128,6 +128,8 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         package's fit() sets for its epochs: +1.5..4 % in the steady state of a run of training calls);
  *                         2: only the negatives; 0 (default of a bare ctx): everything in order on the caller's stream
  *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
+ *   "prefetch_wait"       measurement switch: 1 = slk_bilinear_prefetch's chunk waits for everything `stream` holds, as it did up
+ *                         to ABI 8 (default 0: it runs beside the passes `stream` still holds)
  *   "item_grid_mult"      item pass: workgroups per CU (default 128)
  *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
@@ -151,6 +153,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
+/* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --
+ * a ctx is shared by every model of a process on its device (spotlight_amd/_native.py: `with engine.options(...)`). */
+int slk_ctx_get_option(slk_ctx *ctx, const char *name, int64_t *value);
 /* Diagnostics of the last calls (no effect on results): "shuffle_sweeps" / "shuffle_fallbacks" (slk_shuffle_perm: full
  * fixpoint sweeps run, ranges that left the band and were redone), "epoch_refused" (the persistent launch was refused once),
  * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created),
@@ -220,7 +225,11 @@ int slk_bilinear_train_explicit(slk_ctx *ctx, const slk_tables *tables, slk_opti
  * pipelined; the draws are the ones `sample_items` would make first, sampling.py:34).  h_key (uint32[624]) / pos: optional --
  * the MT19937 state the call's draws start from, written without waiting for the ctx's stream (the caller has waited for the
  * last draw: slk_rng_get_state_sampled).  The next slk_bilinear_train must be that call (same ids, n, batch_size, loss,
- * n_neg, no d_neg_in): anything else is refused -- the prepared draws are consumed -- until slk_rng_set_state.  A no-op for
+ * n_neg, no d_neg_in): anything else is refused -- the prepared draws are consumed -- until slk_rng_set_state (a call that
+ * draws nothing -- d_neg_in given, explicit feedback -- drops the prepared chunk instead).  d_users / d_items must be COMPLETE
+ * when this call is made (written by work the caller has waited for): the prepared chunk does not wait for `stream`, so that it
+ * runs beside the passes `stream` still holds, not behind them (with "overlap_prep" 2 it does wait: sorts on `stream` read the
+ * draws of the running call).  A no-op for
  * calls that would not pipeline their prep (one chunk, minibatches below "overlap_min_batch", the persistent route, option
  * "overlap_prep" 0). */
 int slk_bilinear_prefetch(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, const int64_t *d_users,

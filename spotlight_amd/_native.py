@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 8
+SLK_ABI_VERSION = 9
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -52,6 +52,7 @@ _PROTOTYPES = {
     'slk_ctx_destroy': (None, [C.c_void_p]),
     'slk_last_error': (C.c_char_p, [C.c_void_p]),
     'slk_ctx_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    'slk_ctx_get_option': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -197,6 +198,35 @@ class Engine(object):
     def set_option(self, name, value):
         """include/spotlight_hip.h: slk_ctx_set_option (tuning knobs; results do not change)."""
         self._check(self._lib.slk_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name):
+        """include/spotlight_hip.h: slk_ctx_get_option (the current value of a tuning knob)."""
+        v = C.c_int64(0)
+        self._check(self._lib.slk_ctx_get_option(self._ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def options(self, **values):
+        """Context manager: the given options for the duration of the block, the previous values afterwards -- on every way out.
+        A ctx is shared by every model of a process on its device (factorization/implicit.py::_engine_for), so a caller that
+        wants a route for ITS work sets it for that work only:
+
+            with engine.options(overlap_prep=1):
+                ... training calls ...
+        """
+        engine = self
+
+        class _Scoped(object):
+            def __enter__(self_):
+                self_.saved = [(k, engine.get_option(k)) for k in values]
+                for k, v in values.items():
+                    engine.set_option(k, v)
+                return engine
+
+            def __exit__(self_, *exc):
+                for k, v in reversed(self_.saved):
+                    engine.set_option(k, v)
+                return False
+        return _Scoped()
 
     def get_stat(self, name):
         """include/spotlight_hip.h: slk_ctx_get_stat (diagnostics of the last calls)."""

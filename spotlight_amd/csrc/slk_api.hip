@@ -133,8 +133,14 @@ SLK_EXPORT int slk_ctx_create(slk_ctx **out, int device_id) {
         return slk_fail(nullptr, SLK_EIO, "slk_ctx_create: hipSetDevice(%d) failed", device_id);
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->num_cus = prop.multiProcessorCount;
+        // LDS a workgroup may be granted (gfx950: the CU's whole 160 KB); kernels that pad their dynamic LDS request to cap
+        // occupancy (slk_eval.hip) derive the pad from this, not from a constant
+        if (prop.sharedMemPerBlock > 0) ctx->lds_per_block = prop.sharedMemPerBlock;
+        if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+        if (ctx->lds_per_cu < ctx->lds_per_block) ctx->lds_per_cu = ctx->lds_per_block;
+    }
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_rng), sizeof(slk_rng_dev)) != hipSuccess) {
         delete ctx;
         return slk_fail(nullptr, SLK_ENOMEM, "slk_ctx_create: hipMalloc(rng) failed");
@@ -186,60 +192,69 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
 
 SLK_EXPORT const char *slk_last_error(const slk_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
+// Options: one table for set and get (slk_ctx_get_option exists so that a caller can change an option for the duration of
+// one piece of work and put the previous value back: spotlight_amd/_native.py, Engine.options).
+namespace {
+struct slk_opt_desc {
+    const char *name;
+    int64_t lo, hi;
+    int64_t (*get)(const slk_ctx *);
+    void (*set)(slk_ctx *, int64_t);
+};
+#define SLK_OPT(name_, member_, lo_, hi_)                                              \
+    {name_, (int64_t)(lo_), (int64_t)(hi_), [](const slk_ctx *c) -> int64_t { return (int64_t)c->member_; }, \
+     [](slk_ctx *c, int64_t v) { c->member_ = (decltype(c->member_))v; }}
+const int64_t SLK_OPT_MAX = INT64_MAX;
+const slk_opt_desc slk_options[] = {
+    SLK_OPT("chunk_interactions", opt_chunk_interactions, 1, SLK_OPT_MAX),
+    SLK_OPT("overlap_prep", opt_overlap_prep, 0, 2),
+    SLK_OPT("overlap_min_batch", opt_overlap_min_batch, 0, SLK_OPT_MAX),
+    SLK_OPT("prefetch_wait", opt_prefetch_wait, 0, 1),
+    SLK_OPT("sort_big_min", opt_sort_big_min, 1, SLK_OPT_MAX),
+    SLK_OPT("sort_debug", opt_sort_debug, 0, 3),
+    SLK_OPT("item_grid_mult", opt_item_grid_mult, 1, 4096),
+    SLK_OPT("user_grid_mult", opt_user_grid_mult, 1, 4096),
+    SLK_OPT("seq_variant", opt_seq_variant, 0, 1),
+    SLK_OPT("explicit_fused", opt_explicit_fused, 0, 1),
+    SLK_OPT("epoch_kernel", opt_epoch_kernel, 0, 1),
+    SLK_OPT("item_lat_max_tiles", opt_item_lat_max_tiles, 0, SLK_OPT_MAX),
+    SLK_OPT("epoch_adaptive", opt_epoch_adaptive, 0, 1),
+    SLK_OPT("epoch_adaptive_max_batch", opt_epoch_adaptive_max_batch, 1, (int64_t)1 << 20),
+    SLK_OPT("epoch_max_batch", opt_epoch_max_batch, 1, (int64_t)1 << 20),
+    SLK_OPT("epoch_max_grid", opt_epoch_max_grid, 1, 1024),
+    SLK_OPT("epoch_barrier", opt_epoch_barrier, -1, 1),
+    SLK_OPT("epoch_cooperative", opt_epoch_cooperative, 0, 1),
+    SLK_OPT("epoch_debug", opt_epoch_debug, 0, 63),
+    SLK_OPT("epoch_dense_elems", opt_epoch_dense_elems, 0, SLK_OPT_MAX),
+    SLK_OPT("user_lat_max_batch", opt_user_lat_max_batch, 0, SLK_OPT_MAX),
+    SLK_OPT("item_long_gate", opt_item_long_gate, 0, 1),
+    SLK_OPT("adaptive_late_min_batch", opt_adaptive_late_min_batch, 0, SLK_OPT_MAX),
+    SLK_OPT("shuffle_band", opt_shuffle_band, 0, 1024),
+    SLK_OPT("nt", opt_nt, 0, 15),
+};
+#undef SLK_OPT
+const slk_opt_desc *slk_find_option(const char *name) {
+    for (const slk_opt_desc &d : slk_options)
+        if (!strcmp(name, d.name)) return &d;
+    return nullptr;
+}
+}  // namespace
+
 SLK_EXPORT int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return SLK_EINVAL;
-    if (!strcmp(name, "chunk_interactions") && value >= 1) {
-        ctx->opt_chunk_interactions = value;
-    } else if (!strcmp(name, "overlap_prep") && value >= 0 && value <= 2) {
-        ctx->opt_overlap_prep = (int)value;
-    } else if (!strcmp(name, "overlap_min_batch") && value >= 0) {
-        ctx->opt_overlap_min_batch = value;
-    } else if (!strcmp(name, "sort_big_min") && value >= 1) {
-        ctx->opt_sort_big_min = value;
-    } else if (!strcmp(name, "sort_debug") && value >= 0 && value <= 3) {
-        ctx->opt_sort_debug = (int)value;
-    } else if (!strcmp(name, "item_grid_mult") && value >= 1 && value <= 4096) {
-        ctx->opt_item_grid_mult = (int)value;
-    } else if (!strcmp(name, "user_grid_mult") && value >= 1 && value <= 4096) {
-        ctx->opt_user_grid_mult = (int)value;
-    } else if (!strcmp(name, "seq_variant") && (value == 0 || value == 1)) {
-        ctx->opt_seq_variant = (int)value;
-    } else if (!strcmp(name, "explicit_fused") && (value == 0 || value == 1)) {
-        ctx->opt_explicit_fused = (int)value;
-    } else if (!strcmp(name, "epoch_kernel") && (value == 0 || value == 1)) {
-        ctx->opt_epoch_kernel = (int)value;
-    } else if (!strcmp(name, "item_lat_max_tiles") && value >= 0) {
-        ctx->opt_item_lat_max_tiles = value;
-    } else if (!strcmp(name, "epoch_adaptive") && (value == 0 || value == 1)) {
-        ctx->opt_epoch_adaptive = (int)value;
-    } else if (!strcmp(name, "epoch_adaptive_max_batch") && value >= 1 && value <= ((int64_t)1 << 20)) {
-        ctx->opt_epoch_adaptive_max_batch = value;
-    } else if (!strcmp(name, "epoch_max_batch") && value >= 1 && value <= ((int64_t)1 << 20)) {
-        ctx->opt_epoch_max_batch = value;
-    } else if (!strcmp(name, "epoch_max_grid") && value >= 1 && value <= 1024) {
-        ctx->opt_epoch_max_grid = (int)value;
-    } else if (!strcmp(name, "epoch_barrier") && value >= -1 && value <= 1) {
-        ctx->opt_epoch_barrier = (int)value;
-    } else if (!strcmp(name, "epoch_cooperative") && (value == 0 || value == 1)) {
-        ctx->opt_epoch_cooperative = (int)value;
-    } else if (!strcmp(name, "epoch_debug") && value >= 0 && value <= 63) {
-        ctx->opt_epoch_debug = (int)value;
-    } else if (!strcmp(name, "epoch_dense_elems") && value >= 0) {
-        ctx->opt_epoch_dense_elems = value;
-    } else if (!strcmp(name, "user_lat_max_batch") && value >= 0) {
-        ctx->opt_user_lat_max_batch = value;
-    } else if (!strcmp(name, "item_long_gate") && (value == 0 || value == 1)) {
-        ctx->opt_item_long_gate = (int)value;
-    } else if (!strcmp(name, "adaptive_late_min_batch") && value >= 0) {
-        ctx->opt_adaptive_late_min_batch = value;
-    } else if (!strcmp(name, "shuffle_band") && value >= 0 && value <= 1024) {
-        ctx->opt_shuffle_band = (int)value;
-    } else if (!strcmp(name, "nt") && value >= 0 && value <= 15) {
-        ctx->opt_nt = (int)value;
-    } else {
+    const slk_opt_desc *d = slk_find_option(name);
+    if (!d || value < d->lo || value > d->hi)
         return slk_fail(ctx, SLK_EINVAL, "slk_ctx_set_option: unknown option or bad value: %s = %lld", name,
                         (long long)value);
-    }
+    d->set(ctx, value);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_ctx_get_option(slk_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return SLK_EINVAL;
+    const slk_opt_desc *d = slk_find_option(name);
+    if (!d) return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_option: unknown option %s", name);
+    *value = d->get(ctx);
     return SLK_OK;
 }
 
@@ -252,6 +267,8 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "item_long_launches")) *value = ctx->stat_item_long;
     else if (!strcmp(name, "overlapped_chunks")) *value = ctx->stat_overlapped;
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
+    else if (!strcmp(name, "lds_per_block")) *value = (int64_t)ctx->lds_per_block;
+    else if (!strcmp(name, "lds_per_cu")) *value = (int64_t)ctx->lds_per_cu;
     else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);
     else return slk_fail(ctx, SLK_EINVAL, "slk_ctx_get_stat: unknown statistic %s", name);
     return SLK_OK;

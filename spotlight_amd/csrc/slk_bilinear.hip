@@ -1526,6 +1526,9 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     };
 
     // a chunk prepared ahead by slk_bilinear_prefetch: it must be THIS call's first chunk (its negatives are already drawn)
+    // (a call that draws nothing -- negatives handed in, explicit feedback -- cannot be confused with the prepared one: it drops
+    // the chunk instead of refusing; fit() of another model after one that left its loop by an exception)
+    if (!prefetch_only && ctx->pf.valid && (d_neg_in || expl)) ctx->pf.valid = false;
     const bool have0 = !prefetch_only && ctx->pf.valid;
     if (have0 && (nsets != 2 || epoch_route || ctx->pf.users != (const void *)d_users || ctx->pf.items != (const void *)d_items ||
                   ctx->pf.n != n || ctx->pf.bsz != bsz || ctx->pf.loss != (int)loss || ctx->pf.nn != nn || ctx->pf.nc0 != cb[1] || d_neg_in)) {
@@ -1541,8 +1544,17 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         hipStream_t ps = ctx->prep_stream;
         // the set the call before did NOT finish on: its last reader were the passes two chunks back (ev_done of that set)
         const int set = ctx->last_pipe_set >= 0 ? (ctx->last_pipe_set ^ 1) : 0;
-        SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));  // inputs produced on the caller's stream
-        SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+        // What the prepared chunk waits for (it used to wait for everything the caller's stream held -- every pass of
+        // the epoch before -- and so ran BEHIND those passes, not beside them): the id arrays are complete when this call is made
+        // (the header says so; fit() has read the shuffle's RNG state back, which synchronises the lane that wrote them); buffer
+        // set `set` was last read by the passes two chunks back (ev_done); the sampler's and the sorts' scratch and, with
+        // "overlap_prep" 1, the earlier readers of pf_neg (the sorts of the running call's later chunks) live on the prep stream
+        // itself.  Only with "overlap_prep" 2 do sorts that read pf_neg run on the caller's stream: then, and only then, the
+        // new draw waits for that stream's tail.
+        if (ctx->opt_overlap_prep != 1 || ctx->opt_prefetch_wait) {
+            SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));
+            SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+        }
         SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set], 0));
         // The negatives of the WHOLE call in one draw (it is one contiguous draw however the call is chunked): the stream
         // position behind them -- where the NEXT epoch's shuffle starts -- is then known an epoch ahead

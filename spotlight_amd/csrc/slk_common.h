@@ -82,6 +82,8 @@ struct slk_prof_span {
 struct slk_ctx {
     int device = 0;
     int num_cus = 256;
+    size_t lds_per_block = (size_t)160 * 1024;  // LDS one workgroup may be granted (hipDeviceProp_t::sharedMemPerBlock)
+    size_t lds_per_cu = (size_t)160 * 1024;     // LDS of a CU (maxSharedMemoryPerMultiProcessor; gfx950: 160 KB): occupancy pads
     char err[512] = {0};
     hipStream_t last_stream = nullptr;
     slk_rng_dev *d_rng = nullptr;
@@ -99,6 +101,7 @@ struct slk_ctx {
                                    // steady state of a run of training calls it gains 1.5-4 % (profiles/r03_*); a lone call of a few
                                    // chunks gains nothing, every pass runs ~10 % longer beside the sorts, and kernel timings under a
                                    // tracer stop agreeing with the untraced ones -- so a bare ctx keeps everything on one stream
+    int opt_prefetch_wait = 0;     // measurement switch (A/B of round 5): 1 = slk_bilinear_prefetch waits for the caller's stream as it did up to round 4
     int64_t opt_overlap_min_batch = (int64_t)1 << 16;  // the prep overlaps the passes only for minibatches of at least this size
                                    // (measured: +3 % at 8192, where the passes are short latency-bound kernels; -1..-3 % at 65 536)
     int64_t opt_sort_big_min = (int64_t)1 << 20;  // radix sort: sorts of at least this many pairs use tiles of 512 threads x 16 keys, smaller ones 256 x 16

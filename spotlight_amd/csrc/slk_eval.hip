@@ -551,7 +551,12 @@ static int eval_gemm(slk_ctx *ctx, const slk_tables *tables, slk_gemm_args a, bo
     size_t lds = ((size_t)(32 * mt + SLK_GEMM_IB) * SLK_GEMM_KS + 4 * 32 * mt) * 4;
     // two resident workgroups per CU, by LDS footprint: the registers would allow three, and three share the LDS bandwidth and
     // the L2 worse (4096 x 10^6: 8.3 ms against 7.06, profiles/r04_h_bench_eval_{2,3}wg.json)
-    if (lds < (size_t)160 * 1024 / 2 - 256) lds = (size_t)160 * 1024 / 2 - 256;
+    // (the pad is half of the CU's LDS as the DEVICE reports it -- 160 KB on gfx950 -- and is skipped where a workgroup cannot be
+    // granted that much: never more than the device can give)
+    if (lds > ctx->lds_per_block)
+        return slk_fail(ctx, SLK_EINVAL, "scoring: the sweep needs %zu B of LDS per workgroup, the device grants %zu", lds, ctx->lds_per_block);
+    const size_t half_lds = ctx->lds_per_cu / 2 - 256;
+    if (lds < half_lds && half_lds <= ctx->lds_per_block) lds = half_lds;
     const bool areg = vec4 && a.D <= SLK_GEMM_KC;
     gemm_fn fn = count ? gemm_kernel<true>(mt, vec4, areg) : gemm_kernel<false>(mt, vec4, areg);
     if (lds > 48 * 1024) SLK_HIP(ctx, hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -467,7 +467,8 @@ static int rs_sort(slk_ctx *ctx, slk_buf &scratch, rs_args a, size_t n, size_t s
     if (n >= ((size_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "sort of %zu pairs: at most 2^31 - 1", n);
     if (bits > 8 * sizeof(KeyT)) bits = 8 * sizeof(KeyT);
     if (bits < 1) bits = 1;
-    const bool single = LOADER == RS_LOAD_PLAIN && n <= 4096;
+    // (one tile, one workgroup -- for an UNSEGMENTED sort only: a segmented request of <= 4096 pairs keeps its segments)
+    const bool single = LOADER == RS_LOAD_PLAIN && n <= 4096 && (seg_len == 0 || seg_len >= n);
     const int cfg = (!single && n >= (size_t)ctx->opt_sort_big_min) ? 1 : 0;
     const unsigned tile = rs_tile_of(cfg);
     rs_plan pl;

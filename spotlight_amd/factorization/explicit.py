@@ -52,6 +52,10 @@ class ExplicitFactorizationModel(ImplicitFactorizationModel):
     def fit(self, interactions, verbose=False):
         """Fit the model on interactions that carry ratings; repeated calls resume
         (explicit.py:173-243)."""
+        with _host.fit_scope(self):
+            return self._fit(interactions, verbose)
+
+    def _fit(self, interactions, verbose):
         user_ids, item_ids = interactions.user_ids, interactions.item_ids
 
         if not self._initialized:

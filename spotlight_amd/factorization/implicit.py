@@ -31,10 +31,21 @@ def _engine_for(device):
     index = device.index if device.index is not None else torch.cuda.current_device()
     if index not in _ENGINES:
         _ENGINES[index] = _native.Engine(index)
-        # epochs are runs of multi-chunk training calls: the next chunk's negatives + sorts go to the ctx's second stream beside
-        # the current chunk's passes (include/spotlight_hip.h, option "overlap_prep"; a bare ctx keeps them in line)
-        _ENGINES[index].set_option('overlap_prep', 1)
     return _ENGINES[index]
+
+
+# What a fit() asks of the shared ctx FOR ITS OWN DURATION (it used to be set once, process-wide, on the
+# ctx every model, evaluation and to_sequence of the process share).  Epochs are runs of multi-chunk training calls: the next
+# chunk's negatives + sorts go to the ctx's second stream beside the current chunk's passes (include/spotlight_hip.h, option
+# "overlap_prep"; a bare ctx keeps them in line).
+_FIT_OPTIONS = {'overlap_prep': 1}
+
+
+def fit_scope(model):
+    """`with fit_scope(model):` -- _FIT_OPTIONS on the model's engine for the block, the previous values afterwards."""
+    net = getattr(model, '_net', None)
+    device = net.tables()[0].device if (net is not None and hasattr(net, 'tables')) else _model_device()
+    return _engine_for(device).options(**_FIT_OPTIONS)
 
 
 def _stream_for(device):
@@ -438,6 +449,10 @@ class ImplicitFactorizationModel(object):
     def fit(self, interactions, verbose=False):
         """Fit the model; repeated calls resume from the current parameters and optimizer
         state (implicit.py:184-252)."""
+        with fit_scope(self):
+            return self._fit(interactions, verbose)
+
+    def _fit(self, interactions, verbose):
         user_ids, item_ids = interactions.user_ids, interactions.item_ids
 
         if not self._initialized:
@@ -601,6 +616,11 @@ class ImplicitFactorizationModel(object):
             upload.result()  # (joins the upload thread on the exceptional paths too)
             check.join()
             self._random_state.set_state(consumed)
+            # a chunk prepared ahead for an epoch that will not run (an exception left the loop): its draws are dropped and the
+            # ctx's stream is put back where the reference's would be, so that the next training call on this engine -- any
+            # model's -- finds no stale prefetch (slk_bilinear_train would refuse it once)
+            if _PREFETCH and engine.get_stat('prefetch_pending'):
+                engine.rng_set_state(consumed)
             # the epoch's device buffers go back to the caching allocator NOW (closures above hold cells, not tensors, once
             # these names are cleared): the next fit() reuses them instead of allocating
             del bufs[:]

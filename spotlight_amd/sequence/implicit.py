@@ -145,6 +145,10 @@ class ImplicitSequenceModel(object):
     def fit(self, interactions, verbose=False):
         """Fit the model on a SequenceInteractions dataset; repeated calls resume
         (sequence/implicit.py:193-264)."""
+        with _host.fit_scope(self):
+            return self._fit(interactions, verbose)
+
+    def _fit(self, interactions, verbose):
         sequences = interactions.sequences
 
         if not self._initialized:

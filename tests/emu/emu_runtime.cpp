@@ -280,6 +280,8 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     std::snprintf(p->name, sizeof(p->name), "emu");
     std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
     p->totalGlobalMem = size_t(1) << 34;
+    p->sharedMemPerBlock = size_t(160) * 1024;
+    p->maxSharedMemoryPerMultiProcessor = size_t(160) * 1024;
     return hipSuccess;
 }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event_(); return hipSuccess; }

@@ -57,6 +57,8 @@ struct hipDeviceProp_t {
     char name[64];
     char gcnArchName[64];
     size_t totalGlobalMem;
+    size_t sharedMemPerBlock;
+    size_t maxSharedMemoryPerMultiProcessor;
 };
 
 namespace emu {

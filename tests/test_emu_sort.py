@@ -60,6 +60,9 @@ def test_sort_segmented(be, kind):
     # segments sorted on their own; a short last segment; tiles that end inside a segment
     check_sort(be, kind, 3 * 5000 + 123, 13, seg_len=5000, seed=7)
     check_sort(be, kind, 2 * 4096, 10, seg_len=4096, seed=8)
+    # a segmented request small enough for the one-tile form keeps its segments (it was sorted as one array)
+    check_sort(be, kind, 4005, 9, seg_len=100, seed=9)
+    check_sort(be, kind, 4096, 12, seg_len=4096, seed=10)
 
 
 def test_sort_skewed_digits(be):

@@ -342,6 +342,67 @@ def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(
             host._PIPELINE_MAX_DRAWS = old
 
 
+def test_exception_inside_a_prefetching_fit_leaves_no_stale_prefetch(emu_device, monkeypatch):
+    """the large-epoch loop prepares epoch e + 1's first chunk (slk_bilinear_prefetch) before it checks epoch e.  An
+    exception between the two used to leave the prepared chunk on the shared engine, and the next training call that set no RNG
+    state -- a small model's pipelined fit(), an explicit-feedback model -- was refused once (SlkError -22).  Now the loop's
+    way out drops it and puts the stream back where the reference's would be."""
+    rs = np.random.RandomState(12)
+    inter = Interactions(rs.randint(0, 90, 9000).astype(np.int32), rs.randint(0, 60, 9000).astype(np.int32), num_users=90, num_items=60)
+    small = Interactions(inter.user_ids[:600], inter.item_ids[:600], num_users=90, num_items=60)
+    old = host._PIPELINE_MAX_DRAWS
+    emu_device.set_option('chunk_interactions', 4096)
+    emu_device.set_option('overlap_min_batch', 0)
+    emu_device.set_option('overlap_prep', 1)
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        model = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=3, batch_size=2048, optimizer_func=_adagrad,
+                                           random_state=np.random.RandomState(7))
+        real_check, calls = emu_device.check, []
+
+        def failing_check():
+            calls.append(1)
+            if len(calls) == 1:
+                raise RuntimeError('injected: epoch 0 failed after epoch 1 was prepared ahead')
+            return real_check()
+        monkeypatch.setattr(emu_device, 'check', failing_check)
+        with pytest.raises(RuntimeError, match='injected'):
+            model.fit(inter)
+        assert emu_device.get_stat('prefetch_pending') == 0
+        # the RandomState is where the reference's would be: behind epoch 0's negatives
+        ref = np.random.RandomState(7)
+        ref.randint(-10**8, 10**8)
+        ref.shuffle(np.arange(9000))
+        ref.randint(0, 60, 9000, dtype=np.int64)
+        got, want = model._random_state.get_state(), ref.get_state()
+        assert np.array_equal(got[1], want[1]) and got[2] == want[2]
+        # the next fit() on the same engine takes the pipelined route (negatives handed in: it sets no RNG state) and trains
+        host._PIPELINE_MAX_DRAWS = old
+        other = ImplicitFactorizationModel(loss='bpr', embedding_dim=8, n_iter=2, batch_size=256, optimizer_func=_adagrad,
+                                           random_state=np.random.RandomState(3))
+        other.fit(small)
+        # ... and a stale chunk that does reach such a call is dropped, not refused (the C-ABI side of the same fix)
+        host._PIPELINE_MAX_DRAWS = 0
+        st = np.random.RandomState(5).get_state()
+        model2 = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=1, batch_size=2048, optimizer_func=_adagrad,
+                                            random_state=np.random.RandomState(7))
+        model2.fit(inter)
+        binding = model2._bind()
+        d_u = torch.from_numpy(inter.user_ids.astype(np.int64))
+        d_i = torch.from_numpy(inter.item_ids.astype(np.int64))
+        emu_device.bilinear_prefetch(model2._slk_tables(), binding.as_struct(), d_u.data_ptr(), d_i.data_ptr(), 9000, 2048, 'bpr', 1,
+                                     state=st, stream=0)
+        assert emu_device.get_stat('prefetch_pending') != 0
+        host._PIPELINE_MAX_DRAWS = old
+        other.fit(small)
+        assert emu_device.get_stat('prefetch_pending') == 0
+    finally:
+        host._PIPELINE_MAX_DRAWS = old
+        emu_device.set_option('chunk_interactions', 1 << 23)
+        emu_device.set_option('overlap_min_batch', 1 << 16)
+        emu_device.set_option('overlap_prep', 0)
+
+
 def test_id_checks_on_worker_threads_raise_like_the_serial_ones(emu_device):
     """Large fits run the id-range checks (implicit.py:169-182) on worker threads beside the upload and the first shuffle: the
     same exceptions in the same order, before anything is trained, RandomState and tables as they were."""
