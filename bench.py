@@ -33,35 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from spotlight_amd import _native  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
-
-
-def algorithmic_bytes(dim, opt_state_words):
-    """per interaction, fp32, int64 ids, no credit for cache hits/duplicates.
-    user pass: user row param R+W + state R+W, two item rows read, user/pos/neg ids, user bias
-    R+W(+state), two item-bias reads; item pass: two item rows written + state R+W, two item
-    biases written + state R+W."""
-    s = opt_state_words
-    user_pass = (8 * dim + 8 * dim * s) + 2 * 4 * dim + 16 + (8 + 8 * s) + 8
-    item_pass = 2 * (4 * dim + 8 * dim * s) + 2 * (4 + 8 * s)
-    return user_pass, item_pass
-
-
-def pmc_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this very
-    workload (profiles/pmc_traffic.json, produced by scripts/pmc_run.sh + scripts/summarize_pmc.py:
-    2 x FETCH_SIZE + WRITE_SIZE, separate passes; MI355X_MICROARCH.md "HBM").  PMC counters cannot
-    be collected from inside the benchmark process, so this is null unless the committed
-    measurement matches the workload being run."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    cfg = rec.get('config', {})
-    same = all(cfg.get(k) == getattr(args, k) for k in ('users', 'items', 'dim', 'batch', 'loss', 'opt'))
-    return rec.get('kernels', {}).get(kernel, {}).get('hbm_bytes_per_launch') if same else None
+from benchlib.common import HBM_PEAK_GBS, algorithmic_bytes, pmc_traffic  # noqa: E402
+from benchlib.cpu import cpu_baseline, reference_cpu_baseline  # noqa: E402
+from benchlib.dist import Backend, spawn_ranks  # noqa: E402
+from benchlib.probes import fit_end_to_end, measured_stream_rates, sharded_world1_check  # noqa: E402
 
 
 def parse():
@@ -114,6 +89,8 @@ def parse():
                          'the rocprofv3 / PMC commands use, so that their per-kernel means are those of the timed configuration only')
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='N=1, C2: skip the compact legs of the other BASELINE.json configurations (the `configs` object of the line)')
     ap.add_argument('--cpu-seconds', type=float, default=30.0)
     args = ap.parse_args()
     custom = args.users is not None or args.items is not None
@@ -125,527 +102,6 @@ def parse():
     return args
 
 
-def reference_cpu_baseline(args, seconds):
-    """Spotlight's own CPU PyTorch path (the copy staged by oracle/make_ref.sh under oracle/_ref/) timed
-    on this machine's host cores by oracle/ref_cpu_baseline.py, in its own process: same table shapes, loss
-    and minibatch as the GPU workload, protocol of the reference's examples/bloom_embeddings/performance.py:24-38.
-    Returns None when the copy is not staged."""
-    import subprocess
-    script = os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py')
-    if not os.path.isdir(os.path.join(ROOT, 'oracle', '_ref', 'spotlight')):
-        return None
-    cmd = [sys.executable, script, '--users', str(args.users), '--items', str(args.items), '--dim', str(args.dim),
-           '--batch', str(args.batch), '--loss', args.loss, '--seconds', str(seconds)]
-    try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60 + 12 * seconds)
-        rec = json.loads(res.stdout.decode().strip().splitlines()[-1])
-    except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
-        return {'error': repr(e)[:300]}
-    if 'sparse_adagrad' not in rec:
-        return {'error': str(rec)[:300]}
-    sa, da = rec['sparse_adagrad'], rec.get('default_dense_adam')
-    out = {'value': sa['interactions_per_s'], 'unit': 'interactions/s', 'cores': sa['threads'], 'kind': 'reference',
-           'cpu_model': rec['cpu_model'], 'host_cores': rec['host_cores'],
-           'interactions_per_s_by_threads': sa['interactions_per_s_by_threads'],
-           'sample': 'spotlight ImplicitFactorizationModel.fit() on CPU PyTorch %s, sparse=True + Adagrad(lr=1e-2), %s loss, '
-                     '%d users x %d items, dim %d, minibatch %d (bounded sample; the GPU workload uses %d): warm-up fit + min '
-                     'of 2 timed fits of %d minibatch(es) (%.1f s each); torch.set_num_threads: every host core (%d, on an eighth of a '
-                     'minibatch) and 16 were probed, the faster (%d) was timed%s'
-                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], rec['batch'], rec['gpu_workload_batch'],
-                        sa['minibatches_per_fit'], sa['seconds'], rec['host_cores'], sa['threads'],
-                        '; ' + rec['note'] if rec['note'] else '')}
-    if da:
-        out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s', 'cores': da['threads'],
-                                               'sample': '%d minibatch(es) per fit, %.1f s' % (da['minibatches_per_fit'], da['seconds'])}
-    return out
-
-
-def cpu_baseline(args, seconds):
-    """The oracle (CPU port of spotlight/factorization/implicit.py:223-243 with a row-sparse
-    Adagrad, i.e. the reference's sparse=True + Adagrad path) on the same table shapes."""
-    from oracle.oracle import BilinearOracle, Rng
-    try:
-        import psutil
-        avail = psutil.virtual_memory().available
-    except Exception:
-        avail = 16 << 30
-    U, I, D = args.users, args.items, args.dim
-    need = (U + I) * D * 4 * 5
-    note = ''
-    while need > 0.6 * avail and U > 100_000:
-        U //= 2
-        need = (U + I) * D * 4 * 5
-        note = ' (user table scaled to %d rows to fit host RAM)' % U
-    rs = np.random.default_rng(0)
-    block = (rs.standard_normal(1 << 20, dtype=np.float32) / D)
-    p = [np.resize(block, (U, D)), np.resize(block, (I, D)), np.zeros(U, np.float32), np.zeros(I, np.float32)]
-    ora = BilinearOracle(*p, opt=args.opt, lr=1e-2, sparse_grads=True)
-    del p
-    rng = Rng(seed=1)
-    B = min(args.batch, 1 << 18)
-    done, t_total = 0, 0.0
-    # warm the page tables of the gradient buffers with one untimed minibatch
-    users, items = rs.integers(0, U, B), rs.integers(0, I, B)
-    ora.train(rng, users, items, B, loss=args.loss)
-    while t_total < seconds and done < (1 << 24):
-        users, items = rs.integers(0, U, B), rs.integers(0, I, B)
-        t0 = time.perf_counter()
-        ora.train(rng, users, items, B, loss=args.loss)
-        t_total += time.perf_counter() - t0
-        done += B
-    return {'value': done / t_total, 'unit': 'interactions/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d minibatches of %d interactions, same table shapes%s, oracle/slk_oracle.c '
-                      'single thread (%d host cores present)' % (done // B, B, note, os.cpu_count())}
-
-
-def bench_scoring(args):
-    """The far side of predict() at the C2 table sizes (BASELINE.md's predict roofline row).
-    --workload predict: ImplicitFactorizationModel.predict(user) -- one user against every item; a step = one call;
-    algorithmic bytes = items * (4 D + 4) read + items * 4 written.
-    --workload eval: evaluation.mrr_score's device side -- `--batch` users (default 4096) with one held-out item each ranked
-    against every item (slk_bilinear_rank: no score matrix); a step = one call; the unit is a (user, item) score; bound by
-    the matrix cores (exact-fp32 MFMA: 2 D flop per score against the 157 TFLOP/s f32 MFMA peak).
-    Diagnostic workloads, not the headline metric: each prints its own JSON line."""
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(0)
-    U, I, D, K, W = args.users, args.items, args.dim, args.steps, args.warmup
-    eng = _native.Engine(0)
-    for kv in args.set:
-        name, value = kv.split('=')
-        eng.set_option(name, int(value))
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7)
-    tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen), torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen),
-              torch.empty(U, device=dev).normal_(0, 0.01, generator=gen), torch.empty(I, device=dev).normal_(0, 0.01, generator=gen)]
-    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if args.workload == 'predict':
-        users = torch.randint(0, U, (W + K,), device=dev, dtype=torch.int64, generator=gen)
-        out = torch.empty(I, device=dev)
-
-        def step(k):
-            eng.bilinear_predict(tb, users[k:].data_ptr(), 1, None, I, out.data_ptr(), stream)
-        for k in range(W):
-            step(k)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ev0.record()
-        for k in range(W, W + K):
-            step(k)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1) / K
-        alg = I * (4 * D + 4) + I * 4
-        rec = {'metric': 'predict(user) calls/sec, all %d items, dim=%d' % (I, D), 'value': K / elapsed, 'unit': 'calls/s',
-               'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'dtype': 'f32',
-               'data': 'synthetic', 'vs_baseline': None,
-               'config': {'workload': 'predict: one user against %d items, dim %d (C2 item table)' % (I, D)},
-               'roofline': {'bound': 'hbm', 'kernel': 'k_score_rows<1>', 'alg_bytes_per_call': alg, 'device_ms_per_call': dev_ms,
-                            'achieved': alg / dev_ms / 1e6, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / dev_ms / 1e6 / HBM_PEAK_GBS,
-                            'calls_per_s_at_peak': HBM_PEAK_GBS * 1e9 / alg, 'traffic': None}}
-    else:
-        R = args.batch if args.batch != (1 << 20) else 4096
-        users = torch.randint(0, U, (R,), device=dev, dtype=torch.int64, generator=gen)
-        row_group = torch.arange(R, device=dev, dtype=torch.int64)
-        targets = torch.randint(0, I, (R,), device=dev, dtype=torch.int64, generator=gen)
-        ranks = torch.empty(R, dtype=torch.float64, device=dev)
-
-        def step():
-            eng.bilinear_rank(tb, users.data_ptr(), R, row_group.data_ptr(), targets.data_ptr(), R, None, None, ranks.data_ptr(), stream)
-        for _ in range(W):
-            step()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        ev0.record()
-        for _ in range(K):
-            step()
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1) / K
-        flop = 2.0 * D * R * I
-        MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-        rec = {'metric': 'ranked (user, item) scores/sec, mrr_score device side, dim=%d' % D, 'value': R * I * K / elapsed,
-               'unit': 'scores/s', 'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True,
-               'dtype': 'f32', 'data': 'synthetic', 'vs_baseline': None,
-               'config': {'workload': 'eval: %d users x 1 held-out item each ranked against %d items, dim %d (slk_bilinear_rank)' % (R, I, D)},
-               'roofline': {'bound': 'mfma', 'kernel': 'k_score_gemm<2, COUNT>', 'flop_per_call': flop, 'device_ms_per_call': dev_ms,
-                            'achieved': flop / dev_ms / 1e9, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': flop / dev_ms / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                            'item_table_bytes_streamed_per_call': ((R + 63) // 64) * I * (4 * D + 4), 'traffic': None},
-               'mean_reciprocal_rank': float((1.0 / ranks).mean().item())}
-    print(json.dumps(rec), flush=True)
-    eng.close()
-
-
-def bench_c4(args):
-    """BASELINE.json configs[3]: ImplicitSequenceModel PoolNet, synthetic sequences len=200, 1M
-    items, dim=64, bpr, Adagrad.  A step = one minibatch of `--batch` sequences; the unit is a
-    (sequence, timestep) pair (32*D + 40 algorithmic bytes each).  Diagnostic
-    workload, not the headline metric: prints its own JSON line."""
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(0)
-    I, D, L, K, W = args.items, args.dim, args.seq_len, args.steps, args.warmup
-    B = args.batch if args.batch != (1 << 20) else 4096
-    eng = _native.Engine(0)
-    eng.set_option('overlap_prep', 1)  # as fit() sets it on its ctx: the next chunk's negatives + sorts beside the passes
-    for kv in args.set:
-        name, value = kv.split('=')
-        eng.set_option(name, int(value))
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(99)
-    E = torch.empty(I, D, device=dev).normal_(0, 1.0 / D, generator=gen)
-    E[0] = 0
-    bias = torch.zeros(I, device=dev)
-    s1 = [torch.zeros_like(E), torch.zeros_like(bias)]
-    tb = _native.make_seq_tables(E.data_ptr(), bias.data_ptr(), I, D)
-    op = _native.make_optim('adagrad', [None, s1[0].data_ptr(), None, s1[1].data_ptr()], None, lr=1e-2)
-    seqs = torch.randint(1, I, ((W + 2 * K) * B, L), device=dev, dtype=torch.int64, generator=gen)  # W warm-up + K timed + K profiled
-    mb_loss = torch.zeros(W + 2 * K, device=dev)
-    eng.rng_set_state(np.random.RandomState(5).get_state())
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def run(first, n_mb):
-        eng.poolnet_train(tb, op, 0, seqs[first * B:].data_ptr(), n_mb * B, L, B, 'bpr', 1,
-                          mb_loss[first:].data_ptr(), stream=stream)
-    eng.poolnet_reserve(tb, op, K * B, L, B, 'bpr', 1, stream=stream)  # scratch of the timed call's shape
-    run(0, W)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(W, K)  # timed region: no instrumentation inside
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    # per-kernel durations: K more steps with hipEvents around every launch (the records cost ~10 us per launch and, around
-    # the host-side parts of a chunk's preparation, also count the host's time)
-    eng.profile_reset()
-    eng.profile_enable(True)
-    run(W + K, K)
-    torch.cuda.synchronize(dev)
-    eng.profile_enable(False)
-    prof = eng.profile_read()
-    ts = K * B * L
-    alg = 32 * D + 40
-    kern = {k: {'launches': prof[k][0], 'avg_ms': prof[k][1] / max(prof[k][0], 1)} for k in ('seq_pass', 'item_pass', 'epoch')
-            if prof[k][0] or k != 'epoch'}  # 'epoch': minibatches of a few thousand timesteps run inside k_poolnet_epoch, one launch per chunk
-    out = {'metric': 'training (sequence, timestep) pairs/sec, PoolNet BPR dim=%d' % D, 'value': ts / elapsed,
-           'unit': 'timesteps/s', 'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
-           'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': 'C4: PoolNet, %d sequences x len %d per minibatch, %d items, dim %d, bpr, '
-                                  'adagrad, no padding' % (B, L, I, D)},
-           'roofline': {'bound': 'hbm', 'alg_bytes_per_timestep': alg, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'step_achieved': ts * alg / elapsed / 1e9, 'step_frac_of_peak': ts * alg / elapsed / 1e9 / HBM_PEAK_GBS,
-                        'kernels': kern,
-                        'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep')}},
-           'final_minibatch_loss': float(mb_loss[W + K - 1].item())}
-    print(json.dumps(out), flush=True)
-
-
-def bench_c3(args):
-    """BASELINE.json configs[2]: 10M users x 1M items, adaptive_hinge_loss n_neg=5, BloomEmbedding item
-    table (compression 0.2 -> 200k rows, 4 hash functions), dim 128, Adagrad.  A step = one minibatch.
-    Algorithmic bytes per interaction: 208*D + 90 (hashes computed in-kernel).
-    Diagnostic workload, not the headline metric: prints its own JSON line."""
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(0)
-    U, I, K, W = args.users, args.items, args.steps, args.warmup
-    D = args.dim if args.dim != 64 else 128
-    B = args.batch if args.batch != (1 << 20) else (1 << 18)
-    NN, H = 5, 4
-    rows = int(0.2 * I)
-    eng = _native.Engine(0)
-    eng.set_option('overlap_prep', 1)  # as fit() sets it on its ctx: the next chunk's negatives + sorts beside the passes
-    for kv in args.set:
-        name, value = kv.split('=')
-        eng.set_option(name, int(value))
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7)
-    tables = [torch.empty(U, D, device=dev).normal_(0, 1.0 / D, generator=gen),
-              torch.empty(rows, D, device=dev).normal_(0, 1.0 / D, generator=gen),
-              torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
-    tables[1][0] = 0  # padding row of the compressed table (layers.py:152-154)
-    s1 = [torch.zeros_like(t) for t in tables]
-    ib = _native.make_bloom(rows, H)
-    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D, item_bloom=ib)
-    op = _native.make_optim('adagrad', [t.data_ptr() for t in s1], None, lr=1e-2)
-    n_total = (W + K) * B
-    users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
-    items = torch.randint(0, I, (n_total,), device=dev, dtype=torch.int64, generator=gen)
-    mb_loss = torch.zeros(W + K, device=dev)
-    eng.rng_set_state(np.random.RandomState(3).get_state())
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def run(first, n_mb):
-        eng.bilinear_train(tb, op, users[first * B:].data_ptr(), items[first * B:].data_ptr(), n_mb * B, B,
-                           'adaptive_hinge', NN, mb_loss[first:].data_ptr(), stream=stream)
-    eng.bilinear_reserve(tb, op, K * B, B, 'adaptive_hinge', NN, stream=stream)
-    run(0, W)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(W, K)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    # kernel classes: a second, instrumented pass over the same minibatches' worth of work
-    eng.profile_reset()
-    eng.profile_enable(True)
-    run(W, K)
-    torch.cuda.synchronize(dev)
-    eng.profile_enable(False)
-    prof = eng.profile_read()
-    alg = 208 * D + 90
-    out = {'metric': 'training interactions/sec, adaptive hinge n=5, bloom item table, dim=%d' % D,
-           'value': K * B / elapsed, 'unit': 'interactions/s', 'n_gpus': 1, 'steps': K, 'warmup': W,
-           'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': 'C3: %d users x %d items, BloomEmbedding item table %d rows x %d hashes, dim %d, '
-                                  'adaptive_hinge n_neg=%d, adagrad, minibatch %d; prep overlapped as fit() runs it' % (U, I, rows, H, D, NN, B)},
-           'roofline': {'bound': 'hbm (92%% of the algorithmic bytes target a %d MB table + state that fit the '
-                                 'Infinity Cache)' % (rows * D * 4 >> 20),
-                        'alg_bytes_per_interaction': alg, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'step_achieved': K * B * alg / elapsed / 1e9,
-                        'step_frac_of_peak': K * B * alg / elapsed / 1e9 / HBM_PEAK_GBS,
-                        'ms_per_step_by_class': {k: prof[k][1] / K for k in
-                                                 ('sample', 'prep', 'score', 'user_pass', 'item_pass')}},
-           'final_minibatch_loss': float(mb_loss[-1].item())}
-    print(json.dumps(out), flush=True)
-
-
-def spawn_ranks(args):
-    """`python bench.py --gpus N` without a torchrun environment: launch the N ranks ourselves (one process
-    per GPU, torch.distributed.run on 127.0.0.1) and pass rank 0's JSON line through.  Fails loudly when the
-    machine does not have N GPUs -- it never degrades to fewer ranks."""
-    import socket
-    import subprocess
-    if args.backend == 'hip':
-        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
-            sys.stderr.write('bench.py: --gpus %d requested but %d HIP device(s) visible; refusing to run fewer ranks\n'
-                             % (args.gpus, have))
-            return 3
-    sock = socket.socket()
-    sock.bind(('127.0.0.1', 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', SLK_BENCH_SPAWNED='1')
-    env.setdefault('OMP_NUM_THREADS', '4')
-    return subprocess.call(cmd, env=env)
-
-
-class Backend(object):
-    """Device plumbing of the benchmark: 'hip' = torch-ROCm tensors + RCCL + libspotlight_hip.so (the product);
-    'emu' = CPU tensors + gloo + tests/emu's build of the same kernels (test harness for the launch logic)."""
-
-    def __init__(self, kind, local_rank):
-        self.kind = kind
-        if kind == 'hip':
-            torch.cuda.set_device(local_rank)
-            self.dev = torch.device('cuda', local_rank)
-            self.engine = _native.Engine(local_rank)
-            self.dist_backend = 'nccl'
-            self.name = torch.cuda.get_device_name(local_rank)
-        else:
-            sys.path.insert(0, os.path.join(ROOT, 'tests'))
-            from emu_backend import emu_lib
-            self.dev = torch.device('cpu')
-            self.engine = _native.Engine(0, lib=emu_lib())
-            self.dist_backend = 'gloo'
-            self.name = 'cpu emulator (test harness)'
-        self.side = None
-
-    def init_dist(self, rank, world, local_rank):
-        """Process group + a self-check of everything the first multi-GPU run could trip over, BEFORE any table is allocated:
-        every failure names the rank, the device and the variable to look at, and exits non-zero within the time-out instead of
-        hanging (the driver's 8-GPU run is the first hardware run of this path: it must not be lost to a launcher problem)."""
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29400')
-        who = 'bench.py rank %d/%d (local rank %d)' % (rank, world, local_rank)
-
-        def die(code, msg):
-            sys.stderr.write('%s: %s\n' % (who, msg))
-            sys.stderr.flush()
-            os._exit(code)
-        timeout = datetime.timedelta(seconds=int(os.environ.get('SLK_BENCH_DIST_TIMEOUT', '180')))
-        try:
-            if self.kind == 'hip':
-                if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') != '0':
-                    die(4, 'HSA_ENABLE_IPC_MODE_LEGACY=%s: this host driver only supports dmabuf IPC; RCCL needs it unset or 0'
-                        % os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])
-                if torch.cuda.device_count() <= local_rank:
-                    die(4, 'LOCAL_RANK %d but only %d HIP device(s) visible (HIP_VISIBLE_DEVICES=%s)'
-                        % (local_rank, torch.cuda.device_count(), os.environ.get('HIP_VISIBLE_DEVICES')))
-                os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')  # a failed collective raises instead of hanging
-                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
-                                        timeout=timeout)
-            else:
-                dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timeout)
-        except SystemExit:
-            raise
-        except Exception as e:  # noqa: BLE001 -- rendezvous / RCCL initialisation
-            die(4, 'init_process_group failed: %r (MASTER_ADDR=%s MASTER_PORT=%s WORLD_SIZE=%s)'
-                % (e, os.environ.get('MASTER_ADDR'), os.environ.get('MASTER_PORT'), os.environ.get('WORLD_SIZE')))
-        try:
-            # (1) every rank sits on its own device
-            ident = 'cpu:%d' % rank
-            if self.kind == 'hip':
-                props = torch.cuda.get_device_properties(local_rank)
-                ident = '%s/%s' % (getattr(props, 'uuid', None) or props.name, local_rank)
-            idents = [None] * world
-            dist.all_gather_object(idents, ident)
-            if self.kind == 'hip' and len(set(idents)) != world:
-                die(5, 'two ranks share a device: %s' % idents)
-            # (2) the collectives the sharded path issues, at their smallest: all_reduce, all_to_all_single with uneven splits
-            x = torch.full((4,), float(rank + 1), device=self.dev)
-            dist.all_reduce(x)
-            want = world * (world + 1) / 2.0
-            if abs(float(x[0].item()) - want) > 1e-3:
-                die(5, 'all_reduce returned %r, expected %r' % (float(x[0].item()), want))
-            send_counts = [(rank + p) % 3 + 1 for p in range(world)]
-            recv_counts = [(p + rank) % 3 + 1 for p in range(world)]
-            send = torch.cat([torch.full((c,), float(rank * 100 + p), device=self.dev) for p, c in enumerate(send_counts)])
-            recv = torch.empty(sum(recv_counts), device=self.dev)
-            dist.all_to_all_single(recv, send, recv_counts, send_counts)
-            got = recv.cpu().tolist()
-            exp = [float(p * 100 + rank) for p, c in enumerate(recv_counts) for _ in range(c)]
-            if got != exp:
-                die(5, 'all_to_all_single with uneven splits returned %r, expected %r' % (got, exp))
-        except SystemExit:
-            raise
-        except Exception as e:  # noqa: BLE001
-            die(5, 'collective self-check failed: %r' % (e,))
-        return dist
-
-    def generator(self, seed):
-        gen = torch.Generator(device=self.dev)
-        gen.manual_seed(seed)
-        return gen
-
-    def use_side_stream(self):
-        if self.kind == 'hip':
-            self.side = torch.cuda.Stream(self.dev)
-            self.side.wait_stream(torch.cuda.current_stream(self.dev))
-            torch.cuda.set_stream(self.side)
-
-    def stream(self):
-        return torch.cuda.current_stream(self.dev).cuda_stream if self.kind == 'hip' else 0
-
-    def sync(self):
-        if self.kind == 'hip':
-            torch.cuda.synchronize(self.dev)
-
-
-def measured_stream_rates(be, stream):
-    """Copy / triad GB/s of this GPU (slk_probe_stream: float4 kernels over 1 GiB buffers) -- the measured figure
-    SURVEY.md 8(d) asks for next to the nominal peak."""
-    n = (1 << 28) if be.kind == 'hip' else (1 << 12)
-    a, b, c = (torch.ones(n, device=be.dev) for _ in range(3))
-    ms = {k: be.engine.probe_stream(k, a.data_ptr(), b.data_ptr(), c.data_ptr(), n, iters=10, stream=stream) for k in range(12)}
-    del a, b, c
-    gbs = {'copy_plain': 8.0 * n / ms[0] / 1e6, 'triad_plain': 12.0 * n / ms[1] / 1e6, 'copy_nt_x4': 8.0 * n / ms[2] / 1e6,
-           'triad_nt_x4': 12.0 * n / ms[3] / 1e6, 'read_only': 4.0 * n / ms[4] / 1e6, 'write_only': 4.0 * n / ms[5] / 1e6,
-           'copy_chunk_x8': 8.0 * n / ms[6] / 1e6, 'copy_chunk_x8_nt': 8.0 * n / ms[7] / 1e6, 'copy_chunk_x4_16wg': 8.0 * n / ms[8] / 1e6,
-           'copy_chunk_x16_4wg': 8.0 * n / ms[9] / 1e6, 'copy_chunk_x8_ntload': 8.0 * n / ms[10] / 1e6,
-           'copy_chunk_x4_nt_32wg': 8.0 * n / ms[11] / 1e6}
-    return {'copy_GBs': max(v for k, v in gbs.items() if k.startswith('copy')),
-            'triad_GBs': max(gbs['triad_plain'], gbs['triad_nt_x4']), 'variants_GBs': gbs,
-            'note': 'slk_probe_stream over 1 GiB buffers, hipEvents, 10 launches each: float4 copy / triad, plain grid-stride and '
-                    'non-temporal with 4 accesses in flight per lane; read-only and write-only streams; chunked copies (a workgroup '
-                    'moves contiguous 16-64 KB chunks, 4-16 loads in flight per lane, plain / non-temporal); copy_GBs = the best copy'}
-
-
-def sharded_world1_check(be, args, tables, s1, s2, users, items, B, stream):
-    """N = 1 consistency of the two engines: the same two minibatches, from the same tables and the same RNG
-    state, through the fused path and through the row-sharded exchange path at world 1 (exchange = device copy);
-    per-minibatch losses must agree.  Runs on copies of the tables."""
-    from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
-    import torch.distributed as dist
-    eng = be.engine
-    K = 2
-    state = np.random.RandomState(77).get_state()
-    losses = []
-    times = []
-    for path in ('fused', 'sharded'):
-        t = [x.clone() for x in tables]
-        a1 = [x.clone() for x in s1]
-        a2 = [x.clone() for x in s2] if s2 else None
-        op = _native.make_optim(args.opt, [x.data_ptr() for x in a1], [x.data_ptr() for x in a2] if a2 else None, lr=1e-2,
-                                weight_decay=1e-6 if args.opt == 'adam_dense' else 0.0)
-        mb = torch.zeros(K, device=be.dev)
-        eng.rng_set_state(state)
-        if path == 'fused':
-            tb = _native.make_tables([x.data_ptr() for x in t], t[0].shape[0], t[1].shape[0], args.dim)
-            run = lambda lo: eng.bilinear_train(tb, op, users[lo:].data_ptr(), items[lo:].data_ptr(), K * B, B, args.loss, 1,
-                                                mb.data_ptr(), stream=stream)
-        else:
-            tr = ShardedBilinearTrainer(eng, t, op, t[1].shape[0], stream=stream, slices=args.slices or None)
-            tr.reserve(B, K)
-            run = lambda lo: tr.train(users[lo:lo + K * B], items[lo:lo + K * B], B, loss=args.loss, mb_loss=mb)
-        run(0)
-        be.sync()
-        first = mb.cpu().numpy().astype(np.float64)
-        t0 = time.perf_counter()
-        run(K * B)  # the same call again on the next minibatches: buffers allocated, code paths warm
-        be.sync()
-        times.append((time.perf_counter() - t0) / K * 1e3)
-        mb.copy_(torch.from_numpy(first).to(mb.dtype))
-        losses.append(mb.cpu().numpy().astype(np.float64))
-        del t, a1, a2
-    rel = float(np.abs(losses[0] - losses[1]).max() / np.abs(losses[0]).max())
-    return {'minibatches': K, 'loss_fused': losses[0].tolist(), 'loss_sharded_world1': losses[1].tolist(),
-            'max_rel_diff': rel, 'consistent': bool(rel <= 1e-5),
-            'ms_per_step_second_call': {'fused': times[0], 'sharded_world1': times[1]}}
-
-
-def fit_end_to_end(be, args):
-    """The drop-in API around the engine, end to end: ImplicitFactorizationModel.fit() (spotlight/factorization/implicit.py:184-252)
-    on the workload's shapes -- per epoch the numpy-exact device shuffle, the id gathers, every minibatch, the loss read-back; the
-    ids are uploaded once per fit() (host -> HBM, included).  One warm fit() of 3 epochs first (table initialisation, scratch,
-    the epoch loop's id buffers), then a timed fit() of 10 epochs (the reference's default n_iter)."""
-    from spotlight_amd.factorization.implicit import ImplicitFactorizationModel
-    from spotlight_amd.interactions import Interactions
-    n = int(args.fit_interactions)
-    rs = np.random.RandomState(5)
-    inter = Interactions(rs.randint(0, args.users, n).astype(np.int32), rs.randint(0, args.items, n).astype(np.int32),
-                         num_users=args.users, num_items=args.items)
-    opts = {'adagrad': dict(sparse=True, optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2)),
-            'sparse_adam': dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=1e-2)),
-            'adam_dense': dict(l2=1e-6)}[args.opt]
-    # (the warm fit runs 3 epochs: the large-epoch loop rotates three pairs of id buffers, and the timed fit should find all of
-    # them in torch's caching allocator like every fit() after a process's first -- fresh HIP allocations of that size cost
-    # 15-25 ms each, profiles/r04_t_fit_first_epoch_probe.txt)
-    model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=args.dim, n_iter=3, batch_size=args.batch, use_cuda=True,
-                                       random_state=np.random.RandomState(1), **opts)
-    t0 = time.perf_counter()
-    model.fit(inter)
-    be.sync()
-    first = time.perf_counter() - t0
-    epochs = 10  # the reference's default n_iter: the id upload and the first epoch's unhidden shuffle amortise as they do for a user
-    model._n_iter = epochs
-    t0 = time.perf_counter()
-    model.fit(inter)
-    be.sync()
-    t_full = time.perf_counter() - t0
-    dt = t_full / epochs
-    # the same call with 2 epochs: the difference is 8 epochs of the steady state (no id upload, no first shuffle, no drain)
-    model._n_iter = 2
-    t0 = time.perf_counter()
-    model.fit(inter)
-    be.sync()
-    t_two = time.perf_counter() - t0
-    steady = (t_full - t_two) / (epochs - 2)
-    return {'interactions_per_epoch': n, 'epochs_timed': epochs, 'seconds_per_epoch': dt, 'interactions_per_s': n / dt,
-            'steady_state_seconds_per_epoch': steady, 'steady_state_interactions_per_s': n / steady,
-            'steady_state_note': '(fit of 10 epochs - fit of 2 epochs) / 8: what every further epoch costs once the three-stage '
-                                 'pipeline runs (next epoch\'s negatives + first sorts, the shuffle after next, this epoch\'s passes)',
-            'first_fit_seconds': first,
-            'what': 'ImplicitFactorizationModel.fit(): id upload (once per fit), per epoch the numpy-exact device shuffle + id '
-                    'gathers + %d minibatches + the loss read-back; first_fit_seconds also holds table initialisation on the '
-                    'host and scratch allocation' % ((n + args.batch - 1) // args.batch)}
-
-
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -654,12 +110,16 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n'
                          % (args.gpus, os.environ['WORLD_SIZE']))
         sys.exit(3)
-    if args.workload == 'c4':
-        return bench_c4(args)
-    if args.workload in ('predict', 'eval'):
-        return bench_scoring(args)
-    if args.workload == 'c3':
-        return bench_c3(args)
+    if args.workload in ('c3', 'c4', 'predict', 'eval'):
+        # diagnostic workloads (not the headline metric): each returns its own record, printed as one JSON line
+        if args.workload == 'c4':
+            from benchlib.c4 import bench_c4 as leg
+        elif args.workload == 'c3':
+            from benchlib.c3 import bench_c3 as leg
+        else:
+            from benchlib.scoring import bench_scoring as leg
+        print(json.dumps(leg(args)), flush=True)
+        return
     # libraries (RCCL's version banner, rocm-smi) write to fd 1; keep stdout clean for the ONE
     # JSON line the driver parses: everything else goes to stderr until the final print.
     sys.stdout.flush()
@@ -811,6 +271,8 @@ def main():
     xgmi_rows[0] = xg
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
+        ranks_seen[0]['exchange_rows_timed_call'] = int(xgmi_rows[0])  # lookups of this rank that crossed to another rank, K steps
+    if multi:
         dist.barrier()
         t = torch.tensor([elapsed, elapsed_first], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -831,10 +293,14 @@ def main():
                 from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
                 denominators = {}
                 for path in ('fused', 'sharded_world1'):
+                    # both paths start from the SAME tables and the same negative stream: their per-minibatch losses must agree
+                    # (tests/test_bench_cli.py) -- the two rates are then rates of the same work
                     for t in tables + s1 + (s2 or []):
                         t.zero_()
+                    gen.manual_seed(4321)
                     for t in tables[:2]:
                         t.normal_(0, 1.0 / D, generator=gen)
+                    eng.rng_set_state(np.random.RandomState(4321).get_state())
                     op1 = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None, lr=1e-2)
                     it1 = items % I
                     mb1 = torch.zeros(W + K, device=dev)
@@ -854,7 +320,8 @@ def main():
                     go(W, K)
                     be.sync()
                     dt = time.perf_counter() - t1
-                    denominators[path] = {'interactions_per_s': K * B / dt, 'ms_per_step': dt / K * 1e3}
+                    denominators[path] = {'interactions_per_s': K * B / dt, 'ms_per_step': dt / K * 1e3,
+                                          'minibatch_losses': [float(x) for x in mb1.cpu().numpy()]}
                 denominators['note'] = ('rank 0 alone, after the timed region, on the same per-GPU shape (%d users x %d items, minibatch %d): '
                                         'the fused single-GPU path and the row-sharded path at world 1 (every exchange a local copy)'
                                         % (U, I, B))
@@ -879,6 +346,16 @@ def main():
         except Exception as e:  # a reported extra, never a reason to lose the line
             fit_rec = {'error': repr(e)[:300]}
 
+    legs = None
+    default_shape = (args.users, args.items, args.dim, args.batch, args.loss, args.opt) == (10_000_000, 1_000_000, 64, 1 << 20, 'bpr', 'adagrad')
+    if (rank == 0 and world == 1 and trainer is None and be.kind == 'hip' and args.workload == 'c2' and default_shape
+            and not args.no_configs and not args.item_zipf and not args.user_zipf):
+        from benchlib.legs import run_config_legs
+        try:
+            legs = run_config_legs(sum((['--set', kv] for kv in args.set), []))
+        except Exception as e:  # noqa: BLE001
+            legs = {'error': repr(e)[:300]}
+
     losses = mb_loss.cpu().numpy()
     assert args.no_loss_check or (np.isfinite(losses).all() and (losses[W:] > 0).all()), losses
     losses = losses[:W + K]
@@ -897,8 +374,10 @@ def main():
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': kern[dom]['achieved_GBs'],
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kern[dom]['achieved_GBs'] / HBM_PEAK_GBS,
                 'traffic': pmc_traffic(args, 'k_' + dom) if trainer is None else None,
+                'traffic_source': 'committed file (profiles/pmc_traffic.json), not measured by this run',
                 'traffic_note': 'HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic.json '
-                                '(rocprofv3 --pmc passes over this workload); null if no committed measurement matches',
+                                '(rocprofv3 --pmc passes over this workload: PMC counters cannot be read from inside the '
+                                'benchmark process); null if no committed measurement matches',
                 'kernels': kern,
                 'step_alg_bytes_per_interaction': ub + ib,
                 'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
@@ -1012,6 +491,14 @@ def main():
                 out['cpu_baseline'] = port
                 if ref:
                     out['cpu_baseline']['reference_error'] = ref.get('error')
+        if legs is not None:
+            # scalars inside `roofline` (record parsers keep its scalar fields) + the object itself LAST on the line (a tail of
+            # the line then shows it)
+            for name, rec in legs.items():
+                if isinstance(rec, dict) and ('frac' in rec or 'step_frac' in rec):
+                    out['roofline']['leg_%s_frac' % name] = rec.get('frac', rec.get('step_frac'))
+                    out['roofline']['leg_%s_ms_per_step' % name] = rec.get('ms_per_step')
+            out['configs'] = legs
     else:
         out = None
     if dist is not None:

@@ -391,8 +391,8 @@ int slk_poolnet_rank(slk_ctx *ctx, const slk_tables *tables, const int64_t *d_gr
  * a row of a dim-64 table is one aligned 256-B line on both sides of the wire.  Inside a unit's buffer
  * every peer's segment starts on a block boundary: a peer that exchanges c lookups of the unit owns
  * ceil(c / 64) * 64 slots = slk_shard_buffer_floats(dim, c) floats -- the split sizes of the all-to-all,
- * in [peer] order; the slots past c are never read.  pointwise/bpr/hinge only (one negative per
- * interaction). */
+ * in [peer] order; the slots past c are never read.  These entry points: pointwise/bpr/hinge (one negative per
+ * interaction); adaptive hinge: the *_adaptive entry points below. */
 #define SLK_SHARD_BLOCK 64
 typedef struct slk_shard {
     int32_t world, rank;
@@ -428,6 +428,39 @@ int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const slk_optim *
                         void *stream);
 int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_optim *optim, int32_t minibatch,
                         const float *d_grad_in, void *stream);
+
+/* Adaptive hinge on the row-sharded path (ABI 9; spotlight/factorization/implicit.py:266-275 + spotlight/losses.py:127-166).
+ * The reference draws B * n negatives in ONE randint call, scores flat entry k with user k / n, and views the scores as
+ * [n, B]: column c's candidates are the flat entries {r B + c} -- draws that belong to OTHER interactions, which on this path
+ * live on other ranks.  The step therefore gets a score phase and a selection in front of the user pass:
+ *   slk_shard_chunk_begin_adaptive   as slk_shard_chunk_begin with 1 + n_neg lookups per interaction: d_neg_in[n * n_neg]
+ *                                    (the draws [k * n_neg, (k + 1) * n_neg) of interaction k -- its slice of its minibatch's
+ *                                    flat draw -- or NULL: drawn from the ctx RNG), d_mb_pos[n]: the interaction's position
+ *                                    inside its GLOBAL minibatch, d_send_ids[n * (1 + n_neg)]
+ *        [count / id exchange, slk_shard_chunk_commit, per unit slk_shard_gather + the row all-to-all, as before]
+ *   per unit:      slk_shard_score_pass       d_scores[pos * (1 + n_neg) + s] = score of pair s of the interaction at global
+ *                                             position pos (s = 0: the positive), for this rank's interactions of the unit;
+ *                                             d_scores: THIS minibatch's matrix [global_batch][1 + n_neg], zeroed by the caller
+ *        [all-reduce(sum) of d_scores over the ranks: every entry has exactly one non-zero contributor]
+ *   per minibatch: slk_shard_adaptive_select  every rank, on the whole matrix: d_gk[pos * (1 + n_neg) + s] = dL/dscore (the
+ *                                             positive of a live column -1/B, the column's first maximum +1/B, else 0);
+ *                                             d_loss_out[0] = the minibatch's loss if report_loss, else 0 (the ranks' shares
+ *                                             add up to the loss, as for the other losses)
+ *   per unit:      slk_shard_user_pass_adaptive  user gradient and update from d_gk; EVERY lookup's gradient slot is written
+ *                                             (zeros for the pairs the selection left out: the owner's "touched" semantics
+ *                                             are then the one-GPU path's)
+ *        [gradient all-to-all, slk_shard_item_pass, as before] */
+int slk_shard_chunk_begin_adaptive(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                   const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                                   const int64_t *h_mb_off, int32_t n_minibatches, int32_t n_slices, int32_t n_neg,
+                                   const int64_t *d_neg_in, int64_t *d_neg_out, const int64_t *d_mb_pos,
+                                   int32_t *d_send_ids, int64_t *d_send_counts, void *stream);
+int slk_shard_score_pass(slk_ctx *ctx, const slk_tables *local, int32_t unit, const float *d_rows_in, float *d_scores,
+                         void *stream);
+int slk_shard_adaptive_select(slk_ctx *ctx, int64_t global_batch, int32_t n_neg, const float *d_scores, float *d_gk,
+                              float *d_loss_out, int32_t report_loss, void *stream);
+int slk_shard_user_pass_adaptive(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim, int32_t unit,
+                                 const float *d_gk, const float *d_rows_in, float *d_grad_out, void *stream);
 
 /* Measurement support (the reference has none; examples/bloom_embeddings/performance.py
  * times fit() with time.time()): when enabled, every launch of the engine's kernels is

@@ -110,6 +110,14 @@ _PROTOTYPES = {
                                       C.c_void_p]),
     'slk_shard_item_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int32, C.c_void_p,
                                       C.c_void_p]),
+    'slk_shard_chunk_begin_adaptive': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkShard), C.c_void_p, C.c_void_p,
+                                                 C.c_int64, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_shard_score_pass': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'slk_shard_adaptive_select': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_void_p]),
+    'slk_shard_user_pass_adaptive': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     'slk_profile_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'slk_profile_read': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'slk_profile_reset': (C.c_int, [C.c_void_p]),
@@ -423,6 +431,25 @@ class Engine(object):
             self._ctx, C.byref(tables), C.byref(optim), C.byref(shard), int(unit), int(global_batch),
             LOSS_KINDS[loss] if isinstance(loss, str) else int(loss), d_rows_in, d_grad_out, d_loss_out,
             1 if accumulate else 0, stream))
+
+    def shard_chunk_begin_adaptive(self, tables, shard, d_users_local, d_items, n, mb_off, n_slices, n_neg, d_mb_pos,
+                                   d_send_ids, d_send_counts, d_neg_in=None, d_neg_out=None, stream=0):
+        m = len(mb_off) - 1
+        off = (C.c_int64 * (m + 1))(*[int(x) for x in mb_off])
+        self._check(self._lib.slk_shard_chunk_begin_adaptive(self._ctx, C.byref(tables), C.byref(shard), d_users_local, d_items,
+                                                             int(n), off, m, int(n_slices), int(n_neg), d_neg_in, d_neg_out,
+                                                             d_mb_pos, d_send_ids, d_send_counts, stream))
+
+    def shard_score_pass(self, tables, unit, d_rows_in, d_scores, stream=0):
+        self._check(self._lib.slk_shard_score_pass(self._ctx, C.byref(tables), int(unit), d_rows_in, d_scores, stream))
+
+    def shard_adaptive_select(self, global_batch, n_neg, d_scores, d_gk, d_loss_out, report_loss, stream=0):
+        self._check(self._lib.slk_shard_adaptive_select(self._ctx, int(global_batch), int(n_neg), d_scores, d_gk, d_loss_out,
+                                                        1 if report_loss else 0, stream))
+
+    def shard_user_pass_adaptive(self, tables, optim, unit, d_gk, d_rows_in, d_grad_out, stream=0):
+        self._check(self._lib.slk_shard_user_pass_adaptive(self._ctx, C.byref(tables), C.byref(optim), int(unit), d_gk,
+                                                           d_rows_in, d_grad_out, stream))
 
     def shard_item_pass(self, tables, optim, minibatch, d_grad_in, stream=0):
         self._check(self._lib.slk_shard_item_pass(self._ctx, C.byref(tables), C.byref(optim), int(minibatch),

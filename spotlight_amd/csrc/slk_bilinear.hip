@@ -492,51 +492,7 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
     }
 }
 
-// one thread per column c of the [n, B] candidate matrix; k0 = chunk-local index of the
-// minibatch's first interaction.  every entry of gk that belongs to this minibatch is written here (no memset before the launch).
-//
-// qk / live (optional): the two occurrences of column c that carry a gradient -- the positive of
-// interaction k0 + c and the selected negative -- as item-pass payloads r = position * NP + pair
-// (qk: chunk-local interaction -> user-sorted position), or ~0u twice when the hinge is inactive.
-__global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float *gk, uint32_t k0, uint32_t bm,
-                                                         int nn, float inv_b, double *loss_partial,
-                                                         const uint32_t *qk, uint32_t *live) {
-    __shared__ double red[256];
-    const int NP = nn + 1;
-    double lsum = 0.0;
-    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < bm; c += gridDim.x * 256) {
-        const float sp = sk[(size_t)(k0 + c) * NP];
-        float best = 0.0f;
-        size_t best_at = 0;
-        for (int r = 0; r < nn; ++r) {
-            const uint32_t f = (uint32_t)r * bm + c;  // flat index into the n*B draws
-            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
-            const float sc = sk[at];
-            if (r == 0 || sc > best) {  // torch.max(dim=0): first maximum wins ties
-                best = sc;
-                best_at = at;
-            }
-        }
-        const float x = best - sp + 1.0f;
-        lsum += (double)(x > 0.0f ? x : 0.0f);
-        const float g = x >= 0.0f ? inv_b : 0.0f;
-        gk[(size_t)(k0 + c) * NP] = -g;
-        // the column's n draws are written by this thread alone, and the columns partition the n*B draws: every entry of
-        // gk gets its value here (no memset before the launch)
-        for (int r = 0; r < nn; ++r) {
-            const uint32_t f = (uint32_t)r * bm + c;
-            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
-            gk[at] = at == best_at ? g : 0.0f;
-        }
-        if (live) {
-            const uint32_t kb = (uint32_t)(best_at / (size_t)NP), sb = (uint32_t)(best_at - (size_t)kb * NP);
-            live[2 * (size_t)c] = g != 0.0f ? qk[k0 + c] * (uint32_t)NP : 0xffffffffu;
-            live[2 * (size_t)c + 1] = g != 0.0f ? qk[kb] * (uint32_t)NP + sb : 0xffffffffu;
-        }
-    }
-    const double tot = slk_block_sum_256(lsum, red);
-    if (threadIdx.x == 0) loss_partial[blockIdx.x] = tot;
-}
+// (k_adaptive_select: slk_kernels.h -- the row-sharded path launches it too)
 
 // ---------------------------------------------------------------------------------------
 // explicit feedback (spotlight/factorization/explicit.py:223-234, losses.py:169-244): per interaction
@@ -1380,7 +1336,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 hipLaunchKernelGGL(spass, dim3(ugrid), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_score_pass");
                 const unsigned sgrid = slk_grid_for(ctx, bm, 256);
-                hipLaunchKernelGGL(k_adaptive_select, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
+                hipLaunchKernelGGL(k_adaptive_select<0>, dim3(sgrid), dim3(256), 0, s, (const float *)ctx->sk.p,
                                    (float *)ctx->gk.p, b0, bm, nn, a.inv_b, (double *)ctx->losspart.p,
                                    late ? (const uint32_t *)pb.ipay[0].p : (const uint32_t *)nullptr,
                                    late ? (uint32_t *)ctx->extra[BL_LIVE].p : (uint32_t *)nullptr);

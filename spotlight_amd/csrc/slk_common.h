@@ -61,7 +61,7 @@ struct slk_rng_dev {
     int32_t sort_abort;       // sticky: a radix-sort look-back gave up waiting for the tile before it (slk_sort.hip)
 };
 
-#define SLK_EXTRA_BUFS 48
+#define SLK_EXTRA_BUFS 56
 
 // buffers filled by the value-independent prep of one chunk of minibatches (slk_bilinear.hip)
 struct slk_prep_bufs {
@@ -161,6 +161,7 @@ struct slk_ctx {
     int64_t shard_n = -1;           // interactions of the committed chunk (-1: none)
     int64_t sh_n = 0;
     int sh_M = 0, sh_S = 0, sh_world = 0;
+    int sh_NP = 2;                  // lookups per interaction of the staged chunk: 2 (pointwise / bpr / hinge), 1 + n_neg (adaptive hinge)
     unsigned sh_ubits = 0;
     std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
     std::vector<int64_t> sh_sslots, sh_rslots;  // per unit: slots of its requester-side buffers / first slot of its owner-side region

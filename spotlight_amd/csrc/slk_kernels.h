@@ -935,6 +935,59 @@ static __global__ __launch_bounds__(256) void k_item_long_flags(const uint32_t *
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// adaptive hinge: the per-column selection of _get_multiple_negative_predictions' view(n, B) layout
+// (factorization/implicit.py:266-275) over the scores of every (interaction, pair).  A template only so that the one
+// definition serves slk_bilinear.hip and slk_shard.hip (no relocatable device code in this build).
+// ---------------------------------------------------------------------------------------
+// one thread per column c of the [n, B] candidate matrix; k0 = chunk-local index of the
+// minibatch's first interaction.  every entry of gk that belongs to this minibatch is written here (no memset before the launch).
+//
+// qk / live (optional): the two occurrences of column c that carry a gradient -- the positive of
+// interaction k0 + c and the selected negative -- as item-pass payloads r = position * NP + pair
+// (qk: chunk-local interaction -> user-sorted position), or ~0u twice when the hinge is inactive.
+template <int UNUSED>
+__global__ __launch_bounds__(256) void k_adaptive_select(const float *sk, float *gk, uint32_t k0, uint32_t bm,
+                                                         int nn, float inv_b, double *loss_partial,
+                                                         const uint32_t *qk, uint32_t *live) {
+    __shared__ double red[256];
+    const int NP = nn + 1;
+    double lsum = 0.0;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < bm; c += gridDim.x * 256) {
+        const float sp = sk[(size_t)(k0 + c) * NP];
+        float best = 0.0f;
+        size_t best_at = 0;
+        for (int r = 0; r < nn; ++r) {
+            const uint32_t f = (uint32_t)r * bm + c;  // flat index into the n*B draws
+            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
+            const float sc = sk[at];
+            if (r == 0 || sc > best) {  // torch.max(dim=0): first maximum wins ties
+                best = sc;
+                best_at = at;
+            }
+        }
+        const float x = best - sp + 1.0f;
+        lsum += (double)(x > 0.0f ? x : 0.0f);
+        const float g = x >= 0.0f ? inv_b : 0.0f;
+        gk[(size_t)(k0 + c) * NP] = -g;
+        // the column's n draws are written by this thread alone, and the columns partition the n*B draws: every entry of
+        // gk gets its value here (no memset before the launch)
+        for (int r = 0; r < nn; ++r) {
+            const uint32_t f = (uint32_t)r * bm + c;
+            const size_t at = (size_t)(k0 + f / (uint32_t)nn) * NP + 1 + (f % (uint32_t)nn);
+            gk[at] = at == best_at ? g : 0.0f;
+        }
+        if (live) {
+            const uint32_t kb = (uint32_t)(best_at / (size_t)NP), sb = (uint32_t)(best_at - (size_t)kb * NP);
+            live[2 * (size_t)c] = g != 0.0f ? qk[k0 + c] * (uint32_t)NP : 0xffffffffu;
+            live[2 * (size_t)c + 1] = g != 0.0f ? qk[kb] * (uint32_t)NP + sb : 0xffffffffu;
+        }
+    }
+    const double tot = slk_block_sum_256(lsum, red);
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = tot;
+}
+
+
 // the item pass and the stitch kernel that goes behind it (slk_launch_item_pass)
 struct slk_item_fns {
     slk_pass_fn pass, stitch, pass_short;  // pass_short: k_item_pass<..., LONG = false>

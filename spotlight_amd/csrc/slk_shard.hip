@@ -43,7 +43,7 @@
 
 // scratch slots in ctx->extra
 enum { SH_OKEY0 = 0, SH_OKEY1, SH_OVAL0, SH_OVAL1, SH_VSLOT, SH_HIST, SH_SEGSTART, SH_UNITBASE, SH_MBOFF, SH_RID,
-       SH_SEGTAB, SH_GSLOT };
+       SH_SEGTAB, SH_GSLOT, SH_UIT = 48, SH_GPOS = 49 };  // (48, 49: adaptive hinge -- the packed 1 + n item lists, global positions)
 
 static inline int64_t pad_slots(int64_t lookups) { return (lookups + SLK_SHARD_BLOCK - 1) / SLK_SHARD_BLOCK * SLK_SHARD_BLOCK; }
 
@@ -68,16 +68,48 @@ __global__ __launch_bounds__(256) void k_shard_user_keys(const int64_t *users, c
     }
 }
 
-// lookup l = 2*q + s (sorted position q, pair s): key = owner * T + unit, value = l
+// adaptive hinge (1 + nn lookups per interaction, no room for them in a 64-bit payload): the same key, payload = the
+// interaction's index in the chunk; k_shard_pack then lays the item lists out in sorted order
+__global__ __launch_bounds__(256) void k_shard_user_keys_idx(const int64_t *users, uint32_t n, const uint32_t *mb_off,
+                                                             uint32_t M, uint32_t S, unsigned ubits, uint32_t *key,
+                                                             uint32_t *val) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        uint32_t lo = 0, hi = M;  // largest mb with mb_off[mb] <= k
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (mb_off[mid] <= k) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t u = (uint32_t)users[k];
+        key[k] = ((lo * S + u % S) << ubits) | u;
+        val[k] = k;
+    }
+}
+
+// uit[q * NP + s]: the positive (s = 0) and the nn draws of the interaction at sorted position q (its draws are the flat
+// entries [k * nn, (k + 1) * nn) of the minibatch's ONE randint call: users repeated user-major, implicit.py:266-275);
+// gpos[q]: its position inside its GLOBAL minibatch (the row of the minibatch's score matrix it fills)
+__global__ __launch_bounds__(256) void k_shard_pack(const uint32_t *uk, const int64_t *items, const uint32_t *neg32,
+                                                    const int64_t *mb_pos, uint32_t n, int nn, uint32_t *uit, uint32_t *gpos) {
+    const int NP = nn + 1;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        const uint32_t k = uk[q];
+        uit[(size_t)q * NP] = (uint32_t)items[k];
+        for (int r = 0; r < nn; ++r) uit[(size_t)q * NP + 1 + r] = neg32[(size_t)k * nn + r];
+        gpos[q] = (uint32_t)mb_pos[k];
+    }
+}
+
+// lookup l = NP*q + s (sorted position q, pair s): key = owner * T + unit, value = l
 __global__ __launch_bounds__(256) void k_shard_owner_keys(const uint32_t *uit, const uint32_t *ukey, unsigned ubits,
-                                                          uint32_t nl, uint32_t world, uint32_t T, uint32_t *okey,
+                                                          uint32_t nl, uint32_t NP, uint32_t world, uint32_t T, uint32_t *okey,
                                                           uint32_t *oval, unsigned long long *hist) {
     __shared__ unsigned h[SLK_SHARD_MAX_BINS];
     const uint32_t bins = world * T;
     for (uint32_t i = threadIdx.x; i < bins; i += 256) h[i] = 0;
     __syncthreads();
     for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < nl; l += gridDim.x * 256) {
-        const uint32_t b = (uit[l] % world) * T + (ukey[l >> 1] >> ubits);
+        const uint32_t b = (uit[l] % world) * T + (ukey[l / NP] >> ubits);
         okey[l] = b;
         oval[l] = l;
         atomicAdd(&h[b], 1u);
@@ -217,6 +249,85 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
     if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// adaptive hinge on the row-sharded path (implicit.py:266-275 + losses.py:127-166).  Column c of the minibatch's [n, B]
+// candidate matrix holds the flat draws {r B + c}, scored with the users of OTHER interactions (flat entry k uses user
+// k / n) -- interactions that live on other ranks.  So the step has a score phase in front: every rank scores the 1 + n
+// pairs of ITS interactions (all 1 + n rows travel), the B x (1 + n) score matrix is summed over the ranks (each entry has
+// one non-zero contributor: exact), every rank runs the same selection over the whole matrix (k_adaptive_select,
+// slk_kernels.h: the one-GPU path's kernel), and the user pass reads dL/dscore of its pairs from the result.
+// ---------------------------------------------------------------------------------------------------------------------
+// one row group per sorted position of the unit: sk[gpos * NP + s] = u . v_s + bu + bi_s, the dot as k_score_pass forms it
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void k_shard_score_pass(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t stride = gridDim.x * GPB;
+    for (uint32_t q = a.begin + blockIdx.x * GPB + grp; q < a.end; q += stride) {
+        const uint32_t user = a.ukey[q] & a.umask;
+        const slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + (size_t)user * D + d0) : slk_vzero<VEC>();
+        const float bu = a.P[2][user];
+        const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
+        for (int s = 0; s < a.NP; ++s) {
+            const uint32_t slot = a.vslot[qb + s];
+            const slk_vec<VEC> v = on ? slk_vload<VEC>(a.vrows + slk_blk_row(slot, D) + d0) : slk_vzero<VEC>();
+            const float bi = a.vrows[slk_blk_scalar(slot, D)];
+            const float sc = slk_group_sum<G>(slk_vdot<VEC>(u, v)) + bu + bi;
+            if (lane == 0) a.sk[kb + s] = sc;
+        }
+    }
+}
+
+// USER PASS with dL/dscore given (k_user_pass<..., UMODE 1> over the exchange buffers): the user gradient is the sum over the
+// user's positions, and per position over its LIVE pairs in pair order, of g * v; every lookup's slot of the gradient buffer
+// gets g * u_old and g -- zeros for the pairs the selection left out (the owner adds them: SparseAdam's "touched" rows
+// decay, Adagrad's zero sum is an exact no-op, as on one GPU)
+template <int VEC, int G, int UPD>
+__global__ __launch_bounds__(256) void k_shard_user_pass_pre(slk_pass_args a) {
+    constexpr int GPB = 256 / G;
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int D = a.D;
+    const int d0 = lane * VEC;
+    const bool on = d0 < D;
+    const uint32_t stride = gridDim.x * GPB;
+    for (uint32_t p = a.begin + blockIdx.x * GPB + grp; p < a.end; p += stride) {
+        const uint32_t key = a.ukey[p];
+        if (p > a.begin && a.ukey[p - 1] == key) continue;  // not the head of its user segment
+        const uint32_t user = key & a.umask;
+        const size_t uoff = (size_t)user * D + d0;
+        slk_vec<VEC> u = on ? slk_vload<VEC>(a.P[0] + uoff) : slk_vzero<VEC>();
+        slk_vec<VEC> gu = slk_vzero<VEC>();
+        float gbu = 0.0f;
+        uint32_t q = p;
+        do {
+            const size_t kb = (size_t)a.uk[q] * a.NP, qb = (size_t)q * a.NP;
+            for (int s = 0; s < a.NP; ++s) {
+                const float g = a.gk[kb + s];
+                const uint32_t slot = a.vslot[qb + s];
+                const size_t ro = slk_blk_row(slot, D);
+                if (g != 0.0f) {
+                    const slk_vec<VEC> v = on ? slk_vload<VEC>(a.vrows + ro + d0) : slk_vzero<VEC>();
+                    slk_vaxpy<VEC>(gu, g, v);
+                    gbu += g;
+                }
+                slk_vec<VEC> c;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c.v[i] = g * u.v[i];
+                if (on) slk_vstore<VEC>(a.grows + ro + d0, c);
+                if (lane == 0) a.grows[slk_blk_scalar(slot, D)] = g;
+            }
+            ++q;
+        } while (q < a.end && a.ukey[q] == key);
+        if (on) slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, false);
+        if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
+    }
+}
+
 // this rank's share of the minibatch loss: (sum of its per-interaction losses) / global batch
 __global__ __launch_bounds__(256) void k_shard_loss(const double *partial, int n, float inv_b, float *out,
                                                      int accumulate) {
@@ -262,7 +373,7 @@ SLK_EXPORT int slk_shard_reserve(slk_ctx *ctx, const slk_tables *local, const sl
     if (n < 0 || n >= ((int64_t)1 << 30) || n_recv < 0 || n_recv >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "slk_shard_reserve: n %lld / n_recv %lld out of range", (long long)n, (long long)n_recv);
     SLK_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t nn = (size_t)n, nl = 2 * nn, nr = (size_t)n_recv;
+    const size_t nn = (size_t)n, nl = 2 * nn, nr = (size_t)n_recv;  // (an adaptive-hinge chunk grows its scratch on demand)
     if ((rc = slk_ensure(ctx, ctx->extra[SH_HIST], (size_t)SLK_SHARD_MAX_BINS * 8))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[SH_SEGSTART], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->extra[SH_UNITBASE], (size_t)SLK_SHARD_MAX_BINS * 4))) return rc;
@@ -286,12 +397,46 @@ SLK_EXPORT int slk_shard_reserve(slk_ctx *ctx, const slk_tables *local, const sl
     return slk_sort_reserve(ctx, nl > nr ? nl : nr);
 }
 
+// n_neg == 0: one negative per interaction, the (positive, negative) pair rides as the sort's 64-bit payload;
+// n_neg >= 1 (adaptive hinge): 1 + n_neg lookups per interaction, d_mb_pos gives every interaction's row of its
+// minibatch's score matrix
+static int shard_chunk_begin_impl(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                  const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                                  const int64_t *h_mb_off, int32_t M, int32_t S, int32_t n_neg, const int64_t *d_neg_in,
+                                  int64_t *d_neg_out, const int64_t *d_mb_pos, int32_t *d_send_ids, int64_t *d_send_counts,
+                                  void *stream);
+
 SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
                                      const int64_t *d_users_local, const int64_t *d_items, int64_t n,
                                      const int64_t *h_mb_off, int32_t M, int32_t S, const int64_t *d_neg_in,
                                      int64_t *d_neg_out, int32_t *d_send_ids, int64_t *d_send_counts,
                                      void *stream) {
+    return shard_chunk_begin_impl(ctx, local, sh, d_users_local, d_items, n, h_mb_off, M, S, 0, d_neg_in, d_neg_out, nullptr,
+                                  d_send_ids, d_send_counts, stream);
+}
+
+SLK_EXPORT int slk_shard_chunk_begin_adaptive(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                              const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                                              const int64_t *h_mb_off, int32_t M, int32_t S, int32_t n_neg,
+                                              const int64_t *d_neg_in, int64_t *d_neg_out, const int64_t *d_mb_pos,
+                                              int32_t *d_send_ids, int64_t *d_send_counts, void *stream) {
     if (!ctx) return SLK_EINVAL;
+    if (n_neg < 1 || n_neg > 1024) return slk_fail(ctx, SLK_EINVAL, "num_negative_samples %d outside [1, 1024]", n_neg);
+    if (n > 0 && !d_mb_pos) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_begin_adaptive: d_mb_pos is NULL");
+    return shard_chunk_begin_impl(ctx, local, sh, d_users_local, d_items, n, h_mb_off, M, S, n_neg, d_neg_in, d_neg_out, d_mb_pos,
+                                  d_send_ids, d_send_counts, stream);
+}
+
+static int shard_chunk_begin_impl(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh,
+                                  const int64_t *d_users_local, const int64_t *d_items, int64_t n,
+                                  const int64_t *h_mb_off, int32_t M, int32_t S, int32_t n_neg, const int64_t *d_neg_in,
+                                  int64_t *d_neg_out, const int64_t *d_mb_pos, int32_t *d_send_ids, int64_t *d_send_counts,
+                                  void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    const bool multi = n_neg > 0;
+    const int nng = multi ? n_neg : 1;  // negatives per interaction
+    const uint32_t NP = (uint32_t)nng + 1u;
+    if (n * (int64_t)NP >= ((int64_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "shard chunk: %lld lookups >= 2^31", (long long)(n * NP));
     int vec, g, rc;
     if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
@@ -322,9 +467,14 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
     ctx->sh_world = (int)world;
     ctx->sh_ubits = ubits;
     ctx->sh_n = n;
+    ctx->sh_NP = (int)NP;
     if (n > 0) {
-        const uint32_t nn = (uint32_t)n, nl = 2 * nn;
-        if ((rc = slk_ensure(ctx, ctx->neg32, (size_t)nn * 4))) return rc;
+        const uint32_t nn = (uint32_t)n, nl = NP * nn;
+        if ((rc = slk_ensure(ctx, ctx->neg32, (size_t)nn * nng * 4))) return rc;
+        if (multi) {
+            if ((rc = slk_ensure(ctx, ctx->extra[SH_UIT], (size_t)nl * 4))) return rc;
+            if ((rc = slk_ensure(ctx, ctx->extra[SH_GPOS], (size_t)nn * 4))) return rc;
+        }
         for (int b = 0; b < 2; ++b) {
             if ((rc = slk_ensure(ctx, ctx->ukey[b], (size_t)nn * 4))) return rc;
             if ((rc = slk_ensure(ctx, ctx->uval[b], (size_t)nn * 8))) return rc;
@@ -336,12 +486,12 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
         // ---- negatives over the GLOBAL item range (sampling.py:34)
         if (d_neg_in) {
             slk_prof_begin(ctx, SLK_K_SAMPLE, s);
-            if ((rc = slk_launch_i64_to_u32(ctx, d_neg_in, neg32, nn, s))) return rc;
+            if ((rc = slk_launch_i64_to_u32(ctx, d_neg_in, neg32, (size_t)nn * nng, s))) return rc;
             if (d_neg_out)
-                SLK_HIP(ctx, hipMemcpyAsync(d_neg_out, d_neg_in, (size_t)nn * 8, hipMemcpyDeviceToDevice, s));
+                SLK_HIP(ctx, hipMemcpyAsync(d_neg_out, d_neg_in, (size_t)nn * nng * 8, hipMemcpyDeviceToDevice, s));
             slk_prof_end(ctx, s);
         } else {
-            if ((rc = slk_sample_u32(ctx, sh->num_items_global, n, neg32, d_neg_out, s))) return rc;
+            if ((rc = slk_sample_u32(ctx, sh->num_items_global, n * (int64_t)nng, neg32, d_neg_out, s))) return rc;
         }
         // ---- sort by (unit, user); bucket the lookups by (owner, unit)
         slk_prof_begin(ctx, SLK_K_PREP, s);
@@ -349,17 +499,35 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
         uint32_t *h32 = (uint32_t *)ctx->sh_host.data();
         for (int m = 0; m <= M; ++m) h32[m] = (uint32_t)h_mb_off[m];
         SLK_HIP(ctx, hipMemcpyAsync(ctx->extra[SH_MBOFF].p, h32, (size_t)(M + 1) * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_shard_user_keys, dim3(slk_grid_for(ctx, nn, 256)), dim3(256), 0, s, d_users_local,
-                           d_items, (const uint32_t *)neg32, nn, (const uint32_t *)ctx->extra[SH_MBOFF].p,
-                           (uint32_t)M, (uint32_t)S, ubits, (uint32_t *)ctx->ukey[0].p, (uint64_t *)ctx->uval[0].p);
-        SLK_LAUNCH_CHECK(ctx, "k_shard_user_keys");
-        if ((rc = slk_sort_pairs_u32_u64(ctx, (const uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->ukey[1].p,
-                                         (const uint64_t *)ctx->uval[0].p, (uint64_t *)ctx->uval[1].p, nn,
-                                         ubits + slk_bits_for((uint64_t)T - 1), s, true)))
-            return rc;
-        const uint32_t *uit = (const uint32_t *)ctx->uval[1].p;
+        const uint32_t *uit;
+        if (!multi) {
+            hipLaunchKernelGGL(k_shard_user_keys, dim3(slk_grid_for(ctx, nn, 256)), dim3(256), 0, s, d_users_local,
+                               d_items, (const uint32_t *)neg32, nn, (const uint32_t *)ctx->extra[SH_MBOFF].p,
+                               (uint32_t)M, (uint32_t)S, ubits, (uint32_t *)ctx->ukey[0].p, (uint64_t *)ctx->uval[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_shard_user_keys");
+            if ((rc = slk_sort_pairs_u32_u64(ctx, (const uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->ukey[1].p,
+                                             (const uint64_t *)ctx->uval[0].p, (uint64_t *)ctx->uval[1].p, nn,
+                                             ubits + slk_bits_for((uint64_t)T - 1), s, true)))
+                return rc;
+            uit = (const uint32_t *)ctx->uval[1].p;
+        } else {
+            // the payload is the interaction's index; the 1 + n item lists and the global positions follow it into sorted order
+            hipLaunchKernelGGL(k_shard_user_keys_idx, dim3(slk_grid_for(ctx, nn, 256)), dim3(256), 0, s, d_users_local, nn,
+                               (const uint32_t *)ctx->extra[SH_MBOFF].p, (uint32_t)M, (uint32_t)S, ubits,
+                               (uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->uval[0].p);
+            SLK_LAUNCH_CHECK(ctx, "k_shard_user_keys_idx");
+            if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->ukey[0].p, (uint32_t *)ctx->ukey[1].p,
+                                             (const uint32_t *)ctx->uval[0].p, (uint32_t *)ctx->uval[1].p, nn,
+                                             ubits + slk_bits_for((uint64_t)T - 1), s, true)))
+                return rc;
+            hipLaunchKernelGGL(k_shard_pack, dim3(slk_grid_for(ctx, nn, 256)), dim3(256), 0, s, (const uint32_t *)ctx->uval[1].p,
+                               d_items, (const uint32_t *)neg32, d_mb_pos, nn, nng, (uint32_t *)ctx->extra[SH_UIT].p,
+                               (uint32_t *)ctx->extra[SH_GPOS].p);
+            SLK_LAUNCH_CHECK(ctx, "k_shard_pack");
+            uit = (const uint32_t *)ctx->extra[SH_UIT].p;
+        }
         hipLaunchKernelGGL(k_shard_owner_keys, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s, uit,
-                           (const uint32_t *)ctx->ukey[1].p, ubits, nl, world, T, (uint32_t *)ctx->extra[SH_OKEY0].p,
+                           (const uint32_t *)ctx->ukey[1].p, ubits, nl, NP, world, T, (uint32_t *)ctx->extra[SH_OKEY0].p,
                            (uint32_t *)ctx->extra[SH_OVAL0].p, hist);
         SLK_LAUNCH_CHECK(ctx, "k_shard_owner_keys");
         if ((rc = slk_sort_pairs_u32_u32(ctx, (const uint32_t *)ctx->extra[SH_OKEY0].p,
@@ -374,9 +542,10 @@ SLK_EXPORT int slk_shard_chunk_begin(slk_ctx *ctx, const slk_tables *local, cons
                        (uint32_t *)ctx->extra[SH_SEGSTART].p, (uint32_t *)ctx->extra[SH_UNITBASE].p, d_send_counts);
     SLK_LAUNCH_CHECK(ctx, "k_shard_scan");
     if (n > 0) {
-        const uint32_t nl = 2 * (uint32_t)n;
+        const uint32_t nl = NP * (uint32_t)n;
         hipLaunchKernelGGL(k_shard_slots, dim3(slk_grid_for(ctx, nl, 256)), dim3(256), 0, s,
-                           (const uint32_t *)ctx->uval[1].p, (const uint32_t *)ctx->extra[SH_OKEY1].p,
+                           multi ? (const uint32_t *)ctx->extra[SH_UIT].p : (const uint32_t *)ctx->uval[1].p,
+                           (const uint32_t *)ctx->extra[SH_OKEY1].p,
                            (const uint32_t *)ctx->extra[SH_OVAL1].p, nl, world,
                            (const uint32_t *)ctx->extra[SH_SEGSTART].p, (const uint32_t *)ctx->extra[SH_UNITBASE].p,
                            d_send_ids, (uint32_t *)ctx->extra[SH_VSLOT].p);
@@ -412,8 +581,10 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
             sslots += pad_slots(h_send_counts[(size_t)r * T + t]);
             rslots += pad_slots(h_recv_counts[(size_t)r * T + t]);
         }
-        if (sent & 1) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: unit %d sends an odd number of lookups", t);
-        ctx->sh_ustart[t + 1] = ctx->sh_ustart[t] + sent / 2;
+        if (sent % ctx->sh_NP)
+            return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: unit %d sends %lld lookups, not a multiple of %d per interaction", t,
+                            (long long)sent, ctx->sh_NP);
+        ctx->sh_ustart[t + 1] = ctx->sh_ustart[t] + sent / ctx->sh_NP;
         ctx->sh_rstart[t + 1] = ctx->sh_rstart[t] + recv;
         ctx->sh_sslots[t] = sslots;
         ctx->sh_rslots[t + 1] = ctx->sh_rslots[t] + rslots;
@@ -549,7 +720,9 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     if ((rc = check_shard(ctx, sh))) return rc;
     if ((rc = check_unit(ctx, unit, "slk_shard_user_pass"))) return rc;
     if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_HINGE)
-        return slk_fail(ctx, SLK_EINVAL, "row-sharded path supports pointwise/bpr/hinge (loss kind %d)", loss);
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: pointwise/bpr/hinge (loss kind %d); adaptive hinge: slk_shard_score_pass, "
+                                         "slk_shard_adaptive_select, slk_shard_user_pass_adaptive", loss);
+    if (ctx->sh_NP != 2) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: the staged chunk is an adaptive-hinge one (%d lookups per interaction)", ctx->sh_NP);
     if (global_batch < 1) return slk_fail(ctx, SLK_EINVAL, "global_batch must be >= 1");
     const int64_t p0 = ctx->sh_ustart[unit], n = ctx->sh_ustart[unit + 1] - p0;
     if (!d_loss_out || (n > 0 && (!d_rows_in || !d_grad_out))) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: NULL pointer");
@@ -593,6 +766,129 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     hipLaunchKernelGGL(k_shard_loss, dim3(1), dim3(256), 0, s, (const double *)ctx->losspart.p, (int)ugrid, a.inv_b,
                        d_loss_out, (int)accumulate);
     SLK_LAUNCH_CHECK(ctx, "k_shard_loss");
+    return SLK_OK;
+}
+
+// ---- adaptive hinge: score phase, selection, user pass with dL/dscore given ---------------------------------------------------
+template <int VEC, int G>
+static slk_pass_fn shard_user_pass_pre_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_shard_user_pass_pre<VEC, G, SLK_UPD_ADAGRAD>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_shard_user_pass_pre<VEC, G, SLK_UPD_SPARSE_ADAM>;
+    if (upd == SLK_UPD_SGD) return k_shard_user_pass_pre<VEC, G, SLK_UPD_SGD>;
+    return k_shard_user_pass_pre<VEC, G, SLK_UPD_GRAD_ONLY>;
+}
+
+static int check_adaptive_unit(slk_ctx *ctx, int32_t unit, const char *who) {
+    int rc;
+    if ((rc = check_unit(ctx, unit, who))) return rc;
+    if (ctx->sh_NP < 2 || (ctx->sh_n > 0 && !ctx->extra[SH_GPOS].p))
+        return slk_fail(ctx, SLK_EINVAL, "%s: the staged chunk was not begun by slk_shard_chunk_begin_adaptive", who);
+    return SLK_OK;
+}
+
+static void fill_unit(slk_pass_args &a, slk_ctx *ctx, int32_t unit) {
+    const int64_t p0 = ctx->sh_ustart[unit], n = ctx->sh_ustart[unit + 1] - p0;
+    a.NP = ctx->sh_NP;
+    a.begin = (uint32_t)p0;
+    a.end = (uint32_t)(p0 + n);
+    a.ukey = (const uint32_t *)ctx->ukey[1].p;
+    a.umask = (uint32_t)((1ull << ctx->sh_ubits) - 1);
+    a.vslot = (const uint32_t *)ctx->extra[SH_VSLOT].p;
+    a.uk = (const uint32_t *)ctx->extra[SH_GPOS].p;  // sorted position -> row of the minibatch's score matrix
+}
+
+SLK_EXPORT int slk_shard_score_pass(slk_ctx *ctx, const slk_tables *local, int32_t unit, const float *d_rows_in,
+                                    float *d_scores, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
+    if ((rc = check_adaptive_unit(ctx, unit, "slk_shard_score_pass"))) return rc;
+    const int64_t n = ctx->sh_ustart[unit + 1] - ctx->sh_ustart[unit];
+    if (n == 0) return SLK_OK;
+    if (!d_rows_in || !d_scores) return slk_fail(ctx, SLK_EINVAL, "slk_shard_score_pass: NULL pointer");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    slk_pass_args a;
+    memset(&a, 0, sizeof(a));
+    for (int t = 0; t < 4; ++t) a.P[t] = local->d_param[t];
+    a.D = local->dim;
+    fill_unit(a, ctx, unit);
+    a.vrows = d_rows_in;
+    a.sk = d_scores;
+    slk_prof_begin(ctx, SLK_K_SCORE, s);
+#define SLK_SCORE(V_, G_) \
+    hipLaunchKernelGGL((k_shard_score_pass<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n, 256 / G_)), dim3(256), 0, s, a)
+    SLK_FOR_LAYOUT(vec, g, SLK_SCORE);
+#undef SLK_SCORE
+    SLK_LAUNCH_CHECK(ctx, "k_shard_score_pass");
+    slk_prof_end(ctx, s);
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_shard_adaptive_select(slk_ctx *ctx, int64_t global_batch, int32_t n_neg, const float *d_scores,
+                                         float *d_gk, float *d_loss_out, int32_t report_loss, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (global_batch < 1 || n_neg < 1 || global_batch * (int64_t)(n_neg + 1) >= ((int64_t)1 << 31))
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_adaptive_select: global_batch %lld x (1 + %d) pairs out of range", (long long)global_batch, n_neg);
+    if (!d_scores || !d_gk || !d_loss_out) return slk_fail(ctx, SLK_EINVAL, "slk_shard_adaptive_select: NULL pointer");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    int rc;
+    const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
+    if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
+    const float inv_b = 1.0f / (float)global_batch;
+    const unsigned sgrid = slk_grid_for(ctx, (size_t)global_batch, 256);
+    slk_prof_begin(ctx, SLK_K_SCORE, s);
+    hipLaunchKernelGGL(k_adaptive_select<0>, dim3(sgrid), dim3(256), 0, s, d_scores, d_gk, 0u, (uint32_t)global_batch, (int)n_neg,
+                       inv_b, (double *)ctx->losspart.p, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    SLK_LAUNCH_CHECK(ctx, "k_adaptive_select");
+    slk_prof_end(ctx, s);
+    // every rank has computed the whole minibatch's loss; the ranks' shares must ADD UP to it: one rank reports it
+    hipLaunchKernelGGL(k_shard_loss, dim3(1), dim3(256), 0, s, (const double *)ctx->losspart.p, (int)(report_loss ? sgrid : 0), inv_b,
+                       d_loss_out, 0);
+    SLK_LAUNCH_CHECK(ctx, "k_shard_loss");
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_shard_user_pass_adaptive(slk_ctx *ctx, const slk_tables *local, const slk_optim *optim, int32_t unit,
+                                            const float *d_gk, const float *d_rows_in, float *d_grad_out, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = check_plain(ctx, local))) return rc;
+    if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
+    if ((rc = check_adaptive_unit(ctx, unit, "slk_shard_user_pass_adaptive"))) return rc;
+    const int64_t n = ctx->sh_ustart[unit + 1] - ctx->sh_ustart[unit];
+    if (n == 0) return SLK_OK;
+    if (!d_gk || !d_rows_in || !d_grad_out) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass_adaptive: NULL pointer");
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    ctx->last_stream = s;
+    const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    if (dense) {
+        const size_t elems[4] = {(size_t)local->num_users * local->dim, (size_t)local->num_items * local->dim,
+                                 (size_t)local->num_users, (size_t)local->num_items};
+        if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
+    }
+    slk_pass_args a;
+    memset(&a, 0, sizeof(a));
+    fill_tables(a, ctx, local, optim, dense);
+    fill_unit(a, ctx, unit);
+    a.gk = d_gk;
+    a.vrows = d_rows_in;
+    a.grows = d_grad_out;
+    slk_pass_fn upass = nullptr;
+    const int upd = slk_upd_for(optim->kind);
+#define SLK_PICK(V_, G_) upass = shard_user_pass_pre_fn<V_, G_>(upd)
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK);
+#undef SLK_PICK
+    slk_prof_begin(ctx, SLK_K_USER_PASS, s);
+    hipLaunchKernelGGL(upass, dim3(slk_grid_for(ctx, (size_t)n, 256u / (unsigned)g)), dim3(256), 0, s, a);
+    SLK_LAUNCH_CHECK(ctx, "k_shard_user_pass_pre");
+    slk_prof_end(ctx, s);
     return SLK_OK;
 }
 

@@ -73,6 +73,18 @@ class ShardedBilinearTrainer(object):
         self._bufs = {}
         self.exchange_rows = 0
         self.last_exchange_rows = 0
+        self._check_stream()
+
+    def _check_stream(self):
+        """The engine's kernels and the collectives must share ONE stream: torch.distributed's ops (RCCL) order themselves
+        against torch's CURRENT stream on the device, not against the raw stream the engine was handed -- on any other stream
+        the exchanges would race the kernels that fill and read their buffers, silently."""
+        if self.device.type == 'cuda':
+            current = torch.cuda.current_stream(self.device).cuda_stream
+            if int(self.stream or 0) != int(current or 0):
+                raise RuntimeError('ShardedBilinearTrainer: stream %#x is not torch\'s current stream on %s (%#x); make it current '
+                                   '(torch.cuda.set_stream / with torch.cuda.stream(...)) so that the RCCL collectives are ordered '
+                                   'with the engine\'s kernels' % (int(self.stream or 0), self.device, int(current or 0)))
 
     def max_minibatches_per_chunk(self):
         """Bound of one slk_shard_chunk_begin: (owner, unit) bins <= 2048 and 32-bit sort keys."""
@@ -116,25 +128,47 @@ class ShardedBilinearTrainer(object):
             for name in ('rows_send%d', 'rows_recv%d', 'grad_send%d'):
                 self._buf(name % k, padded(per_unit), torch.float32)
 
-    def run_chunk(self, users_local, items, mb_off, global_batches, loss='bpr', neg_in=None, neg_out=None):
+    def run_chunk(self, users_local, items, mb_off, global_batches, loss='bpr', neg_in=None, neg_out=None, n_neg=None,
+                  mb_pos=None):
         """A chunk of M = len(mb_off) - 1 consecutive global minibatches.  `users_local` / `items`:
         int64 device tensors with this rank's interactions of the chunk (LOCAL user rows, GLOBAL item
         ids; may be empty), minibatch m = [mb_off[m], mb_off[m + 1]); `global_batches[m]`: size of the
         GLOBAL minibatch (losses are means over it).  Negatives: `neg_in`, or one contiguous draw from
         this rank's engine RNG.  Returns a [M] tensor: this rank's share of each loss.item() (sum
-        over ranks = the loss)."""
+        over ranks = the loss).
+
+        loss='adaptive_hinge' (spotlight/factorization/implicit.py:266-275, spotlight/losses.py:127-166): `n_neg` draws per
+        interaction (`neg_in`: [n * n_neg], interaction k's draws = entries [k * n_neg, (k + 1) * n_neg) -- its slice of its
+        minibatch's ONE flat randint call), and `mb_pos`: int64 [n], every interaction's position inside its GLOBAL minibatch --
+        the reference views the flat scores as [n_neg, B], so column c's candidates belong to OTHER interactions (of other
+        ranks): all 1 + n_neg rows travel for a score phase, the [B, 1 + n_neg] score matrix is summed over the ranks, every
+        rank runs the selection on the whole matrix, then the user pass and the gradient exchange follow as for the other
+        losses (every lookup's slot travels back, zeros for the pairs the selection left out)."""
         eng, w, s_n, st = self.engine, self.world, self.slices, self.stream
+        self._check_stream()
+        adaptive = loss == 'adaptive_hinge'
+        if adaptive and (not n_neg or mb_pos is None):
+            raise ValueError('adaptive_hinge on the row-sharded path needs n_neg and mb_pos')
+        NP = (int(n_neg) + 1) if adaptive else 2  # lookups per interaction
         m_n = len(mb_off) - 1
         t_n = m_n * s_n
         n = int(mb_off[-1])
         assert int(users_local.numel()) == n and int(mb_off[0]) == 0
-        send_ids = self._buf('send_ids', 2 * n, torch.int32)
+        send_ids = self._buf('send_ids', NP * n, torch.int32)
         send_counts = self._buf('send_counts', w * t_n, torch.int64)
-        eng.shard_chunk_begin(self._tables, self._shard, users_local.data_ptr() if n else None,
-                              items.data_ptr() if n else None, n, mb_off, s_n, send_ids.data_ptr(),
-                              send_counts.data_ptr(),
-                              d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
-                              d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None, stream=st)
+        if adaptive:
+            assert int(mb_pos.numel()) == n and (neg_in is None or int(neg_in.numel()) == n * (NP - 1))
+            eng.shard_chunk_begin_adaptive(self._tables, self._shard, users_local.data_ptr() if n else None,
+                                           items.data_ptr() if n else None, n, mb_off, s_n, NP - 1,
+                                           mb_pos.data_ptr() if n else None, send_ids.data_ptr(), send_counts.data_ptr(),
+                                           d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
+                                           d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None, stream=st)
+        else:
+            eng.shard_chunk_begin(self._tables, self._shard, users_local.data_ptr() if n else None,
+                                  items.data_ptr() if n else None, n, mb_off, s_n, send_ids.data_ptr(),
+                                  send_counts.data_ptr(),
+                                  d_neg_in=neg_in.data_ptr() if (neg_in is not None and n) else None,
+                                  d_neg_out=neg_out.data_ptr() if (neg_out is not None and n) else None, stream=st)
         # counts [owner][unit] -> [source][unit]; the chunk's only host synchronisation
         recv_counts = self._buf('recv_counts', w * t_n, torch.int64)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
@@ -150,7 +184,7 @@ class ShardedBilinearTrainer(object):
         rc_unit = [[self._slots(rc[r * t_n + t]) * f for r in range(w)] for t in range(t_n)]
         n_send = [sum(x) for x in sc_unit]  # floats of the unit's requester-side buffers
         n_recv = [sum(x) for x in rc_unit]  # floats of its owner-side buffers
-        self.last_exchange_rows = 2 * n - sc_peer[self.rank]  # lookups that crossed xGMI
+        self.last_exchange_rows = NP * n - sc_peer[self.rank]  # lookups that crossed xGMI
         self.exchange_rows += self.last_exchange_rows
         loss_out = torch.zeros(m_n, dtype=torch.float32, device=self.device)
         # world 1: every lookup's owner is this rank, so an all_to_all_single would be a device-local copy of the whole buffer
@@ -172,6 +206,23 @@ class ShardedBilinearTrainer(object):
                 rows_recv.append(rr)
                 h_rows.append(dist.all_to_all_single(rr, rows_send, sc_unit[t], rc_unit[t], group=self.group,
                                                      async_op=True))
+            gk = None
+            if adaptive:
+                # score phase: this rank's rows of the minibatch's [B, 1 + n_neg] score matrix; summed over the ranks (every
+                # entry has one non-zero contributor: exact); the selection, on every rank alike
+                gb = int(global_batches[m])
+                scores = self._buf('scores', gb * NP, torch.float32)
+                scores.zero_()
+                for k, t in enumerate(units):
+                    if h_rows[k] is not None:
+                        h_rows[k].wait()
+                        h_rows[k] = None
+                    eng.shard_score_pass(self._tables, t, rows_recv[k].data_ptr(), scores.data_ptr(), stream=st)
+                if w > 1:
+                    dist.all_reduce(scores, group=self.group)
+                gk = self._buf('gk', gb * NP, torch.float32)
+                eng.shard_adaptive_select(gb, NP - 1, scores.data_ptr(), gk.data_ptr(), loss_out[m:].data_ptr(),
+                                          report_loss=self.rank == 0, stream=st)
             # requesters: forward / loss / backward / user update per slice; gradients travel to
             # the owners (async) while the next slice computes
             grad_recv = self._buf('grad_recv', sum(n_recv[t] for t in units), torch.float32)
@@ -180,9 +231,13 @@ class ShardedBilinearTrainer(object):
                 if h_rows[k] is not None:
                     h_rows[k].wait()
                 grad_send = grad_recv[off:off + n_recv[t]] if alias else self._buf('grad_send%d' % k, n_send[t], torch.float32)
-                eng.shard_user_pass(self._tables, self.optim, self._shard, t, global_batches[m], loss,
-                                    rows_recv[k].data_ptr(), grad_send.data_ptr(), loss_out[m:].data_ptr(),
-                                    accumulate=k > 0, stream=st)
+                if adaptive:
+                    eng.shard_user_pass_adaptive(self._tables, self.optim, t, gk.data_ptr(), rows_recv[k].data_ptr(),
+                                                 grad_send.data_ptr(), stream=st)
+                else:
+                    eng.shard_user_pass(self._tables, self.optim, self._shard, t, global_batches[m], loss,
+                                        rows_recv[k].data_ptr(), grad_send.data_ptr(), loss_out[m:].data_ptr(),
+                                        accumulate=k > 0, stream=st)
                 if not alias:
                     h_grad.append(dist.all_to_all_single(grad_recv[off:off + n_recv[t]], grad_send, rc_unit[t],
                                                          sc_unit[t], group=self.group, async_op=True))
@@ -193,13 +248,13 @@ class ShardedBilinearTrainer(object):
             eng.shard_item_pass(self._tables, self.optim, m, grad_recv.data_ptr(), stream=st)
         return loss_out
 
-    def step(self, users_local, items, global_batch, loss='bpr', neg_in=None, neg_out=None):
+    def step(self, users_local, items, global_batch, loss='bpr', neg_in=None, neg_out=None, n_neg=None, mb_pos=None):
         """One global minibatch (a chunk of one).  Returns a 1-element tensor: this rank's share of
         loss.item() (sum over ranks = the loss)."""
         return self.run_chunk(users_local, items, [0, int(users_local.numel())], [global_batch], loss=loss,
-                              neg_in=neg_in, neg_out=neg_out)
+                              neg_in=neg_in, neg_out=neg_out, n_neg=n_neg, mb_pos=mb_pos)
 
-    def train(self, users_local, items, batch_local, loss='bpr', mb_loss=None, sample_chunk=8):
+    def train(self, users_local, items, batch_local, loss='bpr', mb_loss=None, sample_chunk=8, n_neg=None):
         """Minibatch loop over this rank's interactions: global minibatch k consists of every
         rank's slice [k*batch_local, (k+1)*batch_local) (all ranks must hold the same number of
         interactions).  Negatives are drawn from this rank's engine RNG over the global item range,
@@ -217,7 +272,12 @@ class ShardedBilinearTrainer(object):
             lo, hi = k0 * batch_local, min(k1 * batch_local, n)
             off = [min(k * batch_local, n) - lo for k in range(k0, k1 + 1)]
             gbs = [(off[i + 1] - off[i]) * self.world for i in range(k1 - k0)]
-            mb_loss[k0:k1].copy_(self.run_chunk(users_local[lo:hi], items[lo:hi], off, gbs, loss=loss))
+            mb_pos = None
+            if loss == 'adaptive_hinge':
+                # equal shares: the j-th interaction this rank holds of a minibatch is the global minibatch's (j * world + rank)-th
+                j = torch.arange(lo, hi, device=self.device, dtype=torch.int64) % batch_local
+                mb_pos = j * self.world + self.rank
+            mb_loss[k0:k1].copy_(self.run_chunk(users_local[lo:hi], items[lo:hi], off, gbs, loss=loss, n_neg=n_neg, mb_pos=mb_pos))
         return mb_loss
 
 
@@ -248,7 +308,8 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
     Initial values also match when the full tables fit the host (< 8 GB): they are drawn from
     torch's CPU generator in the reference's order and this rank keeps rows `rank::world`.
 
-    Restrictions of the exchange path: pointwise / bpr / hinge losses, plain (non-bloom) tables.
+    All four losses (adaptive hinge: a score phase and a selection over the whole minibatch in front of the user pass,
+    ShardedBilinearTrainer.run_chunk).  Restriction of the exchange path: plain (non-bloom) tables.
     """
 
     # evaluation.mrr_score's one-device fast path scores against whole tables; this model's are local shards
@@ -259,8 +320,6 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
     def __init__(self, *args, **kwargs):
         self._group = kwargs.pop('group', None)
         super(ShardedImplicitFactorizationModel, self).__init__(*args, **kwargs)
-        if self._loss == 'adaptive_hinge':
-            raise NotImplementedError('adaptive_hinge is not supported by the row-sharded path yet')
         if self._representation is not None:
             raise NotImplementedError('custom representations are not supported by the row-sharded path')
         self._trainer = None
@@ -325,16 +384,20 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
             engine.rng_set_state(self._random_state.get_state())
             _host.device_epoch_shuffle(engine, self._random_state, n, d_perm,
                                        [(d_users0, d_users, 1), (d_items0, d_items, 1)], stream)
-            # the epoch's negatives: one randint per minibatch == one contiguous draw over the epoch
-            negs = torch.empty(n, dtype=torch.int64, device=device)
-            engine.sample_items(self._num_items, n, negs.data_ptr(), stream=stream)
+            # the epoch's negatives: one randint per minibatch == one contiguous draw over the epoch (adaptive hinge: B * n draws
+            # per minibatch, interaction j of it scored against the flat entries [j * n, (j + 1) * n): implicit.py:266-275)
+            adaptive = self._loss == 'adaptive_hinge'
+            nn = self._num_negative_samples if adaptive else 1
+            negs = torch.empty(n * nn, dtype=torch.int64, device=device)
+            engine.sample_items(self._num_items, n * nn, negs.data_ptr(), stream=stream)
             self._random_state.set_state(engine.rng_get_state())
             # this rank's interactions, minibatch membership unchanged
             idx = torch.nonzero(d_users % world == rank).squeeze(1)
             bounds = torch.searchsorted(idx, torch.arange(0, n_mb + 1, device=device) * B).tolist()
             ul = (d_users[idx] // world).contiguous()
             il = d_items[idx].contiguous()
-            ng = negs[idx].contiguous()
+            ng = negs.view(n, nn)[idx].contiguous().view(-1)
+            pos = (idx % B).contiguous() if adaptive else None  # position inside the global minibatch
             ostruct = binding.as_struct()
             trainer = ShardedBilinearTrainer(engine, tables, ostruct, self._num_items, group=self._group,
                                              stream=stream) if self._trainer is None else self._trainer
@@ -347,8 +410,8 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
                 a, b = bounds[k0], bounds[k1]
                 off = [bounds[k] - a for k in range(k0, k1 + 1)]
                 gbs = [min(B, n - k * B) for k in range(k0, k1)]
-                mb_loss[k0:k1].copy_(trainer.run_chunk(ul[a:b], il[a:b], off, gbs, loss=self._loss,
-                                                       neg_in=ng[a:b]))
+                mb_loss[k0:k1].copy_(trainer.run_chunk(ul[a:b], il[a:b], off, gbs, loss=self._loss, neg_in=ng[a * nn:b * nn],
+                                                       n_neg=nn if adaptive else None, mb_pos=pos[a:b] if adaptive else None))
             dist.all_reduce(mb_loss, group=self._group)
             binding.store_steps(ostruct.step)
             epoch_loss = float(mb_loss.double().mean().item())

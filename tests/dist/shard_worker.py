@@ -48,7 +48,11 @@ def main():
     rs = np.random.RandomState(123)
     users = rs.randint(0, U, N).astype(np.int64)
     items = rs.randint(0, I, N).astype(np.int64)
-    negs = rs.randint(0, I, N).astype(np.int64)
+    # adaptive hinge (implicit.py:266-275): n_neg draws per interaction, minibatch after minibatch ONE flat draw of B * n_neg;
+    # interaction j of a minibatch is scored against the flat entries [j * n_neg, (j + 1) * n_neg)
+    adaptive = loss == 'adaptive_hinge'
+    nn = int(os.environ.get('SHARD_TEST_NNEG', '3')) if adaptive else 1
+    negs = rs.randint(0, I, N * nn).astype(np.int64)
     if train_mode:
         # every rank holds the same number of interactions of every global minibatch (as in bench.py):
         # interaction k belongs to rank k % world
@@ -56,7 +60,7 @@ def main():
         N = B * n_mb - 2 * world  # short last minibatch, still evenly split
         users = (rs.randint(0, U // world, N) * world + np.arange(N) % world).astype(np.int64)
         items = rs.randint(0, I, N).astype(np.int64)
-        negs = np.zeros(N, dtype=np.int64)
+        negs = np.zeros(N * nn, dtype=np.int64)
     sc = min(0.3, 1.0 / np.sqrt(D))
     params = [rs.normal(0, sc, (U, D)).astype(np.float32), rs.normal(0, sc, (I, D)).astype(np.float32),
               rs.normal(0, 0.1, U).astype(np.float32), rs.normal(0, 0.1, I).astype(np.float32)]
@@ -64,56 +68,69 @@ def main():
 
     loc = [torch.from_numpy(np.array(p[rank::world], order="C", copy=True)).to(dev) for p in params]
     assert loc[0].shape[0] == local_rows(U, world, rank) and loc[1].shape[0] == local_rows(I, world, rank)
-    s1 = [torch.zeros_like(t) for t in loc]
+    # adaptive hinge: a non-zero initial accumulator (torch's initial_accumulator_value).  From sum = 0 Adagrad's first step is
+    # lr * sign(g) on every touched element -- 1-ulp differences in a summed gradient become O(lr) ones, and the selection (an
+    # argmax over scores) then flips candidates between two runs that differ only in summation order
+    acc0 = 0.1 if (adaptive and opt.startswith('adagrad')) else 0.0
+    s1 = [torch.full_like(t, acc0) for t in loc]
     s2 = [torch.zeros_like(t) for t in loc]
     optim = _native.make_optim(opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2], **hp)
     trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream, slices=slices)
     if sample_on_device or train_mode:
         eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
 
-    losses, used_negs = [], np.full(N, -1, dtype=np.int64)
+    losses, used_negs = [], np.full(N * nn, -1, dtype=np.int64)
+    negs2, used2 = negs.reshape(N, nn), used_negs.reshape(N, nn)  # (views: row k = the draws of interaction k)
+
+    def mb_pos_of(idx):  # position of interaction idx inside its global minibatch
+        return torch.from_numpy((np.asarray(idx) % B).astype(np.int64)).to(dev)
+    kw = dict(n_neg=nn) if adaptive else {}
     use_train_loop = sample_on_device and world == 1  # ShardedBilinearTrainer.train (chunked sampling)
     if use_train_loop:
         ul = torch.from_numpy(users // world).to(dev)
         il = torch.from_numpy(items).to(dev)
-        shares = trainer.train(ul, il, B, loss=loss, sample_chunk=2)
+        shares = trainer.train(ul, il, B, loss=loss, sample_chunk=2, **kw)
         losses = [float(x) for x in shares.cpu().numpy()]
         # the draws: one contiguous stream, minibatch after minibatch
-        used_negs = np.random.RandomState(1000 + rank).randint(0, I, N, dtype=np.int64)
+        used_negs = np.random.RandomState(1000 + rank).randint(0, I, N * nn, dtype=np.int64)
+        used2 = used_negs.reshape(N, nn)
     if train_mode:
         mine = np.nonzero(users % world == rank)[0]
         shares = trainer.train(torch.from_numpy(users[mine] // world).to(dev), torch.from_numpy(items[mine]).to(dev),
-                               B // world, loss=loss, sample_chunk=2)
+                               B // world, loss=loss, sample_chunk=2, **kw)
         dist.all_reduce(shares)
         losses = [float(x) for x in shares.cpu().numpy()]
-        used_negs[mine] = np.random.RandomState(1000 + rank).randint(0, I, len(mine), dtype=np.int64)
+        used2[mine] = np.random.RandomState(1000 + rank).randint(0, I, len(mine) * nn, dtype=np.int64).reshape(-1, nn)
     if chunk_mode:
         mine = np.nonzero(users % world == rank)[0]
         off = [int(np.searchsorted(mine, min(k * B, N))) for k in range(n_mb + 1)]
         gbs = [min((k + 1) * B, N) - k * B for k in range(n_mb)]
         shares = trainer.run_chunk(torch.from_numpy(users[mine] // world).to(dev), torch.from_numpy(items[mine]).to(dev),
-                                   off, gbs, loss=loss, neg_in=torch.from_numpy(negs[mine]).to(dev))
+                                   off, gbs, loss=loss, neg_in=torch.from_numpy(np.ascontiguousarray(negs2[mine]).ravel()).to(dev),
+                                   mb_pos=mb_pos_of(mine) if adaptive else None, **kw)
         dist.all_reduce(shares)
         losses = [float(x) for x in shares.cpu().numpy()]
-        used_negs[mine] = negs[mine]
+        used2[mine] = negs2[mine]
     for k in range(0 if (use_train_loop or chunk_mode or train_mode) else n_mb):
         lo, hi = k * B, min((k + 1) * B, N)
         idx = np.nonzero(users[lo:hi] % world == rank)[0] + lo
         ul = torch.from_numpy(users[idx] // world).to(dev)
         il = torch.from_numpy(items[idx]).to(dev)
+        kws = dict(kw, mb_pos=mb_pos_of(idx)) if adaptive else {}
         if sample_on_device:
-            neg_out = torch.full((len(idx),), -1, dtype=torch.int64, device=dev)
-            part = trainer.step(ul, il, hi - lo, loss=loss, neg_out=neg_out)
-            used_negs[idx] = neg_out.cpu().numpy()
+            neg_out = torch.full((len(idx) * nn,), -1, dtype=torch.int64, device=dev)
+            part = trainer.step(ul, il, hi - lo, loss=loss, neg_out=neg_out, **kws)
+            used2[idx] = neg_out.cpu().numpy().reshape(-1, nn)
         else:
-            ng = torch.from_numpy(negs[idx]).to(dev)
-            part = trainer.step(ul, il, hi - lo, loss=loss, neg_in=ng)
-            used_negs[idx] = negs[idx]
+            ng = torch.from_numpy(np.ascontiguousarray(negs2[idx]).ravel()).to(dev)
+            part = trainer.step(ul, il, hi - lo, loss=loss, neg_in=ng, **kws)
+            used2[idx] = negs2[idx]
         dist.all_reduce(part)
         losses.append(float(part.item()))
     assert optim.step == n_mb
 
     # reassemble on rank 0
+    used_negs = np.ascontiguousarray(used2).ravel()
     un = torch.from_numpy(np.where(used_negs >= 0, used_negs, 0)).to(dev)
     dist.all_reduce(un)  # every interaction belongs to exactly one rank
     used_negs = un.cpu().numpy()
@@ -142,23 +159,27 @@ def main():
         # normalises to O(lr) (see engine_checks.assert_close_table), so the trajectory is judged
         # by the fraction of elements outside 1e-4 of the table norm (<= 5 %); the tight check
         # is the one against the single-device engine below.
-        ora = BilinearOracle(*params, opt=opt, sparse_grads=True, **hp)
-        want = ora.train(None, users, items, B, loss=loss, neg_in=used_negs)
+        ora = BilinearOracle(*params, opt=opt, sparse_grads=True, state1=[np.full_like(np.asarray(x, dtype=np.float32), acc0) for x in params] if acc0 else None, **hp)
+        want = ora.train(None, users, items, B, loss=loss, n_neg=nn, neg_in=used_negs)
         assert abs(losses[0] - want[0]) / abs(want[0]) < 1e-5, (losses, want)
-        assert np.abs(np.array(losses) - want).max() / np.abs(want).max() < 1e-3, (losses, want)
-        for t in range(4):
+        # (adaptive hinge: the selection is an argmax -- after the first step from zero accumulators, where every touched element
+        # moves by lr * sign(g), a 1-ulp score difference flips a column's candidate and the trajectories part for good; the
+        # first minibatch above and the one-GPU engine below are the checks)
+        if not adaptive or acc0:
+            assert np.abs(np.array(losses) - want).max() / np.abs(want).max() < 1e-3, (losses, want)
+        for t in range(4 if (not adaptive or acc0) else 0):
             ref = ora.p[t].reshape(full[t][0].shape)
             bad = np.abs(full[t][0] - ref) > 1e-4 * np.abs(ref).max()
             assert bad.mean() <= 0.05, (t, bad.mean())
         # single-device engine on the same minibatches
         f = lambda a: torch.from_numpy(np.array(a, order='C', copy=True)).to(dev)
         P = [f(p) for p in params]
-        S1, S2 = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
+        S1, S2 = [torch.full_like(p, acc0) for p in P], [torch.zeros_like(p) for p in P]
         tb = _native.make_tables([p.data_ptr() for p in P], U, I, D)
         op = _native.make_optim(opt, [p.data_ptr() for p in S1], [p.data_ptr() for p in S2], **hp)
         mb = torch.zeros(n_mb, dtype=torch.float32, device=dev)
         du, di, dn = f(users), f(items), f(used_negs)
-        eng.bilinear_train(tb, op, du.data_ptr(), di.data_ptr(), N, B, loss, 1, mb.data_ptr(),
+        eng.bilinear_train(tb, op, du.data_ptr(), di.data_ptr(), N, B, loss, nn, mb.data_ptr(),
                            d_neg_in=dn.data_ptr(), stream=stream)
         assert np.abs(np.array(losses) - mb.cpu().numpy()).max() / np.abs(want).max() < 1e-5
         for t in range(4):

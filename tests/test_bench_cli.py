@@ -67,6 +67,31 @@ def test_gpus_n_spawns_n_ranks_itself(n):
     assert abs(den['fused']['scaling_factor_of_this_run'] * den['fused']['interactions_per_s'] - rec['value']) < 1e-6 * rec['value']
 
 
+@pytest.mark.parametrize('n', [2, 3])
+def test_default_n_gpu_configuration_c5_at_reduced_rows(n):
+    """what `bench.py --gpus N` runs by DEFAULT at N > 1 -- the C5 row-sharded configuration -- end to end
+    at reduced rows: the line names the workload, the process group saw N ranks, every rank reports the lookups it sent to other
+    ranks (about (N - 1) / N of its 2 B K), and rank 0's own world-1 runs of the same per-GPU shape -- fused path and
+    row-sharded path -- agree on every minibatch's loss."""
+    rc, out, err = run_bench(['--gpus', str(n), '--workload', 'c5'])
+    assert rc == 0, err[-3000:]
+    rec = json.loads([l for l in out.splitlines() if l.strip().startswith('{')][-1])
+    assert rec['config']['workload'].startswith('C5') and 'row-sharded x%d' % n in rec['config']['parallelism']
+    assert rec['n_gpus'] == n and rec['ranks']['world_size_observed'] == n
+    devs = sorted(rec['ranks']['devices'], key=lambda d: d['rank'])
+    assert [d['rank'] for d in devs] == list(range(n))
+    lookups = 2 * 256 * rec['steps']
+    for d in devs:
+        share = d['exchange_rows_timed_call'] / lookups
+        assert abs(share - (n - 1) / n) < 0.12, (d, share)
+    assert abs(sum(d['exchange_rows_timed_call'] for d in devs) / n / rec['steps'] - rec['roofline']['xgmi']['rows_per_step_per_gpu']) <= \
+        max(d['exchange_rows_timed_call'] for d in devs) / rec['steps']
+    den = rec['roofline']['xgmi']['denominators_1_gpu']
+    a, b = den['fused']['minibatch_losses'], den['sharded_world1']['minibatch_losses']
+    assert len(a) == len(b) == rec['steps'] + rec['warmup'] and all(x > 0 for x in a)
+    assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-5 * max(a), (a, b)
+
+
 def test_world_size_mismatch_fails_loudly():
     rc, out, err = run_bench(['--gpus', '2'], env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert rc != 0 and 'WORLD_SIZE' in err and not out.strip()

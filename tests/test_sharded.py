@@ -76,6 +76,25 @@ def test_sharded_bench_loop_equal_shares(world, slices):
     run_world(world, ['bpr', 'adagrad', 16, 'train', slices])
 
 
+@pytest.mark.parametrize('world,mode,slices,opt', [(2, None, None, 'adagrad'), (3, 'chunk', 2, 'adagrad'), (2, 'chunk', 3, 'sparse_adam'),
+                                                   (1, 'chunk', 2, 'adagrad'), (2, 'train', 2, 'adagrad'), (3, None, None, 'adam_dense'),
+                                                   (1, 'sample', None, 'adagrad')])
+def test_sharded_adaptive_hinge(world, mode, slices, opt):
+    """loss='adaptive_hinge' on the row-sharded path (VERDICT r04 missing 1; spotlight/factorization/implicit.py:266-275,
+    spotlight/losses.py:127-166): the view(n, B) quirk makes a column's candidates the draws of OTHER interactions -- other
+    ranks' -- so the step scores all 1 + n pairs first, sums the score matrix over the ranks and selects on every rank.
+    Against the oracle and the one-GPU engine on the same minibatches and draws."""
+    args = ['adaptive_hinge', opt, 8]
+    if mode:
+        args += [mode] + ([slices] if slices else [])
+    run_world(world, args)
+
+
+def test_sharded_adaptive_hinge_many_draws_dim64(monkeypatch):
+    monkeypatch.setenv('SHARD_TEST_NNEG', '7')
+    run_world(2, ['adaptive_hinge', 'adagrad', 64, 'chunk', 2])
+
+
 def test_sharded_world3_device_sampled_negatives():
     run_world(3, ['bpr', 'adagrad', 16, 'sample'])
 
@@ -89,7 +108,8 @@ def test_sharded_train_loop_chunked_sampling():
     run_world(1, ['bpr', 'adagrad', 16, 'sample'])
 
 
-@pytest.mark.parametrize('world,loss,opt', [(2, 'bpr', 'adagrad'), (3, 'pointwise', 'adam'), (2, 'hinge', 'sparse_adam')])
+@pytest.mark.parametrize('world,loss,opt', [(2, 'bpr', 'adagrad'), (3, 'pointwise', 'adam'), (2, 'hinge', 'sparse_adam'),
+                                            (2, 'adaptive_hinge', 'adagrad'), (3, 'adaptive_hinge', 'adagrad')])
 def test_sharded_model_fit_predict_match_single_device_model(world, loss, opt):
     """The drop-in ShardedImplicitFactorizationModel: same seed => same RandomState consumption
     (shuffles, negatives), same tables and predictions as ImplicitFactorizationModel."""
@@ -108,6 +128,17 @@ def test_gpu_sharded_phases_world1_nccl(loss, opt, D):
     """The real gfx950 kernels of the four shard phases + RCCL all_to_all_single (a single rank:
     the exchange degenerates to a device copy), against the oracle and the fused one-GPU path."""
     run_world(1, [loss, opt, D], backend='hip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opt,D', [('adagrad', 64), ('sparse_adam', 32)])
+def test_gpu_sharded_adaptive_hinge_world1_nccl(opt, D):
+    run_world(1, ['adaptive_hinge', opt, D, 'chunk', 2], backend='hip')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_adaptive_hinge_model_world1_nccl():
+    run_world(1, ['adaptive_hinge', 'adagrad'], backend='hip', worker=MODEL_WORKER, token='SHARD_MODEL_OK')
 
 
 @pytest.mark.gpu
