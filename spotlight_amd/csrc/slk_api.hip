@@ -164,7 +164,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg};
+                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->mt_tmp};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -186,7 +186,8 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->d_rng) (void)hipFree(ctx->d_rng);
-    if (ctx->d_jump) (void)hipFree(ctx->d_jump);
+    for (uint32_t *j : ctx->d_jump)
+        if (j) (void)hipFree(j);
     delete ctx;
 }
 
@@ -210,6 +211,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("overlap_prep", opt_overlap_prep, 0, 2),
     SLK_OPT("overlap_min_batch", opt_overlap_min_batch, 0, SLK_OPT_MAX),
     SLK_OPT("prefetch_wait", opt_prefetch_wait, 0, 1),
+    SLK_OPT("mt_long_min_blocks", opt_mt_long_min_blocks, 2, SLK_OPT_MAX),
     SLK_OPT("sort_big_min", opt_sort_big_min, 1, SLK_OPT_MAX),
     SLK_OPT("sort_debug", opt_sort_debug, 0, 3),
     SLK_OPT("item_grid_mult", opt_item_grid_mult, 1, 4096),
@@ -221,7 +223,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("epoch_adaptive", opt_epoch_adaptive, 0, 1),
     SLK_OPT("epoch_adaptive_max_batch", opt_epoch_adaptive_max_batch, 1, (int64_t)1 << 20),
     SLK_OPT("epoch_max_batch", opt_epoch_max_batch, 1, (int64_t)1 << 20),
-    SLK_OPT("epoch_max_grid", opt_epoch_max_grid, 1, 1024),
+    SLK_OPT("epoch_max_grid", opt_epoch_max_grid, 1, 16384),
     SLK_OPT("epoch_barrier", opt_epoch_barrier, -1, 1),
     SLK_OPT("epoch_cooperative", opt_epoch_cooperative, 0, 1),
     SLK_OPT("epoch_debug", opt_epoch_debug, 0, 63),

@@ -32,6 +32,22 @@
 #define SLK_DRAIN_VMEM() ((void)0)
 #endif
 
+// Synchronisation of a workgroup that is ONE wavefront (kernels launched with 64 threads: the MT19937 generator,
+// slk_rng.hip): the wave's LDS accesses execute in program order, so nothing has to be waited for -- the wavefront-scope
+// fences only keep the compiler from moving a read of another lane's word above the write that produces it.  No
+// s_barrier and, unlike __syncthreads()'s workgroup-scope release, no wait for the global stores still in flight.
+// The test harness runs every HIP thread as a fiber: there the marker is a switch point like __syncthreads().
+#if defined(__HIPCC__)
+#define SLK_WAVE_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#else
+#define SLK_WAVE_SYNC() __syncthreads()
+#endif
+
 // Marks the next plain kernel launch as one whose workgroups wait for each other inside the kernel (grid barrier): all of
 // them must be resident at once.  On the GPU that is a property of the launch geometry (at most one wavefront-sized
 // workgroup per CU, slk_epoch.hip) and the marker is empty; the test harness, which otherwise executes one block at a
@@ -87,8 +103,9 @@ struct slk_ctx {
     char err[512] = {0};
     hipStream_t last_stream = nullptr;
     slk_rng_dev *d_rng = nullptr;
-    uint32_t *d_jump = nullptr;  // device copy of the jump polynomial table
-    bool mt_attr_set = false;    // k_mt_generate_jump's dynamic-LDS limit raised on this device
+    uint32_t *d_jump[2] = {nullptr, nullptr};  // device copies of the jump polynomial tables (SLK_MT_JUMP_LEVELS)
+    bool mt_attr_set = false;    // k_mt_jump's dynamic-LDS limit raised on this device
+    slk_buf mt_tmp;              // generator scratch: the 33-block prefix + one start block per stream (slk_rng.hip)
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
     slk_buf raw, cnt, neg32, ukey[2], uval[2], uit, ikey[2], ipay[2], gk, sk, snap, losspart,
@@ -101,6 +118,7 @@ struct slk_ctx {
                                    // steady state of a run of training calls it gains 1.5-4 % (profiles/r03_*); a lone call of a few
                                    // chunks gains nothing, every pass runs ~10 % longer beside the sorts, and kernel timings under a
                                    // tracer stop agreeing with the untraced ones -- so a bare ctx keeps everything on one stream
+    int64_t opt_mt_long_min_blocks = 16385;  // (= SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS + 1, asserted below)  // draws of at least this many state blocks: 256 blocks per stream
     int opt_prefetch_wait = 0;     // measurement switch (A/B of round 5): 1 = slk_bilinear_prefetch waits for the caller's stream as it did up to round 4
     int64_t opt_overlap_min_batch = (int64_t)1 << 16;  // the prep overlaps the passes only for minibatches of at least this size
                                    // (measured: +3 % at 8192, where the passes are short latency-bound kernels; -1..-3 % at 65 536)
@@ -229,14 +247,21 @@ hipStream_t slk_copy_stream(slk_ctx *ctx);
             return slk_fail((ctx), SLK_EIO, "launch of %s failed: %s", (what), hipGetErrorString(e_)); \
     } while (0)
 
-// MT19937 jump-ahead geometry: workgroup w of k_mt_generate_jump produces state blocks
-// [w*SLK_MT_JUMP_BLOCKS, (w+1)*SLK_MT_JUMP_BLOCKS); one launch covers up to
+// MT19937 jump-ahead geometry: stream w of a draw (one wavefront of k_mt_stream, started by workgroup w - 1 of k_mt_jump)
+// produces state blocks [w*SLK_MT_JUMP_BLOCKS, (w+1)*SLK_MT_JUMP_BLOCKS); one group of launches covers up to
 // SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS blocks of 624 words (10.2 M words).
+// Two stream lengths (round 5): draws of up to SLK_MT_JUMP_WG * 64 blocks use 64 blocks per stream; larger ones (a whole
+// epoch's negatives, the epoch shuffle) 256 blocks per stream -- a jump costs a CU ~80 us whatever its distance, a block
+// ~0.5 us, so one group of 256 long streams beats four groups of short ones.  Option "mt_long_min_blocks" moves the
+// switch (test hook).
 #define SLK_MT_JUMP_BLOCKS 64
+#define SLK_MT_JUMP_LEVELS 2
+static inline int slk_mt_jump_blocks(int level) { return level ? 4 * SLK_MT_JUMP_BLOCKS : SLK_MT_JUMP_BLOCKS; }
 #define SLK_MT_JUMP_WG 256
+static_assert(SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS + 1 == 16385, "slk_ctx::opt_mt_long_min_blocks");
 #define SLK_MT_JUMP_TERMS 10752                 // exponent-list capacity per polynomial (multiple of 8)
 #define SLK_MT_JUMP_PAD (33 * 624 - 1)          // exponent whose window X[1 + e + j] is the zero block
-const uint32_t *slk_mt_jump_table(slk_ctx *ctx);  // slk_mtjump.hip (host)
+const uint32_t *slk_mt_jump_table(slk_ctx *ctx, int level);  // slk_mtjump.hip (host)
 
 // sampler (slk_rng.hip): `count` negatives into ctx->neg32 (uint32) [+ int64 copy to d_out64]
 int slk_sample_u32(slk_ctx *ctx, int64_t num_items, int64_t count, uint32_t *d_out32, int64_t *d_out64,
@@ -288,6 +313,8 @@ int slk_epoch_run_chunk(slk_ctx *ctx, const slk_tables *tables, slk_optim *optim
 // slk_rng.hip: regenerate `nblocks` MT19937 state blocks from the ctx's key into ctx->raw
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s);
 int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count);
+int slk_mt_jump_reserve(slk_ctx *ctx, int level);  // jump table on the device + the generator's scratch (once per ctx)
+int slk_mt_level_for(const slk_ctx *ctx, unsigned long long nblocks);  // stream length class of a draw of nblocks state blocks
 // slk_rng.hip: numpy state -> d_rng without waiting for the ctx's stream (the caller knows no draw is in flight)
 int slk_rng_write_state(slk_ctx *ctx, const uint32_t *h_key, int32_t pos);
 

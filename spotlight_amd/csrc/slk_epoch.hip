@@ -831,6 +831,9 @@ static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_opt
         if (by_rows > grid) grid = by_rows;
     }
     unsigned cap = (unsigned)ctx->num_cus < (unsigned)ctx->opt_epoch_max_grid ? (unsigned)ctx->num_cus : (unsigned)ctx->opt_epoch_max_grid;
+    // measurement switch (round 5, the mid-size single-launch A/B: profiles/r05_*): "epoch_max_grid" above 1024 lifts the
+    // one-workgroup-per-CU limit -- several one-wave workgroups per CU, still bounded by what the device holds resident
+    if (ctx->opt_epoch_max_grid > 1024) cap = (unsigned)ctx->opt_epoch_max_grid;
     int per_cu = 0;
     if (fn && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SLK_EPOCH_TB, lds) == hipSuccess && per_cu >= 0) {
         const unsigned resident = (unsigned)per_cu * (unsigned)ctx->num_cus;

@@ -2,7 +2,7 @@
 //
 // The reference draws every negative from ONE serial MT19937 stream (spotlight/sampling.py:34
 // through numpy's RandomState).  To generate that same stream on many CUs at once, workgroup w
-// of k_mt_generate_jump must start from the state block 624*(w*L) words ahead.  The MT19937
+// (k_mt_jump, slk_rng.hip) must find the state block 624*(w*L) words ahead.  The MT19937
 // transition T is linear over GF(2) on its 19937-bit state with characteristic polynomial phi;
 // if g_m(x) = x^(624 m - 1) mod phi then, for the raw word stream x_0, x_1, ... of the current
 // state,
@@ -170,38 +170,43 @@ void xpow(const Field &F, clmul_fn cm, uint64_t e, uint64_t *r) {
 }
 
 std::mutex g_mu;
-std::vector<uint32_t> g_table;  // [SLK_MT_JUMP_WG - 1][SLK_MT_JUMP_TERMS]: exponents of the set
-                                // coefficients of g_w, padded with SLK_MT_JUMP_PAD
-bool g_ok = false;
+// per level: [SLK_MT_JUMP_WG - 1][SLK_MT_JUMP_TERMS] exponents of the set coefficients of g_w, padded with SLK_MT_JUMP_PAD
+std::vector<uint32_t> g_table[SLK_MT_JUMP_LEVELS];
+bool g_ok[SLK_MT_JUMP_LEVELS] = {false};
+Field g_field;
+bool g_field_ok = false;
 
 }  // namespace
 
-// Host table of jump polynomials g_w = x^(624 * SLK_MT_JUMP_BLOCKS * w - 1) mod phi,
-// w = 1 .. SLK_MT_JUMP_WG-1, stored as exponent lists (~10k set coefficients each, padded to
-// SLK_MT_JUMP_TERMS with SLK_MT_JUMP_PAD, which the kernel maps onto a zeroed LDS block);
-// computed once per process (~0.1-1 s).
-const uint32_t *slk_mt_jump_table(slk_ctx *ctx) {
+// Host table of jump polynomials g_w = x^(624 * L * w - 1) mod phi, w = 1 .. SLK_MT_JUMP_WG-1, L = slk_mt_jump_blocks(level)
+// state blocks per stream, stored as exponent lists (~10k set coefficients each, padded to SLK_MT_JUMP_TERMS with
+// SLK_MT_JUMP_PAD, which the kernel maps onto a zeroed LDS block); computed once per process and level (~0.1-1 s).
+const uint32_t *slk_mt_jump_table(slk_ctx *ctx, int level) {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (g_ok) return g_table.data();
+    if (level < 0 || level >= SLK_MT_JUMP_LEVELS) return nullptr;
+    if (g_ok[level]) return g_table[level].data();
 
-    // phi from 2*DEG bits of the stream (bit 0 of x_{n+1})
-    std::vector<uint32_t> x;
-    mt_words(5489u, x, 2 * DEG + 700);
-    std::vector<uint8_t> s(2 * DEG);
-    for (int n = 0; n < 2 * DEG; ++n) s[n] = (uint8_t)(x[n + 1] & 1u);
-    poly C;
-    const int L = berlekamp_massey(s, C);
-    if (L != DEG) {
-        slk_fail(ctx, SLK_EIO, "MT19937 minimal polynomial has degree %d, expected %d", L, DEG);
-        return nullptr;
+    if (!g_field_ok) {
+        // phi from 2*DEG bits of the stream (bit 0 of x_{n+1})
+        std::vector<uint32_t> x;
+        mt_words(5489u, x, 2 * DEG + 700);
+        std::vector<uint8_t> s(2 * DEG);
+        for (int n = 0; n < 2 * DEG; ++n) s[n] = (uint8_t)(x[n + 1] & 1u);
+        poly C;
+        const int L = berlekamp_massey(s, C);
+        if (L != DEG) {
+            slk_fail(ctx, SLK_EIO, "MT19937 minimal polynomial has degree %d, expected %d", L, DEG);
+            return nullptr;
+        }
+        // characteristic polynomial phi(x) = x^L C(1/x): phi_{L-i} = C_i
+        for (int i = 1; i <= DEG; ++i)
+            if (getbit(C.data(), i)) g_field.terms.push_back(DEG - i);
+        g_field_ok = true;
     }
-    // characteristic polynomial phi(x) = x^L C(1/x): phi_{L-i} = C_i
-    Field F;
-    for (int i = 1; i <= DEG; ++i)
-        if (getbit(C.data(), i)) F.terms.push_back(DEG - i);
+    const Field &F = g_field;
     const clmul_fn cm = pick_clmul();
 
-    const uint64_t stride = 624ull * SLK_MT_JUMP_BLOCKS;
+    const uint64_t stride = 624ull * (uint64_t)slk_mt_jump_blocks(level);
     std::vector<uint64_t> h(NW), g(NW), nxt(NW);
     xpow(F, cm, stride, h.data());      // x^(624 L)
     xpow(F, cm, stride - 1, g.data());  // x^(624 L - 1)
@@ -220,9 +225,10 @@ const uint32_t *slk_mt_jump_table(slk_ctx *ctx) {
             }
         }
     }
-    g_table.assign((size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS, (uint32_t)SLK_MT_JUMP_PAD);
+    std::vector<uint32_t> &tab = g_table[level];
+    tab.assign((size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS, (uint32_t)SLK_MT_JUMP_PAD);
     for (int w = 1; w < SLK_MT_JUMP_WG; ++w) {
-        uint32_t *dst = g_table.data() + (size_t)(w - 1) * SLK_MT_JUMP_TERMS;
+        uint32_t *dst = tab.data() + (size_t)(w - 1) * SLK_MT_JUMP_TERMS;
         int n = 0;
         for (int i = 0; i < DEG; ++i)
             if (getbit(g.data(), i)) {
@@ -232,13 +238,12 @@ const uint32_t *slk_mt_jump_table(slk_ctx *ctx) {
                 }
                 dst[n++] = (uint32_t)i;
             }
-        dst[SLK_MT_JUMP_TERMS - 1] = (uint32_t)((n + 15) / 16 * 16);  // rounded length; the kernel
-                                                                      // prefetches 16 entries past it
+        dst[SLK_MT_JUMP_TERMS - 1] = (uint32_t)((n + 15) / 16 * 16);  // rounded length: the kernel takes the list 8 at a time
         if (w + 1 < SLK_MT_JUMP_WG) {
             mulmod(F, cm, g.data(), h.data(), nxt.data());
             g = nxt;
         }
     }
-    g_ok = true;
-    return g_table.data();
+    g_ok[level] = true;
+    return tab.data();
 }

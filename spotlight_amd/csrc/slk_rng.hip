@@ -5,10 +5,9 @@
 // rejection over the raw MT19937 32-bit stream: v = next32() & mask until v <= num_items-1.
 // The k-th accepted word is the k-th output, so the whole draw is
 //     raw stream  ->  temper  ->  mask/accept  ->  order-preserving stream compaction.
-//   k_mt_generate   one workgroup advances the 624-word state block by block (the twist has
-//                   227-way parallelism: words [0,227) need only old words, [227,454) need
-//                   the first round, [454,624) the second) and streams the UNTEMPERED blocks
-//                   to HBM;
+//   k_mt_prefix / k_mt_jump / k_mt_stream   the raw stream on up to 256 CUs at once: GF(2) jump-ahead
+//                   to one start block per stream, then one wavefront per stream advances the 624-word
+//                   state block by block and streams the UNTEMPERED blocks to HBM;
 //   k_accept_count / k_scan_counts / k_accept_scatter   all CUs temper, test and compact;
 //   k_rng_finalize  restores (key, pos) to exactly what numpy would hold after the draw:
 //                   the state block containing the last CONSUMED word, pos = offset + 1.
@@ -33,90 +32,164 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-#define SLK_MT_THREADS 640  // 10 waves: one lane per state word in the jump convolution
+// ---- the generator: three launches per draw (round 5; rounds 1-4: one kernel whose workgroups regenerated the prefix,
+// jumped and then advanced block by block with ten waves and three s_barriers per block -- every barrier's release fence
+// also waited for the block's global stores, 1.1 us per block, 0.22 ms per 8.8 M words).
+//   k_mt_prefix   ONE wavefront: the 33-block prefix of the stream every jump is evaluated from (the twist has 227-way
+//                 parallelism and a single wave needs no s_barrier: a workgroup of 64 threads synchronises by program order)
+//   k_mt_jump     workgroup w (1 .. W-1): the state block 624 * (w L) words ahead, x[624 m + j] = XOR_{i in g_m} x[1 + i + j]
+//                 (slk_mtjump.hip), evaluated from the prefix held in LDS; the exponent list of g_m is staged in LDS as
+//                 16-bit values, every lane XORs the windows of TWO output words per term (five waves: a workgroup that
+//                 fits beside the row passes' six workgroups per CU when the draw runs on the second stream)
+//   k_mt_stream   workgroup w = ONE wavefront: blocks [w L, (w+1) L) from its start block, streamed UNTEMPERED to HBM
+#define SLK_MT_JUMP_THREADS 320  // 5 waves: lane t owns the output words t and t + 320
+#define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
+// LDS of k_mt_jump: prefix X[33*624] | zero block [624] (target of the padding exponent) | the exponent list as uint16
+#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 1) * SLK_MT_N + SLK_MT_JUMP_TERMS / 2)
 
-// One regeneration: n[0..624) = next state block of o[0..624) (both in LDS).  The twist
-// x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old
-// words, [227,454) need the first round, [454,624) the second.  Ends with a barrier.
-__device__ __forceinline__ void mt_regen_block(const uint32_t *o, uint32_t *n, int t) {
-    if (t < 227) n[t] = mt_twist(o[t], o[t + 1], o[t + 397]);
-    __syncthreads();
-    if (t < 227) {
-        const int i = t + 227;
-        n[i] = mt_twist(o[i], o[i + 1], n[i - 227]);
+// One regeneration by ONE wavefront: n[0..624) = next state block of o[0..624) (both in LDS).  The twist
+// x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old words, [227,454) need the
+// first round, [454,624) the second.  SLK_WAVE_SYNC orders the wave's own LDS writes before its later reads (no s_barrier,
+// no wait for the global stores in flight).
+#define SLK_MT_PAD 704  // LDS words per state block buffer: the rounds below read (never write) up to word 652 unconditionally
+__device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, int lane, uint32_t *dst) {
+    // every read of a round is issued before the first wait (straight-line: only the WRITES are predicated); the new words
+    // go to HBM (dst[0..624)) from the registers they were formed in
+    {
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = lane + 64 * r;
+            v[r] = mt_twist(o[i], o[i + 1], o[i + 397]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = lane + 64 * r;
+            if (r < 3 || i < 227) {
+                n[i] = v[r];
+                dst[i] = v[r];
+            }
+        }
     }
-    __syncthreads();
-    if (t < 170) {
-        const int i = t + 454;
-        const uint32_t nx = (i == SLK_MT_N - 1) ? n[0] : o[i + 1];
-        n[i] = mt_twist(o[i], nx, n[i - 227]);
+    SLK_WAVE_SYNC();
+    {
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 227 + lane + 64 * r;
+            v[r] = mt_twist(o[i], o[i + 1], n[i - 227]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 227 + lane + 64 * r;
+            if (r < 3 || i < 454) {
+                n[i] = v[r];
+                dst[i] = v[r];
+            }
+        }
     }
-    __syncthreads();
+    SLK_WAVE_SYNC();
+    {
+        uint32_t v[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = 454 + lane + 64 * r;
+            const uint32_t nx = (i == SLK_MT_N - 1) ? n[0] : o[i + 1];
+            v[r] = mt_twist(o[i], nx, n[i - 227]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = 454 + lane + 64 * r;
+            if (r < 2 || i < SLK_MT_N) {
+                n[i] = v[r];
+                dst[i] = v[r];
+            }
+        }
+    }
+    SLK_WAVE_SYNC();
 }
 
-#define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
-// LDS: prefix X[33*624] | zero block [624] (target of the padding exponent) | ping | pong |
-// the workgroup's exponent list as uint16 (SLK_MT_JUMP_TERMS / 2 words)
-#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 3) * SLK_MT_N + SLK_MT_JUMP_TERMS / 2)
+// pre[b*624 ..] = state block b of the stream that starts with key_src, b = 0 .. 32
+__global__ __launch_bounds__(64) void k_mt_prefix(const uint32_t *key_src, uint32_t *pre) {
+    __shared__ uint32_t pp[2][SLK_MT_PAD];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < SLK_MT_N; i += 64) {
+        const uint32_t v = key_src[i];
+        pp[0][i] = v;
+        pre[i] = v;
+    }
+    SLK_WAVE_SYNC();
+    for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b) {
+        const uint32_t *o = pp[(b - 1) & 1];
+        uint32_t *n = pp[b & 1];
+        mt_regen_wave(o, n, lane, pre + (size_t)b * SLK_MT_N);
+    }
+}
 
-// raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.
-// Workgroup w owns blocks [w*L, (w+1)*L).  w > 0 first jumps to block w*L:
-//   x[624 m + j] = XOR_{i in g_m} x[1 + i + j]   (slk_mtjump.hip), evaluated from a 33-block
-// prefix of the stream that every workgroup regenerates for itself in LDS; the exponent list
-// of g_m is wave-uniform (scalar loads), lane j XORs one LDS word per term.
-__global__ __launch_bounds__(SLK_MT_THREADS) void k_mt_generate_jump(const uint32_t *key_src,
-                                                                     const uint32_t *polys, uint32_t *raw,
-                                                                     int nblocks) {
+// start[(w-1)*624 ..] = state block w*L of the stream whose first 33 blocks are pre[], w = blockIdx.x + 1; polys row w - 1 is
+// the exponent list of g_{w L} (wave-uniform), padding exponents hit the zero block.
+__global__ __launch_bounds__(SLK_MT_JUMP_THREADS) void k_mt_jump(const uint32_t *pre, const uint32_t *polys, uint32_t *start) {
     HIP_DYNAMIC_SHARED(uint32_t, lds)
     uint32_t *X = lds;
     uint32_t *zero = lds + SLK_MT_PREFIX_BLOCKS * SLK_MT_N;
-    uint32_t *pp0 = zero + SLK_MT_N;
-    uint32_t *pp1 = pp0 + SLK_MT_N;
+    uint16_t *sx = reinterpret_cast<uint16_t *>(zero + SLK_MT_N);
     const int t = threadIdx.x;
-    const int first = (int)blockIdx.x * SLK_MT_JUMP_BLOCKS;
-    if (first >= nblocks) return;
-    const int last = (first + SLK_MT_JUMP_BLOCKS < nblocks) ? first + SLK_MT_JUMP_BLOCKS : nblocks;
-
-    if (t < SLK_MT_N) {
-        X[t] = key_src[t];
-        zero[t] = 0u;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pre);
+        uint4 *dst = reinterpret_cast<uint4 *>(X);
+        for (int i = t; i < SLK_MT_PREFIX_BLOCKS * SLK_MT_N / 4; i += SLK_MT_JUMP_THREADS) dst[i] = src[i];
+        for (int i = t; i < SLK_MT_N; i += SLK_MT_JUMP_THREADS) zero[i] = 0u;
     }
-    const uint32_t *cur = X;
-    if (blockIdx.x > 0) {
-        __syncthreads();
-        for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b)
-            mt_regen_block(X + (b - 1) * SLK_MT_N, X + b * SLK_MT_N, t);
-        const uint32_t *e = polys + (size_t)(blockIdx.x - 1) * SLK_MT_JUMP_TERMS;
-        const uint32_t *xj = X + 1 + (t < SLK_MT_N ? t : 0);
-        // The exponent list (every workgroup its own 40 KB: no reuse in the scalar cache, and a
-        // dependent scalar load per group of terms cost more than the LDS reads it fed) is staged
-        // in LDS as 16-bit values by coalesced vector loads; the loop then reads eight exponents
-        // with one broadcast ds_read_b128.  Padding exponents hit the zero block.
-        const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];  // list length rounded up to 16
-        uint16_t *sx = reinterpret_cast<uint16_t *>(pp1 + SLK_MT_N);
-        for (int i = t; i < nterms; i += SLK_MT_THREADS) sx[i] = (uint16_t)e[i];
-        __syncthreads();
-        uint32_t acc = 0;
-        for (int k = 0; k < nterms; k += 8) {
-            const uint4 ev = *reinterpret_cast<const uint4 *>(sx + k);
-            uint32_t a0 = xj[ev.x & 0xffffu] ^ xj[ev.y & 0xffffu];
-            uint32_t a1 = xj[ev.x >> 16] ^ xj[ev.y >> 16];
-            a0 ^= xj[ev.z & 0xffffu] ^ xj[ev.w & 0xffffu];
-            a1 ^= xj[ev.z >> 16] ^ xj[ev.w >> 16];
-            acc ^= a0 ^ a1;
-        }
-        if (t < SLK_MT_N) pp0[t] = acc;
-        cur = pp0;
-    }
+    const uint32_t *e = polys + (size_t)blockIdx.x * SLK_MT_JUMP_TERMS;
+    const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];  // list length rounded up to 16
+    for (int i = t; i < nterms; i += SLK_MT_JUMP_THREADS) sx[i] = (uint16_t)e[i];
     __syncthreads();
+    // lane t: output words j0 = t and j1 = t + 320 -- one address per term, the second window at a constant offset (the last
+    // 16 lanes own one word: their second window runs at most 16 words past the zero block, into the exponent list: in
+    // bounds, read and dropped)
+    const int j1 = t + SLK_MT_JUMP_THREADS;
+    const uint32_t *x0 = X + 1 + t;
+    const uint32_t *x1 = x0 + SLK_MT_JUMP_THREADS;
+    uint32_t a0 = 0, a1 = 0;
+    for (int k = 0; k < nterms; k += 8) {
+        const uint4 ev = *reinterpret_cast<const uint4 *>(sx + k);  // eight exponents, one broadcast read
+        const uint32_t e0 = ev.x & 0xffffu, e1 = ev.x >> 16, e2 = ev.y & 0xffffu, e3 = ev.y >> 16;
+        const uint32_t e4 = ev.z & 0xffffu, e5 = ev.z >> 16, e6 = ev.w & 0xffffu, e7 = ev.w >> 16;
+        uint32_t p0 = x0[e0] ^ x0[e1], p1 = x1[e0] ^ x1[e1];
+        uint32_t q0 = x0[e2] ^ x0[e3], q1 = x1[e2] ^ x1[e3];
+        p0 ^= x0[e4] ^ x0[e5];
+        p1 ^= x1[e4] ^ x1[e5];
+        q0 ^= x0[e6] ^ x0[e7];
+        q1 ^= x1[e6] ^ x1[e7];
+        a0 ^= p0 ^ q0;
+        a1 ^= p1 ^ q1;
+    }
+    uint32_t *dst = start + (size_t)blockIdx.x * SLK_MT_N;
+    dst[t] = a0;
+    if (j1 < SLK_MT_N) dst[j1] = a1;
+}
+
+// raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.  Workgroup w (one wavefront)
+// owns blocks [w*L, (w+1)*L): it starts from key_src (w = 0) or from the block k_mt_jump left in start[] and advances
+// block by block through two LDS buffers; the blocks leave as coalesced stores nothing in the loop waits for.
+__global__ __launch_bounds__(64) void k_mt_stream(const uint32_t *key_src, const uint32_t *start, uint32_t *raw, int nblocks, int L) {
+    __shared__ uint32_t pp[2][SLK_MT_PAD];
+    const int lane = threadIdx.x;
+    const int first = (int)blockIdx.x * L;
+    if (first >= nblocks) return;
+    const int last = (first + L < nblocks) ? first + L : nblocks;
+    const uint32_t *src = blockIdx.x == 0 ? key_src : start + (size_t)(blockIdx.x - 1) * SLK_MT_N;
     uint32_t *dst = raw + (size_t)first * SLK_MT_N;
-    if (t < SLK_MT_N) dst[t] = cur[t];
+    for (int i = lane; i < SLK_MT_N; i += 64) {
+        const uint32_t v = src[i];
+        pp[0][i] = v;
+        dst[i] = v;
+    }
+    SLK_WAVE_SYNC();
+    int cur = 0;
     for (int b = first + 1; b < last; ++b) {
-        uint32_t *nxt = (cur == pp0) ? pp1 : pp0;
-        mt_regen_block(cur, nxt, t);
-        dst = raw + (size_t)b * SLK_MT_N;
-        if (t < SLK_MT_N) dst[t] = nxt[t];
-        cur = nxt;
+        mt_regen_wave(pp[cur], pp[cur ^ 1], lane, raw + (size_t)b * SLK_MT_N);
+        cur ^= 1;
     }
 }
 
@@ -127,78 +200,102 @@ struct slk_accept_args {
     uint32_t mask, rng;
 };
 
-__device__ __forceinline__ bool accept_word(const slk_accept_args &a, unsigned long long t, int pos0,
-                                            uint32_t *v) {
-    if (t < (unsigned long long)pos0 || t >= a.total_words) return false;
-    *v = mt_temper(a.raw[t]) & a.mask;
-    return *v <= a.rng;
+// The eight words of thread t of tile b (stream order: word = tile * 2048 + t * 8 + j), tempered and masked; ok bit j set
+// when word j is part of the draw (at or behind the stream position, inside the generated range, value accepted).
+__device__ __forceinline__ unsigned accept_words8(const slk_accept_args &a, unsigned long long base, int pos0, uint32_t *v) {
+    uint32_t w[8];
+    if (base + 8 <= a.total_words) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(a.raw + base), hi = *reinterpret_cast<const uint4 *>(a.raw + base + 4);
+        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+        w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = base + j < a.total_words ? a.raw[base + j] : 0u;
+    }
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = mt_temper(w[j]) & a.mask;
+        const unsigned long long t = base + j;
+        if (t >= (unsigned long long)pos0 && t < a.total_words && v[j] <= a.rng) ok |= 1u << j;
+    }
+    return ok;
+}
+
+// exclusive scan of one value per thread over a workgroup of 256 threads; *total = the workgroup's sum
+__device__ __forceinline__ uint32_t accept_excl_scan_256(uint32_t v, uint32_t *s_wsum, uint32_t *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wsum[w] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) off += s_wsum[i];
+        tot += s_wsum[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
 }
 
 __global__ __launch_bounds__(256) void k_accept_count(slk_accept_args a, uint32_t *cnt) {
-    __shared__ double red[256];
+    __shared__ uint32_t s_w[4];
     const int pos0 = a.st->pos;
     const unsigned long long base = (unsigned long long)blockIdx.x * SLK_TILE + (unsigned long long)threadIdx.x * 8;
-    unsigned c = 0;
-    for (int j = 0; j < 8; ++j) {
-        uint32_t v;
-        c += accept_word(a, base + j, pos0, &v) ? 1u : 0u;
-    }
-    const double tot = slk_block_sum_256((double)c, red);
-    if (threadIdx.x == 0) cnt[blockIdx.x] = (uint32_t)tot;
+    uint32_t v[8];
+    uint32_t c = (uint32_t)__popc(accept_words8(a, base, pos0, v));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// exclusive scan of cnt[nb] in place -> block offsets (64-bit); total -> st->accepted
+// exclusive scan of cnt[nb] -> tile offsets (64-bit); total -> st->accepted.  One workgroup: thread t adds up its
+// contiguous share of the tiles, one scan over the 256 shares, then every thread writes its tiles' offsets.
 __global__ __launch_bounds__(256) void k_scan_counts(const uint32_t *cnt, unsigned long long *off, int nb,
                                                      slk_rng_dev *st) {
     __shared__ unsigned long long s[256];
-    __shared__ unsigned long long carry;
     const int t = threadIdx.x;
-    if (t == 0) carry = 0;
+    const int per = (nb + 255) / 256;
+    const int i0 = t * per < nb ? t * per : nb, i1 = i0 + per < nb ? i0 + per : nb;
+    unsigned long long sum = 0;
+    for (int i = i0; i < i1; ++i) sum += cnt[i];
+    s[t] = sum;
     __syncthreads();
-    for (int base = 0; base < nb; base += 256) {
-        const int i = base + t;
-        const unsigned long long v = (i < nb) ? cnt[i] : 0ull;
-        s[t] = v;
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned long long x = (t >= d) ? s[t - d] : 0ull;
         __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const unsigned long long x = (t >= d) ? s[t - d] : 0ull;
-            __syncthreads();
-            s[t] += x;
-            __syncthreads();
-        }
-        if (i < nb) off[i] = carry + s[t] - v;
-        __syncthreads();
-        if (t == 255) carry += s[255];
+        s[t] += x;
         __syncthreads();
     }
-    if (t == 0) st->accepted = carry;
+    unsigned long long run = s[t] - sum;
+    for (int i = i0; i < i1; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (t == 255) st->accepted = s[255];
 }
 
 __global__ __launch_bounds__(256) void k_accept_scatter(slk_accept_args a, const unsigned long long *off,
                                                         unsigned long long count, uint32_t *out32,
                                                         int64_t *out64, slk_rng_dev *st) {
-    __shared__ unsigned s[256];
+    __shared__ uint32_t s_w[4];
     const int t = threadIdx.x;
     const int pos0 = a.st->pos;
     const unsigned long long base = (unsigned long long)blockIdx.x * SLK_TILE + (unsigned long long)t * 8;
     uint32_t v[8];
-    bool ok[8];
-    unsigned c = 0;
+    const unsigned ok = accept_words8(a, base, pos0, v);
+    uint32_t tot;
+    unsigned long long rank = off[blockIdx.x] + (unsigned long long)accept_excl_scan_256((uint32_t)__popc(ok), s_w, &tot);
+#pragma unroll
     for (int j = 0; j < 8; ++j) {
-        ok[j] = accept_word(a, base + j, pos0, &v[j]);
-        c += ok[j] ? 1u : 0u;
-    }
-    s[t] = c;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const unsigned x = (t >= d) ? s[t - d] : 0u;
-        __syncthreads();
-        s[t] += x;
-        __syncthreads();
-    }
-    unsigned long long rank = off[blockIdx.x] + (unsigned long long)(s[t] - c);
-    for (int j = 0; j < 8; ++j) {
-        if (!ok[j]) continue;
+        if (!((ok >> j) & 1u)) continue;
         if (rank < count) {
             if (out32) out32[rank] = v[j];
             if (out64) out64[rank] = (int64_t)v[j];
@@ -234,37 +331,59 @@ __global__ __launch_bounds__(256) void k_fill_zero(uint32_t *out32, int64_t *out
 
 // ctx->raw[b*624 ..] = state block b (untempered) for b = 0 .. nblocks-1, block 0 = the ctx's
 // current key block (ctx->raw must hold nblocks*624 words).
+int slk_mt_level_for(const slk_ctx *ctx, unsigned long long nblocks) {
+    return nblocks >= (unsigned long long)ctx->opt_mt_long_min_blocks ? 1 : 0;
+}
+
 int slk_mt_generate_blocks(slk_ctx *ctx, unsigned long long nblocks, hipStream_t s) {
     uint32_t *raw = (uint32_t *)ctx->raw.p;
-    {
-        // block 0 of every launch is its input key block; further launches (> 10.2 M words)
-        // restart from the last block of the previous one
-        const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * SLK_MT_JUMP_BLOCKS;
-        const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
-        if (!ctx->mt_attr_set) {  // per ctx, i.e. per device: function attributes live in the device's context
-            SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_generate_jump,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            ctx->mt_attr_set = true;
+    // block 0 of every launch group is its input key block; further groups (> 10.2 M words with 64 blocks per stream, > 40.9 M
+    // with 256) restart from the last block of the previous one
+    const int level = slk_mt_level_for(ctx, nblocks);
+    const unsigned long long L = (unsigned long long)slk_mt_jump_blocks(level);
+    const unsigned long long cap = (unsigned long long)SLK_MT_JUMP_WG * L;
+    const size_t lds_bytes = (size_t)SLK_MT_LDS_WORDS * 4;
+    if (!ctx->mt_attr_set) {  // per ctx, i.e. per device: function attributes live in the device's context
+        SLK_HIP(ctx, hipFuncSetAttribute((const void *)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        ctx->mt_attr_set = true;
+    }
+    int rc;
+    if (nblocks > L && (rc = slk_mt_jump_reserve(ctx, level))) return rc;
+    uint32_t *pre = (uint32_t *)ctx->mt_tmp.p;
+    uint32_t *start = pre ? pre + (size_t)SLK_MT_PREFIX_BLOCKS * SLK_MT_N : nullptr;
+    unsigned long long first = 0;  // index of the group's block 0
+    const uint32_t *key_src = ctx->d_rng->key;
+    while (true) {
+        const unsigned long long nb_l = (nblocks - first < cap) ? nblocks - first : cap;
+        const unsigned wgs = (unsigned)((nb_l + L - 1) / L);
+        if (wgs > 1) {
+            hipLaunchKernelGGL(k_mt_prefix, dim3(1), dim3(64), 0, s, key_src, pre);
+            SLK_LAUNCH_CHECK(ctx, "k_mt_prefix");
+            hipLaunchKernelGGL(k_mt_jump, dim3(wgs - 1), dim3(SLK_MT_JUMP_THREADS), lds_bytes, s, (const uint32_t *)pre,
+                               (const uint32_t *)ctx->d_jump[level], start);
+            SLK_LAUNCH_CHECK(ctx, "k_mt_jump");
         }
-        unsigned long long start = 0;  // index of the launch's block 0
-        const uint32_t *key_src = ctx->d_rng->key;
-        while (true) {
-            const unsigned long long nb_l = (nblocks - start < cap) ? nblocks - start : cap;
-            const unsigned wgs = (unsigned)((nb_l + SLK_MT_JUMP_BLOCKS - 1) / SLK_MT_JUMP_BLOCKS);
-            if (wgs > 1 && !ctx->d_jump) {
-                const uint32_t *tab = slk_mt_jump_table(ctx);
-                if (!tab) return SLK_EIO;
-                const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
-                SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
-                SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
-            }
-            hipLaunchKernelGGL(k_mt_generate_jump, dim3(wgs), dim3(SLK_MT_THREADS), lds_bytes, s, key_src,
-                               (const uint32_t *)ctx->d_jump, raw + start * SLK_MT_N, (int)nb_l);
-            SLK_LAUNCH_CHECK(ctx, "k_mt_generate_jump");
-            if (start + nb_l >= nblocks) break;
-            start += nb_l - 1;
-            key_src = raw + start * SLK_MT_N;
-        }
+        hipLaunchKernelGGL(k_mt_stream, dim3(wgs), dim3(64), 0, s, key_src, (const uint32_t *)start, raw + first * SLK_MT_N, (int)nb_l,
+                           (int)L);
+        SLK_LAUNCH_CHECK(ctx, "k_mt_stream");
+        if (first + nb_l >= nblocks) break;
+        first += nb_l - 1;
+        key_src = raw + first * SLK_MT_N;
+    }
+    return SLK_OK;
+}
+
+// the jump polynomial table of a stream length class on the device + the generator's scratch (prefix, start blocks):
+// allocated once per ctx
+int slk_mt_jump_reserve(slk_ctx *ctx, int level) {
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->mt_tmp, ((size_t)SLK_MT_PREFIX_BLOCKS + SLK_MT_JUMP_WG) * SLK_MT_N * 4))) return rc;
+    if (!ctx->d_jump[level]) {
+        const uint32_t *tab = slk_mt_jump_table(ctx, level);
+        if (!tab) return SLK_EIO;
+        const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
+        SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump[level]), bytes));
+        SLK_HIP(ctx, hipMemcpy(ctx->d_jump[level], tab, bytes, hipMemcpyHostToDevice));
     }
     return SLK_OK;
 }
@@ -344,13 +463,9 @@ int slk_sample_reserve(slk_ctx *ctx, int64_t num_items, int64_t count) {
     int rc;
     if ((rc = slk_ensure(ctx, ctx->raw, total_words * 4))) return rc;
     if ((rc = slk_ensure(ctx, ctx->cnt, nb * 4 + nb * 8 + 64))) return rc;
-    if (nblocks > SLK_MT_JUMP_BLOCKS && !ctx->d_jump) {
-        const uint32_t *tab = slk_mt_jump_table(ctx);
-        if (!tab) return SLK_EIO;
-        const size_t bytes = (size_t)(SLK_MT_JUMP_WG - 1) * SLK_MT_JUMP_TERMS * 4;
-        SLK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_jump), bytes));
-        SLK_HIP(ctx, hipMemcpy(ctx->d_jump, tab, bytes, hipMemcpyHostToDevice));
-    }
+    if (nblocks > (unsigned long long)slk_mt_jump_blocks(slk_mt_level_for(ctx, nblocks)) &&
+        (rc = slk_mt_jump_reserve(ctx, slk_mt_level_for(ctx, nblocks))))
+        return rc;
     return SLK_OK;
 }
 

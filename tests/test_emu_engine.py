@@ -33,6 +33,14 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 128 * 2 + 5,))
 
 
+def test_sampler_long_streams(be):
+    # the second stream length class (256 state blocks per stream: the jump table of stride 256), forced at a small size; a
+    # draw of several groups (the group's last block is the next one's key) by lowering the class's switch below one stream
+    with be.engine.options(mt_long_min_blocks=300):
+        ec.check_sampler_bit_exact(be, 10 ** 6, counts=(624 * 256 * 2 + 11, 3, 200000))
+        ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 700,))
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
 @pytest.mark.parametrize('D', [8, 6])

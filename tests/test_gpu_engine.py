@@ -33,6 +33,14 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 1682, counts=(5000000,))
 
 
+def test_sampler_long_streams(be):
+    # draws of more than 16384 state blocks take 256 blocks per stream (the stride-256 jump table): 12 M and 45 M words (the
+    # latter also crosses that class's 40.9 M-word group limit); the class forced at a small size
+    ec.check_sampler_bit_exact(be, 10 ** 6, counts=(11000000, 5, 43000000))
+    with be.engine.options(mt_long_min_blocks=300):
+        ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 256 * 2 + 11, 624 * 700))
+
+
 @pytest.mark.parametrize('loss', ec.ALL_LOSSES)
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
 def test_train_matches_oracle(be, loss, opt):
