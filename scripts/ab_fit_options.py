@@ -44,8 +44,8 @@ def main():
     for label in configs:
         ctx_opts, fit_opts = {}, dict(base_fit)
         for kv in filter(None, label.split(',')):
-            k, v = kv.split('=')
-            if k.startswith('fit:'):
+            k, v = kv.rsplit("=", 1)
+            if k.startswith('fit:') or k.startswith('fit.'):  # ('fit.': scripts/gpu_run.sh splits its stage arguments at ':')
                 fit_opts[k[4:]] = int(v)
             else:
                 ctx_opts[k] = int(v)

@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 CATS = [('passes', ('k_user_pass', 'k_item_pass', 'k_user_stitch', 'k_item_stitch')),
-        ('sampler', ('k_mt_generate', 'k_accept', 'k_scan_counts', 'k_rng_finalize')),
+        ('sampler', ('k_mt_', 'k_accept', 'k_scan_counts', 'k_rng_finalize')),
         ('sort', ('k_rs_', 'k_item_long_flags', 'k_user_long_flags')),
         ('shuffle', ('k_fy', 'k_gather')),
         ('torch', ('at::native', 'elementwise', 'reduce_kernel')),

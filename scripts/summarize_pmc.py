@@ -19,7 +19,7 @@ def cls(name):
         m = re.search(r'k_item_pass<\s*\d+,\s*\d+,\s*\d+,\s*\d+,\s*(\d+)', name)
         part = m.group(1) if m else '0'
         return 'k_item_pass' if part == '0' else 'k_item_pass<PART %s>' % part
-    for key in ('k_user_pass', 'k_score_pass', 'k_adaptive_select', 'k_seq_pass', 'k_shard_user_pass', 'k_mt_generate', 'k_rs_scatter', 'k_rs_hist',
+    for key in ('k_user_pass', 'k_score_pass', 'k_adaptive_select', 'k_seq_pass', 'k_shard_user_pass', 'k_mt_jump', 'k_mt_stream', 'k_mt_prefix', 'k_rs_scatter', 'k_rs_hist',
                 'k_score_gemm'):
         if key in name:
             return key

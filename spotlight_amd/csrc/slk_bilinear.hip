@@ -1575,6 +1575,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             // the other buffer set was last read by the passes of the previous chunk (with a chunk prepared ahead: by the last
             // passes of the call before this one)
             if (ck > 0 || have0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
+            if (!sort_ahead) {
+                // "overlap_prep" 2: the next chunk's draw starts behind THIS chunk's sorts, i.e. beside its passes.  Started
+                // together with the sorts (round 4) the generator's workgroups -- whole CUs by their LDS -- took the sorts'
+                // CUs: the in-line sorts ran 17 % longer and the overlap gained nothing (profiles/r05_b_sweep_overlap_prep.jsonl)
+                SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));
+                SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+            }
             if ((rc = do_sample(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             if (sort_ahead && (rc = do_sort(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));

@@ -38,23 +38,35 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 //   k_mt_prefix   ONE wavefront: the 33-block prefix of the stream every jump is evaluated from (the twist has 227-way
 //                 parallelism and a single wave needs no s_barrier: a workgroup of 64 threads synchronises by program order)
 //   k_mt_jump     workgroup w (1 .. W-1): the state block 624 * (w L) words ahead, x[624 m + j] = XOR_{i in g_m} x[1 + i + j]
-//                 (slk_mtjump.hip), evaluated from the prefix held in LDS; the exponent list of g_m is staged in LDS as
-//                 16-bit values, every lane XORs the windows of TWO output words per term (five waves: a workgroup that
-//                 fits beside the row passes' six workgroups per CU when the draw runs on the second stream)
+//                 (slk_mtjump.hip).  6.2 M word-XORs per jump: the kernel is bound by the instructions it issues per XOR, not by
+//                 bytes (measured, profiles/r05_*: one output word per lane and a dword read per term -- rounds 1-4 -- spends
+//                 three VALU instructions per XOR on unpacking the exponent and forming the address).  So a lane owns TWO
+//                 adjacent output words and a term costs it one address add, one ds_read_b64 (256 B/clk/CU against
+//                 ds_read_b32's 128) and two XORs: the prefix is held twice, once shifted by a word, so that every window is
+//                 8-byte aligned, in two passes over the exponent range (10 240 exponents each: half the prefix per pass); the
+//                 term list is staged as ready-made byte offsets; the terms of a pass are split between three groups of five
+//                 waves (four waves per SIMD), whose partial sums meet in LDS.  ~90 us for the 255 jumps of a draw
 //   k_mt_stream   workgroup w = ONE wavefront: blocks [w L, (w+1) L) from its start block, streamed UNTEMPERED to HBM
-#define SLK_MT_JUMP_THREADS 320  // 5 waves: lane t owns the output words t and t + 320
+#define SLK_MT_JUMP_GROUPS 3      // term groups of five waves; lane l < 312 of a group owns the output words 2l and 2l + 1
+#define SLK_MT_JUMP_GROUP 320
+#define SLK_MT_JUMP_THREADS (SLK_MT_JUMP_GROUPS * SLK_MT_JUMP_GROUP)
 #define SLK_MT_PREFIX_BLOCKS 33  // 33*624 = 20592 >= 1 + 19936 + 624 words feed the jump
-// LDS of k_mt_jump: prefix X[33*624] | zero block [624] (target of the padding exponent) | the exponent list as uint16
-#define SLK_MT_LDS_WORDS ((SLK_MT_PREFIX_BLOCKS + 1) * SLK_MT_N + SLK_MT_JUMP_TERMS / 2)
+#define SLK_MT_PREFIX_WORDS (SLK_MT_PREFIX_BLOCKS * SLK_MT_N)
+#define SLK_MT_WIN 10240                  // exponents per pass (two passes: 20480 > 19937)
+#define SLK_MT_WINW (SLK_MT_WIN + 640)    // words per window copy: index (a - wb) + 2l + 1 <= WIN + 639
+// LDS of k_mt_jump: window copy A | copy B (shifted by one word) | zero block [640] (target of the padding terms) |
+// the pass's term codes (byte offsets, uint32) | the partial sums of the groups behind the first [x 640]
+#define SLK_MT_LDS_WORDS (2 * SLK_MT_WINW + 640 + SLK_MT_JUMP_TERMS + (SLK_MT_JUMP_GROUPS - 1) * 640 + 4)
 
-// One regeneration by ONE wavefront: n[0..624) = next state block of o[0..624) (both in LDS).  The twist
-// x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old words, [227,454) need the
-// first round, [454,624) the second.  SLK_WAVE_SYNC orders the wave's own LDS writes before its later reads (no s_barrier,
-// no wait for the global stores in flight).
-#define SLK_MT_PAD 704  // LDS words per state block buffer: the rounds below read (never write) up to word 652 unconditionally
+// One regeneration by ONE wavefront: n[0..624) = next state block of o[0..624) (both in LDS, SLK_MT_PAD words each), the
+// new words also to dst[0..624) in HBM from the registers they were formed in.  The twist
+// x[k+624] = f(x[k], x[k+1], x[k+397]) has 227-way parallelism: words [0,227) need only old words, [227,454) the first
+// round, [454,624) the second -- three dependent LDS round trips per block.  Every round computes whole 64-lane rows (256,
+// 256, 192 words): the words past a round's range are garbage that the next round overwrites in LDS before anything valid
+// reads them (the rows' reads and writes stay inside the padded buffers); only the stores to HBM are predicated.
+// SLK_WAVE_SYNC orders the wave's own LDS writes before its later reads (no s_barrier, no wait for the stores in flight).
+#define SLK_MT_PAD 704
 __device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, int lane, uint32_t *dst) {
-    // every read of a round is issued before the first wait (straight-line: only the WRITES are predicated); the new words
-    // go to HBM (dst[0..624)) from the registers they were formed in
     {
         uint32_t v[4];
 #pragma unroll
@@ -65,10 +77,8 @@ __device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = lane + 64 * r;
-            if (r < 3 || i < 227) {
-                n[i] = v[r];
-                dst[i] = v[r];
-            }
+            n[i] = v[r];
+            if (r < 3 || i < 227) dst[i] = v[r];
         }
     }
     SLK_WAVE_SYNC();
@@ -82,10 +92,8 @@ __device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 227 + lane + 64 * r;
-            if (r < 3 || i < 454) {
-                n[i] = v[r];
-                dst[i] = v[r];
-            }
+            n[i] = v[r];
+            if (r < 3 || i < 454) dst[i] = v[r];
         }
     }
     SLK_WAVE_SYNC();
@@ -100,10 +108,8 @@ __device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, in
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int i = 454 + lane + 64 * r;
-            if (r < 2 || i < SLK_MT_N) {
-                n[i] = v[r];
-                dst[i] = v[r];
-            }
+            n[i] = v[r];
+            if (r < 2 || i < SLK_MT_N) dst[i] = v[r];
         }
     }
     SLK_WAVE_SYNC();
@@ -113,60 +119,98 @@ __device__ __forceinline__ void mt_regen_wave(const uint32_t *o, uint32_t *n, in
 __global__ __launch_bounds__(64) void k_mt_prefix(const uint32_t *key_src, uint32_t *pre) {
     __shared__ uint32_t pp[2][SLK_MT_PAD];
     const int lane = threadIdx.x;
-    for (int i = lane; i < SLK_MT_N; i += 64) {
-        const uint32_t v = key_src[i];
+    for (int i = lane; i < SLK_MT_PAD; i += 64) {
+        const uint32_t v = i < SLK_MT_N ? key_src[i] : 0u;
         pp[0][i] = v;
-        pre[i] = v;
+        pp[1][i] = 0u;
+        if (i < SLK_MT_N) pre[i] = v;
     }
     SLK_WAVE_SYNC();
-    for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b) {
-        const uint32_t *o = pp[(b - 1) & 1];
-        uint32_t *n = pp[b & 1];
-        mt_regen_wave(o, n, lane, pre + (size_t)b * SLK_MT_N);
-    }
+    for (int b = 1; b < SLK_MT_PREFIX_BLOCKS; ++b) mt_regen_wave(pp[(b - 1) & 1], pp[b & 1], lane, pre + (size_t)b * SLK_MT_N);
 }
 
 // start[(w-1)*624 ..] = state block w*L of the stream whose first 33 blocks are pre[], w = blockIdx.x + 1; polys row w - 1 is
-// the exponent list of g_{w L} (wave-uniform), padding exponents hit the zero block.
+// the ascending exponent list of g_{w L} (wave-uniform), padded with SLK_MT_JUMP_PAD.
 __global__ __launch_bounds__(SLK_MT_JUMP_THREADS) void k_mt_jump(const uint32_t *pre, const uint32_t *polys, uint32_t *start) {
+    // NO static __shared__ in this kernel: eight bytes of it in front of the dynamic region took the region off its 16-byte
+    // alignment and every ds_read_b128 of the codes was replayed at ~50 clocks -- the convolution ran 0.40 ms instead of 0.09
+    // (profiles/r05_f_sampler_jump_variants.jsonl, r05_h_*; cdna_hip_programming.md, guideline 17).  The two counters live
+    // behind the partial sums.
     HIP_DYNAMIC_SHARED(uint32_t, lds)
-    uint32_t *X = lds;
-    uint32_t *zero = lds + SLK_MT_PREFIX_BLOCKS * SLK_MT_N;
-    uint16_t *sx = reinterpret_cast<uint16_t *>(zero + SLK_MT_N);
-    const int t = threadIdx.x;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(pre);
-        uint4 *dst = reinterpret_cast<uint4 *>(X);
-        for (int i = t; i < SLK_MT_PREFIX_BLOCKS * SLK_MT_N / 4; i += SLK_MT_JUMP_THREADS) dst[i] = src[i];
-        for (int i = t; i < SLK_MT_N; i += SLK_MT_JUMP_THREADS) zero[i] = 0u;
-    }
+    uint32_t *A = lds, *B = lds + SLK_MT_WINW, *Z = lds + 2 * SLK_MT_WINW;
+    uint32_t *cx = Z + 640;
+    uint32_t *comb = cx + SLK_MT_JUMP_TERMS;
+    uint32_t *s_cnt = comb + (SLK_MT_JUMP_GROUPS - 1) * 640;
+    const int t = threadIdx.x, g = t / SLK_MT_JUMP_GROUP, l = t - g * SLK_MT_JUMP_GROUP;
     const uint32_t *e = polys + (size_t)blockIdx.x * SLK_MT_JUMP_TERMS;
-    const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];  // list length rounded up to 16
-    for (int i = t; i < nterms; i += SLK_MT_JUMP_THREADS) sx[i] = (uint16_t)e[i];
+    const int nterms = (int)e[SLK_MT_JUMP_TERMS - 1];
+    if (t < 2) s_cnt[t] = 0u;
+    if (t < 640) Z[t] = 0u;
     __syncthreads();
-    // lane t: output words j0 = t and j1 = t + 320 -- one address per term, the second window at a constant offset (the last
-    // 16 lanes own one word: their second window runs at most 16 words past the zero block, into the exponent list: in
-    // bounds, read and dropped)
-    const int j1 = t + SLK_MT_JUMP_THREADS;
-    const uint32_t *x0 = X + 1 + t;
-    const uint32_t *x1 = x0 + SLK_MT_JUMP_THREADS;
-    uint32_t a0 = 0, a1 = 0;
-    for (int k = 0; k < nterms; k += 8) {
-        const uint4 ev = *reinterpret_cast<const uint4 *>(sx + k);  // eight exponents, one broadcast read
-        const uint32_t e0 = ev.x & 0xffffu, e1 = ev.x >> 16, e2 = ev.y & 0xffffu, e3 = ev.y >> 16;
-        const uint32_t e4 = ev.z & 0xffffu, e5 = ev.z >> 16, e6 = ev.w & 0xffffu, e7 = ev.w >> 16;
-        uint32_t p0 = x0[e0] ^ x0[e1], p1 = x1[e0] ^ x1[e1];
-        uint32_t q0 = x0[e2] ^ x0[e3], q1 = x1[e2] ^ x1[e3];
-        p0 ^= x0[e4] ^ x0[e5];
-        p1 ^= x1[e4] ^ x1[e5];
-        q0 ^= x0[e6] ^ x0[e7];
-        q1 ^= x1[e6] ^ x1[e7];
-        a0 ^= p0 ^ q0;
-        a1 ^= p1 ^ q1;
+    {
+        uint32_t c0 = 0, c1 = 0;
+        for (int i = t; i < nterms; i += SLK_MT_JUMP_THREADS) {
+            const uint32_t x = e[i];
+            c0 += x < (uint32_t)SLK_MT_WIN ? 1u : 0u;
+            c1 += x != (uint32_t)SLK_MT_JUMP_PAD ? 1u : 0u;
+        }
+        if (c0) atomicAdd(&s_cnt[0], c0);
+        if (c1) atomicAdd(&s_cnt[1], c1);
     }
-    uint32_t *dst = start + (size_t)blockIdx.x * SLK_MT_N;
-    dst[t] = a0;
-    if (j1 < SLK_MT_N) dst[j1] = a1;
+    __syncthreads();
+    const int split = (int)s_cnt[0], nreal = (int)s_cnt[1];
+    uint32_t a0 = 0, a1 = 0;
+    for (int p = 0; p < 2; ++p) {
+        const int lo = p ? split : 0, T = (p ? nreal : split) - lo, Tpad = (T + 7) & ~7;
+        const uint32_t wb = (uint32_t)p * SLK_MT_WIN;
+        if (p) __syncthreads();
+        for (int k = t; k < SLK_MT_WINW / 4; k += SLK_MT_JUMP_THREADS) {
+            const uint32_t idx = wb + 4u * (uint32_t)k;
+            reinterpret_cast<uint4 *>(A)[k] = idx < (uint32_t)SLK_MT_PREFIX_WORDS ? *reinterpret_cast<const uint4 *>(pre + idx)
+                                                                                 : make_uint4(0u, 0u, 0u, 0u);
+        }
+        for (int k = t; k < SLK_MT_WINW; k += SLK_MT_JUMP_THREADS) {
+            const uint32_t idx = wb + (uint32_t)k + 1u;
+            B[k] = idx < (uint32_t)SLK_MT_PREFIX_WORDS ? pre[idx] : 0u;
+        }
+        // term code = LDS byte offset of the window of output word 0: exponent i, a = 1 + i: x[a + 2l], x[a + 2l + 1] is the
+        // aligned pair A[(a - wb) + 2l] when a is even, B[(a - 1 - wb) + 2l] when it is odd; padding terms read the zero block
+        for (int i = t; i < Tpad; i += SLK_MT_JUMP_THREADS) {
+            uint32_t c = 2u * SLK_MT_WINW;
+            if (i < T) {
+                const uint32_t a = e[lo + i] + 1u;
+                c = ((a & 1u) ? (uint32_t)SLK_MT_WINW : 0u) + ((a - wb) & ~1u);
+            }
+            cx[i] = 4u * c;
+        }
+        __syncthreads();
+        // the codes are wave-uniform: four per ds_read_b128 (same address in every lane: a broadcast), each the offset of one
+        // ds_read_b64 of the lane's two words.  (A/B, profiles/r05_h_*: a code per lane by ds_read_b32 + v_readlane is 3 % slower.)
+        const char *xl = reinterpret_cast<const char *>(lds + 2 * l);
+        for (int k = g * 8; k < Tpad; k += 8 * SLK_MT_JUMP_GROUPS) {
+            const uint4 c0 = *reinterpret_cast<const uint4 *>(cx + k), c1 = *reinterpret_cast<const uint4 *>(cx + k + 4);  // eight codes
+#define SLK_MT_LD(off_) (*reinterpret_cast<const uint2 *>(xl + (off_)))
+            const uint2 r0 = SLK_MT_LD(c0.x), r1 = SLK_MT_LD(c0.y), r2 = SLK_MT_LD(c0.z), r3 = SLK_MT_LD(c0.w);
+            const uint2 r4 = SLK_MT_LD(c1.x), r5 = SLK_MT_LD(c1.y), r6 = SLK_MT_LD(c1.z), r7 = SLK_MT_LD(c1.w);
+#undef SLK_MT_LD
+            a0 ^= ((r0.x ^ r1.x) ^ (r2.x ^ r3.x)) ^ ((r4.x ^ r5.x) ^ (r6.x ^ r7.x));
+            a1 ^= ((r0.y ^ r1.y) ^ (r2.y ^ r3.y)) ^ ((r4.y ^ r5.y) ^ (r6.y ^ r7.y));
+        }
+    }
+    if (g > 0) {
+        comb[(g - 1) * 640 + 2 * l] = a0;
+        comb[(g - 1) * 640 + 2 * l + 1] = a1;
+    }
+    __syncthreads();
+    if (g == 0 && 2 * l < SLK_MT_N) {
+        uint32_t *dst = start + (size_t)blockIdx.x * SLK_MT_N;
+        for (int q = 0; q < SLK_MT_JUMP_GROUPS - 1; ++q) {
+            a0 ^= comb[q * 640 + 2 * l];
+            a1 ^= comb[q * 640 + 2 * l + 1];
+        }
+        dst[2 * l] = a0;
+        dst[2 * l + 1] = a1;
+    }
 }
 
 // raw[b*624 ..] = state block b (untempered), b = 0 .. nblocks-1, block 0 = key_src itself.  Workgroup w (one wavefront)
@@ -180,10 +224,11 @@ __global__ __launch_bounds__(64) void k_mt_stream(const uint32_t *key_src, const
     const int last = (first + L < nblocks) ? first + L : nblocks;
     const uint32_t *src = blockIdx.x == 0 ? key_src : start + (size_t)(blockIdx.x - 1) * SLK_MT_N;
     uint32_t *dst = raw + (size_t)first * SLK_MT_N;
-    for (int i = lane; i < SLK_MT_N; i += 64) {
-        const uint32_t v = src[i];
+    for (int i = lane; i < SLK_MT_PAD; i += 64) {
+        const uint32_t v = i < SLK_MT_N ? src[i] : 0u;
         pp[0][i] = v;
-        dst[i] = v;
+        pp[1][i] = 0u;
+        if (i < SLK_MT_N) dst[i] = v;
     }
     SLK_WAVE_SYNC();
     int cur = 0;

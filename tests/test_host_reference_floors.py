@@ -15,10 +15,15 @@ SUBSET = ('pooling-0.001', 'pooling-loss-adaptive_hinge', 'cnn-0.001', 'bloom-ls
 @pytest.fixture()
 def emu_device(monkeypatch):
     eng = _native.Engine(0, lib=emu_lib())
+    # single-threaded CPU torch, like the recorded reference values: with the host's cores shared (pytest-xdist) the conv /
+    # LSTM reductions reassociate and the CNN case lands within 0.005 of its floor on either side (0.6467 seen, floor 0.65)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     monkeypatch.setattr(host, '_engine_for', lambda device: eng)
     monkeypatch.setattr(host, '_stream_for', lambda device: 0)
     monkeypatch.setattr(host, '_model_device', lambda: torch.device('cpu'))
     yield eng
+    torch.set_num_threads(threads)
     eng.close()
 
 
