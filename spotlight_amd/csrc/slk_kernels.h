@@ -298,15 +298,13 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
         } else {
+            // PoolNet (slk_seq.hip): record = [representation | the own item's ready-made contribution g * representation +
+            // history gradient].  The own item (s == 0) takes the second half as it is, a sampled item g times the first:
+            // ONE 4D-byte read per occurrence (rounds 1-4: both halves for s == 0)
             gb = a.gsn[r - a.begin * NP];
-            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+            const slk_vec<VEC> u = on ? slk_vload<VEC>(rec + (s == 0 ? D : 0) + d0) : slk_vzero<VEC>();
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
-            if (s == 0 && on) {
-                const slk_vec<VEC> h = slk_vload<VEC>(rec + D + d0);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) c.v[i] += h.v[i];
-            }
+            for (int i = 0; i < VEC; ++i) c.v[i] = s == 0 ? u.v[i] : gb * u.v[i];
         }
     }
 }

@@ -13,11 +13,15 @@
 //        sums are stitched with a block-level scan (forward: prefix sum + non-zero count ->
 //        representation -> scores -> loss -> dL/dscore; backward: suffix sum of
 //        dL/d(prefix sum)).  Per timestep it writes one record
-//             [ representation (D) | history gradient (D) | dL/dscore of the 1+n pairs ]
-//        -- everything the item rows' owners need.
+//             [ representation (D) | the own item's contribution g_pos * representation + history gradient (D) ]
+//        (+ dL/dscore of the 1+n pairs in a side array) -- everything the item rows' owners need.  Round 5: the second half
+//        used to be the history gradient alone and the own item's occurrence read BOTH halves (768 B of records read per
+//        timestep; now each occurrence reads one half: 512 B) -- same products, same additions, same bits.  The backward
+//        scan forms it from what the forward scan left in the record (its own stores: L2 hits), so the forward scan -- at its
+//        register limit -- is untouched.
 //   ITEM PASS (slk_kernels.h, SEQ mode)  occurrences (timestep, pair) sorted by item; one
-//        owner group per unique item sums  g * representation (+ history gradient for the
-//        sequence's own item)  and applies the optimizer once.
+//        owner group per unique item sums  the ready-made contribution (the sequence's own item)
+//        or g * representation (a sampled item)  and applies the optimizer once.
 #include <math.h>
 
 #include "slk_kernels.h"
@@ -246,7 +250,14 @@ __global__ __launch_bounds__(256) void k_seq_pass(slk_seq_args a) {
                 for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
             }
             for (int t = t1 - 1; t >= t0; --t) {
-                if (on) slk_vstore<VEC>(recs + (size_t)t * a.RS + D + d0, suf);
+                if (on) {  // the own item's ready-made contribution (see k_seq_pass_reg)
+                    float *rec = recs + (size_t)t * a.RS;
+                    slk_vec<VEC> c0 = slk_vload<VEC>(rec + d0);
+                    const float gpt = a.gsn[(bl * (uint32_t)L + (uint32_t)t) * (uint32_t)a.NP];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) c0.v[i] = gpt * c0.v[i] + suf.v[i];
+                    slk_vstore<VEC>(rec + D + d0, c0);
+                }
                 const slk_vec<VEC> x = slk_vload<VEC>(sE + t * DL + d0);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
@@ -448,12 +459,37 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(2) void k_seq_pass_reg(slk_se
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) suf.v[i] += x.v[i];
             }
+            // The own item's contribution, ready-made for its owner: g_pos * representation (what this lane and lane 0 of its
+            // row group stored in (B2): the group's own stores, read back behind the barriers above -- L2 hits) + the history
+            // gradient.  Four timesteps' read-backs are in flight at a time (one dependent round trip per timestep cost the
+            // pass 20 %, profiles/r05_l_*).
+            constexpr int RB = CMAX < 4 ? CMAX : 4;  // (CMAX is a power of two)
 #pragma unroll
-            for (int k = CMAX - 1; k >= 0; --k) {
-                if (k < cnt) {
-                    if (on) slk_vstore<VEC>(recs + (size_t)(t0 + k) * a.RS + D + d0, suf);
+            for (int kb = CMAX - RB; kb >= 0; kb -= RB) {
+                if (kb >= cnt) continue;
+                slk_vec<VEC> c0[RB];
+                float gpt[RB];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) suf.v[i] += e[k].v[i];
+                for (int j = RB - 1; j >= 0; --j) {
+                    c0[j] = slk_vzero<VEC>();
+                    gpt[j] = 0.0f;
+                    if (kb + j < cnt && on) {
+                        c0[j] = slk_vload<VEC>(recs + (size_t)(t0 + kb + j) * a.RS + d0);
+                        gpt[j] = a.gsn[(bl * (uint32_t)L + (uint32_t)(t0 + kb + j)) * (uint32_t)a.NP];
+                    }
+                }
+#pragma unroll
+                for (int j = RB - 1; j >= 0; --j) {
+                    const int k = kb + j;
+                    if (k < cnt) {
+                        if (on) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) c0[j].v[i] = gpt[j] * c0[j].v[i] + suf.v[i];
+                            slk_vstore<VEC>(recs + (size_t)(t0 + k) * a.RS + D + d0, c0[j]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) suf.v[i] += e[k < CMAX ? k : 0].v[i];
+                    }
                 }
             }
         }

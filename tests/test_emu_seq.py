@@ -89,6 +89,13 @@ def test_seq_item_pass_with_every_head_early_is_bit_neutral(be):
     ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 16, bloom=3, chunk=1 << 23, overlap=0, option=('item_lat_max_tiles', 2048, 0, 2048))
 
 
+@pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('hinge', 'adam_dense', 3)])
+def test_seq_pass_forms_are_bit_identical(be, loss, opt, bloom):
+    """Both forms of the sequence pass leave the same record (representation | own item's contribution): register-resident (1,
+    the default) and LDS-staged (0)"""
+    ec.check_seq_chunking_is_bit_neutral(be, loss, opt, 16, bloom=bloom, chunk=1 << 23, overlap=0, option=('seq_variant', 1, 0, 1))
+
+
 @pytest.mark.parametrize('loss,opt,bloom', [('bpr', 'adagrad', 0), ('adaptive_hinge', 'sparse_adam', 0), ('pointwise', 'adam_dense', 0),
                                             ('bpr', 'adagrad', 4)])
 @pytest.mark.parametrize('overlap', [0, 1])

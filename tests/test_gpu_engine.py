@@ -302,6 +302,16 @@ def test_seq_item_pass_with_every_head_early_is_bit_neutral(be):
                                          option=('item_lat_max_tiles', 1 << 30, 0, 2048))
 
 
+def test_seq_pass_forms_are_bit_identical(be):
+    """register-resident sequence pass (1, the default) and the LDS-staged pass (0): the same record, the same tables"""
+    ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, I=20000, N=2000, L=10, B=256, chunk=1 << 23, overlap=0,
+                                         option=('seq_variant', 1, 0, 1))
+    ec.check_seq_chunking_is_bit_neutral(be, 'adaptive_hinge', 'sparse_adam', 32, chunk=1 << 23, overlap=0,
+                                         option=('seq_variant', 1, 0, 1))
+    ec.check_seq_chunking_is_bit_neutral(be, 'bpr', 'adagrad', 64, I=50000, N=512, L=200, B=128, chunk=1 << 23, overlap=0,
+                                         option=('seq_variant', 1, 0, 1))
+
+
 # ---- persistent epoch kernel (csrc/slk_epoch.hip): one cooperative launch per chunk of minibatches ----
 @pytest.mark.parametrize('loss', ['pointwise', 'bpr', 'hinge'])
 @pytest.mark.parametrize('opt', ec.ALL_OPTS)
