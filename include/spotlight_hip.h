@@ -151,6 +151,11 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         1-3 skip parts of a pass (profiles/r04_b_*; the output is then not sorted)
  *   "shuffle_band"        slk_shuffle_perm: 1 banded acceptance decisions (default), 0 full fixpoint sweeps,
  *                         > 1 a band that many times too narrow (test hook for the fall-back)
+ *   "mt_long_min_blocks"  the MT19937 generator (csrc/slk_rng.hip): draws of at least this many 624-word state blocks (default
+ *                         16385 = more than 10.2 M words) use 256 blocks per stream and the stride-256 jump table, smaller
+ *                         ones 64 (test hook: the long class at a small size)
+ *   "epoch_max_grid"      workgroups of the persistent kernel, at most one per CU -- values above 1024 lift that limit (a
+ *                         measurement switch: several one-wave workgroups per CU, profiles/r05_b_persistent_kernel_wide_grid_*)
  *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --

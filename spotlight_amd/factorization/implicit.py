@@ -528,6 +528,10 @@ class ImplicitFactorizationModel(object):
                     unpacked = upload.result()  # (kept until the prep lane has been waited for, below)
                     upload._out = None
                     d_pairs = torch.empty(2 * n, dtype=torch.int32, device=device)
+                    # INVARIANT: with the id checks on worker threads (`check.threaded`) these ids are NOT validated
+                    # yet -- they are truncated to uint32, permuted and gathered as DATA only.  Nothing may index a table with
+                    # them, and no training call or prefetch may be enqueued, before `check.result()` has returned
+                    # (tests/test_host_model.py::test_id_checks_on_worker_threads_raise_like_the_serial_ones).
                     prep.pack_id_pairs(unpacked[0].data_ptr(), unpacked[1].data_ptr(), n, d_pairs.data_ptr(), stream=prep_stream)
                 return [('pairs', d_pairs, bufs[slot][0], bufs[slot][1])]
             fallback = np.random.RandomState()  # (device_epoch_shuffle's host fall-back draws from it: private to this job)
