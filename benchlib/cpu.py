@@ -33,15 +33,15 @@ def reference_cpu_baseline(args, seconds):
            'cpu_model': rec['cpu_model'], 'host_cores': rec['host_cores'],
            'interactions_per_s_by_threads': sa['interactions_per_s_by_threads'],
            'sample': 'spotlight ImplicitFactorizationModel.fit() on CPU PyTorch %s, sparse=True + Adagrad(lr=1e-2), %s loss, '
-                     '%d users x %d items, dim %d, minibatch %d (bounded sample; the GPU workload uses %d): warm-up fit + min '
-                     'of 2 timed fits of %d minibatch(es) (%.1f s each); torch.set_num_threads: every host core (%d, on an eighth of a '
-                     'minibatch) and 16 were probed, the faster (%d) was timed%s'
-                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], rec['batch'], rec['gpu_workload_batch'],
+                     '%d users x %d items, dim %d, minibatch %d (the GPU workload uses %d): warm-up fit + min of 2 timed fits of %d '
+                     'minibatch(es) (%.1f s each); torch.set_num_threads: every host core (%d, on 32768 interactions) and 16 were '
+                     'probed, the faster (%d) was timed%s'
+                     % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], sa.get('batch', rec['batch']), rec['gpu_workload_batch'],
                         sa['minibatches_per_fit'], sa['seconds'], rec['host_cores'], sa['threads'],
                         '; ' + rec['note'] if rec['note'] else '')}
     if da:
         out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s', 'cores': da['threads'],
-                                               'sample': '%d minibatch(es) per fit, %.1f s' % (da['minibatches_per_fit'], da['seconds'])}
+                                               'sample': '%d minibatch(es) of %d per fit, %.1f s' % (da['minibatches_per_fit'], da.get('batch', rec['batch']), da['seconds'])}
     return out
 
 

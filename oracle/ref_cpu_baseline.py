@@ -77,11 +77,12 @@ def main():
         U //= 2
         note = ' (user table scaled to %d rows to fit host RAM)' % U
 
-    # The CPU sample uses minibatches of at most 2^18 interactions (a 2^20 minibatch costs the reference tens of seconds
-    # on a many-core host): bounded, and stated in the output.
-    Bc = min(B, 1 << 18)
+    # The sparse-Adagrad variant -- the one the line's cpu_baseline.value is -- runs the GPU workload's OWN minibatch (2^20: 2-3 s
+    # per minibatch at 16 threads); the secondary dense-Adam variant (9 s per 2^20 minibatch) keeps a bounded 2^18 one.  Both are
+    # stated in the output.
+    Bc = B
     rs = np.random.RandomState(0)
-    n_max = 16 * Bc
+    n_max = 8 * Bc
     users = rs.randint(0, U, n_max).astype(np.int32)
     items = rs.randint(0, I, n_max).astype(np.int32)
 
@@ -98,9 +99,11 @@ def main():
            'protocol': 'warm-up fit() + min of 2 timed fit()s (reference examples/bloom_embeddings/performance.py:24-38)'}
     variants = [v for v in args.variants.split(',') if v]
     all_threads = args.threads or os.cpu_count()
+    B_full = Bc
     for vi, name in enumerate(variants):
         kw = (dict(sparse=True, optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2))
               if name == 'sparse_adagrad' else dict())
+        Bc = B_full if name == 'sparse_adagrad' else min(B_full, 1 << 18)
         few = min(all_threads, 16)
         torch.set_num_threads(few)
         model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=D, n_iter=1, batch_size=Bc,
@@ -112,7 +115,7 @@ def main():
         rate = {few: Bc / timed_fit(model, inter(Bc))}
         if all_threads != few:
             torch.set_num_threads(all_threads)
-            n_probe = max(Bc // 8, 1)
+            n_probe = max(min(Bc // 8, 1 << 15), 1)
             timed_fit(model, inter(n_probe))  # the larger thread pool's first use
             rate[all_threads] = n_probe / timed_fit(model, inter(n_probe))
         best = max(rate, key=rate.get)
@@ -122,7 +125,7 @@ def main():
         k = int(max(1, min(n_max // Bc, args.seconds / len(variants) / 2.0 / max(per_mb, 1e-6))))
         data = inter(k * Bc)
         timings = [timed_fit(model, data) for _ in range(2)]
-        out[name] = {'interactions_per_fit': k * Bc, 'minibatches_per_fit': k, 'seconds': min(timings), 'timings': timings,
+        out[name] = {'interactions_per_fit': k * Bc, 'minibatches_per_fit': k, 'batch': Bc, 'seconds': min(timings), 'timings': timings,
                      'warmup_seconds': t_warm, 'threads': best, 'interactions_per_s': k * Bc / min(timings),
                      'interactions_per_s_by_threads': {str(th): r for th, r in rate.items()}}
         del model
