@@ -188,7 +188,7 @@ def main():
         # this rank's B interactions of every global minibatch (users it owns; items anywhere)
         lo, hi = first_mb * B, (first_mb + n_mb) * B
         trainer.train(users[lo:hi], items[lo:hi], B, loss=args.loss, mb_loss=mb_loss[first_mb:first_mb + n_mb],
-                      sample_chunk=args.shard_chunk)
+                      sample_chunk=args.shard_chunk, n_neg=5 if args.loss == 'adaptive_hinge' else None)  # (5: the reference's default)
         xgmi_rows[0] += trainer.exchange_rows
 
     multi = world > 1 or args.sharded

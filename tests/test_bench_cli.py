@@ -108,3 +108,13 @@ def test_hip_backend_refuses_more_ranks_than_gpus():
     p = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '1', '--warmup', '0'], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=env, timeout=300)
     assert p.returncode != 0 and b'refusing' in p.stderr and not p.stdout.strip()
+
+
+def test_adaptive_hinge_on_the_row_sharded_bench_path():
+    """`--loss adaptive_hinge` at N > 1 (the reference's default of 5 draws per interaction travels with the call): the line
+    comes out and the ranks' loss shares add up to a finite, positive minibatch loss."""
+    rc, out, err = run_bench(['--gpus', '2', '--loss', 'adaptive_hinge', '--no-denominators'])
+    assert rc == 0, err[-3000:]
+    rec = json.loads([l for l in out.splitlines() if l.strip().startswith('{')][-1])
+    assert rec['n_gpus'] == 2 and rec['ranks']['world_size_observed'] == 2
+    assert 'adaptive_hinge' in rec['config']['workload'] and rec['final_minibatch_loss'] > 0
