@@ -21,11 +21,14 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--cases', default='', help='comma-separated case indices (default: all)')
     ap.add_argument('--cfgs', default='1,0', help='tile shapes to time: 1 = 512 threads x 16 keys (what sorts of >= 2^20 pairs use), 0 = 256 x 16')
+    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE', help='engine option, e.g. sort_wide_digits=1')
     ap.add_argument('--debug-sweep', action='store_true', help='also time the measurement-only forms (sort_debug 1, 2, 3: wrong results)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     eng = _native.Engine(0)
     st = torch.cuda.current_stream(dev).cuda_stream
+    for kv in args.set:
+        eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     cases = [  # (label, kind, n, bits, seg_len)
         ('user side C2: 8 x 2^20 pairs u32+u64, 24 bits, segmented', 1, 8 << 20, 24, 1 << 20),
         ('user side C2 as round 3 sorted it: 27 bits, one array', 1, 8 << 20, 27, 0),
@@ -56,7 +59,7 @@ def main():
             passes = (bits + 7) // 8
             pair = keys.element_size() + vals.element_size()
             traffic = n * (passes * 2 * pair + keys.element_size())
-            rec = {'case': label, 'big_tiles': cfg, 'sort_debug': dbg, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
+            rec = {'case': label, 'options': args.set, 'big_tiles': cfg, 'sort_debug': dbg, 'n': n, 'bits': bits, 'seg_len': seg, 'passes': passes, 'ms': round(ms, 4),
                    'gpairs_per_s': round(n / ms / 1e6, 3), 'tb_per_s_own_traffic': round(traffic / ms / 1e9, 3)}
             print(json.dumps(rec), flush=True)
             if out:
