@@ -1141,6 +1141,15 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
     const unsigned gpb = 256u / (unsigned)g;
+    // The user pass is a grid-stride kernel: workgroups beyond what a CU holds RESIDENT start when others finish and unbalance
+    // the pass.  Its grid is therefore capped at the kernel's own occupancy (slk_occupancy_of: the SparseAdam form needs 72
+    // VGPRs = 7 workgroups per CU; launched 8 per CU it ran 0.58 ms, capped 0.44; Adagrad's 59 VGPRs hold 8).
+    // (one cap for the forms a minibatch may take -- plain, latency-bound, long runs: the grid also counts the loss partials)
+    int occ_user = slk_occupancy_of(ctx, upass);
+    for (pass_fn f : {upass_lat, upass_long, upass_lat_long}) {
+        const int o = slk_occupancy_of(ctx, f);
+        if (o < occ_user) occ_user = o;
+    }
 
     // ---- prep of one chunk into buffer set `pb` (value-independent: ids only), in two halves:
     // the negatives (ALU/latency-bound MT19937 generator), then the sorts (HBM-bound)
@@ -1314,7 +1323,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             // overlapped prep: the user pass is a grid-stride kernel whose workgroups hold their wave slots for the whole run; two
             // of the eight per CU are left to the prep stream's kernels (measured, profiles/r03_a_*: 8 -> 6 costs the pass
             // nothing by itself and gives the overlap 2 % more)
-            const unsigned ugrid = slk_grid_for(ctx, bm, gpb, nsets == 2 && ctx->opt_user_grid_mult > 6 ? 6 : 0);
+            const int ugm = nsets == 2 && ctx->opt_user_grid_mult > 6 ? 6 : ctx->opt_user_grid_mult;
+            const unsigned ugrid = slk_grid_for(ctx, bm, gpb, ugm < occ_user ? ugm : occ_user);
 
             if (expl && ctx->opt_explicit_fused) {
                 // the user pass forms score, loss and dL/dscore itself (one pair per interaction)

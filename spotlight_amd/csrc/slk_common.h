@@ -218,6 +218,7 @@ struct slk_ctx {
     bool prof_on = false;
     std::vector<slk_prof_span> spans;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<const void *, int>> occ_cache;  // kernel -> resident workgroups per CU (slk_occupancy_of)
     int64_t prof_launches[SLK_K_COUNT] = {0};
     double prof_ms[SLK_K_COUNT] = {0};
 };

@@ -866,6 +866,32 @@ static inline unsigned slk_grid_for(const slk_ctx *ctx, size_t work_items, unsig
     return (unsigned)blocks;
 }
 
+// Workgroups of 256 threads of kernel `fn` a CU holds resident (by its registers and static LDS), cached per ctx; 1 << 20 when
+// the runtime cannot tell.  A grid-stride pass launched with more workgroups per CU than that runs the surplus as a second,
+// partial round (round 5: the SparseAdam user pass -- 72 VGPRs, 7 resident workgroups -- launched 8 per CU: 0.58 ms; capped:
+// 0.44, profiles/r05_w_*, r05_x_*).
+template <class Fn>
+static inline int slk_occupancy_of(slk_ctx *ctx, Fn fn) {
+    const void *key = reinterpret_cast<const void *>(fn);
+    if (!key) return 1 << 20;
+    for (const auto &e : ctx->occ_cache)
+        if (e.first == key) return e.second;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1 << 20;
+    }
+    ctx->occ_cache.push_back({key, per_cu});
+    return per_cu;
+}
+
+// grid of a grid-stride row pass: at most min("user_grid_mult", the kernel's own occupancy) workgroups per CU
+template <class Fn>
+static inline unsigned slk_grid_for_fn(slk_ctx *ctx, Fn fn, size_t work_items, unsigned per_block) {
+    const int occ = slk_occupancy_of(ctx, fn);
+    return slk_grid_for(ctx, work_items, per_block, ctx->opt_user_grid_mult < occ ? ctx->opt_user_grid_mult : occ);
+}
+
 // (VEC, G) layout for an embedding dim: 16 B per lane when dim % 4 == 0.
 static inline bool slk_pick_layout(int D, int *vec, int *g) {
     if (D <= 0) return false;

@@ -751,13 +751,13 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     a.loss_kind = loss;
     a.inv_b = 1.0f / (float)global_batch;
     const unsigned gpb = 256u / (unsigned)g;
-    const unsigned ugrid = n > 0 ? slk_grid_for(ctx, (size_t)n, gpb) : 0;
-    if (n > 0) {
-        slk_pass_fn upass = nullptr;
-        const int upd = slk_upd_for(optim->kind);
+    slk_pass_fn upass = nullptr;
+    const int upd = slk_upd_for(optim->kind);
 #define SLK_PICK(V_, G_) upass = shard_user_pass_fn<V_, G_>(upd)
-        SLK_FOR_LAYOUT(vec, g, SLK_PICK);
+    SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
+    const unsigned ugrid = n > 0 ? slk_grid_for_fn(ctx, upass, (size_t)n, gpb) : 0;  // (capped at the kernel's occupancy)
+    if (n > 0) {
         slk_prof_begin(ctx, SLK_K_USER_PASS, s);
         hipLaunchKernelGGL(upass, dim3(ugrid), dim3(256), 0, s, a);
         SLK_LAUNCH_CHECK(ctx, "k_shard_user_pass");
@@ -886,7 +886,7 @@ SLK_EXPORT int slk_shard_user_pass_adaptive(slk_ctx *ctx, const slk_tables *loca
     SLK_FOR_LAYOUT(vec, g, SLK_PICK);
 #undef SLK_PICK
     slk_prof_begin(ctx, SLK_K_USER_PASS, s);
-    hipLaunchKernelGGL(upass, dim3(slk_grid_for(ctx, (size_t)n, 256u / (unsigned)g)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(upass, dim3(slk_grid_for_fn(ctx, upass, (size_t)n, 256u / (unsigned)g)), dim3(256), 0, s, a);
     SLK_LAUNCH_CHECK(ctx, "k_shard_user_pass_pre");
     slk_prof_end(ctx, s);
     return SLK_OK;
