@@ -145,7 +145,7 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "item_lat_max_tiles"  item pass launches of up to this many 64-occurrence tiles (default 2048; PoolNet: a quarter) load every
  *                         head's row + state with the record gather (k_item_pass<..., NPRE 4>: -10..-19 % on minibatches of
  *                         4096-65 536, profiles/r03_y_*); 0: never
- *   "user_lat_max_batch"  minibatches up to this size (default 2^14) take the latency-bound form of the pair-mode user pass
+ *   "user_lat_max_batch"  minibatches up to this size (default 2^17) take the latency-bound form of the pair-mode user pass
  *   "sort_big_min"        radix sort (csrc/slk_sort.hip): sorts of at least this many pairs (default 2^20) use tiles of 512 threads x
  *                         16 keys, smaller ones 256 x 16 (test hook: both shapes at any size);  "sort_debug": measurement only,
  *                         1-3 skip parts of a pass (profiles/r04_b_*; the output is then not sorted)

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from spotlight_amd import _native  # noqa: E402
 
 DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 0, 'overlap_min_batch': 1 << 16, 'item_grid_mult': 128,
-            'user_grid_mult': 8, 'nt': 3, 'user_lat_max_batch': 1 << 14, 'item_long_gate': 1, 'item_lat_max_tiles': 2048}
+            'user_grid_mult': 8, 'nt': 3, 'user_lat_max_batch': 1 << 17, 'item_long_gate': 1, 'item_lat_max_tiles': 2048}
 
 
 def main():

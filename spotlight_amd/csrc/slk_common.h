@@ -133,9 +133,10 @@ struct slk_ctx {
     // (measured: one sort of all 1+n occurrences per chunk is faster up to 2^17 interactions per minibatch, slower from 2^18
     // -- profiles/r02_x_adaptive_small_batches.jsonl); a bloom item table (H rows per occurrence) always re-sorts
     int64_t opt_adaptive_late_min_batch = (int64_t)1 << 18;
-    int64_t opt_user_lat_max_batch = (int64_t)1 << 14;  // (measured, profiles/r03_c_*: user pass 9.2 -> 8.1 us at 2048, 11.6 -> 10.3 at
-                                   // 8192, but 29.3 -> 31.3 at 65 536)  // minibatches up to this size take the latency-bound form of the pair-mode
-                                   // user pass (k_user_pass<..., LAT>): two round trips per position instead of four
+    int64_t opt_user_lat_max_batch = (int64_t)1 << 17;  // minibatches up to this size take the latency-bound form of the pair-mode
+                                   // user pass (k_user_pass<..., LAT>): two round trips per position instead of four.  Round 5
+                                   // re-measured the crossover (profiles/r05_zb_*): user pass 21.2 -> 19.1 us at 32 768, 32.2 ->
+                                   // 30.3 at 65 536, 53.7 -> 52.3 at 131 072, but 95 -> 97 at 262 144 (round 3 had it at 2^14)
     int64_t opt_item_lat_max_tiles = 2048;  // item pass: launches of up to this many 64-occurrence tiles take the form with every head's
                                    // row loaded early (k_item_pass<..., NPRE 4>); 0: never.  Same-box A/B (profiles/r03_y_*): item pass
                                    // 16.1 -> 13.5 us at minibatch 4096, 20.5 -> 16.5 at 16 384, 42.2 -> 38.0 at 65 536 (2048 tiles);
