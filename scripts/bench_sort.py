@@ -21,7 +21,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--cases', default='', help='comma-separated case indices (default: all)')
     ap.add_argument('--cfgs', default='1,0', help='tile shapes to time: 1 = 512 threads x 16 keys (what sorts of >= 2^20 pairs use), 0 = 256 x 16')
-    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE', help='engine option, e.g. sort_wide_digits=1')
+    ap.add_argument('--set', action='append', default=[], metavar='NAME=VALUE', help='engine option, e.g. sort_big_min=1')
     ap.add_argument('--debug-sweep', action='store_true', help='also time the measurement-only forms (sort_debug 1, 2, 3: wrong results)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
