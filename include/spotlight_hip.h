@@ -131,7 +131,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "prefetch_wait"       measurement switch: 1 = slk_bilinear_prefetch's chunk waits for everything `stream` holds, as it did up
  *                         to ABI 8 (default 0: it runs beside the passes `stream` still holds)
  *   "item_grid_mult"      item pass: workgroups per CU (default 128)
- *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond)
+ *   "user_grid_mult"      other row passes: workgroups per CU (default 8, grid-stride beyond); the user passes never launch more
+ *                         than their kernel holds resident per CU (72 VGPRs = 7 for the SparseAdam form: a surplus workgroup per
+ *                         CU ran as a second, partial round and cost the pass 13 %, profiles/r05_w_*)
  *   "epoch_kernel" (0/1), "epoch_max_batch", "epoch_dense_elems", "epoch_max_grid", "epoch_barrier", "epoch_cooperative"
  *                         the persistent epoch kernel of slk_bilinear_train / _explicit (csrc/slk_epoch.hip)
  *   "epoch_adaptive"      1 (default): adaptive hinge takes the persistent kernel too (score phase + in-phase selection),
