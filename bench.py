@@ -87,6 +87,10 @@ def parse():
     ap.add_argument('--no-overlapped', action='store_true',
                     help='skip the secondary roofline.overlapped measurement (three more K-step calls with option overlap_prep = 1): what '
                          'the rocprofv3 / PMC commands use, so that their per-kernel means are those of the timed configuration only')
+    ap.add_argument('--no-bias-shadow', action='store_true',
+                    help='item tables of 2^24 rows and more: keep the item biases and their Adagrad accumulator in two arrays '
+                         '(default: interleaved for the run, as fit() trains such tables -- slk_bias_shadow_begin, opened before '
+                         'the warm-up and closed after the last timed call)')
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-configs', action='store_true',
@@ -178,6 +182,11 @@ def main():
         trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
         trainer.reserve(B, args.shard_chunk)  # exchange buffers of the timed loop's chunks up front
     xgmi_rows = [0]
+    # fit() trains item tables this large with {bias, Adagrad accumulator} interleaved (factorization/implicit.py:
+    # _BIAS_SHADOW_MIN_ITEMS); the scope opens here, outside every timed region, and closes after the last one
+    bias_shadowed = (trainer is None and args.opt == 'adagrad' and I >= (1 << 24) and B >= 4096 and not args.no_bias_shadow)
+    shadow_scope = eng.bias_shadow(tb, op, stream=stream, enabled=bias_shadowed)
+    shadow_scope.__enter__()
 
     def run(first_mb, n_mb):
         if trainer is None:
@@ -269,6 +278,7 @@ def main():
     elapsed = time.perf_counter() - t3
     barrier()
     xgmi_rows[0] = xg
+    shadow_scope.__exit__(None, None, None)  # (the probes and checks below read the two arrays)
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
         ranks_seen[0]['exchange_rows_timed_call'] = int(xgmi_rows[0])  # lookups of this rank that crossed to another rank, K steps
@@ -462,6 +472,9 @@ def main():
                                          ('; USERS ZIPF(%g) -- a stress run, not the metric\'s distribution' % args.user_zipf
                                           if args.user_zipf > 0 else '')),
                           'global_batch': B * world,
+                          'item_bias_layout': ('{bias, Adagrad accumulator} interleaved for the run (slk_bias_shadow_begin before the '
+                                               'warm-up, _end after the last timed call: what fit() does on item tables this large)'
+                                               if bias_shadowed else 'two arrays (torch layout)'),
                           'parallelism': 'single GPU' if trainer is None else
                           'row-sharded x%d: users and items sharded cyclically; RCCL all-to-all of ids per chunk of '
                           'minibatches, of rows and gradient rows per user-slice of a minibatch (async, overlapping '

@@ -29,6 +29,8 @@ def pmc_traffic(args, kernel):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    cfg = rec.get('config', {})
-    same = all(cfg.get(k) == getattr(args, k) for k in ('users', 'items', 'dim', 'batch', 'loss', 'opt'))
-    return rec.get('kernels', {}).get(kernel, {}).get('hbm_bytes_per_launch') if same else None
+    for r in [rec] + list(rec.get('others', [])):  # the headline configuration first, then the other measured ones
+        cfg = r.get('config', {})
+        if all(cfg.get(k) == getattr(args, k) for k in ('users', 'items', 'dim', 'batch', 'loss', 'opt')):
+            return r.get('kernels', {}).get(kernel, {}).get('hbm_bytes_per_launch')
+    return None

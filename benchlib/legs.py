@@ -34,6 +34,9 @@ def _compact(kind, rec):
                     'frac': round(roof.get('frac', 0.0), 4), 'step_frac': round(roof.get('step_frac_of_peak', 0.0), 4)})
         k = roof.get('kernels', {})
         out['kernel_ms'] = {n: round(v['avg_ms'], 4) for n, v in k.items()}
+        layout = rec.get('config', {}).get('item_bias_layout', '')
+        if layout and not layout.startswith('two arrays'):
+            out['item_bias_layout'] = 'interleaved with its Adagrad accumulator for the run (slk_bias_shadow_begin, outside the timed region)'
         if roof.get('persistent_epoch_kernel'):
             out['persistent_us_per_minibatch'] = round(roof['persistent_epoch_kernel']['us_per_minibatch'], 2)
     elif kind == 'step':

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 9
+#define SLK_ABI_VERSION 10
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -168,6 +168,7 @@ int slk_ctx_get_option(slk_ctx *ctx, const char *name, int64_t *value);
  * "user_long_launches" / "item_long_launches" (launches of the long-run forms of the two passes since the ctx was created),
  * "overlapped_chunks" (chunks whose negatives + sorts ran on the ctx's second stream beside the passes of the chunk before),
  * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over),
+ * "shadowed_calls" (slk_bilinear_train calls that ran on the item-bias shadow of slk_bias_shadow_begin),
  * "prefetch_pending" (what the last slk_bilinear_prefetch left for the next training call: 0 nothing -- it was a no-op --,
  * 1 the first chunk, 2 the first chunk and the negatives of the whole call). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
@@ -244,6 +245,17 @@ int slk_bilinear_prefetch(slk_ctx *ctx, const slk_tables *tables, const slk_opti
                           const uint32_t *h_key, int32_t pos, void *stream);
 int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, int64_t n,
                          int64_t batch_size, int32_t loss, int32_t n_neg, void *stream);
+
+/* Item-bias shadow of a training scope (ABI 10).  The reference keeps the item biases as an nn.Embedding of dim 1
+ * (spotlight/factorization/representations.py:80-91) and Adagrad's `sum` for them as a second tensor: two 4-byte scalars in two
+ * arrays.  On a table of 10^8 rows every occurrence then costs the owner pass two cache-line reads and two sector writes for
+ * 8 bytes.  Between _begin and _end the engine trains on an interleaved copy {bias, sum} per item (8 bytes per row in the ctx;
+ * one line per occurrence) -- tables->d_param[3] and optim->d_state1[3] are STALE meanwhile and rewritten by _end; every
+ * slk_bilinear_train / _train_explicit call with these very pointers takes the launch path and uses the copy.  Row-sparse
+ * Adagrad over a plain item table only (SLK_EINVAL otherwise).  Same arithmetic: tables bit-identical to training without it.
+ * What this package's fit() does for item tables of >= 2^24 rows. */
+int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
+int slk_bias_shadow_end(slk_ctx *ctx, void *stream);
 
 /* ImplicitFactorizationModel.predict (factorization/implicit.py:277-311 with
  * _components.py:8-25): d_out[k] = score(user_k, item_k); n_users == 1 broadcasts the user;

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 9
+SLK_ABI_VERSION = 10
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -53,6 +53,8 @@ _PROTOTYPES = {
     'slk_last_error': (C.c_char_p, [C.c_void_p]),
     'slk_ctx_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     'slk_ctx_get_option': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    'slk_bias_shadow_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p]),
+    'slk_bias_shadow_end': (C.c_int, [C.c_void_p, C.c_void_p]),
     'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -235,6 +237,24 @@ class Engine(object):
                     engine.set_option(k, v)
                 return False
         return _Scoped()
+
+    def bias_shadow(self, tables, optim, stream=0, enabled=True):
+        """include/spotlight_hip.h: slk_bias_shadow_begin / _end as a context manager -- the item biases and their Adagrad
+        accumulator interleaved for the duration of the block (the caller's tensors are stale inside it and rewritten on every
+        way out).  `enabled=False`: a no-op scope."""
+        engine = self
+
+        class _Shadow(object):
+            def __enter__(self_):
+                if enabled:
+                    engine._check(engine._lib.slk_bias_shadow_begin(engine._ctx, C.byref(tables), C.byref(optim), C.c_void_p(stream)))
+                return engine
+
+            def __exit__(self_, *exc):
+                if enabled:
+                    engine._check(engine._lib.slk_bias_shadow_end(engine._ctx, C.c_void_p(stream)))
+                return False
+        return _Shadow()
 
     def get_stat(self, name):
         """include/spotlight_hip.h: slk_ctx_get_stat (diagnostics of the last calls)."""

@@ -164,7 +164,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->mt_tmp};
+                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->mt_tmp, &ctx->bias_shadow};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -269,6 +269,7 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "item_long_launches")) *value = ctx->stat_item_long;
     else if (!strcmp(name, "overlapped_chunks")) *value = ctx->stat_overlapped;
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
+    else if (!strcmp(name, "shadowed_calls")) *value = ctx->stat_shadowed;
     else if (!strcmp(name, "lds_per_block")) *value = (int64_t)ctx->lds_per_block;
     else if (!strcmp(name, "lds_per_cu")) *value = (int64_t)ctx->lds_per_cu;
     else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     vi = on ? slk_vload<VEC>(a.P[1] + (size_t)ip * D + d0) : slk_vzero<VEC>();
                     vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
                 }
-                const float bip = a.P[3][ip], bin = a.P[3][in];  // issued with the rows, not behind the dots' shuffles
+                const float bip = a.P[3][SLK_B3(a, ip)], bin = a.P[3][SLK_B3(a, in)];  // issued with the rows, not behind the dots' shuffles
                 const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bip;
                 const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bin;
                 float l, gp, gn;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             } else if (EXPL) {
                 // explicit feedback (one pair per interaction): score, loss and dL/dscore formed here
                 const uint32_t it = e_item;
-                const float bi = a.P[3][it];  // issued with the row, not after the dot's shuffles
+                const float bi = a.P[3][SLK_B3(a, it)];  // issued with the row, not after the dot's shuffles
                 slk_vec<VEC> v;
                 if (BLOOM)
                     v = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_score_pass(slk_pass_args a) {
                 if (s0 + j < a.NP) {
                     const uint32_t it = a.uit[qb + s0 + j];
                     v[j] = slk_emb_vec<VEC>(a.P[1], a.ib, it, D, d0, on);
-                    bi[j] = a.P[3][it];
+                    bi[j] = a.P[3][SLK_B3(a, it)];
                 }
             }
 #pragma unroll
@@ -718,11 +718,14 @@ static pass_fn user_pass_fn(int upd, int umode, bool bloom) {
 }
 
 
-int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g) {
+int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g, bool shadow_ok) {
     if (!t) return slk_fail(ctx, SLK_EINVAL, "tables is NULL");
     for (int i = 0; i < 4; ++i)
         if (((table_mask >> i) & 1u) && !t->d_param[i])
             return slk_fail(ctx, SLK_EINVAL, "tables->d_param[%d] is NULL", i);
+    if (!shadow_ok && (table_mask & 8u) && ctx->shadow_active && t->d_param[3] == ctx->shadow_src_p)
+        return slk_fail(ctx, SLK_EINVAL, "the item biases of these tables are shadowed (slk_bias_shadow_begin): the array is stale until "
+                                         "slk_bias_shadow_end, and only slk_bilinear_train indexes the shadow");
     if (((table_mask & 5u) && (t->num_users < 1 || t->num_users >= ((int64_t)1 << 31))) || t->num_items < 1 ||
         t->num_items >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "table rows must be in [1, 2^31): users %lld items %lld",
@@ -928,7 +931,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                const float *d_ratings, bool prefetch_only) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (n < 0 || batch_size < 1) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: n %lld batch_size %lld",
                                                  (long long)n, (long long)batch_size);
@@ -1060,7 +1063,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     const int RSU = D + 4;  // user-bloom gradient record (+ an unused bias slot)
     if (Hu && (rc = slk_ensure(ctx, ctx->extra[BL_UREC], (size_t)bsz * RSU * 4))) return rc;
     // minibatches of a few thousand interactions: every minibatch of a chunk inside ONE persistent launch (slk_epoch.hip)
-    bool epoch_route = (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    // the item-bias shadow of a training scope (slk_bias_shadow_begin): the launch path's kernels index it, the persistent
+    // kernel does not -- a call whose biases are shadowed takes the launches
+    const bool shadowed = ctx->shadow_active && ctx->shadow_src_p == tables->d_param[3] && !dense &&
+                          optim->kind == SLK_OPT_ADAGRAD && ctx->shadow_src_s == optim->d_state1[3];
+    if (ctx->shadow_active && !shadowed && ctx->shadow_src_p == tables->d_param[3])
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: the item biases are shadowed (slk_bias_shadow_begin) for another optimizer state");
+    if (shadowed && !prefetch_only && !reserve_only) ++ctx->stat_shadowed;
+    bool epoch_route = !shadowed && (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
     auto ensure_dense_buffers = [&]() -> int {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
@@ -1290,6 +1300,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 a.P[t] = tables->d_param[t];
                 a.S1[t] = dense ? (float *)ctx->dgrad[t].p : optim->d_state1[t];
                 a.S2[t] = optim->d_state2[t];
+            }
+            if (shadowed) {
+                a.P[3] = (float *)ctx->bias_shadow.p;
+                a.S1[3] = (float *)ctx->bias_shadow.p + 1;
+                a.bsh3 = 1u;
             }
             a.D = D;
             a.NP = NP;
@@ -1602,5 +1617,60 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     }
     ctx->last_pipe_set = set ^ 1;  // (the loop's last increment undone: the set of the last chunk)
     ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream
+    return SLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Item-bias shadow (round 5).  On tables of 10^8 rows a minibatch's item biases share no cache line: the owner pass pays a
+// 128-byte read and a 64-byte write for the 4-byte bias AND again for its 4-byte Adagrad accumulator -- a quarter of the C5
+// shard's item-pass requests (profiles/r04_ea_c5_pmc.md).  For the duration of a training scope (a fit(): thousands of
+// minibatches) the two arrays are held interleaved, {bias, sum} per item, so an occurrence touches ONE line; torch's own
+// tensors are stale inside the scope and rewritten by slk_bias_shadow_end.  The reference has no counterpart (its biases are
+// an nn.Embedding of dim 1: spotlight/factorization/representations.py:80-91).
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bias_shadow_pack(const float *p, const float *s1, float2 *sh, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) sh[i] = make_float2(p[i], s1[i]);
+}
+
+__global__ __launch_bounds__(256) void k_bias_shadow_unpack(const float2 *sh, float *p, float *s1, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float2 v = sh[i];
+        p[i] = v.x;
+        s1[i] = v.y;
+    }
+}
+
+SLK_EXPORT int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream) {
+    if (!ctx || !tables || !optim) return SLK_EINVAL;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->shadow_active) return slk_fail(ctx, SLK_EINVAL, "slk_bias_shadow_begin: a shadow is already active on this ctx");
+    if (optim->kind != SLK_OPT_ADAGRAD || !tables->d_param[3] || !optim->d_state1[3] || tables->item_bloom || tables->num_items < 1)
+        return slk_fail(ctx, SLK_EINVAL, "slk_bias_shadow_begin: row-sparse Adagrad over a plain item table only");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = slk_ensure(ctx, ctx->bias_shadow, (size_t)tables->num_items * 8))) return rc;
+    hipLaunchKernelGGL(k_bias_shadow_pack, dim3(slk_grid_for(ctx, (size_t)tables->num_items, 256)), dim3(256), 0, s,
+                       (const float *)tables->d_param[3], (const float *)optim->d_state1[3], (float2 *)ctx->bias_shadow.p,
+                       (size_t)tables->num_items);
+    SLK_LAUNCH_CHECK(ctx, "k_bias_shadow_pack");
+    ctx->shadow_src_p = tables->d_param[3];
+    ctx->shadow_src_s = optim->d_state1[3];
+    ctx->shadow_rows = tables->num_items;
+    ctx->shadow_active = true;
+    ctx->last_stream = s;
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_bias_shadow_end(slk_ctx *ctx, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->shadow_active) return SLK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bias_shadow_unpack, dim3(slk_grid_for(ctx, (size_t)ctx->shadow_rows, 256)), dim3(256), 0, s,
+                       (const float2 *)ctx->bias_shadow.p, ctx->shadow_src_p, ctx->shadow_src_s, (size_t)ctx->shadow_rows);
+    SLK_LAUNCH_CHECK(ctx, "k_bias_shadow_unpack");
+    ctx->shadow_active = false;
+    ctx->shadow_src_p = ctx->shadow_src_s = nullptr;
+    ctx->last_stream = s;
     return SLK_OK;
 }

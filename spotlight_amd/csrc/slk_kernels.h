@@ -129,6 +129,8 @@ struct slk_pass_args {
     int UPS;
     uint32_t upart_gen;
     uint32_t *upart_count;
+    uint32_t bsh3;           // item-bias index shift: 0 = plain arrays; 1 = the interleaved shadow {bias, Adagrad sum} of a
+                             // training scope (slk_bias_shadow_begin): P[3] = shadow, S1[3] = shadow + 1, element i at 2 i
     uint32_t pad_item;       // occurrences of this item row are never updated (padding_idx); ~0u = none
     uint32_t pad_item2;      // a second never-updated key (sentinel of non-head positions); ~0u = none
     slk_bloom_dev ub, ib;    // BloomEmbedding user / item layers (n_hash == 0: plain)
@@ -176,6 +178,9 @@ __device__ __forceinline__ size_t slk_blk_row(uint32_t slot, int D) {
 __device__ __forceinline__ size_t slk_blk_scalar(uint32_t slot, int D) {
     return (size_t)(slot >> 6) * (size_t)(SLK_SHARD_BLOCK * (D + 1)) + (size_t)SLK_SHARD_BLOCK * (size_t)D + (slot & 63u);
 }
+
+// index of item i's bias (and of its optimizer state) in P[3] / S1[3] / S2[3]
+#define SLK_B3(a_, i_) ((size_t)(i_) << (a_).bsh3)
 
 // Row update for the elements one lane owns.  GRAD_ONLY stores the summed gradient into the
 // dense gradient buffer (aliased on S1) for the full-table sweep.
@@ -423,11 +428,11 @@ __device__ __forceinline__ void slk_item_apply(const slk_pass_args &a, uint32_t 
             bpv.v[0] = bp;
             bsv.v[0] = bs;
         } else {
-            bpv.v[0] = a.P[3][item];
-            bsv.v[0] = SLK_UPD_HAS_STATE(UPD) ? a.S1[3][item] : 0.0f;
+            bpv.v[0] = a.P[3][SLK_B3(a, item)];
+            bsv.v[0] = SLK_UPD_HAS_STATE(UPD) ? a.S1[3][SLK_B3(a, item)] : 0.0f;
         }
         gbv.v[0] = gb;
-        slk_apply_vec_pre<1, UPD>(a, 3, item, bpv, bsv, gbv);
+        slk_apply_vec_pre<1, UPD>(a, 3, SLK_B3(a, item), bpv, bsv, gbv);
     }
 }
 
@@ -587,8 +592,8 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                     if (SLK_UPD_HAS_STATE(UPD)) sv[h] = slk_vload_if_nt<VEC>(a.S1[1] + voff, nt_rows);
                 }
                 if (PART != SLK_PART_ROWS && UPD != SLK_UPD_GRAD_ONLY) {
-                    pb[h] = a.P[3][item];
-                    if (SLK_UPD_HAS_STATE(UPD)) sb[h] = a.S1[3][item];
+                    pb[h] = a.P[3][SLK_B3(a, item)];
+                    if (SLK_UPD_HAS_STATE(UPD)) sb[h] = a.S1[3][SLK_B3(a, item)];
                 }
             }
         }

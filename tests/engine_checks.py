@@ -1337,6 +1337,47 @@ def check_item_long_gate_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=41, o
         assert np.array_equal(a, b), ('tensor %d differs between the gated and the ungated passes' % k)
 
 
+def check_bias_shadow_is_bit_neutral(be, loss, D, U, I, N, B, nn=1, seed=43, options=None):
+    """Training inside a bias-shadow scope (slk_bias_shadow_begin / _end: item biases and their Adagrad accumulator interleaved
+    in the ctx for the duration) against plain training: losses, every table and state tensor bit for bit, and inside the scope
+    the caller's bias tensors are not what is trained on (the scope's end rewrites them).  Two training calls per scope."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    results = []
+    saved = {k: eng.get_option(k) for k in (options or {})}
+    for shadow in (False, True):
+        for k, v in (options or {}).items():
+            eng.set_option(k, v)
+        try:
+            dev = be.model(params, opt='adagrad', lr=0.05)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            mb_loss = be.alloc(np.zeros(2 * n_mb, dtype=np.float32))
+            with eng.bias_shadow(dev.tables, dev.optim, stream=be.stream, enabled=shadow):
+                for rep in range(2):
+                    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
+                                       be.ptr(mb_loss) + 4 * rep * n_mb, stream=be.stream)
+                if shadow:  # the caller's bias tensor is stale inside the scope: still the initial values
+                    assert np.array_equal(be.get(dev.p[3]).ravel(), params[3].astype(np.float32).ravel())
+            results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+        finally:
+            for k, v in saved.items():
+                eng.set_option(k, v)
+    for k, (a, b) in enumerate(zip(*results)):
+        if k == 0 and B <= 1024:  # the plain run of a small minibatch takes the persistent kernel, the shadowed one the launches:
+            # the same tables bit for bit, the fp32 loss sums associate differently
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (a, b)
+            continue
+        assert np.array_equal(a, b), ('tensor %d differs between shadowed and plain item biases' % k)
+    assert not np.array_equal(results[0][4].ravel(), params[3].astype(np.float32).ravel())  # (the biases did train)
+
+
 # ---------------------------------------------------------------------------------------
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------
@@ -1507,3 +1548,27 @@ def check_fused_ranks(be, D=24, U=90, I=333, n_rows=150, seed=5, ties=True):
         s = ((f32_chain_dot(params[0][u][None, :], V) + params[2][u]) + bi).astype(np.float32)
         t = s[row_target[r]]
         assert got[r] == float((s > t).sum()) + (float((s == t).sum()) + 1.0) * 0.5
+
+
+def check_bias_shadow_refusals(be):
+    """slk_bias_shadow_begin covers the fused row-sparse Adagrad, one scope per ctx; a call that would read the stale bias array
+    inside the scope is refused."""
+    import pytest
+    from spotlight_amd import _native
+    rs = np.random.RandomState(3)
+    params = [rs.normal(0, 0.1, (30, 8)), rs.normal(0, 0.1, (20, 8)), np.zeros(30), np.zeros(20)]
+    dev = be.model(params, opt='sparse_adam', lr=0.05)
+    with pytest.raises(_native.SlkError):
+        with be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream):
+            pass
+    dev = be.model(params, opt='adagrad', lr=0.05)
+    with be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream):
+        with pytest.raises(_native.SlkError):  # one scope per ctx
+            with be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream):
+                pass
+        # the caller's bias array is stale inside the scope: a call that would read it is refused, not answered
+        out, d_u = be.alloc(np.empty(20, dtype=np.float32)), be.alloc(np.array([3], dtype=np.int64))
+        with pytest.raises(_native.SlkError, match='shadowed'):
+            be.engine.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, 20, be.ptr(out), be.stream)
+    be.engine.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, 20, be.ptr(out), be.stream)  # (and answered again outside it)
+    assert np.isfinite(be.get(out)).all()

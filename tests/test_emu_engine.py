@@ -33,6 +33,19 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 128 * 2 + 5,))
 
 
+@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('hinge', 1), ('pointwise', 1), ('adaptive_hinge', 4)])
+def test_bias_shadow_is_bit_neutral(be, loss, nn):
+    # plain passes; items hot enough for the long-run form + stitch; the latency-bound user pass and the every-head-early item pass
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 16, U=400, I=300, N=3000, B=512, nn=nn)
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 8, U=50, I=6, N=4000, B=2048, nn=nn, seed=47)
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 16, U=400, I=300, N=3000, B=512, nn=nn, seed=48,
+                                        options={'user_lat_max_batch': 0, 'item_lat_max_tiles': 0, 'item_long_gate': 0})
+
+
+def test_bias_shadow_refuses_what_it_does_not_cover(be):
+    ec.check_bias_shadow_refusals(be)
+
+
 def test_sampler_long_streams(be):
     # the second stream length class (256 state blocks per stream: the jump table of stride 256), forced at a small size; a
     # draw of several groups (the group's last block is the next one's key) by lowering the class's switch below one stream

@@ -33,6 +33,17 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 1682, counts=(5000000,))
 
 
+@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('pointwise', 1), ('adaptive_hinge', 5)])
+def test_bias_shadow_is_bit_neutral(be, loss, nn):
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 64, U=200000, I=100000, N=300000, B=65536, nn=nn)
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 32, U=943, I=1682, N=20000, B=4096, nn=nn, seed=47)
+    ec.check_bias_shadow_is_bit_neutral(be, loss, 64, U=5000, I=40, N=200000, B=1 << 17, nn=nn, seed=48)  # hot items: long runs + stitch
+
+
+def test_bias_shadow_refuses_what_it_does_not_cover(be):
+    ec.check_bias_shadow_refusals(be)
+
+
 def test_sampler_long_streams(be):
     # draws of more than 16384 state blocks take 256 blocks per stream (the stride-256 jump table): 12 M and 45 M words (the
     # latter also crosses that class's 40.9 M-word group limit); the class forced at a small size

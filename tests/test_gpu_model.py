@@ -283,6 +283,16 @@ def test_prefetched_first_chunk_is_value_neutral_on_gpu():
     check_prefetched_first_chunk_is_value_neutral(engine, use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
 
 
+def test_bias_shadowed_fit_is_value_neutral_on_gpu():
+    """fit() on the item-bias shadow (large item tables; forced here) against the plain layout: tables, accumulators and
+    RandomState bit for bit."""
+    import torch
+    from spotlight_amd.factorization import implicit as host
+    from test_host_model import check_bias_shadowed_fit_is_value_neutral
+    engine = host._engine_for(torch.device('cuda', 0))
+    check_bias_shadowed_fit_is_value_neutral(engine, use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
+
+
 def test_pipelined_seq_fit_is_value_neutral_on_gpu():
     from test_host_seq_model import check_pipelined_seq_fit_is_value_neutral
     check_pipelined_seq_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())

@@ -323,6 +323,44 @@ def test_prefetched_first_chunk_is_value_neutral(emu_device):
     check_prefetched_first_chunk_is_value_neutral(emu_device)
 
 
+def check_bias_shadowed_fit_is_value_neutral(engine, use_cuda=False, to_numpy=lambda w: w.detach().numpy()):
+    """Large item tables train with {item bias, its Adagrad accumulator} interleaved for the duration of fit()
+    (slk_bias_shadow_begin; host: _BIAS_SHADOW_MIN_ITEMS).  Forced on a small table, against the plain layout: tables,
+    accumulators and RandomState bit for bit, over two fit() calls (the second starts from what the first wrote back) and with the
+    SparseAdam model on the side, whose optimizer the shadow does not cover and whose fit() therefore never opens one."""
+    rs = np.random.RandomState(13)
+    inter = Interactions(rs.randint(0, 90, 12000).astype(np.int32), rs.randint(0, 60, 12000).astype(np.int32), num_users=90, num_items=60)
+    results = []
+    old = host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        for floor in (1, 1 << 40):
+            host._BIAS_SHADOW_MIN_ITEMS = floor
+            before = engine.get_stat('shadowed_calls')
+            for loss, kw in (('bpr', dict(optimizer_func=_adagrad)), ('adaptive_hinge', dict(num_negative_samples=3, optimizer_func=_adagrad)),
+                             ('pointwise', dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=0.01)))):
+                model = ImplicitFactorizationModel(loss=loss, embedding_dim=16, n_iter=2, batch_size=4096, use_cuda=use_cuda,
+                                                   random_state=np.random.RandomState(7), **kw)
+                model.fit(inter)
+                model.fit(inter)
+                st = model._random_state.get_state()
+                opt_state = [to_numpy(v['sum']).copy() for v in model._optimizer.state.values() if 'sum' in v]
+                results.append([to_numpy(w).copy() for w in model._net.tables()] + opt_state + [st[1].copy(), np.array(st[2])])
+            # two Adagrad models x two fit() calls x two epochs (one training call each) ran on the shadow; nothing else did
+            assert engine.get_stat('shadowed_calls') - before == (2 * 2 * 2 if floor == 1 else 0)
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS = old
+    half = len(results) // 2
+    for a, b in zip(results[:half], results[half:]):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_bias_shadowed_fit_is_value_neutral(emu_device):
+    check_bias_shadowed_fit_is_value_neutral(emu_device)
+
+
 def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(emu_device):
     """n_iter = 0 is a no-op on both epoch loops (the large-epoch loop raised UnboundLocalError); a degenerate epoch
     leaves the RandomState behind that epoch's negatives -- not behind the shuffle already prepared for the next one."""
