@@ -622,26 +622,28 @@ class ImplicitFactorizationModel(object):
                     # the reference stops here having consumed the stream up to this epoch's negatives only
                     raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
         finally:
-            if shadowed:
-                shadow.__exit__(None, None, None)  # the trained biases and their accumulator back into torch's tensors
-            if job is not None:
-                try:
-                    job.join()
-                except BaseException:  # noqa: BLE001 -- the exception already on its way out wins
-                    pass
-            upload.result()  # (joins the upload thread on the exceptional paths too)
-            check.join()
-            self._random_state.set_state(consumed)
-            # a chunk prepared ahead for an epoch that will not run (an exception left the loop): its draws are dropped and the
-            # ctx's stream is put back where the reference's would be, so that the next training call on this engine -- any
-            # model's -- finds no stale prefetch (slk_bilinear_train would refuse it once)
-            if _PREFETCH and engine.get_stat('prefetch_pending'):
-                engine.rng_set_state(consumed)
-            # the epoch's device buffers go back to the caching allocator NOW (closures above hold cells, not tensors, once
-            # these names are cleared): the next fit() reuses them instead of allocating
-            del bufs[:]
-            d_perm = d_pairs = unpacked = None
-            upload._out = None
+            try:
+                if shadowed:
+                    shadow.__exit__(None, None, None)  # the trained biases and their accumulator back into torch's tensors
+            finally:  # (whatever the write-back raised, the threads are joined and the RandomState is the reference's)
+                if job is not None:
+                    try:
+                        job.join()
+                    except BaseException:  # noqa: BLE001 -- the exception already on its way out wins
+                        pass
+                upload.result()  # (joins the upload thread on the exceptional paths too)
+                check.join()
+                self._random_state.set_state(consumed)
+                # a chunk prepared ahead for an epoch that will not run (an exception left the loop): its draws are dropped and the
+                # ctx's stream is put back where the reference's would be, so that the next training call on this engine -- any
+                # model's -- finds no stale prefetch (slk_bilinear_train would refuse it once)
+                if _PREFETCH and engine.get_stat('prefetch_pending'):
+                    engine.rng_set_state(consumed)
+                # the epoch's device buffers go back to the caching allocator NOW (closures above hold cells, not tensors, once
+                # these names are cleared): the next fit() reuses them instead of allocating
+                del bufs[:]
+                d_perm = d_pairs = unpacked = None
+                upload._out = None
 
     def _fit_pipelined(self, binding, engine, device, stream, tables, d_users0, d_items0, n, nn, mb_loss, verbose):
         """The epoch loop for datasets of the reference's own scale (MovieLens-100K: 80 000 interactions per epoch): there an

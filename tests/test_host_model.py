@@ -441,6 +441,42 @@ def test_exception_inside_a_prefetching_fit_leaves_no_stale_prefetch(emu_device,
         emu_device.set_option('overlap_prep', 0)
 
 
+def test_exception_inside_a_shadowed_fit_writes_the_biases_back(emu_device, monkeypatch):
+    """A fit() that dies between two epochs while its item biases are shadowed (slk_bias_shadow_begin) leaves on its way out what
+    the plain layout leaves: the biases and their accumulator of the epochs that ran, no open scope on the shared engine."""
+    rs = np.random.RandomState(14)
+    inter = Interactions(rs.randint(0, 90, 12000).astype(np.int32), rs.randint(0, 60, 12000).astype(np.int32), num_users=90, num_items=60)
+    old = host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS
+    real_check = emu_device.check
+    left = []
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        for floor in (1, 1 << 40):
+            host._BIAS_SHADOW_MIN_ITEMS = floor
+            model = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=3, batch_size=4096, optimizer_func=_adagrad,
+                                               random_state=np.random.RandomState(7))
+            calls = []
+
+            def failing_check():
+                calls.append(1)
+                if len(calls) == 2:
+                    raise RuntimeError('injected: epoch 1 failed')
+                return real_check()
+            monkeypatch.setattr(emu_device, 'check', failing_check)
+            with pytest.raises(RuntimeError, match='injected'):
+                model.fit(inter)
+            monkeypatch.setattr(emu_device, 'check', real_check)
+            scores = model.predict(3)  # (refused with "shadowed" if the scope were still open)
+            acc = [v['sum'].numpy().copy() for v in model._optimizer.state.values() if 'sum' in v]
+            left.append([w.detach().numpy().copy() for w in model._net.tables()] + acc + [scores])
+            model.fit(inter)  # ... and the engine takes the next fit(), shadowed again or not
+        assert np.abs(left[0][3]).max() > 0  # the item biases did train
+        for x, y in zip(left[0], left[1]):
+            assert np.array_equal(x, y)
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS = old
+
+
 def test_id_checks_on_worker_threads_raise_like_the_serial_ones(emu_device):
     """Large fits run the id-range checks (implicit.py:169-182) on worker threads beside the upload and the first shuffle: the
     same exceptions in the same order, before anything is trained, RandomState and tables as they were."""
