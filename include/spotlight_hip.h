@@ -253,6 +253,10 @@ int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim
  * one line per occurrence) -- tables->d_param[3] and optim->d_state1[3] are STALE meanwhile and rewritten by _end; every
  * slk_bilinear_train / _train_explicit call with these very pointers takes the launch path and uses the copy.  Row-sparse
  * Adagrad over a plain item table only (SLK_EINVAL otherwise).  Same arithmetic: tables bit-identical to training without it.
+ * Every other call that names the shadowed bias array (predict, scores, ranks, the row-sharded and PoolNet calls) is refused with
+ * SLK_EINVAL until _end.  _begin, the training calls and _end are ordered by the caller: the same stream, or events between
+ * them.  One scope per ctx; the copy's storage stays with the ctx for the next scope (slk_ctx_destroy frees it; an open scope is
+ * NOT written back by it).  _end without an open scope is a no-op.
  * What this package's fit() does for item tables of >= 2^24 rows. */
 int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
 int slk_bias_shadow_end(slk_ctx *ctx, void *stream);

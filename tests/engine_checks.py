@@ -1358,9 +1358,14 @@ def check_bias_shadow_is_bit_neutral(be, loss, D, U, I, N, B, nn=1, seed=43, opt
             dev = be.model(params, opt='adagrad', lr=0.05)
             eng.rng_set_state(state)
             d_users, d_items = be.alloc(users), be.alloc(items)
+            d_ratings = be.alloc(_ratings_for(np.random.RandomState(seed + 2), loss, N)) if loss in EXPLICIT_LOSSES else None
             mb_loss = be.alloc(np.zeros(2 * n_mb, dtype=np.float32))
             with eng.bias_shadow(dev.tables, dev.optim, stream=be.stream, enabled=shadow):
                 for rep in range(2):
+                    if d_ratings is not None:  # explicit feedback: the same two passes, one pair per interaction
+                        eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_ratings), N, B,
+                                                    loss, be.ptr(mb_loss) + 4 * rep * n_mb, stream=be.stream)
+                        continue
                     eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn,
                                        be.ptr(mb_loss) + 4 * rep * n_mb, stream=be.stream)
                 if shadow:  # the caller's bias tensor is stale inside the scope: still the initial values

@@ -33,7 +33,7 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 2 ** 32, counts=(624 * 128 * 2 + 5,))
 
 
-@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('hinge', 1), ('pointwise', 1), ('adaptive_hinge', 4)])
+@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('hinge', 1), ('pointwise', 1), ('adaptive_hinge', 4), ('regression', 1), ('logistic', 1)])
 def test_bias_shadow_is_bit_neutral(be, loss, nn):
     # plain passes; items hot enough for the long-run form + stitch; the latency-bound user pass and the every-head-early item pass
     ec.check_bias_shadow_is_bit_neutral(be, loss, 16, U=400, I=300, N=3000, B=512, nn=nn)

@@ -33,7 +33,7 @@ def test_sampler_parallel_jump_ahead(be):
     ec.check_sampler_bit_exact(be, 1682, counts=(5000000,))
 
 
-@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('pointwise', 1), ('adaptive_hinge', 5)])
+@pytest.mark.parametrize('loss,nn', [('bpr', 1), ('pointwise', 1), ('adaptive_hinge', 5), ('poisson', 1)])
 def test_bias_shadow_is_bit_neutral(be, loss, nn):
     ec.check_bias_shadow_is_bit_neutral(be, loss, 64, U=200000, I=100000, N=300000, B=65536, nn=nn)
     ec.check_bias_shadow_is_bit_neutral(be, loss, 32, U=943, I=1682, N=20000, B=4096, nn=nn, seed=47)
