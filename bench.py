@@ -91,6 +91,8 @@ def parse():
                     help='item tables of 2^24 rows and more: keep the item biases and their Adagrad accumulator in two arrays '
                          '(default: interleaved for the run, as fit() trains such tables -- slk_bias_shadow_begin, opened before '
                          'the warm-up and closed after the last timed call)')
+    ap.add_argument('--bias-shadow-min-items', type=int, default=1 << 24,
+                    help='item rows per GPU from which the run trains on the bias shadow (tests force it at small sizes)')
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-configs', action='store_true',
@@ -184,8 +186,10 @@ def main():
     xgmi_rows = [0]
     # fit() trains item tables this large with {bias, Adagrad accumulator} interleaved (factorization/implicit.py:
     # _BIAS_SHADOW_MIN_ITEMS); the scope opens here, outside every timed region, and closes after the last one
-    bias_shadowed = (trainer is None and args.opt == 'adagrad' and I >= (1 << 24) and B >= 4096 and not args.no_bias_shadow)
-    shadow_scope = eng.bias_shadow(tb, op, stream=stream, enabled=bias_shadowed)
+    bias_shadowed = (args.opt == 'adagrad' and I >= args.bias_shadow_min_items and (B >= 4096 or trainer is not None)
+                     and not args.no_bias_shadow)
+    shadow_scope = (eng.bias_shadow(tb, op, stream=stream, enabled=bias_shadowed) if trainer is None else
+                    trainer.bias_shadow(enabled=bias_shadowed))  # (row-sharded: the owner-side gather and item pass index it)
     shadow_scope.__enter__()
 
     def run(first_mb, n_mb):

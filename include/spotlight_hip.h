@@ -251,9 +251,11 @@ int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim
  * arrays.  On a table of 10^8 rows every occurrence then costs the owner pass two cache-line reads and two sector writes for
  * 8 bytes.  Between _begin and _end the engine trains on an interleaved copy {bias, sum} per item (8 bytes per row in the ctx;
  * one line per occurrence) -- tables->d_param[3] and optim->d_state1[3] are STALE meanwhile and rewritten by _end; every
- * slk_bilinear_train / _train_explicit call with these very pointers takes the launch path and uses the copy.  Row-sparse
+ * slk_bilinear_train / _train_explicit call with these very pointers takes the launch path and uses the copy, and so do the
+ * row-sharded calls on a rank's local tables (slk_shard_gather reads the biases it sends from the copy, slk_shard_item_pass
+ * updates it; the other slk_shard_* calls do not touch item biases).  Row-sparse
  * Adagrad over a plain item table only (SLK_EINVAL otherwise).  Same arithmetic: tables bit-identical to training without it.
- * Every other call that names the shadowed bias array (predict, scores, ranks, the row-sharded and PoolNet calls) is refused with
+ * Every other call that names the shadowed bias array (predict, scores, ranks, the PoolNet calls) is refused with
  * SLK_EINVAL until _end.  _begin, the training calls and _end are ordered by the caller: the same stream, or events between
  * them.  One scope per ctx; the copy's storage stays with the ctx for the next scope (slk_ctx_destroy frees it; an open scope is
  * NOT written back by it).  _end without an open scope is a no-op.

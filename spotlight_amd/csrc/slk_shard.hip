@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_shard_regroup(const int32_t *recv_ids, 
 
 // owner side: slot(j) of the unit's row buffer = V[id_j] (D), bias[id_j]
 template <int VEC, int G>
-__global__ __launch_bounds__(256) void k_shard_gather(const float *V, const float *bi, int D, const int32_t *ids,
+__global__ __launch_bounds__(256) void k_shard_gather(const float *V, const float *bi, uint32_t bsh, int D, const int32_t *ids,
                                                       const uint32_t *gslot, int64_t n, float *out) {
     constexpr int GPB = 256 / G;
     const int lane = threadIdx.x % G;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_shard_gather(const float *V, const floa
         const int64_t i = (int64_t)ids[j];
         const uint32_t slot = gslot[j];
         if (on) slk_vstore<VEC>(out + slk_blk_row(slot, D) + d0, slk_vload<VEC>(V + (size_t)i * D + d0));
-        if (lane == 0) out[slk_blk_scalar(slot, D)] = bi[i];
+        if (lane == 0) out[slk_blk_scalar(slot, D)] = bi[(size_t)i << bsh];  // (bsh = 1: the {bias, accumulator} shadow of a training scope)
     }
 }
 
@@ -368,7 +368,7 @@ static int check_chunk(slk_ctx *ctx, const slk_shard *sh, int32_t M, int32_t S) 
 SLK_EXPORT int slk_shard_reserve(slk_ctx *ctx, const slk_tables *local, const slk_shard *sh, int64_t n, int64_t n_recv) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
     if (n < 0 || n >= ((int64_t)1 << 30) || n_recv < 0 || n_recv >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "slk_shard_reserve: n %lld / n_recv %lld out of range", (long long)n, (long long)n_recv);
@@ -438,7 +438,7 @@ static int shard_chunk_begin_impl(slk_ctx *ctx, const slk_tables *local, const s
     const uint32_t NP = (uint32_t)nng + 1u;
     if (n * (int64_t)NP >= ((int64_t)1 << 31)) return slk_fail(ctx, SLK_EINVAL, "shard chunk: %lld lookups >= 2^31", (long long)(n * NP));
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
     if ((rc = check_chunk(ctx, sh, M, S))) return rc;
@@ -560,7 +560,7 @@ SLK_EXPORT int slk_shard_chunk_commit(slk_ctx *ctx, const slk_tables *local, con
                                       const int32_t *d_recv_ids, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
     if (ctx->sh_M < 1 || ctx->sh_world != sh->world) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: no chunk begun for this world size");
     if (!h_send_counts || !h_recv_counts) return slk_fail(ctx, SLK_EINVAL, "slk_shard_chunk_commit: NULL count matrix");
@@ -664,7 +664,7 @@ SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, int32_t u
                                 void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = check_unit(ctx, unit, "slk_shard_gather"))) return rc;
     const int64_t r0 = ctx->sh_rstart[unit], n_ids = ctx->sh_rstart[unit + 1] - r0;
@@ -674,10 +674,14 @@ SLK_EXPORT int slk_shard_gather(slk_ctx *ctx, const slk_tables *local, int32_t u
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
     const int32_t *d_ids = (const int32_t *)ctx->extra[SH_RID].p + r0;
+    // inside a slk_bias_shadow_begin scope the trained item biases live in the ctx's interleaved copy
+    const bool shadowed = ctx->shadow_active && ctx->shadow_src_p == local->d_param[3];
+    const float *bias = shadowed ? (const float *)ctx->bias_shadow.p : (const float *)local->d_param[3];
+    const uint32_t bsh = shadowed ? 1u : 0u;
     slk_prof_begin(ctx, SLK_K_EXCHANGE, s);
 #define SLK_GATHER(V_, G_)                                                                                  \
     hipLaunchKernelGGL((k_shard_gather<V_, G_>), dim3(slk_grid_for(ctx, (size_t)n_ids, 256 / G_)), dim3(256), 0, s, \
-                       (const float *)local->d_param[1], (const float *)local->d_param[3], (int)local->dim,  \
+                       (const float *)local->d_param[1], bias, bsh, (int)local->dim,                         \
                        d_ids, (const uint32_t *)ctx->extra[SH_GSLOT].p + r0, n_ids, d_rows_out)
     SLK_FOR_LAYOUT(vec, g, SLK_GATHER);
 #undef SLK_GATHER
@@ -714,7 +718,7 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
                                    void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if ((rc = check_shard(ctx, sh))) return rc;
@@ -801,7 +805,7 @@ SLK_EXPORT int slk_shard_score_pass(slk_ctx *ctx, const slk_tables *local, int32
                                     float *d_scores, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = check_adaptive_unit(ctx, unit, "slk_shard_score_pass"))) return rc;
     const int64_t n = ctx->sh_ustart[unit + 1] - ctx->sh_ustart[unit];
@@ -857,7 +861,7 @@ SLK_EXPORT int slk_shard_user_pass_adaptive(slk_ctx *ctx, const slk_tables *loca
                                             const float *d_gk, const float *d_rows_in, float *d_grad_out, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if ((rc = check_adaptive_unit(ctx, unit, "slk_shard_user_pass_adaptive"))) return rc;
@@ -896,7 +900,7 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
                                    const float *d_grad_in, void *stream) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g))) return rc;
+    if ((rc = slk_check_tables(ctx, local, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
     if ((rc = check_plain(ctx, local))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (ctx->shard_n < 0 || minibatch < 0 || minibatch >= ctx->sh_M)
@@ -908,16 +912,25 @@ SLK_EXPORT int slk_shard_item_pass(slk_ctx *ctx, const slk_tables *local, slk_op
     hipStream_t s = (hipStream_t)stream;
     ctx->last_stream = s;
     const bool dense = optim->kind == SLK_OPT_ADAM_DENSE || optim->kind == SLK_OPT_ADAGRAD_DENSE;
+    const bool shadowed = ctx->shadow_active && ctx->shadow_src_p == local->d_param[3];
+    if (shadowed && (optim->kind != SLK_OPT_ADAGRAD || optim->d_state1[3] != ctx->shadow_src_s))
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_item_pass: the item biases are shadowed (slk_bias_shadow_begin) for another optimizer state");
     if (dense) {
         const size_t elems[4] = {(size_t)local->num_users * local->dim, (size_t)local->num_items * local->dim,
                                  (size_t)local->num_users, (size_t)local->num_items};
         if ((rc = slk_ensure_dgrad(ctx, elems, 15u, s))) return rc;
     }
+    if (shadowed) ++ctx->stat_shadowed;
     if (nr > 0) {
         const unsigned ibits = slk_bits_for((uint64_t)local->num_items - 1);
         slk_pass_args a;
         memset(&a, 0, sizeof(a));
         fill_tables(a, ctx, local, optim, dense);
+        if (shadowed) {  // {bias, Adagrad accumulator} interleaved: slk_bilinear.hip, slk_bias_shadow_begin
+            a.P[3] = (float *)ctx->bias_shadow.p;
+            a.S1[3] = (float *)ctx->bias_shadow.p + 1;
+            a.bsh3 = 1;
+        }
         a.snap = const_cast<float *>(d_grad_in);  // slots inside this minibatch's gradient buffer
         a.begin = 0;
         a.ibegin = (uint32_t)r0;

@@ -86,6 +86,12 @@ class ShardedBilinearTrainer(object):
                                    '(torch.cuda.set_stream / with torch.cuda.stream(...)) so that the RCCL collectives are ordered '
                                    'with the engine\'s kernels' % (int(self.stream or 0), self.device, int(current or 0)))
 
+    def bias_shadow(self, enabled=True):
+        """Scope in which this rank's item biases and their Adagrad accumulator are trained interleaved (include/spotlight_hip.h:
+        slk_bias_shadow_begin; the owner-side gather and the item pass index the copy).  The two tensors are stale inside it and
+        rewritten on every way out; fused row-sparse Adagrad only."""
+        return self.engine.bias_shadow(self._tables, self.optim, stream=self.stream, enabled=enabled)
+
     def max_minibatches_per_chunk(self):
         """Bound of one slk_shard_chunk_begin: (owner, unit) bins <= 2048 and 32-bit sort keys."""
         s, w = self.slices, self.world
@@ -379,6 +385,16 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
         d_items0 = _host.ids_to_device(item_ids, device)
         d_users, d_items = torch.empty_like(d_users0), torch.empty_like(d_items0)
         d_perm = torch.empty(n, dtype=torch.int64, device=device)
+        # large local item shards train with {bias, Adagrad accumulator} interleaved for the duration of fit(), as the one-GPU
+        # model does (factorization/implicit.py: _BIAS_SHADOW_MIN_ITEMS); the scope's end -- also on an exception -- writes both back
+        shadow = engine.bias_shadow(_native.make_tables([t.data_ptr() for t in tables], tables[0].shape[0], tables[1].shape[0],
+                                                        tables[0].shape[1]), binding.as_struct(), stream=stream,
+                                    enabled=binding.kind == 'adagrad' and tables[1].shape[0] >= _host._BIAS_SHADOW_MIN_ITEMS)
+        with shadow:
+            self._fit_epochs(binding, engine, tables, device, stream, d_users0, d_items0, d_users, d_items, d_perm, n, n_mb, verbose)
+
+    def _fit_epochs(self, binding, engine, tables, device, stream, d_users0, d_items0, d_users, d_items, d_perm, n, n_mb, verbose):
+        world, rank, B = self._world, self._rank, self._batch_size
         for epoch_num in range(self._n_iter):
             # every rank computes the same numpy-exact permutation and negatives on its own GPU
             engine.rng_set_state(self._random_state.get_state())

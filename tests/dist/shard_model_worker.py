@@ -47,8 +47,17 @@ def main():
     kw = dict(loss=loss, embedding_dim=D, n_iter=2, batch_size=B, l2=1e-6, optimizer_func=of,
               sparse=(opt == 'sparse_adam'))
     model = ShardedImplicitFactorizationModel(random_state=np.random.RandomState(42), **kw)
+    floor = os.environ.get('SHARD_TEST_SHADOW_FLOOR')  # local item shards of at least this many rows train bias-shadowed
+    if floor:
+        host._BIAS_SHADOW_MIN_ITEMS = int(floor)
+    calls0 = host._engine_for(torch.device('cpu') if backend == 'emu' else torch.device('cuda', rank)).get_stat('shadowed_calls')
     model.fit(inter)
     model.fit(inter)  # resume
+    if floor:
+        eng_ = host._engine_for(torch.device('cpu') if backend == 'emu' else torch.device('cuda', rank))
+        n_mb = (N + B - 1) // B
+        assert eng_.get_stat('shadowed_calls') - calls0 == (2 * 2 * n_mb if opt == 'adagrad' else 0)  # every item pass of both fits
+        host._BIAS_SHADOW_MIN_ITEMS = 1 << 40  # (the one-GPU model below trains plain)
     pred_all = model.predict(5)
     pu, pi = np.arange(0, 20, dtype=np.int64), (np.arange(0, 20, dtype=np.int64) * 7 + 1) % I
     pred_pairs = model.predict(pu, pi)

@@ -78,6 +78,11 @@ def main():
     trainer = ShardedBilinearTrainer(eng, loc, optim, I, stream=stream, slices=slices)
     if sample_on_device or train_mode:
         eng.rng_set_state(np.random.RandomState(1000 + rank).get_state())
+    # SHARD_TEST_SHADOW=1: the whole run inside a bias-shadow scope (this rank's item biases and their Adagrad accumulator
+    # interleaved in the ctx: the owner-side gather reads the copy, the item pass updates it, the scope's end writes it back)
+    shadow = trainer.bias_shadow(enabled=os.environ.get('SHARD_TEST_SHADOW') == '1')
+    bias0 = loc[3].clone()
+    shadow.__enter__()
 
     losses, used_negs = [], np.full(N * nn, -1, dtype=np.int64)
     negs2, used2 = negs.reshape(N, nn), used_negs.reshape(N, nn)  # (views: row k = the draws of interaction k)
@@ -128,6 +133,12 @@ def main():
         dist.all_reduce(part)
         losses.append(float(part.item()))
     assert optim.step == n_mb
+    if os.environ.get('SHARD_TEST_SHADOW') == '1':
+        assert eng.get_stat('shadowed_calls') == n_mb  # every item pass of the run indexed the copy
+        assert torch.equal(loc[3], bias0)  # the caller's bias tensor is stale inside the scope: still the initial values
+    shadow.__exit__(None, None, None)
+    if os.environ.get('SHARD_TEST_DUMP'):  # this rank's shards after the run (tests compare two runs bit for bit)
+        np.savez(os.environ['SHARD_TEST_DUMP'] + '.rank%d.npz' % rank, *[t.cpu().numpy() for t in loc + s1])
 
     # reassemble on rank 0
     used_negs = np.ascontiguousarray(used2).ravel()

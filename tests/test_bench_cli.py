@@ -92,6 +92,19 @@ def test_default_n_gpu_configuration_c5_at_reduced_rows(n):
     assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-5 * max(a), (a, b)
 
 
+def test_row_sharded_bench_loop_on_the_bias_shadow():
+    """`bench.py --gpus 2` at item-table sizes where the run trains with {item bias, Adagrad accumulator} interleaved (forced at
+    reduced rows): the same per-minibatch loss as the plain layout -- same seeds, same draws --, and the line says which layout ran."""
+    final = []
+    for extra in (['--bias-shadow-min-items', '1'], ['--no-bias-shadow']):
+        rc, out, err = run_bench(['--gpus', '2', '--workload', 'c5', '--no-denominators'] + extra)
+        assert rc == 0, err[-3000:]
+        rec = json.loads([l for l in out.splitlines() if l.strip().startswith('{')][-1])
+        assert rec['config']['item_bias_layout'].startswith('two arrays') == (extra[0] == '--no-bias-shadow')
+        final.append(rec['final_minibatch_loss'])
+    assert final[0] == final[1] and final[0] > 0
+
+
 def test_world_size_mismatch_fails_loudly():
     rc, out, err = run_bench(['--gpus', '2'], env_extra={'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert rc != 0 and 'WORLD_SIZE' in err and not out.strip()

@@ -68,6 +68,25 @@ def test_sharded_whole_chunk_with_slices(world, slices, loss, opt):
     run_world(world, [loss, opt, 8, 'chunk', slices])
 
 
+@pytest.mark.parametrize('world,mode,slices,loss', [(2, 'chunk', 3, 'bpr'), (3, 'train', 2, 'pointwise'), (2, None, None, 'adaptive_hinge')])
+def test_sharded_bias_shadow_is_bit_neutral(world, mode, slices, loss, monkeypatch, tmp_path):
+    """The row-sharded path inside a bias-shadow scope (slk_bias_shadow_begin: every rank's item biases + Adagrad accumulator
+    interleaved; the owner-side gather and the item pass index the copy) against the plain layout: every rank's shards and
+    accumulators bit for bit, and each run against the oracle and the one-GPU engine as always."""
+    import numpy as np
+    args = [loss, 'adagrad', 8] + ([mode, slices] if mode else [])
+    for tag in ('plain', 'shadow'):
+        monkeypatch.setenv('SHARD_TEST_SHADOW', '1' if tag == 'shadow' else '0')
+        monkeypatch.setenv('SHARD_TEST_DUMP', str(tmp_path / tag))
+        run_world(world, args)
+    for r in range(world):
+        a, b = (np.load(str(tmp_path / tag) + '.rank%d.npz' % r) for tag in ('plain', 'shadow'))
+        assert len(a.files) == len(b.files) == 8
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (r, k)
+        assert np.abs(a['arr_3']).max() > 0  # (the item biases did train)
+
+
 @pytest.mark.parametrize('world,slices', [(2, 4), (3, 2), (4, 4), (8, 4), (8, 1)])
 def test_sharded_bench_loop_equal_shares(world, slices):
     """The loop bench.py runs at N > 1: ShardedBilinearTrainer.train over equal per-rank shares of every
@@ -116,8 +135,18 @@ def test_sharded_model_fit_predict_match_single_device_model(world, loss, opt):
     run_world(world, [loss, opt], worker=MODEL_WORKER, token='SHARD_MODEL_OK')
 
 
+@pytest.mark.parametrize('world,loss,opt', [(2, 'bpr', 'adagrad'), (3, 'adaptive_hinge', 'adagrad'), (2, 'hinge', 'sparse_adam')])
+def test_sharded_model_fit_with_shadowed_item_biases(world, loss, opt, monkeypatch):
+    """The same comparison with every rank's item biases shadowed for the duration of fit() (what the model does for local
+    shards of >= 2^24 item rows; forced here): Adagrad trains on the interleaved copy, SparseAdam is left alone."""
+    monkeypatch.setenv('SHARD_TEST_SHADOW_FLOOR', '1')
+    run_world(world, [loss, opt], worker=MODEL_WORKER, token='SHARD_MODEL_OK')
+
+
 @pytest.mark.gpu
-def test_gpu_sharded_model_world1_nccl():
+def test_gpu_sharded_model_world1_nccl(monkeypatch):
+    run_world(1, ['bpr', 'adagrad'], backend='hip', worker=MODEL_WORKER, token='SHARD_MODEL_OK')
+    monkeypatch.setenv('SHARD_TEST_SHADOW_FLOOR', '1')  # ... and with the item biases shadowed for the duration of fit()
     run_world(1, ['bpr', 'adagrad'], backend='hip', worker=MODEL_WORKER, token='SHARD_MODEL_OK')
 
 
@@ -139,6 +168,18 @@ def test_gpu_sharded_adaptive_hinge_world1_nccl(opt, D):
 @pytest.mark.gpu
 def test_gpu_sharded_adaptive_hinge_model_world1_nccl():
     run_world(1, ['adaptive_hinge', 'adagrad'], backend='hip', worker=MODEL_WORKER, token='SHARD_MODEL_OK')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_bias_shadow_world1_nccl(monkeypatch, tmp_path):
+    import numpy as np
+    for tag in ('plain', 'shadow'):
+        monkeypatch.setenv('SHARD_TEST_SHADOW', '1' if tag == 'shadow' else '0')
+        monkeypatch.setenv('SHARD_TEST_DUMP', str(tmp_path / tag))
+        run_world(1, ['bpr', 'adagrad', 64, 'chunk', 2], backend='hip')
+    a, b = (np.load(str(tmp_path / tag) + '.rank0.npz') for tag in ('plain', 'shadow'))
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.gpu
