@@ -332,6 +332,11 @@ def check_bias_shadowed_fit_is_value_neutral(engine, use_cuda=False, to_numpy=la
     inter = Interactions(rs.randint(0, 90, 12000).astype(np.int32), rs.randint(0, 60, 12000).astype(np.int32), num_users=90, num_items=60)
     results = []
     old = host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS
+    # chunks of one minibatch, every chunk's negatives + sorts prepared on the second stream beside the passes of the chunk before
+    # (fit() asks for overlap_prep = 1 itself): the shadowed passes of several chunks, overlapped
+    saved = {k: engine.get_option(k) for k in ('chunk_interactions', 'overlap_min_batch')}
+    engine.set_option('chunk_interactions', 4096)
+    engine.set_option('overlap_min_batch', 0)
     try:
         host._PIPELINE_MAX_DRAWS = 0
         for floor in (1, 1 << 40):
@@ -350,6 +355,8 @@ def check_bias_shadowed_fit_is_value_neutral(engine, use_cuda=False, to_numpy=la
             assert engine.get_stat('shadowed_calls') - before == (2 * 2 * 2 if floor == 1 else 0)
     finally:
         host._PIPELINE_MAX_DRAWS, host._BIAS_SHADOW_MIN_ITEMS = old
+        for k, v in saved.items():
+            engine.set_option(k, v)
     half = len(results) // 2
     for a, b in zip(results[:half], results[half:]):
         assert len(a) == len(b)
