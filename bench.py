@@ -322,18 +322,21 @@ def main():
                         eng.bilinear_reserve(tb, op1, K * B, B, args.loss, 1, stream=stream)
                         go = lambda lo, nmb: eng.bilinear_train(tb, op1, users[lo * B:].data_ptr(), it1[lo * B:].data_ptr(), nmb * B, B,
                                                                 args.loss, 1, mb1[lo:].data_ptr(), stream=stream)
+                        scope = eng.bias_shadow(tb, op1, stream=stream, enabled=bias_shadowed and B >= 4096)
                     else:
                         tr1 = ShardedBilinearTrainer(eng, tables, op1, I, group=g1, stream=stream, slices=args.slices or None)
                         tr1.reserve(B, args.shard_chunk)
                         go = lambda lo, nmb: tr1.train(users[lo * B:(lo + nmb) * B], it1[lo * B:(lo + nmb) * B], B, loss=args.loss,
                                                        mb_loss=mb1[lo:lo + nmb], sample_chunk=args.shard_chunk)
-                    if W:
-                        go(0, W)
-                    be.sync()
-                    t1 = time.perf_counter()
-                    go(W, K)
-                    be.sync()
-                    dt = time.perf_counter() - t1
+                        scope = tr1.bias_shadow(enabled=bias_shadowed)
+                    with scope:  # the item-bias layout of the N-GPU run itself
+                        if W:
+                            go(0, W)
+                        be.sync()
+                        t1 = time.perf_counter()
+                        go(W, K)
+                        be.sync()
+                        dt = time.perf_counter() - t1
                     denominators[path] = {'interactions_per_s': K * B / dt, 'ms_per_step': dt / K * 1e3,
                                           'minibatch_losses': [float(x) for x in mb1.cpu().numpy()]}
                 denominators['note'] = ('rank 0 alone, after the timed region, on the same per-GPU shape (%d users x %d items, minibatch %d): '

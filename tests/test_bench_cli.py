@@ -97,11 +97,15 @@ def test_row_sharded_bench_loop_on_the_bias_shadow():
     reduced rows): the same per-minibatch loss as the plain layout -- same seeds, same draws --, and the line says which layout ran."""
     final = []
     for extra in (['--bias-shadow-min-items', '1'], ['--no-bias-shadow']):
-        rc, out, err = run_bench(['--gpus', '2', '--workload', 'c5', '--no-denominators'] + extra)
+        rc, out, err = run_bench(['--gpus', '2', '--workload', 'c5'] + extra)
         assert rc == 0, err[-3000:]
         rec = json.loads([l for l in out.splitlines() if l.strip().startswith('{')][-1])
         assert rec['config']['item_bias_layout'].startswith('two arrays') == (extra[0] == '--no-bias-shadow')
         final.append(rec['final_minibatch_loss'])
+        # rank 0's own one-GPU runs of the per-GPU shape (the row-sharded one on the same bias layout as the N-GPU run) agree
+        den = rec['roofline']['xgmi']['denominators_1_gpu']
+        a, b = den['fused']['minibatch_losses'], den['sharded_world1']['minibatch_losses']
+        assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-5 * max(a), (a, b)
     assert final[0] == final[1] and final[0] > 0
 
 
