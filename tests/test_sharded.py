@@ -75,6 +75,9 @@ def test_sharded_bias_shadow_is_bit_neutral(world, mode, slices, loss, monkeypat
     accumulators bit for bit, and each run against the oracle and the one-GPU engine as always."""
     import numpy as np
     args = [loss, 'adagrad', 8] + ([mode, slices] if mode else [])
+    if mode == 'chunk':  # 4 items in all: long runs, summed through the per-tile partials + k_item_stitch of the BLK mode
+        monkeypatch.setenv('SHARD_TEST_SHAPE', '300,4,1600,1')
+        args[2] = 64
     for tag in ('plain', 'shadow'):
         monkeypatch.setenv('SHARD_TEST_SHADOW', '1' if tag == 'shadow' else '0')
         monkeypatch.setenv('SHARD_TEST_DUMP', str(tmp_path / tag))
