@@ -3,7 +3,12 @@
 # tests/emu/build_emu.py with AddressSanitizer (or UBSan), under the emulator test suites.  A kernel that reads or writes past a
 # caller's buffer, past its LDS arrays (the emulator's `static` stand-ins carry redzones) or past the ctx's scratch is reported
 # with file:line of the access -- the tests' numpy / torch buffers come from the intercepted malloc.
-#   usage: scripts/emu_sanitize.sh [asan|ubsan] [pytest arguments; default: the emulator, host, sharded and bench-launch suites]
+# Third mode, `reverse` (or `alternate`): no instrumentation, but the emulator's scheduler visits the fibers of a block -- and the
+# resident blocks of a cooperative grid -- in descending order between synchronisation points (SLK_EMU_ORDER, tests/emu/
+# emu_runtime.cpp).  Every order is a legal execution of a correctly synchronised kernel: a missing __syncthreads() / SLK_WAVE_SYNC
+# whose reader happens to run after its writer in ascending thread order fails here (checked by knocking out the barrier of
+# k_rng_finalize: the key block comes back incomplete).
+#   usage: scripts/emu_sanitize.sh [asan|ubsan|reverse|alternate] [pytest arguments; default: the emulator, host, sharded and bench-launch suites]
 # The first run compiles the instrumented library into its own tests/emu/_build_* directory (ASan: ~8 minutes).
 set -u
 MODE=${1:-asan}; shift || true
@@ -15,6 +20,8 @@ if [ "$MODE" = asan ]; then
   # libstdc++ beside libasan: python does not link it, and ASan's __cxa_throw interceptor must find the real one before torch throws
   export LD_PRELOAD="$GCCLIB/libasan.so $(g++ -print-file-name=libstdc++.so.6)"
   export ASAN_OPTIONS=${ASAN_OPTIONS:-detect_leaks=0}
+elif [ "$MODE" = reverse ] || [ "$MODE" = alternate ]; then
+  export SLK_EMU_ORDER=$MODE
 else
   export SLK_EMU_CXXFLAGS="-fsanitize=undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
   export LD_PRELOAD="$GCCLIB/libubsan.so"

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 extern "C" void emu_ctx_switch(void **save_sp, void *load_sp);
@@ -182,14 +184,33 @@ static unsigned check_block(dim3 block) {
     return nthreads;
 }
 
+// SLK_EMU_ORDER: the order in which the scheduler visits the fibers between two synchronisation points.  Any order is a legal
+// execution of a correctly synchronised kernel, so every test must pass under every setting -- a missing __syncthreads() /
+// SLK_WAVE_SYNC whose reader happens to run after its writer in ascending thread order shows up under "reverse":
+//   (unset) / forward   threads 0, 1, 2, ... of block 0, then block 1, ...
+//   reverse             the last thread of the last resident block first
+//   alternate           forward and reverse on alternating sweeps
+static int fiber_order() {
+    static int order = -1;
+    if (order < 0) {
+        const char *e = std::getenv("SLK_EMU_ORDER");
+        order = !e ? 0 : !std::strcmp(e, "reverse") ? 1 : !std::strcmp(e, "alternate") ? 2 : 0;
+    }
+    return order;
+}
+
 // run every fiber of blocks [first, first + count) round-robin until all are done
 static void run_blocks(size_t first, size_t count) {
     unsigned long long spins = 0;
+    const int order = fiber_order();
     for (;;) {
         unsigned alive = 0;
-        for (size_t k = first; k < first + count; ++k) {
-            Block &b = g_blocks[k];
-            for (Fiber &f : b.fibers) {
+        const bool rev = order == 1 || (order == 2 && (spins & 1));
+        for (size_t kk = 0; kk < count; ++kk) {
+            Block &b = g_blocks[first + (rev ? count - 1 - kk : kk)];
+            const size_t nf = b.fibers.size();
+            for (size_t t = 0; t < nf; ++t) {
+                Fiber &f = b.fibers[rev ? nf - 1 - t : t];
                 if (f.done) continue;
                 cur = &f;
                 emu_ctx_switch(&g_sched_sp, cur->sp);
