@@ -143,12 +143,23 @@ unsigned long long ballot_exchange(bool pred) {
     return m;
 }
 
+// the `static` stand-ins of every __shared__ variable of the library (hip_runtime.h puts them into the section "emu_shared")
+extern "C" char __start_emu_shared[] __attribute__((weak));
+extern "C" char __stop_emu_shared[] __attribute__((weak));
+
+// a workgroup finds garbage in its LDS, not zeros and not its own leftovers in a known state: poison before every block of a plain
+// launch (a cooperative grid's blocks share the statics and may not use them: launch_coop poisons once)
+static void poison_static_shared() {
+    if (__start_emu_shared && __stop_emu_shared > __start_emu_shared)
+        std::memset(__start_emu_shared, 0xCD, (size_t)(__stop_emu_shared - __start_emu_shared));
+}
+
 static void init_block(Block &b, uint3_ idx, dim3 block, unsigned nthreads, size_t shmem, char *stacks, size_t stack_bytes) {
     b.idx = idx;
     b.fibers.resize(nthreads);
     b.waves.assign((nthreads + 63) / 64, WaveSync());
     std::memset(b.waves.data(), 0, b.waves.size() * sizeof(WaveSync));
-    b.dyn.assign(shmem + 64, 0);
+    b.dyn.assign(shmem + 64, (char)0xCD);  // (dynamic LDS: poisoned, like hipMalloc's memory)
     b.alive = nthreads;
     b.bar_arrived = 0;
     b.bar_gen = 0;
@@ -237,6 +248,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 init_block(g_blocks[0], uint3_{bx, by, bz}, block, nthreads, shmem, g_stacks, kStack);
+                poison_static_shared();
                 run_blocks(0, 1);
             }
     cur = nullptr;
@@ -262,6 +274,7 @@ void launch_coop(dim3 grid, dim3 block, size_t shmem, const std::function<void()
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx, ++k)
                 init_block(g_blocks[k], uint3_{bx, by, bz}, block, nthreads, shmem, g_stacks + kCoopStack * nthreads * k, kCoopStack);
+    poison_static_shared();
     run_blocks(0, nblocks);
     cur = nullptr;
 }

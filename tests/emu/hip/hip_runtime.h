@@ -22,7 +22,9 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+// __shared__ variables: statics gathered in one ELF section, which the runtime fills with a poison pattern before every block starts
+// (emu_runtime.cpp: poison_static_shared) -- LDS holds whatever the last workgroup left there, never zeros
+#define __shared__ static __attribute__((section("emu_shared")))
 #define __launch_bounds__(...)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(::emu::dyn_shared());
