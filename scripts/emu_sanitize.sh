@@ -9,6 +9,8 @@
 # whose reader happens to run after its writer in ascending thread order fails here (checked by knocking out the barrier of
 # k_rng_finalize: the key block comes back incomplete).
 #   usage: scripts/emu_sanitize.sh [asan|ubsan|reverse|alternate] [pytest arguments; default: the emulator, host, sharded and bench-launch suites]
+# The checker itself was put through the same: `make -C oracle -B _build/libslk_oracle.so CFLAGS="... -fsanitize=address,undefined"`
+# under the oracle-using suites (392 tests, no report), then rebuilt plain -- not part of this script, which never touches oracle/_build.
 # The first run compiles the instrumented library into its own tests/emu/_build_* directory (ASan: ~8 minutes).
 set -u
 MODE=${1:-asan}; shift || true
