@@ -120,7 +120,10 @@ int slk_ctx_create(slk_ctx **out, int device_id);
 void slk_ctx_destroy(slk_ctx *ctx);
 const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create error */
 
-/* Tuning knobs (none changes results).  Round 4 removed the ones whose A/Bs lost everywhere in round 3 ("first_chunk",
+/* Tuning knobs.  None changes results: negatives, RandomState and every table and state tensor come out bit for bit the same under
+ * any setting (tests/test_emu_engine.py: test_option_is_result_neutral walks the library's option table) -- with ONE exception,
+ * "adaptive_late_min_batch", whose two forms sum an item row's contributions in different orders (results agree to fp32
+ * rounding: both are checked against the oracle), and the two debug switches ("sort_debug", "epoch_debug").  Round 4 removed the ones whose A/Bs lost everywhere in round 3 ("first_chunk",
  * "chunk_ramp", "prep_cus", "prep_priority", "epoch_seq" with its PoolNet persistent kernel): the numbers are in
  * profiles/r03_a_*, r03_c_*, r03_w_*, r03_x_*.
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
@@ -140,7 +143,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "epoch_adaptive_max_batch"  for minibatches up to this size (default 1024)
  *   "explicit_fused"      explicit feedback: score + loss inside the user pass (default 1)
  *   "adaptive_late_min_batch"  adaptive hinge on a plain item table: from this minibatch size the live occurrences are
- *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk)
+ *                         re-sorted per minibatch after the selection (default 2^18; below, all 1+n are sorted per chunk).
+ *                         The one option that is not bit-neutral: a row's live contributions are summed in the order of the
+ *                         compacted list instead of the (1+n)-slot order -- 1-ulp differences, deterministic either way.
  *   "item_long_gate"      1 (default): minibatches in which no item row's occurrences fill a whole 64-position tile of the
  *                         item pass take the plain pass; 0: always the partial-writing pass + stitch kernel (same results).
  *                         The same switch gates the user pass's long-run form (hot users: runs that fill a 32-position tile).

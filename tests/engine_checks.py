@@ -1577,3 +1577,98 @@ def check_bias_shadow_refusals(be):
             be.engine.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, 20, be.ptr(out), be.stream)
     be.engine.bilinear_predict(dev.tables, be.ptr(d_u), 1, None, 20, be.ptr(out), be.stream)  # (and answered again outside it)
     assert np.isfinite(be.get(out)).all()
+
+
+# ---------------------------------------------------------------------------------------
+# every engine option is result-neutral (include/spotlight_hip.h: slk_ctx_set_option "tuning knobs that never change results")
+# ---------------------------------------------------------------------------------------
+# option -> values to try against the defaults.  Two debug switches are measurement modes whose results are declared meaningless
+# (sort_debug, epoch_debug) and are excluded by name.
+OPTION_VALUES = {
+    'chunk_interactions': (300, 2048), 'overlap_prep': (1, 2), 'overlap_min_batch': (0,), 'prefetch_wait': (1,),
+    'mt_long_min_blocks': (2, 40), 'sort_big_min': (1, 1 << 40), 'item_grid_mult': (1, 64), 'user_grid_mult': (1, 3, 64),
+    'seq_variant': (0, 1), 'explicit_fused': (0,), 'epoch_kernel': (0,), 'item_lat_max_tiles': (0, 1 << 30),
+    'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
+    'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
+    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15),
+}
+OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
+# adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the
+# same sums in a different order -- neutral to fp32 rounding, not bit for bit (include/spotlight_hip.h says so); one minibatch, so
+# that nothing amplifies the 1-ulp differences
+OPTIONS_NEUTRAL_TO_SUMMATION_ORDER = {'adaptive_late_min_batch': (0, 1 << 30)}
+
+
+def option_names_of_the_library():
+    """The names in csrc/slk_api.hip's option table (the C ABI has a getter per name, no enumeration)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'spotlight_amd', 'csrc', 'slk_api.hip')).read()
+    return re.findall(r'SLK_OPT\("([a-z_]+)"', src)
+
+
+def check_option_is_result_neutral(be, name, values):
+    """Training under `name` = each of `values` against the defaults, on a launch-path shape (several chunks when the option says so,
+    hot items), a persistent-route shape and an adaptive-hinge one: negatives, every table and state tensor bit for bit; the
+    minibatch losses to fp32 summation order."""
+    eng = be.engine
+    shapes = [('bpr', 'adagrad', 16, 400, 30, 6000, 2048, 1), ('pointwise', 'sparse_adam', 8, 300, 170, 2500, 256, 1),
+              ('adaptive_hinge', 'adagrad', 8, 120, 90, 1500, 512, 3), ('hinge', 'adam_dense', 8, 60, 50, 700, 256, 1)]
+    default = eng.get_option(name)
+    for loss, opt, D, U, I, N, B, nn in shapes:
+        rs = np.random.RandomState(77)
+        users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+        sc = min(0.3, 1.0 / np.sqrt(D))
+        params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+        hp = dict(lr=0.05, weight_decay=1e-3 if opt.endswith('dense') else 0.0)
+        state = np.random.RandomState(78).get_state()
+        n_mb = (N + B - 1) // B
+        results = []
+        for v in (default,) + tuple(values):
+            eng.set_option(name, v)
+            try:
+                dev = be.model(params, opt=opt, **hp)
+                eng.rng_set_state(state)
+                d_users, d_items = be.alloc(users), be.alloc(items)
+                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+                neg_out = be.alloc(np.full(N * nn, -1, dtype=np.int64))
+                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, nn, be.ptr(mb_loss),
+                                   d_neg_out=be.ptr(neg_out), stream=be.stream)
+                st = eng.rng_get_state()
+                results.append([be.get(mb_loss)] + [be.get(x) for x in [neg_out] + dev.p + dev.s1 + dev.s2] + [st[1], np.array(st[2])])
+            finally:
+                eng.set_option(name, default)
+        for r in results[1:]:
+            assert np.abs(r[0] - results[0][0]).max() <= 2e-6 * np.abs(results[0][0]).max(), (name, loss)
+            for k, (a, b) in enumerate(zip(results[0][1:], r[1:])):
+                assert np.array_equal(a, b), ('option %s: tensor %d differs (%s, %s)' % (name, k, loss, opt))
+
+
+def check_option_is_neutral_to_summation_order(be, name, values, tol=2e-6):
+    """ONE adaptive-hinge minibatch on the launch path under `name` = each of `values`: the same negatives, every table within
+    `tol` of its largest element (a different association of the same fp32 sums), Adagrad from a non-zero accumulator."""
+    eng = be.engine
+    default = eng.get_option(name)
+    loss, opt, D, U, I, B, nn = 'adaptive_hinge', 'adagrad', 8, 120, 90, 512, 3
+    rs = np.random.RandomState(77)
+    users, items = rs.randint(0, U, B).astype(np.int64), rs.randint(0, I, B).astype(np.int64)
+    params = [rs.normal(0, 0.3, (U, D)), rs.normal(0, 0.3, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    state = np.random.RandomState(78).get_state()
+    results = []
+    with eng.options(epoch_kernel=0):
+        for v in values:
+            eng.set_option(name, v)
+            try:
+                dev = be.model(params, opt=opt, lr=0.05)
+                eng.rng_set_state(state)
+                d_users, d_items = be.alloc(users), be.alloc(items)
+                mb_loss, neg_out = be.alloc(np.zeros(1, dtype=np.float32)), be.alloc(np.full(B * nn, -1, dtype=np.int64))
+                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), B, B, loss, nn, be.ptr(mb_loss),
+                                   d_neg_out=be.ptr(neg_out), stream=be.stream)
+                results.append([be.get(neg_out)] + [be.get(x) for x in [mb_loss] + dev.p + dev.s1])
+            finally:
+                eng.set_option(name, default)
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0])
+        for a, b in zip(results[0][1:], r[1:]):
+            assert np.abs(a - b).max() <= tol * max(np.abs(a).max(), 1e-30), name
+

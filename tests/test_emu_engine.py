@@ -303,3 +303,22 @@ def test_scores_are_the_fma_chain(be, D):
 def test_fused_ranks(be):
     ec.check_fused_ranks(be)
     ec.check_fused_ranks(be, D=64, U=200, I=1500, n_rows=300, seed=9)
+
+
+def test_every_option_of_the_library_is_covered_below():
+    """"result-neutral" is a property the tests must keep proving for every option -- a new row in the
+    library's table without a row here fails."""
+    names = ec.option_names_of_the_library()
+    assert len(names) >= 26 and len(set(names)) == len(names)
+    assert set(names) == set(ec.OPTION_VALUES) | set(ec.OPTIONS_NOT_RESULT_NEUTRAL) | set(ec.OPTIONS_NEUTRAL_TO_SUMMATION_ORDER)
+
+
+@pytest.mark.parametrize('name', sorted(ec.OPTION_VALUES))
+def test_option_is_result_neutral(be, name):
+    ec.check_option_is_result_neutral(be, name, ec.OPTION_VALUES[name])
+
+
+@pytest.mark.parametrize('name', sorted(ec.OPTIONS_NEUTRAL_TO_SUMMATION_ORDER))
+def test_option_is_neutral_to_summation_order(be, name):
+    ec.check_option_is_neutral_to_summation_order(be, name, ec.OPTIONS_NEUTRAL_TO_SUMMATION_ORDER[name])
+
