@@ -1641,6 +1641,53 @@ def check_option_is_result_neutral(be, name, values):
             assert np.abs(r[0] - results[0][0]).max() <= 2e-6 * np.abs(results[0][0]).max(), (name, loss)
             for k, (a, b) in enumerate(zip(results[0][1:], r[1:])):
                 assert np.array_equal(a, b), ('option %s: tensor %d differs (%s, %s)' % (name, k, loss, opt))
+    # the other training entry points: bloom layers on both sides, explicit feedback, PoolNet (plain and over a bloom item layer)
+    from oracle.oracle import bloom_desc
+
+    def run_all(v):
+        out = []
+        eng.set_option(name, v)
+        try:
+            rs = np.random.RandomState(79)
+            U, I, D, N, B = 150, 200, 16, 1800, 512
+            users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+            params, ud, idesc = _bloom_setup(rs, U, I, D, 2, 4, 0.4)
+            dev = be.model(params, opt='adagrad', user_bloom=ud, item_bloom=idesc, lr=0.05)
+            eng.rng_set_state(np.random.RandomState(80).get_state())
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            mb_loss = be.alloc(np.zeros((N + B - 1) // B, dtype=np.float32))
+            eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, 'bpr', 1, be.ptr(mb_loss), stream=be.stream)
+            out.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1])
+            ratings = _ratings_for(rs, 'regression', N)
+            sc = 1.0 / np.sqrt(D)
+            params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+            for B2 in (256, 2048):  # the persistent route and the launches
+                dev = be.model(params, opt='sparse_adam', lr=0.05)
+                mb_loss = be.alloc(np.zeros((N + B2 - 1) // B2, dtype=np.float32))
+                d_r = be.alloc(ratings)
+                eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), be.ptr(d_r), N, B2, 'regression',
+                                            be.ptr(mb_loss), stream=be.stream)
+                out.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+            for bloom in (0, 3):
+                NS, L, BS, IS = 90, 20, 32, 400
+                seqs = make_sequences(rs, NS, L, IS, 0.3)
+                sp = _seq_params(rs, IS, D, rows=int(0.4 * IS) if bloom else None)
+                dev = be.seq_model(sp, opt='adagrad', item_bloom=bloom_desc(n_hash=bloom) if bloom else None, lr=0.05)
+                eng.rng_set_state(np.random.RandomState(81).get_state())
+                d_seqs = be.alloc(seqs)
+                mb_loss = be.alloc(np.zeros((NS + BS - 1) // BS, dtype=np.float32))
+                eng.poolnet_train(dev.tables, dev.optim, 0, be.ptr(d_seqs), NS, L, BS, 'bpr', 1, be.ptr(mb_loss), stream=be.stream)
+                st = eng.rng_get_state()
+                out.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1] + [st[1], np.array(st[2])])
+        finally:
+            eng.set_option(name, default)
+        return out
+    base = run_all(default)
+    for v in values:
+        for j, (ra, rb) in enumerate(zip(base, run_all(v))):
+            assert np.abs(ra[0] - rb[0]).max() <= 2e-6 * np.abs(ra[0]).max(), (name, j)
+            for k, (a, b) in enumerate(zip(ra[1:], rb[1:])):
+                assert np.array_equal(a, b), ('option %s = %r: run %d, tensor %d differs' % (name, v, j, k))
 
 
 def check_option_is_neutral_to_summation_order(be, name, values, tol=2e-6):
