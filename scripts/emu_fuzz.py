@@ -8,7 +8,7 @@ feedback, the shuffle, the sampler and the fused ranks.  Meant to run under Addr
 
 ASan aborts the process on any out-of-bounds access.  The checks' numeric asserts are IGNORED here: at random shapes they are
 ill-posed (hinge gradients cancel to order-dependent residues that Adagrad / Adam normalise to O(lr); a single near-zero score has no
-meaningful relative error) -- the tests proper choose their shapes and bounds.  Round 5: 28 000 cases, no report."""
+meaningful relative error) -- the tests proper choose their shapes and bounds.  Round 5: 60 000 cases over two rounds, no report."""
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,13 +17,18 @@ import numpy as np
 import engine_checks as ec
 from emu_backend import EmuBackend
 be = EmuBackend()
+import torch  # noqa: E402 -- the embedding front-end (spotlight_amd/embedding.py) asks the host module for its engine
+from spotlight_amd.factorization import implicit as _host  # noqa: E402
+_host._engine_for = lambda device: be.engine
+_host._stream_for = lambda device: 0
+_host._model_device = lambda: torch.device('cpu')
 rs = np.random.RandomState(int(sys.argv[1]))
 budget = float(sys.argv[2])
 t0 = time.time(); n = 0; errs = 0
 Ds = [1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128, 192, 256]
 pick = lambda xs: xs[rs.randint(len(xs))]
 while time.time() - t0 < budget:
-    kind = rs.randint(7)
+    kind = rs.randint(9)
     seed = int(rs.randint(1 << 30))
     cfg = None
     try:
@@ -58,6 +63,22 @@ while time.time() - t0 < budget:
             ni = int(pick([1, 2, 3, 50, 1682, 10 ** 6, 2 ** 31, 2 ** 32]))
             cfg = ('sampler', ni)
             ec.check_sampler_bit_exact(be, ni, counts=(int(pick([1, 5, 623, 624, 625, 3000, 40000])), int(pick([1, 700]))))
+        elif kind == 7:
+            n_int, nu = int(pick([1, 2, 50, 700, 5000])), int(pick([1, 3, 40, 900]))
+            L = int(pick([1, 2, 5, 10, 33]))
+            cfg = ('to_sequence', n_int, nu, L)
+            ec.check_to_sequence(be, n_int, nu, int(pick([2, 30, 5000])), pick(['int32', 'int64_wide', 'negative', 'float']), L,
+                                 pick([None, 1, min(3, L)]), pick([None, 1, 2, L + 3]), seed=seed % 1000)
+        elif kind == 8:
+            import torch
+            from spotlight_amd.embedding import lookup
+            rows, dim = int(pick([1, 2, 37, 1000])), int(pick(Ds))
+            shape = pick([(1,), (7,), (9, 13), (64, 5), (3000,)])
+            cfg = ('lookup', rows, dim, shape)
+            w = torch.from_numpy(rs.normal(size=(rows, dim)).astype(np.float32)).requires_grad_(True)
+            ids = torch.from_numpy(rs.randint(0, rows, shape))
+            out = lookup(w, ids, padding_idx=pick([None, 0]), sparse=bool(rs.randint(2)))
+            out.sum().backward()
         else:
             D = pick([4, 8, 24, 64, 128])
             cfg = ('ranks', D)
