@@ -313,6 +313,15 @@ def test_every_option_of_the_library_is_covered_below():
     assert set(names) == set(ec.OPTION_VALUES) | set(ec.OPTIONS_NOT_RESULT_NEUTRAL) | set(ec.OPTIONS_NEUTRAL_TO_SUMMATION_ORDER)
 
 
+def test_every_option_is_documented_in_the_header():
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'spotlight_hip.h')).read()
+    doc = hdr[hdr.index('/* Tuning knobs'):hdr.index('int slk_ctx_set_option')]
+    missing = set(ec.option_names_of_the_library()) - set(re.findall(r'"([a-z_]+)"', doc))
+    assert not missing, missing
+
+
 @pytest.mark.parametrize('name', sorted(ec.OPTION_VALUES))
 def test_option_is_result_neutral(be, name):
     ec.check_option_is_result_neutral(be, name, ec.OPTION_VALUES[name])
