@@ -51,8 +51,10 @@ def parse():
     ap.add_argument('--loss', default='bpr')
     ap.add_argument('--opt', default='adagrad', choices=['adagrad', 'sparse_adam', 'adam_dense'],
                     help='adam_dense = the reference default: Adam(lr=1e-2, weight_decay=1e-6) over every row every step')
-    ap.add_argument('--workload', default=None, choices=['c2', 'c3', 'c4', 'c5', 'predict', 'eval'],
-                    help='c2: BilinearNet BPR step (the headline metric; the default at --gpus 1); c3: adaptive hinge n=5 over a '
+    ap.add_argument('--workload', default=None, choices=['c1', 'c2', 'c3', 'c4', 'c5', 'predict', 'eval'],
+                    help='c1: the reference\'s own test configuration (MovieLens-100K shape, dim 32, bpr, default Adam, minibatch '
+                         '1024), the whole 10-epoch fit(); '
+                         'c2: BilinearNet BPR step (the headline metric; the default at --gpus 1); c3: adaptive hinge n=5 over a '
                          'BloomEmbedding item table, dim 128; c4: PoolNet sequence step; c5: the per-GPU shard of the 1B-item x '
                          '100M-user table (12.5M users x 125M items per GPU; at --gpus 8 the full C5; the default at --gpus > 1: '
                          'the row-sharded configuration BASELINE.json names).  Explicit --users / --items override the shape.')
@@ -60,6 +62,10 @@ def parse():
                     help='N > 1: skip rank 0\'s world-1 runs of the same per-GPU shape (fused path, row-sharded path) that give '
                          'the scaling factor its stated denominators')
     ap.add_argument('--seq-len', type=int, default=200)
+    ap.add_argument('--pad-frac', type=float, default=0.0,
+                    help='c4: this share of all positions is left padding (SURVEY.md 8(d): the 20 %%-left-padded variant = 0.2)')
+    ap.add_argument('--n-neg', type=int, default=5,
+                    help='--loss adaptive_hinge: num_negative_samples (5: the reference\'s default, factorization/implicit.py:88)')
     ap.add_argument('--sharded', action='store_true',
                     help='run the row-sharded exchange path even at N=1 (diagnostic; default at N>1)')
     ap.add_argument('--slices', type=int, default=0, help='row-sharded path: user-slices per minibatch (0: default)')
@@ -116,9 +122,11 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n'
                          % (args.gpus, os.environ['WORLD_SIZE']))
         sys.exit(3)
-    if args.workload in ('c3', 'c4', 'predict', 'eval'):
+    if args.workload in ('c1', 'c3', 'c4', 'predict', 'eval'):
         # diagnostic workloads (not the headline metric): each returns its own record, printed as one JSON line
-        if args.workload == 'c4':
+        if args.workload == 'c1':
+            from benchlib.c1 import bench_c1 as leg
+        elif args.workload == 'c4':
             from benchlib.c4 import bench_c4 as leg
         elif args.workload == 'c3':
             from benchlib.c3 import bench_c3 as leg
@@ -136,7 +144,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     be = Backend(args.backend, local_rank)
-    want_sharded_check = (world == 1 and not args.sharded and not args.no_sharded_check and args.workload in ('c2', 'c5'))
+    want_sharded_check = (world == 1 and not args.sharded and not args.no_sharded_check and args.workload in ('c2', 'c5')
+                          and args.loss != 'adaptive_hinge')
     if world > 1 or args.sharded:
         dist = be.init_dist(rank, world, local_rank)
     dev = be.dev
@@ -184,6 +193,7 @@ def main():
         trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
         trainer.reserve(B, args.shard_chunk)  # exchange buffers of the timed loop's chunks up front
     xgmi_rows = [0]
+    xgmi_bytes = [0, 0]  # measured by the trainer: bytes handed to the collectives for other ranks (with / without slot padding)
     # fit() trains item tables this large with {bias, Adagrad accumulator} interleaved (factorization/implicit.py:
     # _BIAS_SHADOW_MIN_ITEMS); the scope opens here, outside every timed region, and closes after the last one
     bias_shadowed = (args.opt == 'adagrad' and I >= args.bias_shadow_min_items and (B >= 4096 or trainer is not None)
@@ -192,17 +202,21 @@ def main():
                     trainer.bias_shadow(enabled=bias_shadowed))  # (row-sharded: the owner-side gather and item pass index it)
     shadow_scope.__enter__()
 
+    n_neg = args.n_neg if args.loss == 'adaptive_hinge' else 1
+
     def run(first_mb, n_mb):
         if trainer is None:
             off = first_mb * B
-            eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, 1,
+            eng.bilinear_train(tb, op, users[off:].data_ptr(), items[off:].data_ptr(), n_mb * B, B, args.loss, n_neg,
                                mb_loss[first_mb:].data_ptr(), stream=stream)
             return
         # this rank's B interactions of every global minibatch (users it owns; items anywhere)
         lo, hi = first_mb * B, (first_mb + n_mb) * B
         trainer.train(users[lo:hi], items[lo:hi], B, loss=args.loss, mb_loss=mb_loss[first_mb:first_mb + n_mb],
-                      sample_chunk=args.shard_chunk, n_neg=5 if args.loss == 'adaptive_hinge' else None)  # (5: the reference's default)
+                      sample_chunk=args.shard_chunk, n_neg=args.n_neg if args.loss == 'adaptive_hinge' else None)
         xgmi_rows[0] += trainer.exchange_rows
+        xgmi_bytes[0] += trainer.exchange_bytes
+        xgmi_bytes[1] += trainer.exchange_payload_bytes
 
     multi = world > 1 or args.sharded
 
@@ -220,11 +234,12 @@ def main():
     if want_probes:
         probes = measured_stream_rates(be, stream)
     if trainer is None:
-        eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # scratch for the timed call's shape
+        eng.bilinear_reserve(tb, op, K * B, B, args.loss, n_neg, stream=stream)  # scratch for the timed call's shape
     if W:
         run(0, W)
     barrier()
     xgmi_rows[0] = 0
+    xgmi_bytes[:] = [0, 0]
     # timed region: EXACTLY K steps, no instrumentation inside
     t0 = time.perf_counter()
     run(W, K)
@@ -233,7 +248,7 @@ def main():
     barrier()
     # per-kernel durations: K more steps with hipEvents around every launch (slk_profile_*);
     # outside the timed region because the event records themselves cost ~10 us per launch
-    xg = xgmi_rows[0]
+    xg, xgb = xgmi_rows[0], list(xgmi_bytes)
     eng.profile_reset()
     eng.profile_enable(True)
     t1 = time.perf_counter()
@@ -243,6 +258,7 @@ def main():
     eng.profile_enable(False)
     prof = eng.profile_read()
     xgmi_rows[0] = xg
+    xgmi_bytes[:] = xgb
     # The timed region above runs a bare ctx's default: negatives, sorts and passes in order on one stream.  fit() switches
     # the ctx to "overlap_prep" (the next chunk's negatives + sorts on a second stream beside the passes); the same K
     # minibatches are run that way three more times -- untimed warm-up, un-instrumented, with the kernel timers -- and go
@@ -251,7 +267,7 @@ def main():
     if trainer is None and world == 1 and not args.no_overlapped and not any(kv.startswith('overlap_prep=') for kv in args.set):
         eng.set_option('overlap_prep', 1)
         try:
-            eng.bilinear_reserve(tb, op, K * B, B, args.loss, 1, stream=stream)  # the second buffer set, the prep stream
+            eng.bilinear_reserve(tb, op, K * B, B, args.loss, n_neg, stream=stream)  # the second buffer set, the prep stream
             run(W + K, K)
             be.sync()
             t2 = time.perf_counter()
@@ -275,17 +291,22 @@ def main():
     # of steps long.  Both figures go into the line (first_call); the bracket is the same: barrier + sync, exactly K steps, sync.
     elapsed_first = elapsed
     barrier()
-    xg = xgmi_rows[0]
+    xg, xgb = xgmi_rows[0], list(xgmi_bytes)
     t3 = time.perf_counter()
     run(W, K)
     be.sync()
     elapsed = time.perf_counter() - t3
     barrier()
     xgmi_rows[0] = xg
+    xgmi_bytes[:] = xgb
     shadow_scope.__exit__(None, None, None)  # (the probes and checks below read the two arrays)
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
         ranks_seen[0]['exchange_rows_timed_call'] = int(xgmi_rows[0])  # lookups of this rank that crossed to another rank, K steps
+        # MEASURED: the bytes this rank handed to the collectives for other ranks in those K steps (ids + rows + gradient rows;
+        # slot padding included / excluded) -- to be read against roofline.xgmi's modelled bytes_per_step_per_gpu_each_way
+        ranks_seen[0]['exchange_bytes_timed_call'] = int(xgmi_bytes[0])
+        ranks_seen[0]['exchange_payload_bytes_timed_call'] = int(xgmi_bytes[1])
     if multi:
         dist.barrier()
         t = torch.tensor([elapsed, elapsed_first], device=dev, dtype=torch.float64)
@@ -319,9 +340,9 @@ def main():
                     it1 = items % I
                     mb1 = torch.zeros(W + K, device=dev)
                     if path == 'fused':
-                        eng.bilinear_reserve(tb, op1, K * B, B, args.loss, 1, stream=stream)
+                        eng.bilinear_reserve(tb, op1, K * B, B, args.loss, n_neg, stream=stream)
                         go = lambda lo, nmb: eng.bilinear_train(tb, op1, users[lo * B:].data_ptr(), it1[lo * B:].data_ptr(), nmb * B, B,
-                                                                args.loss, 1, mb1[lo:].data_ptr(), stream=stream)
+                                                                args.loss, n_neg, mb1[lo:].data_ptr(), stream=stream)
                         scope = eng.bias_shadow(tb, op1, stream=stream, enabled=bias_shadowed and B >= 4096)
                     else:
                         tr1 = ShardedBilinearTrainer(eng, tables, op1, I, group=g1, stream=stream, slices=args.slices or None)
@@ -380,7 +401,7 @@ def main():
     if rank == 0:
         value, roof = build_roofline(args, world=world, K=K, B=B, D=D, elapsed=elapsed, prof=prof, prof_ov=prof_ov,
                                      elapsed_ov=elapsed_ov, elapsed_ov_prof=elapsed_ov_prof, probes=probes, ceiling=ceiling,
-                                     trainer=trainer, xgmi_rows=xgmi_rows, denominators=denominators)
+                                     trainer=trainer, xgmi_rows=xgmi_rows, denominators=denominators, xgmi_bytes=xgmi_bytes)
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -429,6 +450,21 @@ def main():
                 out['cpu_baseline'] = port
                 if ref:
                     out['cpu_baseline']['reference_error'] = ref.get('error')
+        if legs is not None and isinstance(out.get('cpu_baseline'), dict):
+            # the reference's own runs of two legs' workloads, timed by the cpu_baseline leg (the one place that runs the staged
+            # reference): its CPU fit() of the C1 call beside configs.c1, and the reference on this GPU through stock PyTorch-ROCm
+            cb = out['cpu_baseline']
+            ref_c1 = cb.get('c1_reference_fit')
+            if isinstance(legs.get('c1'), dict) and isinstance(ref_c1, dict) and 'fit_seconds' in ref_c1:
+                legs['c1']['reference_cpu_fit'] = {'fit_seconds': round(ref_c1['fit_seconds'], 4), 'threads': ref_c1['threads'],
+                                                   'interactions_per_s': float('%.5g' % ref_c1['interactions_per_s'])}
+            hip = cb.get('reference_on_hip')
+            if isinstance(hip, dict):
+                legs['reference_on_hip'] = ({'ms_per_step': round(hip['ms_per_minibatch'], 3), 'value': float('%.5g' % hip['interactions_per_s']),
+                                             'unit': 'interactions/s', 'steps': hip['minibatches_per_fit'], 'warmup': hip['minibatches_per_fit'],
+                                             'alg_bytes_per_unit': out['roofline']['step_alg_bytes_per_interaction'],
+                                             'step_frac': round(hip['interactions_per_s'] * out['roofline']['step_alg_bytes_per_interaction'] / 8e12, 5),
+                                             'what': hip['what']} if 'interactions_per_s' in hip else hip)
         if legs is not None:
             # scalars inside `roofline` (record parsers keep its scalar fields) + the object itself LAST on the line (a tail of
             # the line then shows it)

@@ -32,6 +32,12 @@ def bench_c4(args):
     tb = _native.make_seq_tables(E.data_ptr(), bias.data_ptr(), I, D)
     op = _native.make_optim('adagrad', [None, s1[0].data_ptr(), None, s1[1].data_ptr()], None, lr=1e-2)
     seqs = torch.randint(1, I, ((W + 2 * K) * B, L), device=dev, dtype=torch.int64, generator=gen)  # W warm-up + K timed + K profiled
+    pad = float(getattr(args, 'pad_frac', 0.0) or 0.0)
+    if pad > 0:
+        # "+ a 20 %-left-padded variant" -- every sequence gets a left padding whose length is uniform in
+        # [0, 2 * pad * L], so that `pad` of all positions are padding (id 0) and the sequences are ragged, as to_sequence's are
+        npad = torch.randint(0, int(2 * pad * L) + 1, (seqs.shape[0],), device=dev, generator=gen)
+        seqs[torch.arange(L, device=dev)[None, :] < npad[:, None]] = 0
     mb_loss = torch.zeros(W + 2 * K, device=dev)
     eng.rng_set_state(np.random.RandomState(5).get_state())
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -54,7 +60,7 @@ def bench_c4(args):
     torch.cuda.synchronize(dev)
     eng.profile_enable(False)
     prof = eng.profile_read()
-    ts = K * B * L
+    ts = int((seqs[W * B:(W + K) * B] != 0).sum().item())  # the unit: non-padding (sequence, timestep) pairs = mask.sum() (sequence/implicit.py:250)
     alg = 32 * D + 40
     kern = {k: {'launches': prof[k][0], 'avg_ms': prof[k][1] / max(prof[k][0], 1)} for k in ('seq_pass', 'item_pass', 'epoch')
             if prof[k][0] or k != 'epoch'}  # 'epoch': minibatches of a few thousand timesteps run inside k_poolnet_epoch, one launch per chunk
@@ -62,7 +68,9 @@ def bench_c4(args):
            'unit': 'timesteps/s', 'n_gpus': 1, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
            'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': 'C4: PoolNet, %d sequences x len %d per minibatch, %d items, dim %d, bpr, '
-                                  'adagrad, no padding' % (B, L, I, D)},
+                                  'adagrad, %s' % (B, L, I, D, 'no padding' if pad <= 0 else
+                                                   '%g of the positions left padding (length uniform in [0, %d] per sequence); '
+                                                   'unit = non-padding timesteps' % (pad, int(2 * pad * L)))},
            'roofline': {'bound': 'hbm', 'alg_bytes_per_timestep': alg, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'step_achieved': ts * alg / elapsed / 1e9, 'step_frac_of_peak': ts * alg / elapsed / 1e9 / HBM_PEAK_GBS,
                         'kernels': kern,

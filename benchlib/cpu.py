@@ -21,8 +21,11 @@ def reference_cpu_baseline(args, seconds):
         return None
     cmd = [sys.executable, script, '--users', str(args.users), '--items', str(args.items), '--dim', str(args.dim),
            '--batch', str(args.batch), '--loss', args.loss, '--seconds', str(seconds)]
+    default_c2 = (args.users, args.items, args.dim, args.batch, args.loss, args.opt) == (10_000_000, 1_000_000, 64, 1 << 20, 'bpr', 'adagrad')
+    if default_c2 and not getattr(args, 'no_configs', False):
+        cmd += ['--c1', '1', '--hip', '1']  # the reference's own operating point on the CPU; the reference on the HIP device (stock PyTorch-ROCm)
     try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60 + 12 * seconds)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150 + 12 * seconds)
         rec = json.loads(res.stdout.decode().strip().splitlines()[-1])
     except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
         return {'error': repr(e)[:300]}
@@ -39,6 +42,10 @@ def reference_cpu_baseline(args, seconds):
                      % (rec['torch'], rec['loss'], rec['users'], rec['items'], rec['dim'], sa.get('batch', rec['batch']), rec['gpu_workload_batch'],
                         sa['minibatches_per_fit'], sa['seconds'], rec['host_cores'], sa['threads'],
                         '; ' + rec['note'] if rec['note'] else '')}
+    if 'c1_fit' in rec:
+        out['c1_reference_fit'] = rec['c1_fit']
+    if 'hip_sparse_adagrad' in rec:
+        out['reference_on_hip'] = rec['hip_sparse_adagrad']
     if da:
         out['reference_default_dense_adam'] = {'value': da['interactions_per_s'], 'unit': 'interactions/s', 'cores': da['threads'],
                                                'sample': '%d minibatch(es) of %d per fit, %.1f s' % (da['minibatches_per_fit'], da.get('batch', rec['batch']), da['seconds'])}

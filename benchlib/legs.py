@@ -20,6 +20,14 @@ LEGS = [
     ('c5_shard', ['--workload', 'c5', '--steps', '8', '--warmup', '2'] + _QUIET, 'main'),
     ('c2_sparse_adam', ['--opt', 'sparse_adam', '--steps', '8', '--warmup', '2'] + _QUIET, 'main'),
     ('c2_b65536', ['--batch', '65536', '--steps', '128', '--warmup', '32'] + _QUIET, 'main'),
+    # the reference's own operating points (VERDICT r05 missing 2): its test configuration end to end, its test minibatch (1024) and
+    # its constructor defaults (batch_size=256, adaptive hinge's num_negative_samples=5: factorization/implicit.py:80,88) on the C2 tables
+    ('c1', ['--workload', 'c1', '--steps', '3'], 'step'),
+    ('c2_b1024', ['--batch', '1024', '--steps', '2048', '--warmup', '256'] + _QUIET, 'main'),
+    ('c2_b256_adaptive', ['--batch', '256', '--loss', 'adaptive_hinge', '--steps', '2048', '--warmup', '256'] + _QUIET, 'main'),
+    # SURVEY.md 8(d) "variants to report": 20 % left padding (C4), Zipf(1.0) positive items (C2)
+    ('c4_padded', ['--workload', 'c4', '--pad-frac', '0.2', '--steps', '8', '--warmup', '2'], 'step'),
+    ('c2_zipf_items', ['--item-zipf', '1.0', '--steps', '8', '--warmup', '2'] + _QUIET, 'main'),
     ('predict', ['--workload', 'predict', '--steps', '400', '--warmup', '40'], 'scoring'),
     ('eval', ['--workload', 'eval', '--steps', '5', '--warmup', '2'], 'scoring'),
 ]
@@ -41,7 +49,12 @@ def _compact(kind, rec):
             out['persistent_us_per_minibatch'] = round(roof['persistent_epoch_kernel']['us_per_minibatch'], 2)
     elif kind == 'step':
         out.update({'alg_bytes_per_unit': roof.get('alg_bytes_per_interaction', roof.get('alg_bytes_per_timestep')),
-                    'step_frac': round(roof.get('step_frac_of_peak', 0.0), 4)})
+                    'step_frac': round(roof.get('step_frac_of_peak', 0.0), 6 if roof.get('step_frac_of_peak', 1.0) < 0.01 else 4)})
+        if 'variants' in roof:  # c1: the whole fit() under the reference's default optimizer and under row-sparse Adagrad
+            out['variants'] = {n: {'fit_seconds': round(v['fit_seconds'], 5), 'interactions_per_s': float('%.5g' % v['interactions_per_s']),
+                                   'us_per_minibatch_end_to_end': round(v['us_per_minibatch_end_to_end'], 2),
+                                   'alg_bytes_per_minibatch': v['alg_bytes_per_minibatch'], 'frac': float('%.3g' % v['frac'])}
+                               for n, v in roof['variants'].items()}
         if 'kernels' in roof:
             out['kernel_ms'] = {n: round(v['avg_ms'], 4) for n, v in roof['kernels'].items()}
         if 'ms_per_step_by_class' in roof:

@@ -4,7 +4,7 @@ from benchlib.common import HBM_PEAK_GBS, algorithmic_bytes, pmc_traffic
 
 
 def build_roofline(args, *, world, K, B, D, elapsed, prof, prof_ov, elapsed_ov, elapsed_ov_prof, probes, ceiling, trainer,
-                   xgmi_rows, denominators):
+                   xgmi_rows, denominators, xgmi_bytes=None):
     """-> (value, roofline dict).  `prof` / `prof_ov`: {class: (launches, ms)} of the instrumented K steps (in line / overlapped);
     `trainer`: the ShardedBilinearTrainer of a row-sharded run or None; `denominators`: rank 0's one-GPU rates at N > 1."""
     value = world * K * B / elapsed
@@ -16,6 +16,14 @@ def build_roofline(args, *, world, K, B, D, elapsed, prof, prof_ov, elapsed_ov, 
         avg_s = ms / max(n, 1) * 1e-3
         kern[name] = {'launches': n, 'avg_ms': ms / max(n, 1), 'alg_bytes_per_launch': per_int * B,
                       'achieved_GBs': per_int * B / avg_s / 1e9 if avg_s > 0 else 0.0}
+    step_bytes, step_bytes_note = ub + ib, None
+    if args.loss == 'adaptive_hinge':
+        # SURVEY.md 8(d), the C3 accounting on plain tables (H = 1): the forward reads 1 user row + (1 + n) item rows; the update
+        # touches the user row and the 2 live item rows (write + state read + write each) -- (2 + n) * 4D + 3 * 12D + ~90 B
+        n = args.n_neg
+        step_bytes = (2 + n) * 4 * D + 36 * D * s_words + 90
+        step_bytes_note = ('adaptive hinge, n_neg %d, plain tables: (2 + n) * 4D forward reads + 3 rows x (write + state R/W) + ~90 B of '
+                           'ids and biases (SURVEY.md 8(d), the C3 formula with H = 1); the per-kernel figures keep the pair accounting' % n)
     dom = max(kern, key=lambda k: kern[k]['avg_ms'])
     roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': kern[dom]['achieved_GBs'],
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kern[dom]['achieved_GBs'] / HBM_PEAK_GBS,
@@ -25,9 +33,13 @@ def build_roofline(args, *, world, K, B, D, elapsed, prof, prof_ov, elapsed_ov, 
                             '(rocprofv3 --pmc passes over this workload: PMC counters cannot be read from inside the '
                             'benchmark process); null if no committed measurement matches',
             'kernels': kern,
-            'step_alg_bytes_per_interaction': ub + ib,
-            'step_frac_of_peak': value / world * (ub + ib) / (HBM_PEAK_GBS * 1e9),
+            'step_alg_bytes_per_interaction': step_bytes,
+            'step_frac_of_peak': value / world * step_bytes / (HBM_PEAK_GBS * 1e9),
             'other_ms_per_step': {k: prof[k][1] / K for k in ('sample', 'prep', 'exchange', 'dense_sweep', 'epoch')}}
+    if step_bytes_note:
+        roof['step_alg_bytes_note'] = step_bytes_note
+    if prof['score'][0]:
+        roof['other_ms_per_step']['score'] = prof['score'][1] / K
     if prof_ov is not None:
         kov = {}
         for name, per_int in (('user_pass', ub), ('item_pass', ib)):
@@ -46,6 +58,12 @@ def build_roofline(args, *, world, K, B, D, elapsed, prof, prof_ov, elapsed_ov, 
     if prof['epoch'][0]:
         roof['persistent_epoch_kernel'] = {'launches': prof['epoch'][0], 'us_per_minibatch': prof['epoch'][1] / K * 1e3,
                                            'note': 'every minibatch of a chunk inside one cooperative launch (slk_epoch.hip)'}
+        if not kern['user_pass']['launches'] and prof['epoch'][1] > 0:
+            # minibatches <= 1024: no pass launches at all -- the dominant (only) training kernel is the persistent one, both
+            # phases of every minibatch of the chunk; its algorithmic bytes are the whole step's
+            ach = step_bytes * B * K / (prof['epoch'][1] * 1e-3) / 1e9
+            roof.update({'kernel': 'k_bilinear_epoch', 'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'bound': 'hbm by its bytes; at this minibatch size the kernel is bound by its two grid barriers per minibatch'})
     if probes:
         roof['measured'] = probes
     if ceiling:
@@ -63,6 +81,11 @@ def build_roofline(args, *, world, K, B, D, elapsed, prof, prof_ov, elapsed_ov, 
                         'slices_per_minibatch': trainer.slices, 'minibatches_per_chunk': args.shard_chunk,
                         'kernel_ms_per_step': kern_ms,
                         'exchange_and_host_ms_per_step': elapsed / K * 1e3 - kern_ms}
+        if xgmi_bytes is not None:
+            # rank 0's MEASURED figures (bytes its trainer handed to the collectives for other ranks) beside the modelled one above
+            roof['xgmi']['bytes_per_step_per_gpu_each_way_measured'] = xgmi_bytes[0] / K
+            roof['xgmi']['payload_bytes_per_step_per_gpu_each_way_measured'] = xgmi_bytes[1] / K
+            roof['xgmi']['measured_bytes_per_interaction'] = xgmi_bytes[0] / K / B
         # the exchange bound: every byte leaves through one of the (world - 1) direct xGMI links of
         # this GPU (point-to-point mesh, ~76.8 GB/s per link and direction)
         xb = roof['xgmi']['bytes_per_step_per_gpu_each_way']

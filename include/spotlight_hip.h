@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 10
+#define SLK_ABI_VERSION 11
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -163,7 +163,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         ones 64 (test hook: the long class at a small size)
  *   "epoch_max_grid"      workgroups of the persistent kernel, at most one per CU -- values above 1024 lift that limit (a
  *                         measurement switch: several one-wave workgroups per CU, profiles/r05_b_persistent_kernel_wide_grid_*)
- *   "nt", "seq_variant"   cache-policy bits of the passes; PoolNet sequence-pass variant */
+ *   "nt", "seq_variant"   cache-policy bits of the passes (non-temporal accesses: 1 user rows + state, 2 item rows + state, 8 key /
+ *                         payload streams, 16 the user pass's record stores, 32 the item pass's record loads; default 3);
+ *                         PoolNet sequence-pass variant */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --
  * a ctx is shared by every model of a process on its device (spotlight_amd/_native.py: `with engine.options(...)`). */
@@ -264,9 +266,20 @@ int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim
  * SLK_EINVAL until _end.  _begin, the training calls and _end are ordered by the caller: the same stream, or events between
  * them.  One scope per ctx; the copy's storage stays with the ctx for the next scope (slk_ctx_destroy frees it; an open scope is
  * NOT written back by it).  _end without an open scope is a no-op.
- * What this package's fit() does for item tables of >= 2^24 rows. */
+ * What this package's fit() does for item tables of >= 2^24 rows.
+ *
+ * LIFETIME CONTRACT (ABI 11) -- the ONE place where the library keeps caller pointers across calls (SURVEY.md 8(b) "no pointer
+ * is retained across calls except inside ctx scratch"): from _begin to _end / _abort the ctx holds tables->d_param[3] and
+ * optim->d_state1[3], and _end WRITES through them.  The caller keeps both arrays alive and in place for the whole scope.
+ *   - _end closes the scope on every return, error returns included (the arrays then keep their _begin values).
+ *   - slk_bias_shadow_abort closes it WITHOUT writing: for a caller whose arrays are gone (the training of the scope is lost).
+ *   - a training call (slk_bilinear_train / _train_explicit / _prefetch) that names the shadowed bias array with ANOTHER
+ *     d_state1[3] (the optimizer state tensor was swapped inside the scope), or that names OTHER tables altogether, is refused
+ *     with SLK_EINVAL: the scope belongs to one model's training.
+ *   - slk_ctx_destroy with an open scope does not write back (it cannot know the arrays still exist) and says so on stderr. */
 int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
 int slk_bias_shadow_end(slk_ctx *ctx, void *stream);
+int slk_bias_shadow_abort(slk_ctx *ctx);
 
 /* ImplicitFactorizationModel.predict (factorization/implicit.py:277-311 with
  * _components.py:8-25): d_out[k] = score(user_k, item_k); n_users == 1 broadcasts the user;

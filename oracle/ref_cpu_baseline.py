@@ -49,6 +49,9 @@ def main():
     ap.add_argument('--seconds', type=float, default=24.0)
     ap.add_argument('--threads', type=int, default=0, help='0: os.cpu_count()')
     ap.add_argument('--variants', default='sparse_adagrad,default_dense_adam')
+    ap.add_argument('--c1', type=int, default=0, help='1: also time the reference\'s CPU fit() of BASELINE.json configs[0] (MovieLens-100K shape)')
+    ap.add_argument('--hip', type=int, default=0, help='1: also time the reference on the HIP device through stock PyTorch-ROCm (use_cuda=True)')
+    ap.add_argument('--hip-minibatches', type=int, default=4)
     args = ap.parse_args()
 
     if not os.path.isdir(os.path.join(REF, 'spotlight')):
@@ -130,6 +133,63 @@ def main():
                      'interactions_per_s_by_threads': {str(th): r for th, r in rate.items()}}
         del model
     out['threads'] = out[variants[0]]['threads'] if variants else all_threads
+
+    if args.c1:
+        # BASELINE.json configs[0], the reference's own test configuration (tests/factorization/test_implicit.py:40-57) on the
+        # MovieLens-100K shape: the WHOLE fit() call, the reference's defaults (dense Adam + l2), on this machine's host cores --
+        # what bench.py's `configs.c1` leg runs through the drop-in API on the GPU.  Same ids: RandomState(42), the reference's
+        # own random_train_test_split.
+        from spotlight.cross_validation import random_train_test_split
+        rs1 = np.random.RandomState(42)
+        full = Interactions(rs1.randint(0, 943, 100000).astype(np.int32), rs1.randint(0, 1682, 100000).astype(np.int32),
+                            num_users=943, num_items=1682)
+        train, _ = random_train_test_split(full, random_state=np.random.RandomState(42))
+        c1 = {}
+        mk = lambda: ImplicitFactorizationModel(loss='bpr', embedding_dim=32, batch_size=1024, n_iter=10, learning_rate=1e-2,
+                                                l2=1e-6, random_state=np.random.RandomState(42))
+        torch.set_num_threads(1)
+        timed_fit(mk(), train)  # warm-up fit
+        for th in sorted({1, min(all_threads, 8)}):  # (tables of 87 K parameters: more threads only add synchronisation)
+            torch.set_num_threads(th)
+            c1[th] = min(timed_fit(mk(), train) for _ in range(2))
+        best = min(c1, key=c1.get)
+        out['c1_fit'] = {'fit_seconds': c1[best], 'threads': best, 'fit_seconds_by_threads': {str(k): v for k, v in c1.items()},
+                         'interactions_per_s': len(train) * 10 / c1[best], 'train_interactions': len(train),
+                         'what': 'spotlight ImplicitFactorizationModel(loss=bpr, embedding_dim=32, batch_size=1024, n_iter=10, '
+                                 'learning_rate=1e-2, l2=1e-6).fit() on CPU PyTorch, 943 x 1682, warm-up fit + min of 2'}
+
+    if args.hip and torch.cuda.is_available():
+        # the reference ITSELF on the HIP device through stock PyTorch-ROCm (use_cuda=True) -- sparse=True +
+        # Adagrad, the algorithmic equivalent of the fused step -- on the GPU workload's shapes and minibatch, a bounded number
+        # of minibatches.  A second baseline, not the target: host-side numpy shuffle + per-minibatch negative draw + H2D as
+        # the reference does them, torch's gather / index_add / coalesce / sparse Adagrad kernels on the device.
+        try:
+            torch.set_num_threads(min(all_threads, 16))
+            U2, I2 = args.users, args.items
+            k = max(1, int(args.hip_minibatches))
+            model = ImplicitFactorizationModel(loss=args.loss, embedding_dim=D, n_iter=1, batch_size=B_full, use_cuda=True, sparse=True,
+                                               optimizer_func=lambda p: torch.optim.Adagrad(p, lr=1e-2),
+                                               random_state=np.random.RandomState(1))
+            rs2 = np.random.RandomState(0)
+            data = Interactions(rs2.randint(0, U2, k * B_full).astype(np.int32), rs2.randint(0, I2, k * B_full).astype(np.int32),
+                                num_users=U2, num_items=I2)
+            t_warm = timed_fit(model, data)
+            torch.cuda.synchronize()
+            timings = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                model.fit(data)
+                torch.cuda.synchronize()
+                timings.append(time.perf_counter() - t0)
+            out['hip_sparse_adagrad'] = {'interactions_per_s': k * B_full / min(timings), 'ms_per_minibatch': min(timings) / k * 1e3,
+                                         'minibatches_per_fit': k, 'batch': B_full, 'timings': timings, 'warmup_seconds': t_warm,
+                                         'device': torch.cuda.get_device_name(0), 'users': U2, 'items': I2,
+                                         'what': 'spotlight ImplicitFactorizationModel(use_cuda=True, sparse=True, optimizer_func=Adagrad'
+                                                 '(lr=1e-2)).fit() through stock PyTorch-ROCm ops on the same GPU: warm-up fit + min of '
+                                                 '2 timed fits (host shuffle, per-minibatch numpy negatives + H2D included, as the '
+                                                 'reference runs)'}
+        except Exception as e:  # noqa: BLE001 -- a reported extra
+            out['hip_sparse_adagrad'] = {'error': repr(e)[:300]}
     print(json.dumps(out))
     return 0
 

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 10
+SLK_ABI_VERSION = 11
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -55,6 +55,7 @@ _PROTOTYPES = {
     'slk_ctx_get_option': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_bias_shadow_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p]),
     'slk_bias_shadow_end': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'slk_bias_shadow_abort': (C.c_int, [C.c_void_p]),
     'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -245,15 +246,30 @@ class Engine(object):
         engine = self
 
         class _Shadow(object):
+            active = False
+
             def __enter__(self_):
                 if enabled:
-                    engine._check(engine._lib.slk_bias_shadow_begin(engine._ctx, C.byref(tables), C.byref(optim), C.c_void_p(stream)))
+                    rc = engine._lib.slk_bias_shadow_begin(engine._ctx, C.byref(tables), C.byref(optim), C.c_void_p(stream))
+                    if rc == SLK_ENOMEM:
+                        # 8 bytes per item row did not fit (0.8 GB at 10^8 rows): the scope is an optimisation, never a
+                        # requirement -- training goes on in the two-array layout, bit-identically
+                        return engine
+                    engine._check(rc)
+                    self_.active = True
                 return engine
 
             def __exit__(self_, *exc):
-                if enabled:
+                if self_.active:
+                    self_.active = False
                     engine._check(engine._lib.slk_bias_shadow_end(engine._ctx, C.c_void_p(stream)))
                 return False
+
+            def abort(self_):
+                """Close the scope without writing back (the caller's arrays are gone): slk_bias_shadow_abort."""
+                if self_.active:
+                    self_.active = False
+                    engine._check(engine._lib.slk_bias_shadow_abort(engine._ctx))
         return _Shadow()
 
     def get_stat(self, name):

@@ -156,6 +156,10 @@ SLK_EXPORT int slk_ctx_create(slk_ctx **out, int device_id) {
 
 SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->shadow_active)  // (void function: the one loud channel left.  The scope is NOT written back -- its arrays may be gone.)
+        fprintf(stderr, "libspotlight_hip: slk_ctx_destroy with an OPEN item-bias shadow (slk_bias_shadow_begin without _end): "
+                        "the caller's item biases and their Adagrad accumulator keep their pre-scope values; the training of the "
+                        "scope is lost\n");
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     slk_prof_drain(ctx);
@@ -232,7 +236,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("item_long_gate", opt_item_long_gate, 0, 1),
     SLK_OPT("adaptive_late_min_batch", opt_adaptive_late_min_batch, 0, SLK_OPT_MAX),
     SLK_OPT("shuffle_band", opt_shuffle_band, 0, 1024),
-    SLK_OPT("nt", opt_nt, 0, 15),
+    SLK_OPT("nt", opt_nt, 0, 63),
 };
 #undef SLK_OPT
 const slk_opt_desc *slk_find_option(const char *name) {

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 e_item = a.uit[q];
                 e_rating = a.ratings[a.uk[q]];
             }
-            if (on) slk_vstore<VEC>(rec + d0, u);
+            if (on) slk_vstore_if_nt<VEC>(rec + d0, u, (SLK_NT_OF(a) & 16) != 0);
             if (!PRE) {
                 uint32_t ip, in;
                 if (LAT && q == p) {
@@ -1069,6 +1069,12 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                           optim->kind == SLK_OPT_ADAGRAD && ctx->shadow_src_s == optim->d_state1[3];
     if (ctx->shadow_active && !shadowed && ctx->shadow_src_p == tables->d_param[3])
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: the item biases are shadowed (slk_bias_shadow_begin) for another optimizer state");
+    // One scope per ctx, and the scope is a TRAINING scope of ONE model (ABI 11): a training call on other tables while it is
+    // open is a caller that has lost track of the scope -- refused, not trained beside it (the scope's _end would otherwise
+    // write through pointers whose owner may have moved on).  slk_bilinear_reserve allocates only and stays allowed.
+    if (ctx->shadow_active && !shadowed && !reserve_only)
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: an item-bias shadow (slk_bias_shadow_begin) is open on this ctx for OTHER "
+                                         "tables; close it (slk_bias_shadow_end / _abort) before training another model");
     if (shadowed && !prefetch_only && !reserve_only) ++ctx->stat_shadowed;
     bool epoch_route = !shadowed && (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
     auto ensure_dense_buffers = [&]() -> int {
@@ -1532,9 +1538,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         // "overlap_prep" 1, the earlier readers of pf_neg (the sorts of the running call's later chunks) live on the prep stream
         // itself.  Only with "overlap_prep" 2 do sorts that read pf_neg run on the caller's stream: then, and only then, the
         // new draw waits for that stream's tail.
-        if (ctx->opt_overlap_prep != 1 || ctx->opt_prefetch_wait) {
+        //  That holds for a ctx whose last training call was a pipelined one.  After an IN-LINE call (one buffer
+        // set, "overlap_prep" 0 / 2: sampler, sorts and buffer set 0 were used on the caller's stream -- ctx->last_pipe_set < 0)
+        // the new draw waits for that stream's tail; after an in-line slk_sample_items it waits for that draw's own event.
+        if (ctx->opt_overlap_prep != 1 || ctx->opt_prefetch_wait || ctx->last_pipe_set < 0) {
             SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));
             SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+        } else if (ctx->sampled_valid && ctx->ev_sampled) {
+            SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_sampled, 0));  // (recorded on the prep stream itself in the steady state: free)
         }
         SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set], 0));
         // The negatives of the WHOLE call in one draw (it is one contiguous draw however the call is chunked): the stream
@@ -1663,14 +1674,27 @@ SLK_EXPORT int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, con
 
 SLK_EXPORT int slk_bias_shadow_end(slk_ctx *ctx, void *stream) {
     if (!ctx) return SLK_EINVAL;
-    SLK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->shadow_active) return SLK_OK;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bias_shadow_unpack, dim3(slk_grid_for(ctx, (size_t)ctx->shadow_rows, 256)), dim3(256), 0, s,
-                       (const float2 *)ctx->bias_shadow.p, ctx->shadow_src_p, ctx->shadow_src_s, (size_t)ctx->shadow_rows);
-    SLK_LAUNCH_CHECK(ctx, "k_bias_shadow_unpack");
+    // Whatever happens below the scope is CLOSED when this call returns (an error return used to leave it open and
+    // every later _begin / predict on that ctx refused); on an error the caller's arrays hold what they held at _begin.
+    float *const dst_p = ctx->shadow_src_p, *const dst_s = ctx->shadow_src_s;
+    const int64_t rows = ctx->shadow_rows;
     ctx->shadow_active = false;
     ctx->shadow_src_p = ctx->shadow_src_s = nullptr;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bias_shadow_unpack, dim3(slk_grid_for(ctx, (size_t)rows, 256)), dim3(256), 0, s,
+                       (const float2 *)ctx->bias_shadow.p, dst_p, dst_s, (size_t)rows);
+    SLK_LAUNCH_CHECK(ctx, "k_bias_shadow_unpack");
     ctx->last_stream = s;
+    return SLK_OK;
+}
+
+// Closes the scope WITHOUT writing back (ABI 11): for a caller whose bias / accumulator arrays no longer exist (the model was
+// deleted inside the scope).  What the scope trained is lost; the arrays -- if they still exist -- keep their _begin values.
+SLK_EXPORT int slk_bias_shadow_abort(slk_ctx *ctx) {
+    if (!ctx) return SLK_EINVAL;
+    ctx->shadow_active = false;
+    ctx->shadow_src_p = ctx->shadow_src_s = nullptr;
     return SLK_OK;
 }

@@ -172,7 +172,9 @@ struct slk_ctx {
     hipEvent_t ev_coef[2] = {nullptr, nullptr};
     int coef_flip = 0;
     int opt_nt = 3;                // cache policy: bit 0 user rows + state, bit 1 item rows + state non-temporal
-                                   // (streamed once per pass); bit 3 key/payload streams (no gain measured)
+                                   // (streamed once per pass); bit 3 key/payload streams (no gain measured); bit 4 the user
+                                   // pass's record stores, bit 5 the item pass's record loads (round 6: the Infinity-Cache A/B,
+                                   // profiles/r06_mall_ab.*)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
     bool prep_warmed = false;           // the one-off tiny prep on the prep stream has run (slk_bilinear_reserve)
@@ -186,6 +188,7 @@ struct slk_ctx {
     int64_t sh_n = 0;
     int sh_M = 0, sh_S = 0, sh_world = 0;
     int sh_NP = 2;                  // lookups per interaction of the staged chunk: 2 (pointwise / bpr / hinge), 1 + n_neg (adaptive hinge)
+    bool sh_adaptive = false;       // the staged chunk was begun by slk_shard_chunk_begin_adaptive (its item lists live in SH_UIT / SH_GPOS)
     unsigned sh_ubits = 0;
     std::vector<int64_t> sh_ustart, sh_rstart;  // per unit: window in the user-sorted / received arrays
     std::vector<int64_t> sh_sslots, sh_rslots;  // per unit: slots of its requester-side buffers / first slot of its owner-side region

@@ -840,6 +840,9 @@ static unsigned epoch_grid(slk_ctx *ctx, const slk_tables *tables, const slk_opt
         if (resident < cap) cap = resident;  // 0: the kernel cannot be resident at all -> the caller takes the launch path
     } else {
         (void)hipGetLastError();
+        // residency unknown: the lifted cap is not trusted -- back to at most one workgroup per CU, which an idle
+        // gfx950 always holds resident (a grid barrier over workgroups that cannot all run never completes)
+        if (cap > (unsigned)ctx->num_cus) cap = (unsigned)ctx->num_cus;
     }
     if (grid > cap) grid = cap;
     return grid;

@@ -299,7 +299,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
             // several negatives per interaction (adaptive hinge): only the positive and the selected
             // negative carry a gradient, so the row is fetched only when dL/dscore != 0 (a dependent
             // load; with one negative every occurrence is live and both loads are issued at once)
-            const slk_vec<VEC> u = (on && (NP <= 2 || gb != 0.0f)) ? slk_vload<VEC>(rec + d0) : slk_vzero<VEC>();
+            const slk_vec<VEC> u = (on && (NP <= 2 || gb != 0.0f)) ? slk_vload_if_nt<VEC>(rec + d0, (SLK_NT_OF(a) & 32) != 0) : slk_vzero<VEC>();
 #pragma unroll
             for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
         } else {

@@ -468,6 +468,7 @@ static int shard_chunk_begin_impl(slk_ctx *ctx, const slk_tables *local, const s
     ctx->sh_ubits = ubits;
     ctx->sh_n = n;
     ctx->sh_NP = (int)NP;
+    ctx->sh_adaptive = multi;  // (an adaptive chunk with n_neg = 1 also has NP == 2: the flag, not NP, tells the layouts apart)
     if (n > 0) {
         const uint32_t nn = (uint32_t)n, nl = NP * nn;
         if ((rc = slk_ensure(ctx, ctx->neg32, (size_t)nn * nng * 4))) return rc;
@@ -726,7 +727,8 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     if (loss < SLK_LOSS_POINTWISE || loss > SLK_LOSS_HINGE)
         return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: pointwise/bpr/hinge (loss kind %d); adaptive hinge: slk_shard_score_pass, "
                                          "slk_shard_adaptive_select, slk_shard_user_pass_adaptive", loss);
-    if (ctx->sh_NP != 2) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: the staged chunk is an adaptive-hinge one (%d lookups per interaction)", ctx->sh_NP);
+    if (ctx->sh_adaptive || ctx->sh_NP != 2)
+        return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: the staged chunk is an adaptive-hinge one (%d lookups per interaction)", ctx->sh_NP);
     if (global_batch < 1) return slk_fail(ctx, SLK_EINVAL, "global_batch must be >= 1");
     const int64_t p0 = ctx->sh_ustart[unit], n = ctx->sh_ustart[unit + 1] - p0;
     if (!d_loss_out || (n > 0 && (!d_rows_in || !d_grad_out))) return slk_fail(ctx, SLK_EINVAL, "slk_shard_user_pass: NULL pointer");
@@ -785,7 +787,7 @@ static slk_pass_fn shard_user_pass_pre_fn(int upd) {
 static int check_adaptive_unit(slk_ctx *ctx, int32_t unit, const char *who) {
     int rc;
     if ((rc = check_unit(ctx, unit, who))) return rc;
-    if (ctx->sh_NP < 2 || (ctx->sh_n > 0 && !ctx->extra[SH_GPOS].p))
+    if (!ctx->sh_adaptive || ctx->sh_NP < 2 || (ctx->sh_n > 0 && !ctx->extra[SH_GPOS].p))
         return slk_fail(ctx, SLK_EINVAL, "%s: the staged chunk was not begun by slk_shard_chunk_begin_adaptive", who);
     return SLK_OK;
 }

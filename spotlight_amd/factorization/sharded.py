@@ -73,6 +73,12 @@ class ShardedBilinearTrainer(object):
         self._bufs = {}
         self.exchange_rows = 0
         self.last_exchange_rows = 0
+        # MEASURED wire bytes: what this rank handed to the collectives for OTHER ranks since train()
+        # began -- ids + rows it owns + gradient rows it computed, block padding of the exchange slots included -- and the same
+        # without the padding ("payload": remote lookups x (4 + 2 (D + 1) 4) bytes, the figure DESIGN.md section 7 models as
+        # 0.92 KB per interaction at 8 GPUs and D = 64)
+        self.exchange_bytes = 0
+        self.exchange_payload_bytes = 0
         self._check_stream()
 
     def _check_stream(self):
@@ -192,6 +198,14 @@ class ShardedBilinearTrainer(object):
         n_recv = [sum(x) for x in rc_unit]  # floats of its owner-side buffers
         self.last_exchange_rows = NP * n - sc_peer[self.rank]  # lookups that crossed xGMI
         self.exchange_rows += self.last_exchange_rows
+        others = [r for r in range(w) if r != self.rank]
+        # ids out (4 B per remote lookup); per unit: rows this rank OWNS out to their requesters (rc_unit), gradient rows of
+        # this rank's REQUESTS out to their owners (sc_unit) -- the split sizes the all_to_all_single calls below are given
+        self.exchange_bytes += 4 * sum(sc_peer[r] for r in others) + 4 * sum(rc_unit[t][r] + sc_unit[t][r] for t in range(t_n) for r in others)
+        self.exchange_payload_bytes += (4 * sum(sc_peer[r] for r in others) +
+                                        4 * f * sum(rc[r * t_n + t] + sc[r * t_n + t] for t in range(t_n) for r in others))
+        if adaptive and w > 1:
+            self.exchange_bytes += 4 * NP * sum(int(g) for g in global_batches)  # the score matrices' all-reduce (sent once per ring step: a lower bound)
         loss_out = torch.zeros(m_n, dtype=torch.float32, device=self.device)
         # world 1: every lookup's owner is this rank, so an all_to_all_single would be a device-local copy of the whole buffer
         # (rcclGenericKernel: 2 x 0.43 ms per C2 minibatch, profiles/r02_o_*): the requester side reads the owner side's
@@ -272,6 +286,7 @@ class ShardedBilinearTrainer(object):
         if mb_loss is None:
             mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=self.device)
         self.exchange_rows = 0
+        self.exchange_bytes = self.exchange_payload_bytes = 0
         per_chunk = max(1, min(int(sample_chunk), self.max_minibatches_per_chunk()))
         for k0 in range(0, n_mb, per_chunk):
             k1 = min(k0 + per_chunk, n_mb)
@@ -418,6 +433,7 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
             trainer = ShardedBilinearTrainer(engine, tables, ostruct, self._num_items, group=self._group,
                                              stream=stream) if self._trainer is None else self._trainer
             trainer.optim = ostruct
+            trainer.stream = stream  # (a later fit() under another current stream: _check_stream validates the one in use)
             self._trainer = trainer
             mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=device)
             per_chunk = min(8, trainer.max_minibatches_per_chunk())

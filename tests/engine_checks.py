@@ -1579,6 +1579,58 @@ def check_bias_shadow_refusals(be):
     assert np.isfinite(be.get(out)).all()
 
 
+def check_bias_shadow_lifetime_contract(be):
+    """include/spotlight_hip.h, LIFETIME CONTRACT (ABI 11): inside a scope the ctx holds the caller's bias / accumulator pointers.
+    A training call that names the shadowed biases with ANOTHER optimizer-state tensor (swapped inside the scope), or that names
+    other tables altogether, is refused; _end closes the scope and writes back; _abort closes it without writing."""
+    import pytest
+    from spotlight_amd import _native
+    rs = np.random.RandomState(5)
+    U, I, D, N, B = 40, 30, 8, 600, 128
+    params = [rs.normal(0, 0.1, (U, D)), rs.normal(0, 0.1, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+    d_u, d_i = be.alloc(users), be.alloc(items)
+    nmb = (N + B - 1) // B
+    loss = be.alloc(np.zeros(nmb, dtype=np.float32))
+
+    def train(dev, optim=None):
+        be.engine.rng_set_state(np.random.RandomState(9).get_state())
+        be.engine.bilinear_train(dev.tables, optim if optim is not None else dev.optim, be.ptr(d_u), be.ptr(d_i), N, B, 'bpr', 1,
+                                 be.ptr(loss), stream=be.stream)
+
+    dev = be.model(params, opt='adagrad', lr=0.05)
+    other = be.model(params, opt='adagrad', lr=0.05)
+    bias0 = be.get(dev.p[3]).copy()
+    scope = be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream)
+    with scope:
+        train(dev)  # the scope's own model trains
+        # (1) the optimizer state tensor swapped inside the scope (nothing freed): refused, loudly
+        swapped_state = be.alloc(np.zeros(I, dtype=np.float32))
+        s1 = [dev.optim.d_state1[k] for k in range(4)]
+        s1[3] = be.ptr(swapped_state)
+        swapped = _native.make_optim('adagrad', s1, lr=0.05)
+        with pytest.raises(_native.SlkError, match='another optimizer state'):
+            train(dev, swapped)
+        # (2) another model's tables while the scope is open: refused
+        with pytest.raises(_native.SlkError, match='OTHER'):
+            train(other)
+        # ... but allocating its scratch is not training
+        be.engine.bilinear_reserve(other.tables, other.optim, N, B, 'bpr', 1, stream=be.stream)
+        assert np.array_equal(be.get(dev.p[3]), bias0)  # the caller's array is still the stale pre-scope one
+    trained = be.get(dev.p[3]).copy()
+    assert not np.array_equal(trained, bias0)  # _end wrote the scope's training back
+    train(other)  # the ctx is free again
+    # (3) _abort: the scope closes, nothing is written
+    scope = be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream)
+    scope.__enter__()
+    train(dev)
+    scope.abort()
+    assert np.array_equal(be.get(dev.p[3]), trained)
+    with be.engine.bias_shadow(dev.tables, dev.optim, stream=be.stream):  # and a new scope can open
+        pass
+    scope.__exit__(None, None, None)  # (a closed scope's exit is a no-op)
+
+
 # ---------------------------------------------------------------------------------------
 # every engine option is result-neutral (include/spotlight_hip.h: slk_ctx_set_option "tuning knobs that never change results")
 # ---------------------------------------------------------------------------------------
@@ -1590,7 +1642,7 @@ OPTION_VALUES = {
     'seq_variant': (0, 1), 'explicit_fused': (0,), 'epoch_kernel': (0,), 'item_lat_max_tiles': (0, 1 << 30),
     'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
     'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
-    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15),
+    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63),
 }
 OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
 # adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the

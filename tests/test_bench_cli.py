@@ -86,6 +86,21 @@ def test_default_n_gpu_configuration_c5_at_reduced_rows(n):
         assert abs(share - (n - 1) / n) < 0.12, (d, share)
     assert abs(sum(d['exchange_rows_timed_call'] for d in devs) / n / rec['steps'] - rec['roofline']['xgmi']['rows_per_step_per_gpu']) <= \
         max(d['exchange_rows_timed_call'] for d in devs) / rec['steps']
+    # MEASURED wire bytes: what every rank's trainer handed to the collectives for other ranks.  A rank sends
+    # the ids (4 B) and gradient rows ((D + 1) floats) of ITS remote lookups and the rows ((D + 1) floats) of the lookups OTHER
+    # ranks make of it, so over all ranks the payload is EXACTLY remote lookups x (4 + 2 (D + 1) 4) bytes -- the per-lookup figure
+    # behind DESIGN.md section 7's 0.92 KB per interaction (2 lookups x 7/8 remote x 524 B at D = 64); per rank it differs from
+    # the line's model (rank 0's own remote lookups x the same figure) only by the imbalance of the uniform draw.  What left with
+    # the slot padding (whole blocks of 64 slots per peer and unit) is at least the payload.
+    D = 16
+    per_lookup = 4 + 2 * (D + 1) * 4
+    assert sum(d['exchange_payload_bytes_timed_call'] for d in devs) == sum(d['exchange_rows_timed_call'] for d in devs) * per_lookup
+    for d in devs:
+        assert abs(d['exchange_payload_bytes_timed_call'] - d['exchange_rows_timed_call'] * per_lookup) <= 0.1 * d['exchange_payload_bytes_timed_call'], d
+        assert d['exchange_payload_bytes_timed_call'] <= d['exchange_bytes_timed_call']
+    xg = rec['roofline']['xgmi']
+    assert xg['bytes_per_step_per_gpu_each_way'] == xg['rows_per_step_per_gpu'] * per_lookup  # the model: rank 0's remote lookups x the figure
+    assert abs(xg['payload_bytes_per_step_per_gpu_each_way_measured'] - xg['bytes_per_step_per_gpu_each_way']) <= 0.1 * xg['bytes_per_step_per_gpu_each_way']
     den = rec['roofline']['xgmi']['denominators_1_gpu']
     a, b = den['fused']['minibatch_losses'], den['sharded_world1']['minibatch_losses']
     assert len(a) == len(b) == rec['steps'] + rec['warmup'] and all(x > 0 for x in a)

@@ -46,6 +46,10 @@ def test_bias_shadow_refuses_what_it_does_not_cover(be):
     ec.check_bias_shadow_refusals(be)
 
 
+def test_bias_shadow_lifetime_contract(be):
+    ec.check_bias_shadow_lifetime_contract(be)
+
+
 def test_sampler_long_streams(be):
     # the second stream length class (256 state blocks per stream: the jump table of stride 256), forced at a small size; a
     # draw of several groups (the group's last block is the next one's key) by lowering the class's switch below one stream

@@ -44,6 +44,10 @@ def test_bias_shadow_refuses_what_it_does_not_cover(be):
     ec.check_bias_shadow_refusals(be)
 
 
+def test_bias_shadow_lifetime_contract(be):
+    ec.check_bias_shadow_lifetime_contract(be)
+
+
 def test_sampler_long_streams(be):
     # draws of more than 16384 state blocks take 256 blocks per stream (the stride-256 jump table): 12 M and 45 M words (the
     # latter also crosses that class's 40.9 M-word group limit); the class forced at a small size
