@@ -288,6 +288,8 @@ int slk_sort_pairs_u64_u32_in(slk_ctx *ctx, slk_buf &scratch, const uint64_t *ki
                               uint32_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
 int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, const uint64_t *vin,
                            uint64_t *vout, size_t n, unsigned end_bit, hipStream_t s, bool clobber = false);
+int slk_sort_fy_steps(slk_ctx *ctx, slk_buf &scratch, const uint32_t *J, uint32_t n, uint32_t *const key[2], uint32_t *const val[2],
+                      hipStream_t s);
 int slk_sort_pairs_any(slk_ctx *ctx, int kind, const void *kin, void *kout, const void *vin, void *vout, size_t n, size_t seg_len,
                        unsigned bits, hipStream_t s, bool clobber);
 // the training prep's sorts: keys built by the first pass from the id arrays, one segment per minibatch of `bsz` interactions;

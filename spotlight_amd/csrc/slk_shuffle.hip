@@ -455,15 +455,6 @@ __global__ __launch_bounds__(64) void k_fy_tail(const uint32_t *raw, unsigned lo
     if (lane == 0) *consumed = starved ? 0xffffffffu : (uint32_t)(w - w0);
 }
 
-// step g (i = n-1-g) writes position j: key = j, value = i; self-swaps get the sentinel key n
-__global__ __launch_bounds__(256) void k_fy_keys(const uint32_t *J, uint32_t n, uint32_t *key, uint32_t *val) {
-    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g + 1 < n; g += gridDim.x * 256) {
-        const uint32_t i = n - 1 - g, j = J[g];
-        key[g] = (j == i) ? n : j;
-        val[g] = i;
-    }
-}
-
 __global__ __launch_bounds__(256) void k_fy_iota(uint32_t *R, uint32_t n) {
     for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) R[p] = p;
 }
@@ -478,34 +469,32 @@ __global__ __launch_bounds__(256) void k_fy_pred(const uint32_t *key, const uint
 }
 
 // X[p] = the value standing at p when step p runs = the end of the chain p -> R[p] -> R[R[p]] -> ...
-// (R[q] > q unless q is terminal, R[q] == q).  The chains are short (a position is the target of
-// ln(n/p) later steps on average and the chain hops to ever larger indices), so every position
-// simply walks its own: one pass instead of log-many pointer-doubling rounds over all n.
-__global__ __launch_bounds__(256) void k_fy_resolve(const uint32_t *R, uint32_t *X, uint32_t n) {
-    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        uint32_t r = R[p];
-        if (r != p) {
-            uint32_t nx = R[r];
-            while (nx != r) {
-                r = nx;
-                nx = R[r];
-            }
-        }
-        X[p] = r;
+// (R[q] > q unless q is terminal, R[q] == q).  The chains are short (a position is the target of ln(n/p) later steps on average
+// and the chain hops to ever larger indices), so whoever needs X[p] simply walks p's chain.
+// Round 6: walked ON DEMAND by k_fy_final.  Rounds 1-5 resolved every position into an array X first (k_fy_resolve: n walks of
+// ~2 random reads each + 8 n bytes of streaming) and k_fy_final then read X[.] at random once more; but X is only needed for
+// the steps that are not the FIRST writer of their target -- about half of them (a position p is never written with
+// probability (p + 1) / n) -- so the fused form makes ~n random reads instead of ~2.5 n.
+__device__ __forceinline__ uint32_t fy_walk(const uint32_t *R, uint32_t p) {
+    uint32_t r = R[p];
+    while (r != p) {
+        p = r;
+        r = R[p];
     }
+    return p;
 }
 
 __global__ __launch_bounds__(256) void k_fy_final(const uint32_t *key, const uint32_t *val, uint32_t m, uint32_t n,
-                                                  const uint32_t *X, int64_t *perm) {
+                                                  const uint32_t *R, int64_t *perm) {
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < m; e += gridDim.x * 256) {
         const uint32_t k = key[e], i = val[e];
         uint32_t out;
-        if (k == n) out = X[i];                                  // swap with itself
+        if (k == n) out = fy_walk(R, i);                         // swap with itself: what stands at i when step i runs
         else if (e == 0 || key[e - 1] != k) out = k;             // first writer of p takes p's own value
-        else out = X[val[e - 1]];                                // ... the next one what the previous moved in
+        else out = fy_walk(R, val[e - 1]);                       // ... the next one what the previous moved in
         perm[i] = (int64_t)out;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) perm[0] = (int64_t)X[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) perm[0] = (int64_t)fy_walk(R, 0u);
 }
 
 __global__ __launch_bounds__(256) void k_fy_rng_finalize(slk_rng_dev *st, const uint32_t *raw, unsigned long long t_last) {
@@ -730,21 +719,19 @@ SLK_EXPORT int slk_shuffle_perm(slk_ctx *ctx, int64_t n, int64_t *d_perm_out, vo
     const uint32_t m = N - 1;
     uint32_t *key0 = (uint32_t *)ctx->extra[FY_B1].p, *val0 = (uint32_t *)ctx->extra[FY_B2].p;
     uint32_t *key1 = (uint32_t *)ctx->extra[FY_B3].p, *val1 = (uint32_t *)ctx->extra[FY_B4].p;
-    hipLaunchKernelGGL(k_fy_keys, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)J, N, key0, val0);
-    SLK_LAUNCH_CHECK(ctx, "k_fy_keys");
+    // (target position, step) pairs sorted by target, stable; the sort's first pass forms them from the draws (k_fy_keys is gone)
     // own temporary storage: the shuffle may be prepared on another stream than the training passes
-    if ((rc = slk_sort_pairs_u32_u32_in(ctx, ctx->extra[FY_SORT], key0, key1, val0, val1, m, slk_bits_for((uint64_t)N), s, true)))
-        return rc;
-    uint32_t *R[2] = {key0, val0};  // the sort's inputs are free again
-    hipLaunchKernelGGL(k_fy_iota, dim3(fy_grid(ctx, N)), dim3(256), 0, s, R[0], N);
+    {
+        uint32_t *const keys[2] = {key0, key1}, *const vals[2] = {val0, val1};
+        if ((rc = slk_sort_fy_steps(ctx, ctx->extra[FY_SORT], (const uint32_t *)J, N, keys, vals, s))) return rc;
+    }
+    uint32_t *R = key0;  // the sort's inputs are free again
+    hipLaunchKernelGGL(k_fy_iota, dim3(fy_grid(ctx, N)), dim3(256), 0, s, R, N);
     hipLaunchKernelGGL(k_fy_pred, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
-                       m, N, R[0]);
+                       m, N, R);
     SLK_LAUNCH_CHECK(ctx, "k_fy_pred");
-    hipLaunchKernelGGL(k_fy_resolve, dim3(fy_grid(ctx, N)), dim3(256), 0, s, (const uint32_t *)R[0], R[1], N);
-    SLK_LAUNCH_CHECK(ctx, "k_fy_resolve");
-    const int cur = 1;
     hipLaunchKernelGGL(k_fy_final, dim3(fy_grid(ctx, m)), dim3(256), 0, s, (const uint32_t *)key1, (const uint32_t *)val1,
-                       m, N, (const uint32_t *)R[cur], d_perm_out);
+                       m, N, (const uint32_t *)R, d_perm_out);
     SLK_LAUNCH_CHECK(ctx, "k_fy_final");
     slk_prof_end(ctx, s);
     return SLK_OK;

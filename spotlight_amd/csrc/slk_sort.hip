@@ -33,7 +33,7 @@ constexpr int RS_HIST_KEYS = 8192;        // keys per histogram workgroup
 constexpr int RS_LBW = 16;                // look-back: status words in flight per digit and round trip
 constexpr uint32_t RS_MAX_SPINS = 1u << 22;  // x (s_sleep + one fabric round trip): seconds; then the sort gives up (sticky flag)
 
-enum { RS_LOAD_PLAIN = 0, RS_LOAD_USER_FAT, RS_LOAD_USER_IDX, RS_LOAD_ITEM_OCC };
+enum { RS_LOAD_PLAIN = 0, RS_LOAD_USER_FAT, RS_LOAD_USER_IDX, RS_LOAD_ITEM_OCC, RS_LOAD_FY_STEPS };
 
 struct rs_args {
     const void *kin, *vin;
@@ -44,6 +44,7 @@ struct rs_args {
     uint32_t n, seg_len, tps, ntiles, hbps;  // pairs, pairs per segment, tiles / histogram workgroups per segment
     uint32_t kseg;                           // fused keys of an UNSEGMENTED sort: pairs per minibatch (0: the segment is the minibatch)
     unsigned idbits;                         // fused keys: (minibatch << idbits) | id
+    uint32_t fy_n;                           // RS_LOAD_FY_STEPS: elements of the shuffle (slk_shuffle.hip)
     int npass, pass;
     int shift[RS_MAX_PASS], width[RS_MAX_PASS];
     uint32_t *hist, *base;   // [segment][pass][RS_RADIX]: digit counts / first output position of the bucket
@@ -63,6 +64,14 @@ __device__ __forceinline__ uint32_t rs_digit(KeyT k, int shift, uint32_t mask) {
 // element gi of the sort's input: (key, payload)
 template <class KeyT, class ValT, int LOADER>
 __device__ __forceinline__ void rs_load(const rs_args &a, uint32_t gi, uint32_t seg, KeyT &k, ValT &v) {
+    if (LOADER == RS_LOAD_FY_STEPS) {
+        // the epoch shuffle's swaps (slk_shuffle.hip): step g (i = n - 1 - g) writes position j = J[g]: key = j, value = i;
+        // a step that swaps with itself gets the sentinel key n
+        const uint32_t i = a.fy_n - 1u - gi, j = a.uit[gi];
+        k = (KeyT)(j == i ? a.fy_n : j);
+        v = (ValT)i;
+        return;
+    }
     if (LOADER != RS_LOAD_PLAIN && a.kseg) seg = gi / a.kseg;
     if (LOADER == RS_LOAD_PLAIN) {
         k = ((const KeyT *)a.kin)[gi];
@@ -84,6 +93,10 @@ __device__ __forceinline__ void rs_load(const rs_args &a, uint32_t gi, uint32_t 
 template <class KeyT, int LOADER>
 __device__ __forceinline__ KeyT rs_load_key(const rs_args &a, uint32_t gi, uint32_t seg) {
     if (LOADER == RS_LOAD_PLAIN) return ((const KeyT *)a.kin)[gi];
+    if (LOADER == RS_LOAD_FY_STEPS) {
+        const uint32_t j = a.uit[gi];
+        return (KeyT)(j == a.fy_n - 1u - gi ? a.fy_n : j);
+    }
     if (a.kseg) seg = gi / a.kseg;
     if (LOADER == RS_LOAD_ITEM_OCC) return (KeyT)((seg << a.idbits) | a.uit[gi]);
     return (KeyT)((seg << a.idbits) | (uint32_t)a.users[gi]);
@@ -582,6 +595,20 @@ int slk_sort_pairs_u32_u64(slk_ctx *ctx, const uint32_t *kin, uint32_t *kout, co
     a.vout = vout;
     return rs_sort<uint32_t, uint64_t, RS_LOAD_PLAIN>(ctx, ctx->sort_tmp, a, n, 0, end_bit, clobber ? (void *)kin : nullptr,
                                                       clobber ? (void *)vin : nullptr, s);
+}
+
+// The epoch shuffle's (target position, step) pairs, formed by the first pass from the draws J[0 .. n - 2] themselves (rounds
+// 1-5: a kernel wrote both arrays first) and sorted by target position, stable: result in (key[1], val[1]), (key[0], val[0]) is
+// the second buffer pair.  `scratch`: the shuffle's own sort scratch (it may run on another stream than the training sorts).
+int slk_sort_fy_steps(slk_ctx *ctx, slk_buf &scratch, const uint32_t *J, uint32_t n, uint32_t *const key[2], uint32_t *const val[2],
+                      hipStream_t s) {
+    rs_args a;
+    memset(&a, 0, sizeof(a));
+    a.uit = J;
+    a.fy_n = n;
+    a.kout = key[1];
+    a.vout = val[1];
+    return rs_sort<uint32_t, uint32_t, RS_LOAD_FY_STEPS>(ctx, scratch, a, (size_t)n - 1, 0, slk_bits_for((uint64_t)n), key[0], val[0], s);
 }
 
 // measurement / test entry (slk_probe.hip): kind 0 = u32 keys + u32 payloads, 1 = u32 + u64, 2 = u64 + u32; seg_len > 0 sorts

@@ -9,10 +9,12 @@ import numpy as np
 from oracle.oracle import BilinearOracle, Rng
 from oracle.replay import ORACLE_OPT, oracle_hparams
 
-# open-loop drift bounds (assert_open_loop_drift): relative 2-norm.  Measured over the 45 recordings (emulator build): embedding
-# tables <= 6.5e-4, bias tables (a few hundred elements, where one sign-flipped first step shows) <= 6.7e-2
+# open-loop drift bounds (assert_open_loop_drift): relative 2-NORM bounds, a coarse "no wrong update rule, no missed row" statement --
+# NOT the parity pin (that is the closed loop: check_train_closed_loop / check_replays_reference_fixture, per element under
+# step_update_bounds).  Measured over the 45 recordings (emulator build): embedding tables <= 6.5e-4, bias tables (a few hundred
+# elements, where one sign-flipped first step shows) <= 6.7e-2
 OPEN_LOOP_DRIFT_ROWS = 5e-3
-OPEN_LOOP_DRIFT_BIAS = 0.2
+OPEN_LOOP_DRIFT_BIAS = 0.2  # (20 % of the bias table's norm: coarse by design, see above)
 
 
 def rel_inf(a, b):
@@ -131,6 +133,18 @@ def check_train_matches_oracle(be, loss, opt, D, U=37, I=29, N=150, B=64, nn=3, 
         else:
             assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-5
     assert dev.optim.step == ora.step_count == epochs * n_mb
+    if degenerate:
+        #  the open-loop tables of such a run are noise-dominated and are not compared; the UPDATE is pinned
+        # the closed-loop way instead: the same run one minibatch per call, before every minibatch the engine's tables go to the
+        # oracle, which takes that one step -- loss within 1e-5, every element of every table and state tensor within
+        # step_update_bounds, and the one-call run above must equal the per-minibatch run bit for bit
+        # (a row's gradient here is a sum of hundreds of cancelling +g / -g terms: the fp32 summation order alone moves it by
+        # percents of its own size, so the gradient allowance carried through the update formulas is the 5e-2 of the loss
+        # statement above, not 1e-5 -- still a per-element statement on every table and state tensor: a missed row, a wrong
+        # update rule or a double-applied gradient is far outside it.  The exact (float64) gradients of such rows are pinned by
+        # check_long_run_gradients_against_exact.)
+        check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=nn, epochs=epochs, seed=seed, open_loss_tol=5e-2, open_drift_bound=None,
+                                grad_rel_delta=5e-2, grad_abs_delta=2.0 ** -22)  # (+ 2 ulp of a sum whose terms add up to <= 1 in magnitude)
     for t in range(0 if degenerate else 4):
         assert_close_table(be.get(dev.p[t]), ora.p[t], tol, ('param', t))
         assert_close_table(be.get(dev.s1[t]), ora.s1[t], tol, ('state1', t))
@@ -289,7 +303,7 @@ def check_long_user_run_gradients_against_exact(be, loss, D, U, I, B, seed=12, t
     return ours, theirs
 
 
-def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, bias_tables=(2, 3)):
+def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, bias_tables=(2, 3), abs_delta=0.0):
     """Per element: how far ONE optimizer step may move a parameter / its state when the summed gradient is perturbed by
     delta = rel_delta * ||g||inf (per embedding table, the bias tables against their joint norm; touched rows only) --
     the north star's gradient tolerance carried through the update formulas:
@@ -306,7 +320,9 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, 
         gt = np.asarray(g[t], np.float64)
         scale = bscale if t in bias_tables else np.abs(gt).max()
         touched = (gt != 0).any(axis=1, keepdims=True) if gt.ndim == 2 else (gt != 0)
-        delta = np.broadcast_to(rel_delta * scale * touched, gt.shape)
+        # abs_delta (degenerate runs only): an absolute floor of the gradient perturbation -- the fp32 rounding of a sum of
+        # hundreds of cancelling terms does not scale with the (arbitrarily small) sum
+        delta = np.broadcast_to((rel_delta * scale + abs_delta) * touched, gt.shape)
         geff = gt + wd * np.asarray(pre_p[t], np.float64).reshape(gt.shape) if opt.endswith('dense') else gt
         if opt == 'sgd':  # p -= lr * g: a gradient perturbation moves the parameter by lr * delta, there is no state
             dp, ds1, ds2 = lr * delta, np.zeros_like(gt), np.zeros_like(gt)
@@ -322,10 +338,10 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, 
     return out
 
 
-def assert_step_within_bounds(be, dev, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, bias_tables=(2, 3), what=''):
+def assert_step_within_bounds(be, dev, ora, pre_p, pre_s1, pre_s2, g, step, opt, hp, bias_tables=(2, 3), what='', rel_delta=1e-5, abs_delta=0.0):
     """After ONE engine step and ONE oracle step from the same tables / state: every element of every parameter and
     optimizer-state tensor within 1e-5 * ||.||inf + step_update_bounds (no quota)."""
-    bounds = step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, bias_tables=bias_tables)
+    bounds = step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=rel_delta, bias_tables=bias_tables, abs_delta=abs_delta)
     adam = opt in ('sparse_adam', 'adam_dense')
     for t in range(len(g)):
         dp, ds1, ds2 = bounds[t]
@@ -340,7 +356,8 @@ def assert_step_within_bounds(be, dev, ora, pre_p, pre_s1, pre_s2, g, step, opt,
                                          % (what, step, t, nm, int((d > tol).sum())), float(d.max()))
 
 
-def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5):
+def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5, open_loss_tol=1e-3, open_drift_bound=0.25,
+                            grad_rel_delta=1e-5, grad_abs_delta=0.0):
     """Multi-minibatch training against the oracle WITHOUT an outlier allowance: one engine call over the whole run (open
     loop: negatives and RNG state bit-exact against the host stream, the first minibatch's loss within 1e-5, later losses
     within 1e-3 -- from zero accumulators a trajectory is chaotic element by element, see check_replays_reference_fixture),
@@ -376,15 +393,15 @@ def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5
         got_loss = be.get(mb_loss)
         if epoch == 0:
             assert abs(got_loss[0] - want_loss[0]) <= 1e-5 * abs(want_loss[0])
-        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < 1e-3
+        assert np.abs(got_loss - want_loss).max() / np.abs(want_loss).max() < open_loss_tol
     got, ref = eng.rng_get_state(), orng.get_state()
     assert (got[1] == ref[1]).all() and got[2] == ref[2]
     open_tables = [be.get(x).copy() for x in dev.p + dev.s1 + dev.s2]
-    for t in range(4):
+    for t in range(4 if open_drift_bound is not None else 0):
         # coarse sanity only (a wrong update rule or a missed row shows; the element-wise statement is the closed loop below):
         # random data from zero accumulators at lr 0.05 drifts further than the recordings the default bounds were measured on --
         # adaptive hinge's arg-max flips on 1-ulp score differences, a handful of users collect every gradient
-        assert_open_loop_drift(open_tables[t], ora.p[t], ('closed-loop check, open-loop run', t), bound=0.25)
+        assert_open_loop_drift(open_tables[t], ora.p[t], ('closed-loop check, open-loop run', t), bound=open_drift_bound)
     # ---- closed loop
     dev2 = be.model(params, opt=opt, **hp)
     step = 0
@@ -404,7 +421,8 @@ def check_train_closed_loop(be, loss, opt, D, U, I, N, B, nn=3, epochs=1, seed=5
                                d_neg_in=be.ptr(d_neg), stream=be.stream)
             assert dev2.optim.step == step
             assert abs(float(be.get(mb_loss)[0]) - want_loss) <= 1e-5 * abs(want_loss), (epoch, off)
-            assert_step_within_bounds(be, dev2, o1, pre_p, pre_s1, pre_s2, g, step, opt, hp, what='%s/%s' % (loss, opt))
+            assert_step_within_bounds(be, dev2, o1, pre_p, pre_s1, pre_s2, g, step, opt, hp, what='%s/%s' % (loss, opt), rel_delta=grad_rel_delta,
+                                      abs_delta=grad_abs_delta)
     for k, x in enumerate(dev2.p + dev2.s1 + dev2.s2):
         assert np.array_equal(be.get(x), open_tables[k]), ('closed-loop run differs from the open-loop one', k)
 
