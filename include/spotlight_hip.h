@@ -129,7 +129,11 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *   "chunk_interactions"  interactions per prep chunk (default 2^23)
  *   "overlap_prep"        1: the negatives + sorts of chunk c+1 run on a second HIP stream while chunk c trains (what this
  *                         package's fit() sets for its epochs: +1.5..4 % in the steady state of a run of training calls);
- *                         2: only the negatives; 0 (default of a bare ctx): everything in order on the caller's stream
+ *                         2: only the negatives; 0 (default of a bare ctx): everything on the caller's stream -- since ABI 11
+ *                         chunk c+1's negatives + sorts are ENQUEUED before chunk c's passes (two buffer sets, one stream: the
+ *                         host's one wait per chunk falls while the GPU prepares the next chunk), and the negatives of a call
+ *                         of several chunks are ONE draw in front of the first chunk (fewer than 2^30 draws; it is one
+ *                         contiguous draw of the stream however the call is chunked)
  *   "overlap_min_batch"   the prep overlaps the passes only for minibatches of at least this size (default 2^16)
  *   "prefetch_wait"       measurement switch: 1 = slk_bilinear_prefetch's chunk waits for everything `stream` holds, as it did up
  *                         to ABI 8 (default 0: it runs beside the passes `stream` still holds)
@@ -165,7 +169,10 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         measurement switch: several one-wave workgroups per CU, profiles/r05_b_persistent_kernel_wide_grid_*)
  *   "nt", "seq_variant"   cache-policy bits of the passes (non-temporal accesses: 1 user rows + state, 2 item rows + state, 8 key /
  *                         payload streams, 16 the user pass's record stores, 32 the item pass's record loads; default 3);
- *                         PoolNet sequence-pass variant */
+ *                         PoolNet sequence-pass variant
+ *   "record_nt_min_bytes" slk_bilinear_train: a minibatch whose pre-step user-row records take at least this many bytes (default
+ *                         192 MB: they would fill the 256 MB Infinity Cache) stores them non-temporally, as "nt" bit 16 does for
+ *                         every size; 0: never (profiles/r06_mall_ab.jsonl) */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --
  * a ctx is shared by every model of a process on its device (spotlight_amd/_native.py: `with engine.options(...)`). */

@@ -38,19 +38,39 @@ def main():
     torch.cuda.synchronize()
     eng = host._engine_for(torch.device('cuda', torch.cuda.current_device()))
     base_fit = dict(host._FIT_OPTIONS)
+    real_shuffle = host.device_epoch_shuffle
     out_f = open(args.out, 'a') if args.out else None
     configs = list(args.configs)
     configs = configs + configs[:1]
     for label in configs:
         ctx_opts, fit_opts = {}, dict(base_fit)
+        dbg_shuffle = 0
         for kv in filter(None, label.split(',')):
             k, v = kv.rsplit("=", 1)
             if k.startswith('fit:') or k.startswith('fit.'):  # ('fit.': scripts/gpu_run.sh splits its stage arguments at ':')
                 fit_opts[k[4:]] = int(v)
+            elif k == 'dbg.shuffle':
+                # MEASUREMENT ONLY (results are not the reference's): 1 = the epoch permutation is the identity, written by one
+                # streaming kernel -- what an epoch costs WITHOUT the numpy-exact shuffle's work beside its passes (the id gathers
+                # still run); 0 = the real shuffle
+                dbg_shuffle = int(v)
             else:
                 ctx_opts[k] = int(v)
         host._FIT_OPTIONS.clear()
         host._FIT_OPTIONS.update(fit_opts)
+        if dbg_shuffle:
+            def identity_shuffle(engine, random_state, n_, d_perm, arrays, stream):
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                    torch.arange(n_, out=d_perm)
+                real_perm = engine.shuffle_perm
+                engine.shuffle_perm = lambda *a, **k: None
+                try:
+                    real_shuffle(engine, random_state, n_, d_perm, arrays, stream)
+                finally:
+                    engine.shuffle_perm = real_perm
+            host.device_epoch_shuffle = identity_shuffle
+        else:
+            host.device_epoch_shuffle = real_shuffle
         with eng.options(**ctx_opts):
             times, steady = [], []
             for _ in range(args.repeat):
@@ -75,6 +95,7 @@ def main():
             out_f.flush()
     host._FIT_OPTIONS.clear()
     host._FIT_OPTIONS.update(base_fit)
+    host.device_epoch_shuffle = real_shuffle
 
 
 if __name__ == '__main__':

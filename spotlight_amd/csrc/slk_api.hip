@@ -168,7 +168,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->mt_tmp, &ctx->bias_shadow};
+                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->call_neg, &ctx->mt_tmp, &ctx->bias_shadow};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -237,6 +237,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("adaptive_late_min_batch", opt_adaptive_late_min_batch, 0, SLK_OPT_MAX),
     SLK_OPT("shuffle_band", opt_shuffle_band, 0, 1024),
     SLK_OPT("nt", opt_nt, 0, 63),
+    SLK_OPT("record_nt_min_bytes", opt_record_nt_min_bytes, 0, SLK_OPT_MAX),
 };
 #undef SLK_OPT
 const slk_opt_desc *slk_find_option(const char *name) {

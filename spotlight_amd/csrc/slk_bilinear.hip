@@ -1012,7 +1012,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         cb.push_back(next < n ? next : n);
     }
     const size_t n_chunks = cb.size() - 1;
-    const int nsets = (ctx->opt_overlap_prep && n_chunks > 1 && bsz >= ctx->opt_overlap_min_batch) ? 2 : 1;
+    // Two buffer sets whenever a call has more than one chunk: chunk c + 1 is prepared (negatives, sorts) BEFORE chunk c's passes are
+    // enqueued.  `side`: that preparation goes to the ctx's second stream and runs BESIDE the passes (option "overlap_prep", what
+    // fit() sets).  Otherwise (a bare ctx; round 6) it goes to the caller's own stream, one chunk ahead: still one stream, every
+    // kernel alone on the GPU -- but the host's one wait per chunk (the long-run flags of do_sort) now falls while the GPU works on
+    // the next chunk's prep instead of idling (a bubble of ~40 us per chunk of 8 minibatches in rounds 1-5).
+    const bool side = ctx->opt_overlap_prep && n_chunks > 1 && bsz >= ctx->opt_overlap_min_batch;
+    const int nsets = n_chunks > 1 ? 2 : 1;
     for (int st = 0; st < nsets; ++st) {
         slk_prep_bufs &pb = ctx->pb[st];
         if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;
@@ -1086,7 +1092,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (dense && !epoch_route && (rc = ensure_dense_buffers())) return rc;
 
     if (reserve_only) {
-        if (nsets == 2 && (rc = slk_prep_stream_init(ctx))) return rc;
+        if (side && (rc = slk_prep_stream_init(ctx))) return rc;
         // the pinned read-back buffers and events of the long-run flags, per buffer set: hipHostMalloc inside a training call
         // costs a device synchronisation (measured: the first overlapped call of a process 0.85 instead of 0.745 ms per step)
         for (int st = 0; st < nsets; ++st) {
@@ -1095,7 +1101,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             pb.h_lflags_n = 0;
             if (!pb.ev_lflags) SLK_HIP(ctx, hipEventCreateWithFlags(&pb.ev_lflags, hipEventDisableTiming));
         }
-        if (nsets == 2 && !ctx->prep_warmed && nn > 0 && nc_max >= 4096) {
+        if (side && !ctx->prep_warmed && nn > 0 && nc_max >= 4096) {
             // One tiny prep on the prep stream, ordered against the caller's stream by the pipeline's own events: whatever the
             // runtime sets up the first time these kernels (sampler, sorts) run on a stream and the first time two
             // streams wait for each other's events then happens here and not inside the first overlapped training call
@@ -1130,8 +1136,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             ctx->prep_warmed = true;
         }
         if (epoch_route && (rc = slk_epoch_reserve(ctx, tables, optim, (uint32_t)((nc_max + bsz - 1) / bsz), bsz, (int)loss, NP))) return rc;
-        // sampler and sort scratch for the largest chunk, so that the training call allocates nothing
-        if ((rc = slk_sample_reserve(ctx, tables->num_items, (int64_t)nc_max * nn))) return rc;
+        // sampler and sort scratch for the largest chunk (the whole call when its negatives are one draw), so that the training
+        // call allocates nothing
+        const bool all_r = nn > 0 && n_chunks > 1 && (uint64_t)n * (uint64_t)nn < ((uint64_t)1 << 30);
+        if (all_r && (rc = slk_ensure(ctx, ctx->call_neg, (size_t)n * nn * 4))) return rc;
+        if ((rc = slk_sample_reserve(ctx, tables->num_items, all_r ? n * (int64_t)nn : (int64_t)nc_max * nn))) return rc;
         return slk_sort_reserve(ctx, nc_max * (size_t)occ_mult);
     }
 
@@ -1341,10 +1350,16 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
             a.nt = ctx->opt_nt;
+            // Round 6 (profiles/r06_mall_ab.jsonl): a minibatch whose records are as large as the Infinity Cache (2^20 x 256 B
+            // = 256 MB) cannot keep them there until the item pass reads them -- written with plain stores they only evict the
+            // item table, which the user pass re-reads twice per interaction.  Non-temporal record stores: C2 step -0.9 %
+            // (item pass 0.3165 -> 0.3122 ms), C5 shard -0.2 %; a minibatch of 65 536 (16 MB of records: they DO stay) +4 %, so
+            // only above "record_nt_min_bytes".
+            if (ctx->opt_record_nt_min_bytes > 0 && (int64_t)bm * RS * 4 >= ctx->opt_record_nt_min_bytes) a.nt |= 16;
             // overlapped prep: the user pass is a grid-stride kernel whose workgroups hold their wave slots for the whole run; two
             // of the eight per CU are left to the prep stream's kernels (measured, profiles/r03_a_*: 8 -> 6 costs the pass
             // nothing by itself and gives the overlap 2 % more)
-            const int ugm = nsets == 2 && ctx->opt_user_grid_mult > 6 ? 6 : ctx->opt_user_grid_mult;
+            const int ugm = side && ctx->opt_user_grid_mult > 6 ? 6 : ctx->opt_user_grid_mult;
             const unsigned ugrid = slk_grid_for(ctx, bm, gpb, ugm < occ_user ? ugm : occ_user);
 
             if (expl && ctx->opt_explicit_fused) {
@@ -1517,7 +1532,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // the chunk instead of refusing; fit() of another model after one that left its loop by an exception)
     if (!prefetch_only && ctx->pf.valid && (d_neg_in || expl)) ctx->pf.valid = false;
     const bool have0 = !prefetch_only && ctx->pf.valid;
-    if (have0 && (nsets != 2 || epoch_route || ctx->pf.users != (const void *)d_users || ctx->pf.items != (const void *)d_items ||
+    if (have0 && (!side || epoch_route || ctx->pf.users != (const void *)d_users || ctx->pf.items != (const void *)d_items ||
                   ctx->pf.n != n || ctx->pf.bsz != bsz || ctx->pf.loss != (int)loss || ctx->pf.nn != nn || ctx->pf.nc0 != cb[1] || d_neg_in)) {
         ctx->pf.valid = false;
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: a chunk was prepared ahead (slk_bilinear_prefetch) for another call; its "
@@ -1526,7 +1541,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (!prefetch_only) ctx->pf.valid = false;
     if (prefetch_only) {
         ctx->pf.valid = false;
-        if (nsets != 2 || epoch_route || d_neg_in) return SLK_OK;  // such a call prepares in line: nothing to run ahead
+        if (!side || epoch_route || d_neg_in) return SLK_OK;  // such a call prepares in line: nothing to run ahead
         if ((rc = slk_prep_stream_init(ctx))) return rc;
         hipStream_t ps = ctx->prep_stream;
         // the set the call before did NOT finish on: its last reader were the passes two chunks back (ev_done of that set)
@@ -1574,35 +1589,46 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return SLK_OK;
     }
     if (nsets == 1) {
-        // everything in order on the caller's stream
-        for (size_t ck = 0; ck < n_chunks; ++ck) {
-            if ((rc = do_sample(ck, ctx->pb[0], s))) return rc;
-            if ((rc = do_sort(ck, ctx->pb[0], s))) return rc;
-            if ((rc = do_chunk(ck, ctx->pb[0]))) return rc;
-        }
+        // one chunk: everything in order on the caller's stream
+        if ((rc = do_sample(0, ctx->pb[0], s))) return rc;
+        if ((rc = do_sort(0, ctx->pb[0], s))) return rc;
+        if ((rc = do_chunk(0, ctx->pb[0]))) return rc;
         ctx->last_stream = s;
         ctx->last_pipe_set = -1;
         return SLK_OK;
     }
-    // pipeline: prep(c+1) on ctx->prep_stream overlaps passes(c) on the caller's stream.
+    // pipeline: prep(c + 1) is enqueued before passes(c) -- on ctx->prep_stream, beside them (`side`), or on the caller's own
+    // stream, ahead of them.
     // overlap_prep = 1: negatives and sorts; = 2: only the negatives (the generator is ALU-bound and
     // shares the chip with the HBM-bound passes; the sorts stay in line on the caller's stream)
-    const bool sort_ahead = ctx->opt_overlap_prep == 1;
-    if ((rc = slk_prep_stream_init(ctx))) return rc;
-    hipStream_t ps = ctx->prep_stream;
-    SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
-    SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+    const bool sort_ahead = !side || ctx->opt_overlap_prep == 1;
+    if (side && (rc = slk_prep_stream_init(ctx))) return rc;
+    hipStream_t ps = side ? ctx->prep_stream : s;
+    if (side) {
+        SLK_HIP(ctx, hipEventRecord(ctx->ev_start, s));      // inputs produced on the caller's stream
+        SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_start, 0));
+    }
     int set = have0 ? ctx->pf.set : 0;
     if (have0) ++ctx->stat_prefetched;
     if (have0 && ctx->pf.all) neg_all = (const uint32_t *)ctx->pf_neg.p;
     if (!have0) {
-        if ((rc = do_sample(0, ctx->pb[set], ps))) return rc;
+        // The negatives of the WHOLE call in ONE draw (it is one contiguous draw however the call is chunked -- what
+        // slk_bilinear_prefetch does for fit()'s epochs): the generator's jump-ahead, ~130 us whatever the draw's length, is
+        // paid once per call instead of once per chunk (round 6: 0.0135 -> 0.0065 ms per C2 step at 20 minibatches per call).
+        // Calls of >= 2^30 draws and calls that are handed their negatives keep drawing / converting by chunk.
+        if (!d_neg_in && nn > 0 && (uint64_t)n * (uint64_t)nn < ((uint64_t)1 << 30)) {
+            if ((rc = slk_ensure(ctx, ctx->call_neg, (size_t)n * nn * 4))) return rc;
+            if ((rc = slk_sample_u32(ctx, tables->num_items, n * (int64_t)nn, (uint32_t *)ctx->call_neg.p, d_neg_out, ps))) return rc;
+            neg_all = (const uint32_t *)ctx->call_neg.p;
+        } else if ((rc = do_sample(0, ctx->pb[set], ps))) {
+            return rc;
+        }
         if (sort_ahead && (rc = do_sort(0, ctx->pb[set], ps))) return rc;
-        SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set], ps));
+        if (side) SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set], ps));
     }
     for (size_t ck = 0; ck < n_chunks; ++ck, set ^= 1) {
-        SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
-        if (ck == 0 && neg_all && d_neg_out) {  // the caller wants the draws: they were made ahead, as uint32
+        if (side) SLK_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prep[set], 0));
+        if (ck == 0 && have0 && neg_all && d_neg_out) {  // the caller wants the draws: they were made ahead, as uint32
             hipLaunchKernelGGL(k_u32_to_i64, dim3(slk_grid_for(ctx, (size_t)n * nn, 256)), dim3(256), 0, s, neg_all, d_neg_out, (size_t)n * nn);
             SLK_LAUNCH_CHECK(ctx, "k_u32_to_i64");
         }
@@ -1610,7 +1636,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (ck + 1 < n_chunks) {
             // the other buffer set was last read by the passes of the previous chunk (with a chunk prepared ahead: by the last
             // passes of the call before this one)
-            if (ck > 0 || have0) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
+            if (side && (ck > 0 || have0)) SLK_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_done[set ^ 1], 0));
             if (!sort_ahead) {
                 // "overlap_prep" 2: the next chunk's draw starts behind THIS chunk's sorts, i.e. beside its passes.  Started
                 // together with the sorts (round 4) the generator's workgroups -- whole CUs by their LDS -- took the sorts'
@@ -1620,11 +1646,18 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             }
             if ((rc = do_sample(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
             if (sort_ahead && (rc = do_sort(ck + 1, ctx->pb[set ^ 1], ps))) return rc;
-            SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
-            ++ctx->stat_overlapped;
+            if (side) {
+                SLK_HIP(ctx, hipEventRecord(ctx->ev_prep[set ^ 1], ps));
+                ++ctx->stat_overlapped;
+            }
         }
         if ((rc = do_chunk(ck, ctx->pb[set]))) return rc;
-        SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
+        if (side) SLK_HIP(ctx, hipEventRecord(ctx->ev_done[set], s));
+    }
+    if (!side) {  // everything ran on the caller's stream: in-line semantics for what follows (slk_bilinear_prefetch)
+        ctx->last_pipe_set = -1;
+        ctx->last_stream = s;
+        return SLK_OK;
     }
     ctx->last_pipe_set = set ^ 1;  // (the loop's last increment undone: the set of the last chunk)
     ctx->last_stream = s;  // every prep is ordered before the tail of the caller's stream

@@ -175,6 +175,8 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured); bit 4 the user
                                    // pass's record stores, bit 5 the item pass's record loads (round 6: the Infinity-Cache A/B,
                                    // profiles/r06_mall_ab.*)
+    int64_t opt_record_nt_min_bytes = (int64_t)192 << 20;  // records of a minibatch from this size on are stored non-temporally
+                                   // (slk_bilinear.hip::do_passes; 0: never)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)
     hipStream_t prep_stream = nullptr;
     bool prep_warmed = false;           // the one-off tiny prep on the prep stream has run (slk_bilinear_reserve)
@@ -213,6 +215,7 @@ struct slk_ctx {
         bool all = false;           // the negatives of the WHOLE call were drawn ahead (into pf_neg), not only the first chunk's
     } pf;
     slk_buf pf_neg;                 // uint32[n * negatives per interaction] of such a call
+    slk_buf call_neg;               // the negatives of a whole (multi-chunk, not prefetched) training call: ONE draw (slk_bilinear.hip)
     int64_t stat_overlapped = 0;    // chunks whose negatives + sorts ran on the prep stream beside the chunk before's passes
     int64_t stat_prefetched = 0;    // chunks prepared ahead that a training call took over (slk_ctx_get_stat)
     int64_t stat_shadowed = 0;      // training calls that ran on the item-bias shadow (slk_bias_shadow_begin)

@@ -322,7 +322,10 @@ def step_update_bounds(opt, hp, pre_p, pre_s1, pre_s2, g, step, rel_delta=1e-5, 
         touched = (gt != 0).any(axis=1, keepdims=True) if gt.ndim == 2 else (gt != 0)
         # abs_delta (degenerate runs only): an absolute floor of the gradient perturbation -- the fp32 rounding of a sum of
         # hundreds of cancelling terms does not scale with the (arbitrarily small) sum
-        delta = np.broadcast_to((rel_delta * scale + abs_delta) * touched, gt.shape)
+        # (the floor also covers rows whose oracle gradient is EXACTLY zero -- a user whose occurrences cancel term by term in
+        # the oracle's summation order and leave a 1e-11 residue in another: Adagrad from a zero accumulator moves such an
+        # element by lr * g / (|g| + eps) whatever |g| is)
+        delta = np.broadcast_to(rel_delta * scale * touched + abs_delta, gt.shape)
         geff = gt + wd * np.asarray(pre_p[t], np.float64).reshape(gt.shape) if opt.endswith('dense') else gt
         if opt == 'sgd':  # p -= lr * g: a gradient perturbation moves the parameter by lr * delta, there is no state
             dp, ds1, ds2 = lr * delta, np.zeros_like(gt), np.zeros_like(gt)
@@ -1660,7 +1663,7 @@ OPTION_VALUES = {
     'seq_variant': (0, 1), 'explicit_fused': (0,), 'epoch_kernel': (0,), 'item_lat_max_tiles': (0, 1 << 30),
     'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
     'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
-    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63),
+    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63), 'record_nt_min_bytes': (0, 1),
 }
 OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
 # adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the
