@@ -52,7 +52,16 @@ def main():
         host._BIAS_SHADOW_MIN_ITEMS = int(floor)
     calls0 = host._engine_for(torch.device('cpu') if backend == 'emu' else torch.device('cuda', rank)).get_stat('shadowed_calls')
     model.fit(inter)
-    model.fit(inter)  # resume
+    if backend == 'hip':
+        # resume under ANOTHER current stream (the cached trainer kept the first fit()'s stream and refused): the
+        # trainer follows the stream in use, the collectives and the kernels stay ordered on it
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.fit(inter)
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        model.fit(inter)  # resume
     if floor:
         eng_ = host._engine_for(torch.device('cpu') if backend == 'emu' else torch.device('cuda', rank))
         n_mb = (N + B - 1) // B

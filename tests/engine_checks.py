@@ -971,6 +971,55 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
 
 
+def check_prefetch_behind_an_inline_draw(be, D=16, U=3000, I=1000, N=30000, B=1000, chunk=4096, seed=23):
+    """slk_bilinear_prefetch used to assume that every earlier user of the sampler's scratch and of the RNG state ran on
+    the ctx's prep stream.  An in-line slk_sample_items (the caller's stream) followed by a prefetch WITHOUT a host synchronisation
+    in between must still draw the stream in order: the sampled ids, the training call's negatives, its tables and the final RNG
+    state equal those of the same sequence with nothing prepared ahead, bit for bit.  (Run twice: the second round's prefetch
+    follows a PIPELINED training call, the first one an in-line state.)"""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+    params = [rs.normal(0, 0.1, (U, D)), rs.normal(0, 0.1, (I, D)), np.zeros(U), np.zeros(I)]
+    state = np.random.RandomState(seed + 1).get_state()
+    M = 5000
+    results = []
+    for ahead in (False, True):
+        eng.set_option('chunk_interactions', chunk)
+        eng.set_option('overlap_prep', 1)
+        eng.set_option('overlap_min_batch', 0)
+        eng.set_option('epoch_kernel', 0)  # (the persistent route of small minibatches prepares nothing ahead)
+        try:
+            dev = be.model(params, opt='adagrad', lr=0.05)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            n_mb = (N + B - 1) // B
+            outs = []
+            for _ in range(2):
+                drawn = be.alloc(np.full(M, -1, dtype=np.int64))
+                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+                neg_out = be.alloc(np.full(N, -1, dtype=np.int64))
+                eng.sample_items(I, M, be.ptr(drawn), be.stream)  # in line, on the caller's stream
+                if ahead:
+                    eng.bilinear_prefetch(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, 'bpr', 1, stream=be.stream)
+                    assert eng.get_stat('prefetch_pending') > 0
+                eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, 'bpr', 1, be.ptr(mb_loss),
+                                   d_neg_out=be.ptr(neg_out), stream=be.stream)
+                outs += [be.get(drawn), be.get(mb_loss), be.get(neg_out)]
+            st = eng.rng_get_state()
+            results.append(outs + [st[1], np.array(st[2])] + [be.get(x) for x in dev.p + dev.s1])
+        finally:
+            eng.set_option('chunk_interactions', 1 << 23)
+            eng.set_option('overlap_prep', 0)
+            eng.set_option('overlap_min_batch', 1 << 16)
+            eng.set_option('epoch_kernel', 1)
+    ref = np.random.RandomState(seed + 1)
+    assert np.array_equal(results[0][0], ref.randint(0, I, M, dtype=np.int64))  # and the stream itself is numpy's
+    assert np.array_equal(results[0][2], ref.randint(0, I, N, dtype=np.int64))
+    for k, (a, b) in enumerate(zip(*results)):
+        assert np.array_equal(a, b), ('tensor %d differs between the prefetched and the in-line sequence' % k)
+
+
 # ---------------------------------------------------------------------------------------
 # epoch shuffle on the device (slk_shuffle_perm)
 # ---------------------------------------------------------------------------------------

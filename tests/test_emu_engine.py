@@ -335,3 +335,6 @@ def test_option_is_result_neutral(be, name):
 def test_option_is_neutral_to_summation_order(be, name):
     ec.check_option_is_neutral_to_summation_order(be, name, ec.OPTIONS_NEUTRAL_TO_SUMMATION_ORDER[name])
 
+
+def test_prefetch_behind_an_inline_draw(be):
+    ec.check_prefetch_behind_an_inline_draw(be, D=8, U=40, I=30, N=500, B=32, chunk=100)

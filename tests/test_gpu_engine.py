@@ -421,3 +421,8 @@ def test_scores_are_the_fma_chain(be, D):
 def test_fused_ranks(be):
     ec.check_fused_ranks(be)
     ec.check_fused_ranks(be, D=64, U=200, I=1500, n_rows=300, seed=9)
+
+
+def test_prefetch_behind_an_inline_draw(be):
+    ec.check_prefetch_behind_an_inline_draw(be)
+    ec.check_prefetch_behind_an_inline_draw(be, D=64, U=200000, I=50000, N=600000, B=65536, chunk=131072)
