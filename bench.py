@@ -164,7 +164,9 @@ def main():
               torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
     s1 = [torch.zeros_like(t) for t in tables]
     s2 = [torch.zeros_like(t) for t in tables] if args.opt != 'adagrad' else None
-    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
+    # (user biases: zeros, as the reference initialises them -- and bpr / hinge never move them; checked on the device, as fit() does,
+    # before the hint is given: include/spotlight_hip.h, SLK_TABLES_USER_BIAS_ZERO)
+    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D, user_bias_zero=not bool(tables[2].any()))
     op = _native.make_optim(args.opt, [t.data_ptr() for t in s1], [t.data_ptr() for t in s2] if s2 else None,
                             lr=1e-2, weight_decay=1e-6 if args.opt == 'adam_dense' else 0.0)
     n_total = (W + 2 * K) * B  # W warmup + K timed + K profiled

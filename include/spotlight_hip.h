@@ -86,12 +86,21 @@ typedef struct slk_bloom {
  * (factorization/representations.py:46-59):
  *   0 user_embeddings.weight [num_users, dim]   1 item_embeddings.weight [num_items, dim]
  *   2 user_biases.weight     [num_users, 1]     3 item_biases.weight     [num_items, 1] */
+/* slk_tables::flags.
+ * SLK_TABLES_USER_BIAS_ZERO: the caller GUARANTEES that d_param[2] (user_biases.weight) is identically zero.  Under bpr and hinge
+ * the user bias enters both scores of a pair and leaves the loss's gradient exactly (+g - g == 0: SURVEY.md 8(a) #11), so a model
+ * the reference initialised (ZeroEmbedding, spotlight/layers.py:41-56) and trained with those losses keeps it at zero forever.
+ * With the flag, slk_bilinear_train's pair-loss user pass (bpr / hinge, row-sparse Adagrad or plain SGD, plain tables) does not
+ * fetch user biases at all -- a random 4-byte read costs a whole cache line per interaction -- and uses 0.0f: same values.  Every
+ * other route ignores the flag.  This package's fit() sets it after checking the tensor on the device. */
+#define SLK_TABLES_USER_BIAS_ZERO 1
+
 typedef struct slk_tables {
     float *d_param[4];
     int64_t num_users;
     int64_t num_items;
     int32_t dim;
-    int32_t reserved;
+    int32_t flags; /* SLK_TABLES_* hints (0: none; the field was `reserved`, always 0, up to ABI 10) */
     /* NULL: plain table ([num_users|num_items, dim]).  Otherwise d_param[0] / d_param[1] is the
      * BloomEmbedding's compressed table [bloom->rows, dim] (BilinearNet's user_embedding_layer /
      * item_embedding_layer arguments, factorization/representations.py:46-56); the bias tables
@@ -172,7 +181,9 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         PoolNet sequence-pass variant
  *   "record_nt_min_bytes" slk_bilinear_train: a minibatch whose pre-step user-row records take at least this many bytes (default
  *                         192 MB: they would fill the 256 MB Infinity Cache) stores them non-temporally, as "nt" bit 16 does for
- *                         every size; 0: never (profiles/r06_mall_ab.jsonl) */
+ *                         every size; 0: never (profiles/r06_mall_ab.jsonl)
+ *   "user_bias_zero_hint" 1 (default): slk_tables::flags' SLK_TABLES_USER_BIAS_ZERO is honoured; 0: the user biases are fetched
+ *                         regardless (A/B and test switch: same results) */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --
  * a ctx is shared by every model of a process on its device (spotlight_amd/_native.py: `with engine.options(...)`). */

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from spotlight_amd import _native  # noqa: E402
 
 DEFAULTS = {'chunk_interactions': 1 << 23, 'overlap_prep': 0, 'overlap_min_batch': 1 << 16, 'item_grid_mult': 128,
-            'user_grid_mult': 8, 'nt': 3, 'user_lat_max_batch': 1 << 17, 'item_long_gate': 1, 'item_lat_max_tiles': 2048}
+            'user_grid_mult': 8, 'nt': 3, 'user_bias_zero_hint': 1, 'record_nt_min_bytes': 192 << 20, 'user_lat_max_batch': 1 << 17, 'item_long_gate': 1, 'item_lat_max_tiles': 2048}
 
 
 def main():
@@ -51,7 +51,7 @@ def main():
               torch.zeros(U, device=dev), torch.zeros(I, device=dev)]
     s1 = [torch.zeros_like(t) for t in tables]
     s2 = [torch.zeros_like(t) for t in tables] if args.opt != 'adagrad' else None
-    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D)
+    tb = _native.make_tables([t.data_ptr() for t in tables], U, I, D, user_bias_zero=not bool(tables[2].any()))  # (as bench.py and fit() do)
     n_total = (W + K) * B
     users = torch.randint(0, U, (n_total,), device=dev, dtype=torch.int64, generator=gen)
     items = torch.randint(0, I, (n_total,), device=dev, dtype=torch.int64, generator=gen)

@@ -30,7 +30,7 @@ class SlkBloom(C.Structure):
 
 class SlkTables(C.Structure):
     _fields_ = [('d_param', C.c_void_p * 4), ('num_users', C.c_int64), ('num_items', C.c_int64),
-                ('dim', C.c_int32), ('reserved', C.c_int32),
+                ('dim', C.c_int32), ('flags', C.c_int32),
                 ('user_bloom', C.POINTER(SlkBloom)), ('item_bloom', C.POINTER(SlkBloom))]
 
 
@@ -550,9 +550,14 @@ def make_bloom(rows, n_hash, padding_idx=0, skip_row=0, seeds=None):
     return b
 
 
-def make_tables(ptrs, num_users, num_items, dim, user_bloom=None, item_bloom=None):
-    """`user_bloom` / `item_bloom`: SlkBloom descriptors (kept alive by the returned struct)."""
+TABLES_USER_BIAS_ZERO = 1  # include/spotlight_hip.h: SLK_TABLES_USER_BIAS_ZERO
+
+
+def make_tables(ptrs, num_users, num_items, dim, user_bloom=None, item_bloom=None, user_bias_zero=False):
+    """`user_bloom` / `item_bloom`: SlkBloom descriptors (kept alive by the returned struct).  `user_bias_zero`: the caller has
+    CHECKED that the user-bias table is identically zero (slk_tables::flags, SLK_TABLES_USER_BIAS_ZERO)."""
     t = SlkTables()
+    t.flags = TABLES_USER_BIAS_ZERO if user_bias_zero else 0
     for i in range(4):
         t.d_param[i] = ptrs[i]
     t.num_users, t.num_items, t.dim = int(num_users), int(num_items), int(dim)

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         else
             u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
-        const float bu = a.P[2][user];
+        const float bu = (UMODE == 0 && !BLOOM && a.ubz) ? 0.0f : a.P[2][user];  // (SLK_TABLES_USER_BIAS_ZERO: a line per interaction for a table of zeros)
         // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
         // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
         // fetching early there only lengthens register lifetimes)
@@ -1349,6 +1349,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             a.urec = (float *)ctx->extra[BL_UREC].p;
             a.RSU = RSU;
             slk_set_opt_coeffs(a, optim);
+            // user biases the caller vouches are all zero, a loss whose user-bias gradient is exactly zero, an update for which a
+            // zero gradient is an exact no-op: nothing of the table is read or written by the pair-mode user pass
+            a.ubz = (tables->flags & SLK_TABLES_USER_BIAS_ZERO) && (loss == SLK_LOSS_BPR || loss == SLK_LOSS_HINGE) && !bloom &&
+                    (optim->kind == SLK_OPT_ADAGRAD || optim->kind == SLK_OPT_SGD) && ctx->opt_user_bias_zero_hint;
             a.nt = ctx->opt_nt;
             // Round 6 (profiles/r06_mall_ab.jsonl): a minibatch whose records are as large as the Infinity Cache (2^20 x 256 B
             // = 256 MB) cannot keep them there until the item pass reads them -- written with plain stores they only evict the

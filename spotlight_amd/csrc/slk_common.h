@@ -175,6 +175,7 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured); bit 4 the user
                                    // pass's record stores, bit 5 the item pass's record loads (round 6: the Infinity-Cache A/B,
                                    // profiles/r06_mall_ab.*)
+    int opt_user_bias_zero_hint = 1;  // 1: honour SLK_TABLES_USER_BIAS_ZERO (0: fetch the user biases regardless -- A/B and test switch)
     int64_t opt_record_nt_min_bytes = (int64_t)192 << 20;  // records of a minibatch from this size on are stored non-temporally
                                    // (slk_bilinear.hip::do_passes; 0: never)
     slk_prep_bufs pb[2];             // double-buffered: prep(c+1) overlaps passes(c)

@@ -150,6 +150,7 @@ struct slk_pass_args {
     float c_eps;
     float c_omb1, c_omb2;  // 1-beta1, 1-beta2
     int nt;                // cache-policy bits (ctx option "nt")
+    int ubz;               // 1: the user biases are identically zero and this pass cannot change them (slk_tables::flags): not fetched
 };
 
 enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_UPD_SGD = 3 };

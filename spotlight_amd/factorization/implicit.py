@@ -485,6 +485,12 @@ class ImplicitFactorizationModel(object):
         engine = _engine_for(device)
         stream = _stream_for(device)
         tables = self._slk_tables()
+        # bpr / hinge leave the user biases' gradient at exactly zero (+g - g), so a model the reference initialised (ZeroEmbedding)
+        # keeps them identically zero; checked HERE, on the device, once per fit(): the user pass then does not fetch a cache line
+        # per interaction for a table of zeros (include/spotlight_hip.h: SLK_TABLES_USER_BIAS_ZERO).  Same values either way.
+        if (self._loss in ('bpr', 'hinge') and binding.kind in ('adagrad', 'sgd') and not tables.user_bloom and not tables.item_bloom
+                and not bool(self._net.tables()[2].any())):
+            tables.flags |= _native.TABLES_USER_BIAS_ZERO
         n_minibatches = (n + self._batch_size - 1) // self._batch_size
         mb_loss = torch.empty(n_minibatches, dtype=torch.float32, device=device)
 

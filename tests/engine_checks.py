@@ -971,6 +971,41 @@ def check_chunking_is_bit_neutral(be, loss, opt, D, U=3000, I=1000, N=30000, B=1
                                       float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
 
 
+def check_user_bias_zero_hint_is_bit_neutral(be, D=16, U=3000, I=1000, N=20000, B=4096, seed=29):
+    """include/spotlight_hip.h, SLK_TABLES_USER_BIAS_ZERO: with user biases that ARE identically zero the pair-mode user pass may skip
+    fetching them.  Under bpr / hinge (row-sparse Adagrad, plain SGD) a run with the hint equals the run without it bit for bit --
+    every table, every state tensor, the losses -- and the user biases are still all zero afterwards (their gradient is exactly
+    zero).  Routes the hint does not cover (pointwise: the user bias DOES get a gradient there) ignore it: same equality."""
+    from spotlight_amd import _native
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+    params = [rs.normal(0, 0.1, (U, D)), rs.normal(0, 0.1, (I, D)), np.zeros(U), rs.normal(0, 0.1, I)]
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    eng.set_option('epoch_kernel', 0)  # (the launch path; the persistent kernel does not look at the hint)
+    try:
+        for loss, opt in (('bpr', 'adagrad'), ('hinge', 'sgd'), ('pointwise', 'adagrad'), ('bpr', 'sparse_adam')):
+            results = []
+            for hinted in (False, True):
+                dev = be.model(params, opt=opt, lr=0.05)
+                if hinted:
+                    dev.tables.flags = _native.TABLES_USER_BIAS_ZERO
+                eng.rng_set_state(state)
+                d_users, d_items = be.alloc(users), be.alloc(items)
+                mb_loss = be.alloc(np.zeros(n_mb, dtype=np.float32))
+                for _ in range(2):
+                    eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1, be.ptr(mb_loss),
+                                       stream=be.stream)
+                results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+            for k, (a, b) in enumerate(zip(*results)):
+                assert np.array_equal(a, b), ('%s / %s: tensor %d differs with the user-bias hint' % (loss, opt, k))
+            if loss != 'pointwise':
+                assert not results[1][3].any(), 'user biases moved under a loss whose user-bias gradient is zero'
+    finally:
+        eng.set_option('epoch_kernel', 1)
+
+
 def check_prefetch_behind_an_inline_draw(be, D=16, U=3000, I=1000, N=30000, B=1000, chunk=4096, seed=23):
     """slk_bilinear_prefetch used to assume that every earlier user of the sampler's scratch and of the RNG state ran on
     the ctx's prep stream.  An in-line slk_sample_items (the caller's stream) followed by a prefetch WITHOUT a host synchronisation
@@ -1712,7 +1747,7 @@ OPTION_VALUES = {
     'seq_variant': (0, 1), 'explicit_fused': (0,), 'epoch_kernel': (0,), 'item_lat_max_tiles': (0, 1 << 30),
     'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
     'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
-    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63), 'record_nt_min_bytes': (0, 1),
+    'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63), 'record_nt_min_bytes': (0, 1), 'user_bias_zero_hint': (0,),
 }
 OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
 # adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the

@@ -338,3 +338,7 @@ def test_option_is_neutral_to_summation_order(be, name):
 
 def test_prefetch_behind_an_inline_draw(be):
     ec.check_prefetch_behind_an_inline_draw(be, D=8, U=40, I=30, N=500, B=32, chunk=100)
+
+
+def test_user_bias_zero_hint_is_bit_neutral(be):
+    ec.check_user_bias_zero_hint_is_bit_neutral(be, D=8, U=60, I=40, N=900, B=256)

@@ -426,3 +426,8 @@ def test_fused_ranks(be):
 def test_prefetch_behind_an_inline_draw(be):
     ec.check_prefetch_behind_an_inline_draw(be)
     ec.check_prefetch_behind_an_inline_draw(be, D=64, U=200000, I=50000, N=600000, B=65536, chunk=131072)
+
+
+def test_user_bias_zero_hint_is_bit_neutral(be):
+    ec.check_user_bias_zero_hint_is_bit_neutral(be)
+    ec.check_user_bias_zero_hint_is_bit_neutral(be, D=64, U=200000, I=50000, N=300000, B=65536)
