@@ -192,7 +192,8 @@ def main():
     trainer = None
     if world > 1 or args.sharded:
         from spotlight_amd.factorization.sharded import ShardedBilinearTrainer
-        trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None)
+        trainer = ShardedBilinearTrainer(eng, tables, op, I_global, stream=stream, slices=args.slices or None,
+                                         user_bias_zero=not bool(tables[2].any()))
         trainer.reserve(B, args.shard_chunk)  # exchange buffers of the timed loop's chunks up front
     xgmi_rows = [0]
     xgmi_bytes = [0, 0]  # measured by the trainer: bytes handed to the collectives for other ranks (with / without slot padding)
@@ -347,7 +348,8 @@ def main():
                                                                 args.loss, n_neg, mb1[lo:].data_ptr(), stream=stream)
                         scope = eng.bias_shadow(tb, op1, stream=stream, enabled=bias_shadowed and B >= 4096)
                     else:
-                        tr1 = ShardedBilinearTrainer(eng, tables, op1, I, group=g1, stream=stream, slices=args.slices or None)
+                        tr1 = ShardedBilinearTrainer(eng, tables, op1, I, group=g1, stream=stream, slices=args.slices or None,
+                                                     user_bias_zero=not bool(tables[2].any()))
                         tr1.reserve(B, args.shard_chunk)
                         go = lambda lo, nmb: tr1.train(users[lo * B:(lo + nmb) * B], it1[lo * B:(lo + nmb) * B], B, loss=args.loss,
                                                        mb_loss=mb1[lo:lo + nmb], sample_chunk=args.shard_chunk)

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_shard_user_pass(slk_pass_args a) {
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
         slk_vec<VEC> u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
-        const float bu = a.P[2][user];
+        const float bu = a.ubz ? 0.0f : a.P[2][user];  // (SLK_TABLES_USER_BIAS_ZERO, as in slk_bilinear.hip's user pass)
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
         uint32_t q = p;
@@ -756,6 +756,8 @@ SLK_EXPORT int slk_shard_user_pass(slk_ctx *ctx, const slk_tables *local, const 
     a.loss_partial = (double *)ctx->losspart.p;
     a.loss_kind = loss;
     a.inv_b = 1.0f / (float)global_batch;
+    a.ubz = (local->flags & SLK_TABLES_USER_BIAS_ZERO) && (loss == SLK_LOSS_BPR || loss == SLK_LOSS_HINGE) &&
+            (optim->kind == SLK_OPT_ADAGRAD || optim->kind == SLK_OPT_SGD) && ctx->opt_user_bias_zero_hint;
     const unsigned gpb = 256u / (unsigned)g;
     slk_pass_fn upass = nullptr;
     const int upd = slk_upd_for(optim->kind);

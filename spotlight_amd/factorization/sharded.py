@@ -54,7 +54,7 @@ class ShardedBilinearTrainer(object):
     slices: user-slices per minibatch (exchange/compute overlap); default 4 when world > 1.
     """
 
-    def __init__(self, engine, tables, optim, num_items_global, group=None, stream=0, slices=None):
+    def __init__(self, engine, tables, optim, num_items_global, group=None, stream=0, slices=None, user_bias_zero=False):
         self.engine = engine
         self.tables = tables
         self.optim = optim
@@ -67,7 +67,10 @@ class ShardedBilinearTrainer(object):
         w = tables
         self.dim = w[0].shape[1]
         self.device = w[0].device
-        self._tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0], self.dim)
+        # user_bias_zero: the caller has CHECKED that this rank's user biases are all zero (include/spotlight_hip.h,
+        # SLK_TABLES_USER_BIAS_ZERO: bpr / hinge never move them and the user pass then does not fetch them)
+        self._tables = _native.make_tables([t.data_ptr() for t in w], w[0].shape[0], w[1].shape[0], self.dim,
+                                           user_bias_zero=user_bias_zero)
         self._shard = _native.make_shard(self.world, self.rank, self.num_items_global)
         self.slot_floats = self.dim + 1  # an exchange slot: a row (dim floats) + its scalar, in blocks of 64 slots
         self._bufs = {}
@@ -433,6 +436,10 @@ class ShardedImplicitFactorizationModel(ImplicitFactorizationModel):
             trainer = ShardedBilinearTrainer(engine, tables, ostruct, self._num_items, group=self._group,
                                              stream=stream) if self._trainer is None else self._trainer
             trainer.optim = ostruct
+            # (this rank's user biases checked on the device each epoch: all zero under bpr / hinge for a model initialised as the
+            # reference initialises it -- the user pass then does not fetch them, implicit.py::_fit)
+            hint = (self._loss in ('bpr', 'hinge') and binding.kind in ('adagrad', 'sgd') and not bool(tables[2].any()))
+            trainer._tables.flags = _native.TABLES_USER_BIAS_ZERO if hint else 0
             trainer.stream = stream  # (a later fit() under another current stream: _check_stream validates the one in use)
             self._trainer = trainer
             mb_loss = torch.zeros(n_mb, dtype=torch.float32, device=device)
