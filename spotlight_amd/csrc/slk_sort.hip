@@ -455,6 +455,14 @@ static void rs_make_plan(rs_plan &pl, size_t n, size_t seg_len, unsigned bits, u
     pl.ctl_bytes = pl.off_data;
 }
 
+// the large sorts' tile shape (build-time: the A/Bs of round 4 and round 6 are in profiles/)
+#ifndef RS_BIG_THREADS
+#define RS_BIG_THREADS 512
+#endif
+#ifndef RS_BIG_KPT
+#define RS_BIG_KPT 16
+#endif
+
 template <class KeyT, class ValT, int LOADER>
 struct rs_kernels {
     // two tile shapes: 256 threads x 16 keys, and 512 x 16 (twice the run length per (tile, bucket): the large sorts)
@@ -462,13 +470,13 @@ struct rs_kernels {
         if (single)
             hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT, 256, 16, RS_LOAD_PLAIN, true>), dim3(1), dim3(256), 0, s, a);
         else if (cfg == 1)
-            hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT, 512, 16, LOADER, false>), dim3(grid), dim3(512), 0, s, a);
+            hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT, RS_BIG_THREADS, RS_BIG_KPT, LOADER, false>), dim3(grid), dim3(RS_BIG_THREADS), 0, s, a);
         else
             hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT, 256, 16, LOADER, false>), dim3(grid), dim3(256), 0, s, a);
     }
 };
 
-static inline unsigned rs_tile_of(int cfg) { return cfg == 1 ? 8192u : 4096u; }
+static inline unsigned rs_tile_of(int cfg) { return cfg == 1 ? (unsigned)(RS_BIG_THREADS * RS_BIG_KPT) : 4096u; }
 
 // The sort.  Pass p reads what pass p - 1 wrote; the last pass writes (kout, vout).  Intermediate passes alternate between
 // (kout, vout) and a second buffer pair: (kalt, valt) when the caller has one (the training prep's double buffers, or an
