@@ -97,6 +97,13 @@ def parse():
                     help='item tables of 2^24 rows and more: keep the item biases and their Adagrad accumulator in two arrays '
                          '(default: interleaved for the run, as fit() trains such tables -- slk_bias_shadow_begin, opened before '
                          'the warm-up and closed after the last timed call)')
+    ap.add_argument('--no-user-pingpong', action='store_true',
+                    help='fused path, pair losses, row-sparse optimizers, minibatches of 2^17 and more: keep the user table ONCE '
+                         '(default: doubled for the run, as fit() trains such minibatches -- slk_user_pingpong_begin: the user pass '
+                         'writes updated rows to the other copy and no pre-step-row record; opened before the warm-up, closed '
+                         'after the last timed call, its closing merge timed separately as roofline.pingpong_merge_ms)')
+    ap.add_argument('--user-pingpong-min-batch', type=int, default=1 << 17,
+                    help='minibatch size from which the run trains on the doubled user table (tests force it at small sizes)')
     ap.add_argument('--bias-shadow-min-items', type=int, default=1 << 24,
                     help='item rows per GPU from which the run trains on the bias shadow (tests force it at small sizes)')
     ap.add_argument('--no-loss-check', action='store_true', help='measurement of debug modes whose results are meaningless')
@@ -204,6 +211,13 @@ def main():
     shadow_scope = (eng.bias_shadow(tb, op, stream=stream, enabled=bias_shadowed) if trainer is None else
                     trainer.bias_shadow(enabled=bias_shadowed))  # (row-sharded: the owner-side gather and item pass index it)
     shadow_scope.__enter__()
+    # ... and minibatches this large on a doubled user table (factorization/implicit.py: _USER_PINGPONG_MIN_BATCH): no pre-step-row
+    # record is written; the scope's closing merge (rows whose current copy is the ctx's -> the caller's table) is timed below
+    pingponged = (trainer is None and args.loss in ('bpr', 'hinge', 'pointwise') and args.opt in ('adagrad', 'sparse_adam')
+                  and B >= args.user_pingpong_min_batch and not args.no_user_pingpong)
+    pp_scope = eng.user_pingpong(tb, op, stream=stream, enabled=pingponged)
+    pp_scope.__enter__()
+    pingponged = pp_scope.active  # (SLK_ENOMEM: the run goes on in the one-table layout)
 
     n_neg = args.n_neg if args.loss == 'adaptive_hinge' else 1
 
@@ -302,6 +316,11 @@ def main():
     barrier()
     xgmi_rows[0] = xg
     xgmi_bytes[:] = xgb
+    be.sync()
+    t4 = time.perf_counter()
+    pp_scope.__exit__(None, None, None)  # the user table is whole again (the probes and checks below read it)
+    be.sync()
+    pingpong_merge_ms = (time.perf_counter() - t4) * 1e3 if pingponged else None
     shadow_scope.__exit__(None, None, None)  # (the probes and checks below read the two arrays)
     ranks_seen = [{'rank': rank, 'local_rank': local_rank, 'device': be.name}]
     if multi:
@@ -406,6 +425,8 @@ def main():
         value, roof = build_roofline(args, world=world, K=K, B=B, D=D, elapsed=elapsed, prof=prof, prof_ov=prof_ov,
                                      elapsed_ov=elapsed_ov, elapsed_ov_prof=elapsed_ov_prof, probes=probes, ceiling=ceiling,
                                      trainer=trainer, xgmi_rows=xgmi_rows, denominators=denominators, xgmi_bytes=xgmi_bytes)
+        if pingpong_merge_ms is not None:
+            roof['pingpong_merge_ms'] = pingpong_merge_ms
         out = {'metric': 'training interactions/sec, BPR dim=64', 'value': value, 'unit': 'interactions/s',
                'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -425,6 +446,10 @@ def main():
                           'item_bias_layout': ('{bias, Adagrad accumulator} interleaved for the run (slk_bias_shadow_begin before the '
                                                'warm-up, _end after the last timed call: what fit() does on item tables this large)'
                                                if bias_shadowed else 'two arrays (torch layout)'),
+                          'user_row_layout': ('the user table doubled for the run (slk_user_pingpong_begin before the warm-up, _end after '
+                                              'the last timed call: what fit() does for minibatches this large) -- updated rows go to '
+                                              'the other copy, no pre-step-row record is written; the closing merge is '
+                                              'roofline.pingpong_merge_ms' if pingponged else 'one table, pre-step rows recorded per position'),
                           'parallelism': 'single GPU' if trainer is None else
                           'row-sharded x%d: users and items sharded cyclically; RCCL all-to-all of ids per chunk of '
                           'minibatches, of rows and gradient rows per user-slice of a minibatch (async, overlapping '

@@ -10,7 +10,8 @@
  *     SLK_EIO HIP failure); text via slk_last_error().
  *   - pointers named d_* are DEVICE pointers owned by the caller (torch tensors'
  *     data_ptr()); h_* are host pointers.  The library owns only the opaque ctx and
- *     its scratch.  No caller pointer is retained across calls.
+ *     its scratch.  No caller pointer is retained across calls (the two training scopes,
+ *     slk_bias_shadow_begin and slk_user_pingpong_begin, are the documented exceptions).
  *   - all work is enqueued on the caller's hipStream_t (`stream`, passed as void*);
  *     calls return without synchronising unless stated.
  *   - a ctx is bound to one device and is not thread-safe.
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SLK_ABI_VERSION 11
+#define SLK_ABI_VERSION 12
 
 #define SLK_OK 0
 #define SLK_EIO (-5)
@@ -194,6 +195,7 @@ int slk_ctx_get_option(slk_ctx *ctx, const char *name, int64_t *value);
  * "overlapped_chunks" (chunks whose negatives + sorts ran on the ctx's second stream beside the passes of the chunk before),
  * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over),
  * "shadowed_calls" (slk_bilinear_train calls that ran on the item-bias shadow of slk_bias_shadow_begin),
+ * "pingpong_calls" (slk_bilinear_train calls that ran on the user-row ping-pong of slk_user_pingpong_begin),
  * "prefetch_pending" (what the last slk_bilinear_prefetch left for the next training call: 0 nothing -- it was a no-op --,
  * 1 the first chunk, 2 the first chunk and the negatives of the whole call). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);
@@ -298,6 +300,31 @@ int slk_bilinear_reserve(slk_ctx *ctx, const slk_tables *tables, const slk_optim
 int slk_bias_shadow_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
 int slk_bias_shadow_end(slk_ctx *ctx, void *stream);
 int slk_bias_shadow_abort(slk_ctx *ctx);
+
+/* User-row ping-pong of a training scope (ABI 12).  Within a minibatch every score and every gradient is formed from PRE-STEP
+ * rows (autograd keeps the gathered user rows alive as saved tensors until backward: spotlight/factorization/representations.py:
+ * 61-91 under implicit.py:229-243), while the two ownership passes update rows in place -- so the user pass used to save every
+ * position's pre-step user row in a record for the item pass (4 * dim bytes written per interaction).  Between _begin and _end
+ * the user embedding table exists TWICE (the second copy, num_users * dim * 4 bytes, and one byte per user -- which copy holds
+ * the user's current row -- live in the ctx): the user pass writes a user's updated row to the copy that does not hold the
+ * current one and flips the byte, the item pass gathers the pre-step row from where it still stands, and no record is written.
+ * Same arithmetic in the same order: tables bit-identical to training without the scope.
+ *   - tables->d_param[0] is a MIX of current and superseded rows inside the scope; _end copies the rows whose current copy is
+ *     the ctx's back into it.  Every call that names it other than slk_bilinear_train / _prefetch / _reserve (predict, scores,
+ *     ranks, the row-sharded calls) is refused with SLK_EINVAL until then.
+ *   - slk_bilinear_train inside the scope: the pair losses (pointwise, bpr, hinge) over plain tables with a row-sparse optimizer
+ *     (Adagrad, SparseAdam, SGD), any minibatch size, on the launch path (not the persistent kernel).  Adaptive hinge,
+ *     explicit feedback, dense optimizers and other tables are refused with SLK_EINVAL -- the scope belongs to one model's
+ *     training.  optimizer state and the three other tables are used in place as always.
+ *   - lifetime: as for the item-bias shadow -- the ctx holds tables->d_param[0] from _begin to _end / _abort and _end WRITES
+ *     through it; _end closes the scope on every return; slk_user_pingpong_abort closes it without writing (the training of
+ *     the scope is lost: the caller's table is left a mix of rows); slk_ctx_destroy with an open scope says so on stderr.
+ *   - _begin, the training calls and _end are ordered by the caller (same stream, or events).  One scope per ctx; may be open
+ *     together with an item-bias shadow.  SLK_ENOMEM when the second copy does not fit: train without it.
+ * What this package's fit() does for minibatches of >= 2^17 interactions ("statistic" pingpong_calls counts the calls). */
+int slk_user_pingpong_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
+int slk_user_pingpong_end(slk_ctx *ctx, void *stream);
+int slk_user_pingpong_abort(slk_ctx *ctx);
 
 /* ImplicitFactorizationModel.predict (factorization/implicit.py:277-311 with
  * _components.py:8-25): d_out[k] = score(user_k, item_k); n_users == 1 broadcasts the user;

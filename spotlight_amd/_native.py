@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspotlight_hip.so')
 
-SLK_ABI_VERSION = 11
+SLK_ABI_VERSION = 12
 SLK_OK, SLK_EIO, SLK_ENOMEM, SLK_EINVAL, SLK_ERANGE = 0, -5, -12, -22, -34
 
 LOSS_KINDS = {'pointwise': 0, 'bpr': 1, 'hinge': 2, 'adaptive_hinge': 3,
@@ -56,6 +56,9 @@ _PROTOTYPES = {
     'slk_bias_shadow_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p]),
     'slk_bias_shadow_end': (C.c_int, [C.c_void_p, C.c_void_p]),
     'slk_bias_shadow_abort': (C.c_int, [C.c_void_p]),
+    'slk_user_pingpong_begin': (C.c_int, [C.c_void_p, C.POINTER(SlkTables), C.POINTER(SlkOptim), C.c_void_p]),
+    'slk_user_pingpong_end': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'slk_user_pingpong_abort': (C.c_int, [C.c_void_p]),
     'slk_ctx_get_stat': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     'slk_rng_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'slk_rng_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
@@ -271,6 +274,38 @@ class Engine(object):
                     self_.active = False
                     engine._check(engine._lib.slk_bias_shadow_abort(engine._ctx))
         return _Shadow()
+
+    def user_pingpong(self, tables, optim, stream=0, enabled=True):
+        """include/spotlight_hip.h: slk_user_pingpong_begin / _end as a context manager -- the user embedding table doubled for
+        the duration of the block: the user pass writes updated rows to the other copy, the item pass gathers pre-step rows
+        where they still stand, no record is written (the caller's tensor is a mix of rows inside the block and made whole on
+        every way out).  `enabled=False`: a no-op scope."""
+        engine = self
+
+        class _PingPong(object):
+            active = False
+
+            def __enter__(self_):
+                if enabled:
+                    rc = engine._lib.slk_user_pingpong_begin(engine._ctx, C.byref(tables), C.byref(optim), C.c_void_p(stream))
+                    if rc == SLK_ENOMEM:  # the second copy did not fit: the scope is an optimisation, never a requirement
+                        return engine
+                    engine._check(rc)
+                    self_.active = True
+                return engine
+
+            def __exit__(self_, *exc):
+                if self_.active:
+                    self_.active = False
+                    engine._check(engine._lib.slk_user_pingpong_end(engine._ctx, C.c_void_p(stream)))
+                return False
+
+            def abort(self_):
+                """Close the scope without writing back (the caller's arrays are gone): slk_user_pingpong_abort."""
+                if self_.active:
+                    self_.active = False
+                    engine._check(engine._lib.slk_user_pingpong_abort(engine._ctx))
+        return _PingPong()
 
     def get_stat(self, name):
         """include/spotlight_hip.h: slk_ctx_get_stat (diagnostics of the last calls)."""

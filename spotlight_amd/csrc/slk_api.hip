@@ -160,6 +160,10 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
         fprintf(stderr, "libspotlight_hip: slk_ctx_destroy with an OPEN item-bias shadow (slk_bias_shadow_begin without _end): "
                         "the caller's item biases and their Adagrad accumulator keep their pre-scope values; the training of the "
                         "scope is lost\n");
+    if (ctx->pp_active)
+        fprintf(stderr, "libspotlight_hip: slk_ctx_destroy with an OPEN user-row ping-pong (slk_user_pingpong_begin without _end): "
+                        "the rows whose current copy is the ctx's are not written back; the caller's user table is a mix of pre- and "
+                        "in-scope rows -- the training of the scope is lost\n");
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     slk_prof_drain(ctx);
@@ -168,7 +172,8 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
                        &ctx->uval[1], &ctx->uit, &ctx->ikey[0], &ctx->ikey[1], &ctx->ipay[0],
                        &ctx->ipay[1], &ctx->gk, &ctx->sk, &ctx->snap, &ctx->losspart,
                        &ctx->sort_tmp, &ctx->dgrad[0], &ctx->dgrad[1], &ctx->dgrad[2], &ctx->dgrad[3], &ctx->ipart,
-                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->call_neg, &ctx->mt_tmp, &ctx->bias_shadow};
+                       &ctx->ipart_meta, &ctx->upart_meta, &ctx->pf_neg, &ctx->call_neg, &ctx->mt_tmp, &ctx->bias_shadow, &ctx->pp_alt,
+                       &ctx->pp_flags};
     for (slk_buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (slk_buf &b : ctx->extra)
@@ -276,6 +281,7 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "overlapped_chunks")) *value = ctx->stat_overlapped;
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
     else if (!strcmp(name, "shadowed_calls")) *value = ctx->stat_shadowed;
+    else if (!strcmp(name, "pingpong_calls")) *value = ctx->stat_pingpong;
     else if (!strcmp(name, "lds_per_block")) *value = (int64_t)ctx->lds_per_block;
     else if (!strcmp(name, "lds_per_cu")) *value = (int64_t)ctx->lds_per_cu;
     else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);

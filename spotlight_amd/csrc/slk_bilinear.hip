@@ -51,9 +51,16 @@
 // same way (a head looks at the first aligned tile behind it, a boundary position at the tile before and the tile behind
 // it).  Short runs are walked and applied exactly as in the plain form; the host launches this form only for minibatches
 // that hold a long run (k_user_long_flags).
-template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false>
+// PP (pair mode, plain tables): inside a user-row ping-pong scope (slk_user_pingpong_begin; slk_pass_args::uflag / P0alt) --
+// the user's current row is read from the copy its flag byte names, the updated row goes to the OTHER copy, the byte is
+// flipped, and no record is written: the item pass (SLK_ITEM_SNAPPP) gathers the pre-step row from where it still stands.
+#ifndef SLK_PP_PIPE
+#define SLK_PP_PIPE 2  // software pipeline of the bandwidth-bound ping-pong user pass (below): 0 none, 1 keys + flag, 2 + item pair, 3 + early state.  Same box, C2 user pass: one-table form 0.3135 ms, 0: 0.306, 1: 0.289, 2: 0.284, 3: 0.295 (profiles/r06_p_*)
+#endif
+template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false, bool PP = false>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     static_assert(!LAT || (UMODE == 0 && !BLOOM), "LAT is the pair mode over plain tables");
+    static_assert(!PP || (UMODE == 0 && !BLOOM), "PP is the pair mode over plain tables");
     static_assert(!ULONG || !BLOOM, "long user runs: plain tables");
     constexpr uint32_t S = SLK_USER_TILE;
     constexpr bool PRE = UMODE != 0;
@@ -75,15 +82,64 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     // profiles/r03_c_*, r03_d_*: Zipf(1.0) users 2.0-2.9 ms per pass.  With a tile per row group the four groups of a
     // wavefront each walk their own tile, hot or not, at the plain form's memory parallelism.
     const uint32_t n_turns = ULONG ? (a.end - a.begin + S - 1u) / S : a.end - a.begin;
+    // PIPE (the bandwidth-bound ping-pong form): a position costs key -> flag byte -> row, one dependent round trip more than the
+    // one-table form's key -> row.  The row group's turns are therefore software-pipelined: entering turn t it holds {key, previous
+    // key, flag} of turn t and {key, previous key} of turn t + 1; it issues the flag load of turn t + 1 and the key loads of turn
+    // t + 2 in front of turn t's own row loads.  (Only the user's owner -- this group, in turn t + 1 -- writes that flag byte.)
+    // SLK_PP_PIPE >= 2: the turn's (positive, negative) item pair travels with its key, so that a head issues its user row, both
+    // item rows and the biases in ONE round trip; >= 3: and the row's optimizer state with them (as the latency-bound form does).
+    constexpr bool PIPE = PP && !LAT && !ULONG && SLK_PP_PIPE >= 1;
+    constexpr bool PIPE_IDS = PIPE && SLK_PP_PIPE >= 2;
+    uint32_t pk_key = 0u, pk_prev = 0u, pk_flag = 0u, pn_key = 0u, pn_prev = 0u;
+    uint32_t pk_ip = 0u, pk_in = 0u, pn_ip = 0u, pn_in = 0u;
+    if (PIPE) {
+        const uint32_t t0 = blockIdx.x * GPB + grp;
+        if (t0 < n_turns) {
+            pk_key = a.ukey[a.begin + t0];
+            pk_prev = t0 > 0u ? a.ukey[a.begin + t0 - 1u] : 0u;
+            if (PIPE_IDS) {
+                pk_ip = a.uit[2 * (size_t)(a.begin + t0)];
+                pk_in = a.uit[2 * (size_t)(a.begin + t0) + 1];
+            }
+            pk_flag = (uint32_t)a.uflag[pk_key & a.umask];
+        }
+        if (t0 + stride < n_turns) {
+            pn_key = a.ukey[a.begin + t0 + stride];
+            pn_prev = a.ukey[a.begin + t0 + stride - 1u];
+            if (PIPE_IDS) {
+                pn_ip = a.uit[2 * (size_t)(a.begin + t0 + stride)];
+                pn_in = a.uit[2 * (size_t)(a.begin + t0 + stride) + 1];
+            }
+        }
+    }
     for (uint32_t turn = blockIdx.x * GPB + grp; turn < n_turns; turn += stride) {
     const uint32_t p_lo = a.begin + (ULONG ? turn * S : turn);
     const uint32_t p_hi = ULONG ? (p_lo + S < a.end ? p_lo + S : a.end) : p_lo + 1u;
     for (uint32_t p = p_lo; p < p_hi; ++p) {
         const bool nt_keys = (SLK_NT_OF(a) & 8) != 0;
-        const uint32_t key = slk_ld_u32(a.ukey + p, nt_keys);
+        const uint32_t key = PIPE ? pk_key : slk_ld_u32(a.ukey + p, nt_keys);
         uint32_t lat_ip = 0u, lat_in = 0u;
         bool is_head;
-        if (LAT) {
+        uint32_t cur_piped = 0u;
+        if (PIPE) {
+            is_head = !(p > a.begin && pk_prev == key);
+            cur_piped = pk_flag;
+            lat_ip = pk_ip;
+            lat_in = pk_in;
+            pk_key = pn_key;
+            pk_prev = pn_prev;
+            pk_ip = pn_ip;
+            pk_in = pn_in;
+            if (turn + stride < n_turns) pk_flag = (uint32_t)a.uflag[pn_key & a.umask];
+            if (turn + 2u * stride < n_turns) {
+                pn_key = a.ukey[p + 2u * stride];
+                pn_prev = a.ukey[p + 2u * stride - 1u];
+                if (PIPE_IDS) {
+                    pn_ip = a.uit[2 * (size_t)(p + 2u * stride)];
+                    pn_in = a.uit[2 * (size_t)(p + 2u * stride) + 1];
+                }
+            }
+        } else if (LAT) {
             const uint32_t prev = p > a.begin ? a.ukey[p - 1] : ~key;
             lat_ip = a.uit[2 * (size_t)p];
             lat_in = a.uit[2 * (size_t)p + 1];
@@ -109,11 +165,16 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         }
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
+        // user-row ping-pong (slk_pass_args::uflag): the copy that holds this user's current row; the updated row goes to the
+        // other copy, the item pass gathers the pre-step row from this one -- no record is written
+        constexpr bool pp = PP;
+        const uint32_t cur = PIPE ? cur_piped : (pp ? (uint32_t)a.uflag[user] : 0u);
+        float *const unew = pp ? (cur ? a.P[0] : a.P0alt) + uoff : nullptr;
         slk_vec<VEC> u;
         if (BLOOM)
             u = slk_emb_vec<VEC>(a.P[0], a.ub, user, D, d0, on);
         else
-            u = on ? slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
+            u = on ? slk_vload_if_nt<VEC>((cur ? a.P0alt : a.P[0]) + uoff, (SLK_NT_OF(a) & 1) != 0) : slk_vzero<VEC>();
         const float bu = (UMODE == 0 && !BLOOM && a.ubz) ? 0.0f : a.P[2][user];  // (SLK_TABLES_USER_BIAS_ZERO: a line per interaction for a table of zeros)
         // explicit feedback: the pass is bound by its chain of dependent loads, so the Adagrad state of the
         // user row is fetched with the row instead of after the loss (the pair mode is bandwidth-bound:
@@ -122,7 +183,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         // starts with a dependent round trip of TWO more rows per user behind the loss (the pass ran at 0.45 of the roofline
         // against Adagrad's 0.63, profiles/r03_final_bench_sparse_adam.json)
         constexpr bool EARLY_ADAM = !BLOOM && UPD == SLK_UPD_SPARSE_ADAM && !ULONG;
-        constexpr bool EARLY_STATE = ((EXPL || LAT) && !BLOOM && UPD == SLK_UPD_ADAGRAD) || EARLY_ADAM;
+        constexpr bool EARLY_STATE = ((EXPL || LAT || (PIPE && SLK_PP_PIPE >= 3)) && !BLOOM && UPD == SLK_UPD_ADAGRAD) || EARLY_ADAM;
         slk_vec<VEC> su = slk_vzero<VEC>(), su2 = slk_vzero<VEC>();
         if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
         if (EARLY_ADAM && on) su2 = slk_vload_if_nt<VEC>(a.S2[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
@@ -146,10 +207,10 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 e_item = a.uit[q];
                 e_rating = a.ratings[a.uk[q]];
             }
-            if (on) slk_vstore_if_nt<VEC>(rec + d0, u, (SLK_NT_OF(a) & 16) != 0);
+            if (on && !pp) slk_vstore_if_nt<VEC>(rec + d0, u, (SLK_NT_OF(a) & 16) != 0);
             if (!PRE) {
                 uint32_t ip, in;
-                if (LAT && q == p) {
+                if ((LAT || PIPE_IDS) && q == p) {
                     ip = lat_ip;
                     in = lat_in;
                 } else {
@@ -173,9 +234,16 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 for (int i = 0; i < VEC; ++i) gu.v[i] += gp * vi.v[i] + gn * vj.v[i];
                 gbu += gp + gn;
                 if (lane == 0) {
-                    float *gq = a.gsn + 2 * (size_t)(q - a.begin);
-                    gq[0] = gp;
-                    gq[1] = gn;
+                    if (pp) {  // {dL/dscore, src} per pair: one 16-B store
+                        float srcf;
+                        const uint32_t src = user | (cur << 31);
+                        memcpy(&srcf, &src, 4);
+                        reinterpret_cast<float4 *>(a.gsn)[q - a.begin] = make_float4(gp, srcf, gn, srcf);
+                    } else {
+                        float *gq = a.gsn + 2 * (size_t)(q - a.begin);
+                        gq[0] = gp;
+                        gq[1] = gn;
+                    }
                     loss_acc += l;
                 }
             } else if (EXPL) {
@@ -268,12 +336,13 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
             if (on) slk_vstore<VEC>(a.urec + (size_t)(p - a.begin) * a.RSU + d0, gu);
         } else if (on) {
             if (EARLY_ADAM)
-                slk_apply_vec_pre<VEC, UPD, true>(a, 0, uoff, u, su, gu, &su2, (SLK_NT_OF(a) & 1) != 0);
+                slk_apply_vec_pre<VEC, UPD, true>(a, 0, uoff, u, su, gu, &su2, (SLK_NT_OF(a) & 1) != 0, unew);
             else if (EARLY_STATE)
-                slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (SLK_NT_OF(a) & 1) != 0);
+                slk_apply_vec_pre<VEC, UPD>(a, 0, uoff, u, su, gu, nullptr, (SLK_NT_OF(a) & 1) != 0, unew);
             else
-                slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
+                slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0, unew);
         }
+        if (pp && lane == 0) a.uflag[user] = (uint8_t)(cur ^ 1u);  // (this group owns the user: nobody else reads or writes the byte in this launch)
         if (EARLY_ADAM) {
             if (lane == 0) {  // (SparseAdam decays the moments of a looked-up row whatever its gradient is)
                 slk_vec<1> bpv, bsv, bsv2, gbv;
@@ -307,7 +376,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
 // run STARTS adds the run's partials in tile order -- its own tile's slot 1, then slot 0 of the following tiles up to the
 // one in which the run ends (the next G tiles' metas are read at once, the lanes that still belong to the run are a
 // prefix) -- and applies the one update of U[u] and its bias.
-template <int VEC, int G, int UPD>
+template <int VEC, int G, int UPD, bool PP = false>
 __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
     constexpr int GPB = 256 / G;
     constexpr uint32_t S = SLK_USER_TILE;
@@ -428,10 +497,16 @@ __global__ __launch_bounds__(256) void k_user_stitch(slk_pass_args a) {
         }
         const uint32_t user = key & a.umask;
         const size_t uoff = (size_t)user * D + d0;
+        // (user-row ping-pong: the long run's segments read the row from the current copy and left the flag alone)
+        constexpr bool pingpong = PP;
+        // (read by lane 0 and handed round: nothing else separates the other lanes' read from lane 0's write below)
+        uint32_t cur = 0u;
+        if (pingpong) cur = __shfl(lane == 0 ? (uint32_t)a.uflag[user] : 0u, 0, G);
         if (on) {
-            slk_vec<VEC> u = slk_vload_if_nt<VEC>(a.P[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
-            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0);
+            slk_vec<VEC> u = slk_vload_if_nt<VEC>((cur ? a.P0alt : a.P[0]) + uoff, (SLK_NT_OF(a) & 1) != 0);
+            slk_apply_vec<VEC, UPD>(a, 0, uoff, u, gu, (SLK_NT_OF(a) & 1) != 0, pingpong ? (cur ? a.P[0] : a.P0alt) + uoff : nullptr);
         }
+        if (pingpong && lane == 0) a.uflag[user] = (uint8_t)(cur ^ 1u);
         if (lane == 0) slk_apply_bias<UPD>(a, 2, user, gbu);
     }
 }
@@ -690,6 +765,34 @@ static pass_fn user_pass_lat_fn(int upd) {
     return k_user_pass<VEC, G, SLK_UPD_GRAD_ONLY, 0, false, true, ULONG>;
 }
 
+// inside a user-row ping-pong scope (pair mode, plain tables, row-sparse optimizers): the four forms of the pass and the stitch
+template <int VEC, int G, bool LAT, bool ULONG>
+static pass_fn user_pass_pp_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, false, LAT, ULONG, true>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, false, LAT, ULONG, true>;
+    return k_user_pass<VEC, G, SLK_UPD_SGD, 0, false, LAT, ULONG, true>;
+}
+template <int VEC, int G>
+static pass_fn user_stitch_pp_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD) return k_user_stitch<VEC, G, SLK_UPD_ADAGRAD, true>;
+    if (upd == SLK_UPD_SPARSE_ADAM) return k_user_stitch<VEC, G, SLK_UPD_SPARSE_ADAM, true>;
+    return k_user_stitch<VEC, G, SLK_UPD_SGD, true>;
+}
+template <int VEC, int G>
+static slk_item_fns item_pass_pp_fn(int upd) {
+    if (upd == SLK_UPD_ADAGRAD)
+        return {k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPP>, k_item_stitch<VEC, G, SLK_UPD_ADAGRAD, SLK_PART_BOTH>,
+                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false>,
+                k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false, 4>};
+    if (upd == SLK_UPD_SPARSE_ADAM)
+        return {k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, SLK_ITEM_SNAPPP>, k_item_stitch<VEC, G, SLK_UPD_SPARSE_ADAM, SLK_PART_BOTH>,
+                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false>,
+                k_item_pass<VEC, G, SLK_UPD_SPARSE_ADAM, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false, 4>};
+    return {k_item_pass<VEC, G, SLK_UPD_SGD, SLK_ITEM_SNAPPP>, k_item_stitch<VEC, G, SLK_UPD_SGD, SLK_PART_BOTH>,
+            k_item_pass<VEC, G, SLK_UPD_SGD, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false>,
+            k_item_pass<VEC, G, SLK_UPD_SGD, SLK_ITEM_SNAPPP, SLK_PART_BOTH, false, 4>};
+}
+
 // plain tables, minibatches that hold a long user run (k_user_pass<..., ULONG = true>) and the stitch kernel behind it
 template <int VEC, int G, int UMODE>
 static pass_fn user_pass_long_fn1(int upd) {
@@ -718,7 +821,7 @@ static pass_fn user_pass_fn(int upd, int umode, bool bloom) {
 }
 
 
-int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g, bool shadow_ok) {
+int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g, bool shadow_ok, bool pingpong_ok) {
     if (!t) return slk_fail(ctx, SLK_EINVAL, "tables is NULL");
     for (int i = 0; i < 4; ++i)
         if (((table_mask >> i) & 1u) && !t->d_param[i])
@@ -726,6 +829,9 @@ int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int
     if (!shadow_ok && (table_mask & 8u) && ctx->shadow_active && t->d_param[3] == ctx->shadow_src_p)
         return slk_fail(ctx, SLK_EINVAL, "the item biases of these tables are shadowed (slk_bias_shadow_begin): the array is stale until "
                                          "slk_bias_shadow_end, and only slk_bilinear_train indexes the shadow");
+    if (!pingpong_ok && (table_mask & 1u) && ctx->pp_active && t->d_param[0] == ctx->pp_src_u)
+        return slk_fail(ctx, SLK_EINVAL, "the user rows of these tables are ping-ponged (slk_user_pingpong_begin): the array holds only "
+                                         "some of the current rows until slk_user_pingpong_end, and only slk_bilinear_train reads both copies");
     if (((table_mask & 5u) && (t->num_users < 1 || t->num_users >= ((int64_t)1 << 31))) || t->num_items < 1 ||
         t->num_items >= ((int64_t)1 << 31))
         return slk_fail(ctx, SLK_EINVAL, "table rows must be in [1, 2^31): users %lld items %lld",
@@ -931,7 +1037,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                                const float *d_ratings, bool prefetch_only) {
     if (!ctx) return SLK_EINVAL;
     int vec, g, rc;
-    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
+    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g, /*shadow_ok=*/true, /*pingpong_ok=*/true))) return rc;
     if ((rc = slk_check_optim(ctx, optim, 15u))) return rc;
     if (n < 0 || batch_size < 1) return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: n %lld batch_size %lld",
                                                  (long long)n, (long long)batch_size);
@@ -1040,7 +1146,18 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_LATE_SORT = 38 };  // ctx->extra slots (24, 25: slk_eval.hip; the user-partial metas, which keep launch stamps across calls, have a buffer of their own: ctx->upart_meta)
     const int RS = (D + 3) / 4 * 4;  // record = the pre-step user row (16-B granular; D = 64: two aligned 128-B lines)
     if ((rc = slk_ensure(ctx, ctx->snap, (size_t)bsz * RS * 4))) return rc;
-    if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * 4))) return rc;  // dL/dscore per (position, pair)
+    // user-row ping-pong of a training scope (slk_user_pingpong_begin): pair mode over plain tables with a row-sparse optimizer on
+    // the launch path -- the user pass writes the updated row to the other copy and no record, the item pass gathers the pre-step
+    // row from the copy the user pass read.  A call the scope cannot serve is refused, not trained beside it.
+    const bool pingpong = ctx->pp_active && ctx->pp_src_u == tables->d_param[0];
+    if (ctx->pp_active && !pingpong && !reserve_only)
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: a user-row ping-pong (slk_user_pingpong_begin) is open on this ctx for OTHER "
+                                         "tables; close it (slk_user_pingpong_end / _abort) before training another model");
+    if (pingpong && (pre || bloom || dense || tables->num_users != ctx->pp_rows || D != ctx->pp_dim))
+        return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: the user rows are ping-ponged (slk_user_pingpong_begin): only the pair losses "
+                                         "(pointwise, bpr, hinge) over plain tables of the scope's shape with a row-sparse optimizer train inside the scope");
+    // dL/dscore per (position, pair); ping-pong: {dL/dscore, src} per (position, pair)
+    if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * (pingpong ? 8 : 4)))) return rc;
     const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
     if ((rc = slk_ensure(ctx, ctx->losspart, (size_t)max_grid * 8))) return rc;
     if (pre) {
@@ -1082,7 +1199,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: an item-bias shadow (slk_bias_shadow_begin) is open on this ctx for OTHER "
                                          "tables; close it (slk_bias_shadow_end / _abort) before training another model");
     if (shadowed && !prefetch_only && !reserve_only) ++ctx->stat_shadowed;
-    bool epoch_route = !shadowed && (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
+    if (pingpong && !prefetch_only && !reserve_only) ++ctx->stat_pingpong;
+    bool epoch_route = !shadowed && !pingpong && (!pre || adaptive || (expl && ctx->opt_explicit_fused)) && slk_epoch_eligible(ctx, tables, optim, bsz, loss, bloom);
     auto ensure_dense_buffers = [&]() -> int {
         const size_t elems[4] = {(size_t)(Hu ? ubd.rows : tables->num_users) * D,
                                  (size_t)(Hi ? ibd.rows : tables->num_items) * D, (size_t)tables->num_users,
@@ -1157,6 +1275,14 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
         if (!bloom) ustitch = user_stitch_fn<V_, G_>(upd);                                \
         ipass = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP>(upd);                             \
         spass = k_score_pass<V_, G_>;                                                     \
+        if (pingpong) {                                                                   \
+            upass = user_pass_pp_fn<V_, G_, false, false>(upd);                           \
+            upass_lat = user_pass_pp_fn<V_, G_, true, false>(upd);                        \
+            upass_long = user_pass_pp_fn<V_, G_, false, true>(upd);                       \
+            upass_lat_long = user_pass_pp_fn<V_, G_, true, true>(upd);                    \
+            ustitch = user_stitch_pp_fn<V_, G_>(upd);                                     \
+            ipass = item_pass_pp_fn<V_, G_>(upd);                                         \
+        }                                                                                 \
         if (bloom) {                                                                      \
             ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_ROWS>(upd);     \
             ipass_bias = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_BIAS>(upd);     \
@@ -1320,6 +1446,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 a.P[3] = (float *)ctx->bias_shadow.p;
                 a.S1[3] = (float *)ctx->bias_shadow.p + 1;
                 a.bsh3 = 1u;
+            }
+            if (pingpong) {
+                a.P0alt = (float *)ctx->pp_alt.p;
+                a.uflag = (uint8_t *)ctx->pp_flags.p;
             }
             a.D = D;
             a.NP = NP;
@@ -1733,5 +1863,75 @@ SLK_EXPORT int slk_bias_shadow_abort(slk_ctx *ctx) {
     if (!ctx) return SLK_EINVAL;
     ctx->shadow_active = false;
     ctx->shadow_src_p = ctx->shadow_src_s = nullptr;
+    return SLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// User-row ping-pong (round 6).  The two ownership passes of a minibatch each need the OTHER side's pre-step rows.  Rounds 1-6
+// saved the user side: the user pass wrote every position's pre-step user row into a record (4D bytes per interaction: 13 % of
+// the pass's real traffic at C2) and the item pass gathered it from there.  With 288 GB of HBM the user table can simply exist
+// twice: a user's updated row is written to the copy that does NOT hold its current row, one byte per user says which copy is
+// current, and the pre-step row stays where it was for the item pass to gather -- the same 4D-byte random read the record cost,
+// and no record write.  The caller's table is the union of both copies until _end copies the rows whose current copy is the
+// ctx's back.  Same arithmetic in the same order: tables bit-identical to training without it.  The reference has no
+// counterpart (autograd keeps the pre-step rows alive as saved tensors: spotlight/factorization/representations.py:61-91).
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pingpong_merge(float *P0, const float *alt, const uint8_t *flag, size_t rows, int D) {
+    if (D % 4 == 0) {
+        const size_t per = (size_t)D / 4, n = rows * per;
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+            if (flag[e / per]) reinterpret_cast<float4 *>(P0)[e] = reinterpret_cast<const float4 *>(alt)[e];
+    } else {
+        const size_t n = rows * (size_t)D;
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+            if (flag[e / (size_t)D]) P0[e] = alt[e];
+    }
+}
+
+SLK_EXPORT int slk_user_pingpong_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (!tables || !optim) return slk_fail(ctx, SLK_EINVAL, "slk_user_pingpong_begin: NULL tables / optim");
+    if (ctx->pp_active) return slk_fail(ctx, SLK_EINVAL, "slk_user_pingpong_begin: a ping-pong is already active on this ctx");
+    if (tables->user_bloom || tables->item_bloom || !tables->d_param[0] ||
+        (optim->kind != SLK_OPT_ADAGRAD && optim->kind != SLK_OPT_SPARSE_ADAM && optim->kind != SLK_OPT_SGD))
+        return slk_fail(ctx, SLK_EINVAL, "slk_user_pingpong_begin: plain tables and a row-sparse optimizer (Adagrad, SparseAdam, SGD) only");
+    int vec, g, rc;
+    if ((rc = slk_check_tables(ctx, tables, 15u, &vec, &g, /*shadow_ok=*/true))) return rc;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)tables->num_users;
+    if ((rc = slk_ensure(ctx, ctx->pp_alt, rows * (size_t)tables->dim * 4))) return rc;
+    if ((rc = slk_ensure(ctx, ctx->pp_flags, (rows + 15) / 16 * 16))) return rc;
+    SLK_HIP(ctx, hipMemsetAsync(ctx->pp_flags.p, 0, (rows + 15) / 16 * 16, s));  // every current row is the caller's
+    ctx->pp_src_u = tables->d_param[0];
+    ctx->pp_rows = tables->num_users;
+    ctx->pp_dim = tables->dim;
+    ctx->pp_active = true;
+    ctx->last_stream = s;
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_user_pingpong_end(slk_ctx *ctx, void *stream) {
+    if (!ctx) return SLK_EINVAL;
+    if (!ctx->pp_active) return SLK_OK;
+    // closed on every return (as slk_bias_shadow_end): a failed launch leaves the caller's table a mix of rows, and says so
+    float *const dst = ctx->pp_src_u;
+    const int64_t rows = ctx->pp_rows;
+    const int D = ctx->pp_dim;
+    ctx->pp_active = false;
+    ctx->pp_src_u = nullptr;
+    SLK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pingpong_merge, dim3(slk_grid_for(ctx, (size_t)rows * (size_t)((D + 3) / 4), 256)), dim3(256), 0, s, dst,
+                       (const float *)ctx->pp_alt.p, (const uint8_t *)ctx->pp_flags.p, (size_t)rows, D);
+    SLK_LAUNCH_CHECK(ctx, "k_pingpong_merge");
+    ctx->last_stream = s;
+    return SLK_OK;
+}
+
+SLK_EXPORT int slk_user_pingpong_abort(slk_ctx *ctx) {
+    if (!ctx) return SLK_EINVAL;
+    ctx->pp_active = false;
+    ctx->pp_src_u = nullptr;
     return SLK_OK;
 }

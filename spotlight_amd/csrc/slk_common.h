@@ -110,6 +110,13 @@ struct slk_ctx {
     float *shadow_src_p = nullptr, *shadow_src_s = nullptr;  // the arrays it stands for (tables->d_param[3], optim->d_state1[3])
     int64_t shadow_rows = 0;
     bool shadow_active = false;
+    // user-row ping-pong of a training scope (slk_user_pingpong_begin / _end, slk_bilinear.hip): the second copy of the user
+    // embedding table and one byte per user (which copy holds the current row)
+    slk_buf pp_alt, pp_flags;
+    float *pp_src_u = nullptr;   // the array it doubles (tables->d_param[0])
+    int64_t pp_rows = 0;
+    int pp_dim = 0;
+    bool pp_active = false;
     slk_buf mt_tmp;              // generator scratch: the 33-block prefix + one start block per stream (slk_rng.hip)
 
     // scratch (grown on demand, freed in slk_ctx_destroy)
@@ -220,6 +227,7 @@ struct slk_ctx {
     int64_t stat_overlapped = 0;    // chunks whose negatives + sorts ran on the prep stream beside the chunk before's passes
     int64_t stat_prefetched = 0;    // chunks prepared ahead that a training call took over (slk_ctx_get_stat)
     int64_t stat_shadowed = 0;      // training calls that ran on the item-bias shadow (slk_bias_shadow_begin)
+    int64_t stat_pingpong = 0;      // training calls that ran on the user-row ping-pong (slk_user_pingpong_begin)
     int last_pipe_set = -1;         // buffer set of the last chunk of the last pipelined training call (-1: none yet)
     uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)
     uint32_t upart_gen = 0;         // user pass, long runs: likewise (slk_bilinear.hip)
@@ -314,7 +322,9 @@ int slk_eval_user_rep(slk_ctx *ctx, const slk_tables *tables, int vec, int g, co
 // shared host helpers (slk_bilinear.hip)
 // shadow_ok: the caller indexes the item-bias shadow of an open slk_bias_shadow_begin scope itself (the training call); every
 // other call that names the shadowed bias array is refused -- the caller's array is stale inside the scope
-int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g, bool shadow_ok = false);
+// pingpong_ok: likewise for the user rows of an open slk_user_pingpong_begin scope (slk_bilinear_train alone reads both copies)
+int slk_check_tables(slk_ctx *ctx, const slk_tables *t, unsigned table_mask, int *vec, int *g, bool shadow_ok = false,
+                     bool pingpong_ok = false);
 int slk_launch_i64_to_u32(slk_ctx *ctx, const int64_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 int slk_sort_reserve(slk_ctx *ctx, size_t n);

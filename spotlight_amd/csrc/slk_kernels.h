@@ -151,6 +151,13 @@ struct slk_pass_args {
     float c_omb1, c_omb2;  // 1-beta1, 1-beta2
     int nt;                // cache-policy bits (ctx option "nt")
     int ubz;               // 1: the user biases are identically zero and this pass cannot change them (slk_tables::flags): not fetched
+    // user-row ping-pong of a training scope (slk_user_pingpong_begin, pair mode over a plain user table): the user table
+    // exists twice.  uflag[u] = the copy that holds user u's current row (0 = P[0], 1 = P0alt).  The user pass reads the row
+    // from that copy, writes the UPDATED row to the other one and flips the flag; the copy it read still holds the pre-step
+    // row, so the item pass gathers u_old from there and the pass writes NO record.  gsn is then [position][pair] of
+    // {dL/dscore, src}: src = user | (copy that holds the pre-step row) << 31.  uflag == nullptr: no ping-pong.
+    float *P0alt;
+    uint8_t *uflag;
 };
 
 enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_UPD_SGD = 3 };
@@ -165,7 +172,10 @@ enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_
 //         vec = g_s * repr (+ hist when s == 0), bias g_s                       (PoolNet)
 //   ROW   r = slot; record(slot) = [vec (D) | bias grad];                        (user-bloom rows)
 //   BLK   r = slot of an exchange buffer (slk_blk_row / slk_blk_scalar): vec, bias grad  (row-sharded)
-enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2, SLK_ITEM_BLK = 3 };
+//   SNAPPP  as SNAP with NP == 2 inside a user-row ping-pong scope: no record; gsn[r - begin*2] = {g_s, src} (8 bytes),
+//         u_old = the row of user (src & 0x7fffffff) in the copy (src >> 31) of the user table (slk_pass_args::P0alt)
+enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2, SLK_ITEM_BLK = 3, SLK_ITEM_SNAPPP = 4 };
+#define SLK_ITEM_IS_SNAP(MODE) ((MODE) == SLK_ITEM_SNAP || (MODE) == SLK_ITEM_SNAPPP)
 
 // Exchange buffers of the row-sharded path (slk_shard.hip): slots come in blocks of 64, a block is 64 rows of D floats
 // followed by the 64 scalars (bias / bias gradient) of those rows.  Every row of a D = 64 table is then one aligned
@@ -187,7 +197,9 @@ __device__ __forceinline__ size_t slk_blk_scalar(uint32_t slot, int D) {
 // dense gradient buffer (aliased on S1) for the full-table sweep.
 template <int VEC, int UPD>
 __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
-                                              const slk_vec<VEC> &g, bool nt = false) {
+                                              const slk_vec<VEC> &g, bool nt = false, float *pdst = nullptr) {
+    // pdst: where the updated parameter elements go (user-row ping-pong: the other copy of the table); default in place
+    float *const pout = pdst ? pdst : a.P[t] + off;
     if (UPD == SLK_UPD_ADAGRAD) {
         // torch/optim/adagrad.py:360-385: sum += g^2; p += -clr * (g / (sqrt(sum) + eps))
         slk_vec<VEC> s = slk_vload_if_nt<VEC>(a.S1[t] + off, nt);
@@ -197,7 +209,7 @@ __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, siz
             p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
         }
         slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else if (UPD == SLK_UPD_SPARSE_ADAM) {
         // torch/optim/_functional.py:61-84
         slk_vec<VEC> m = slk_vload_if_nt<VEC>(a.S1[t] + off, nt);
@@ -212,12 +224,12 @@ __device__ __forceinline__ void slk_apply_vec(const slk_pass_args &a, int t, siz
         }
         slk_vstore_if_nt<VEC>(a.S1[t] + off, m, nt);
         slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else if (UPD == SLK_UPD_SGD) {
         // torch/optim/sgd.py (momentum 0, weight_decay 0): param.add_(grad, alpha=-lr)
 #pragma unroll
         for (int i = 0; i < VEC; ++i) p.v[i] += -a.c_lr * g.v[i];
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else {
         slk_vstore<VEC>(a.S1[t] + off, g);
     }
@@ -295,7 +307,16 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
         const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
         const uint32_t s = r - pos * NP;
         const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
-        if (MODE == SLK_ITEM_SNAP) {
+        if (MODE == SLK_ITEM_SNAPPP) {
+            // user-row ping-pong: {dL/dscore, src} in one 8-byte load, then the pre-step user row from the copy the user pass
+            // left untouched (no record was written)
+            const uint2 t = reinterpret_cast<const uint2 *>(a.gsn)[r - a.begin * 2u];
+            memcpy(&gb, &t.x, 4);
+            const float *urow = ((t.y >> 31) ? a.P0alt : a.P[0]) + (size_t)(t.y & 0x7fffffffu) * D;
+            const slk_vec<VEC> u = on ? slk_vload_if_nt<VEC>(urow + d0, (SLK_NT_OF(a) & 32) != 0) : slk_vzero<VEC>();
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) c.v[i] = gb * u.v[i];
+        } else if (MODE == SLK_ITEM_SNAP) {
             gb = a.gsn[r - a.begin * NP];
             // several negatives per interaction (adaptive hinge): only the positive and the selected
             // negative carry a gradient, so the row is fetched only when dL/dscore != 0 (a dependent
@@ -354,6 +375,10 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
                                // 0.3135 -> 0.2935 ms, minibatch 65 536 45.3 -> 43.1 us, C5 shard unchanged
 #endif
 
+#ifndef SLK_ITEM_GSPF
+#define SLK_ITEM_GSPF 1        // 1: inside a ping-pong scope a tile's {dL/dscore, src} pairs are fetched at the top of the tile (k_item_pass: GSPF)
+#endif
+
 #ifndef SLK_USER_TILE
 #define SLK_USER_TILE 32  // user pass: a user run that wholly covers an aligned tile of this many positions is LONG (k_user_pass<ULONG>)
 #endif
@@ -373,7 +398,8 @@ enum { SLK_PART_BOTH = 0, SLK_PART_ROWS = 1, SLK_PART_BIAS = 2 };
 template <int VEC, int UPD, bool S2PRE = false>
 __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t, size_t off, slk_vec<VEC> &p,
                                                   slk_vec<VEC> &s, const slk_vec<VEC> &g,
-                                                  const slk_vec<VEC> *s2 = nullptr, bool nt = false) {
+                                                  const slk_vec<VEC> *s2 = nullptr, bool nt = false, float *pdst = nullptr) {
+    float *const pout = pdst ? pdst : a.P[t] + off;
     if (UPD == SLK_UPD_ADAGRAD) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -381,7 +407,7 @@ __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t,
             p.v[i] += -a.c_lr * (g.v[i] / (sqrtf(s.v[i]) + a.c_eps));
         }
         slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else if (UPD == SLK_UPD_SPARSE_ADAM) {
         slk_vec<VEC> v = S2PRE ? *s2 : slk_vload<VEC>(a.S2[t] + off);
 #pragma unroll
@@ -394,11 +420,11 @@ __device__ __forceinline__ void slk_apply_vec_pre(const slk_pass_args &a, int t,
         }
         slk_vstore_if_nt<VEC>(a.S1[t] + off, s, nt);
         slk_vstore_if_nt<VEC>(a.S2[t] + off, v, nt);
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else if (UPD == SLK_UPD_SGD) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) p.v[i] += -a.c_lr * g.v[i];
-        slk_vstore_if_nt<VEC>(a.P[t] + off, p, nt);
+        slk_vstore_if_nt<VEC>(pout, p, nt);
     } else {
         slk_vstore<VEC>(a.S1[t] + off, g);
     }
@@ -454,6 +480,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
     __shared__ uint32_t s_far[3];      // key of the previous tile's first position, of the next (full) tile's last position
     __shared__ uint32_t s_pay[T];
     __shared__ float s_g[T];
+    __shared__ uint32_t s_src[T];      // SNAPPP: where the position's pre-step user row stands (GSPF below)
     __shared__ uint8_t s_live[T];
     __shared__ uint16_t s_head[T];
     __shared__ int s_nheads;
@@ -496,6 +523,10 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
             pf_far2 = next_full ? 1u : 0u;
         }
     };
+    // GSPF (ping-pong): a position's {dL/dscore, src} pair is fetched by the thread that holds its payload at the TOP of the tile --
+    // in flight while wave 0 compacts the heads -- and handed to the row groups through LDS, so that the gather of the pre-step user
+    // rows goes out WITH the head's row + state loads instead of one dependent round trip behind them
+    constexpr bool GSPF = MODE == SLK_ITEM_SNAPPP && KEYPF && SLK_ITEM_GSPF != 0;
     if (KEYPF && blockIdx.x < ntiles) tile_fetch(blockIdx.x);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tb = ibegin + tile * T;
@@ -503,6 +534,8 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
         const bool first_tile = tb == ibegin;
         const bool has_next = tb + (uint32_t)tn < iend;
         __syncthreads();  // LDS of the previous tile no longer in use
+        uint2 gs_pf = make_uint2(0u, 0u);
+        if (GSPF && (int)threadIdx.x < tn) gs_pf = reinterpret_cast<const uint2 *>(a.gsn)[pf_pay - a.begin * 2u];
         if (KEYPF) {
             const int i = (int)threadIdx.x;
             if (i <= tn + (LONG ? 1 : 0)) s_key[i] = pf_key;
@@ -565,6 +598,10 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
             }
             if (threadIdx.x == 0) s_nheads = base;
         }
+        if (GSPF && (int)threadIdx.x < tn) {
+            memcpy(&s_g[threadIdx.x], &gs_pf.x, 4);
+            s_src[threadIdx.x] = gs_pf.y;
+        }
         __syncthreads();
         const int nheads = s_nheads;
         // A head's run gets its update here unless it is a piece of a LONG run: the inherited one (position 0) or the one
@@ -615,7 +652,16 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                 const uint32_t item = s_key[j + 1] & a.imask;
                 mine = item != a.pad_item && item != a.pad_item2;
             }
-            if (mine) slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, rows_on, c[it], g[it]);
+            if (mine && GSPF) {
+                g[it] = s_g[j];
+                const uint32_t src = s_src[j];
+                const float *urow = ((src >> 31) ? a.P0alt : a.P[0]) + (size_t)(src & 0x7fffffffu) * D;
+                const slk_vec<VEC> u = rows_on ? slk_vload_if_nt<VEC>(urow + d0, (SLK_NT_OF(a) & 32) != 0) : slk_vzero<VEC>();
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c[it].v[i] = g[it] * u.v[i];
+            } else if (mine) {
+                slk_item_contrib<VEC, MODE>(a, s_pay[j], D, d0, rows_on, c[it], g[it]);
+            }
         }
         if (KEYPF && tile + gridDim.x < ntiles) tile_fetch(tile + gridDim.x);  // in flight behind the gathers
 #pragma unroll
@@ -625,7 +671,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                 slk_vstore<VEC>(s_row + j * DL + d0, c[it]);
                 if (lane == 0) {
                     s_g[j] = g[it];
-                    s_live[j] = (MODE == SLK_ITEM_SNAP) ? (g[it] != 0.0f) : 1;
+                    s_live[j] = SLK_ITEM_IS_SNAP(MODE) ? (g[it] != 0.0f) : 1;
                 }
             }
         }
@@ -681,7 +727,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                             }
 #pragma unroll
                             for (int e = 0; e < SLK_SPILL_BATCH; ++e) {
-                                if (j0 + e < cnt && (MODE != SLK_ITEM_SNAP || gq[e] != 0.0f)) {
+                                if (j0 + e < cnt && (!SLK_ITEM_IS_SNAP(MODE) || gq[e] != 0.0f)) {
 #pragma unroll
                                     for (int i = 0; i < VEC; ++i) gv.v[i] += cc[e].v[i];
                                     gb += gq[e];

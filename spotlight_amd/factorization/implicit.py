@@ -28,6 +28,11 @@ _PREFETCH = True  # large epochs: the next epoch's first chunk is prepared besid
 # of fit() (include/spotlight_hip.h: slk_bias_shadow_begin): on such tables a minibatch's biases share no cache line and the two
 # scalars cost the item pass a quarter of its memory requests (12.5 % of them are saved: C5 shard).
 _BIAS_SHADOW_MIN_ITEMS = 1 << 24
+# Minibatches of at least this many interactions (pair losses, plain tables, row-sparse optimizers) train on a DOUBLED user table
+# for the duration of fit() (include/spotlight_hip.h: slk_user_pingpong_begin): the user pass writes a user's updated row to the
+# copy that does not hold the current one and no pre-step-row record (a row per interaction: 13 % of the pass's traffic), the item
+# pass gathers the pre-step row where it still stands.  Below, the passes are latency-bound and the record is cache-resident.
+_USER_PINGPONG_MIN_BATCH = 1 << 17
 
 
 def _engine_for(device):
@@ -572,12 +577,19 @@ class ImplicitFactorizationModel(object):
                                     enabled=(binding.kind == 'adagrad' and self._num_items >= _BIAS_SHADOW_MIN_ITEMS and
                                              self._batch_size >= 4096 and not tables.item_bloom))
         shadowed = False
+        pingpong = engine.user_pingpong(tables, binding.as_struct(), stream=stream,
+                                        enabled=(self._loss in ('pointwise', 'bpr', 'hinge') and binding.kind in ('adagrad', 'sparse_adam', 'sgd')
+                                                 and min(self._batch_size, n) >= _USER_PINGPONG_MIN_BATCH
+                                                 and not tables.user_bloom and not tables.item_bloom))
+        pingponged = False
         try:
             state = shuffle_into(0, consumed)  # the first epoch's shuffle: the one nothing hides
             mark('shuffle 0')
             check.result()  # raises what _check_input raised
             shadow.__enter__()  # (from here to the `finally` the item-bias tensors are stale: nothing below reads them)
             shadowed = True
+            pingpong.__enter__()  # (... and the user-embedding tensor holds only some of the current rows)
+            pingponged = True
             if _PREFETCH:
                 engine.bilinear_prefetch(tables, binding.as_struct(), bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), n, self._batch_size,
                                          self._loss, self._num_negative_samples, state=state, stream=stream)
@@ -629,8 +641,12 @@ class ImplicitFactorizationModel(object):
                     raise ValueError('Degenerate epoch loss: {}'.format(epoch_loss))
         finally:
             try:
-                if shadowed:
-                    shadow.__exit__(None, None, None)  # the trained biases and their accumulator back into torch's tensors
+                try:
+                    if pingponged:
+                        pingpong.__exit__(None, None, None)  # the rows whose current copy is the ctx's back into torch's tensor
+                finally:
+                    if shadowed:
+                        shadow.__exit__(None, None, None)  # the trained biases and their accumulator back into torch's tensors
             finally:  # (whatever the write-back raised, the threads are joined and the RandomState is the reference's)
                 if job is not None:
                     try:

@@ -1,7 +1,8 @@
 """TEST HARNESS: one rank of the row-sharded training parity check (tests/test_sharded.py).
 
 Backend 'emu': the fiber-emulator build of the engine sources + gloo on CPU tensors (runs
-anywhere).  Backend 'hip': the real gfx950 library + nccl (needs one GPU per rank).  Every
+anywhere).  Backend 'hip': the real gfx950 library + nccl (needs one GPU per rank).  Backend 'hipgloo': the real library, every
+rank on GPU 0, gloo collectives on device tensors (a box with ONE GPU runs world 2 / 3 with real remote peers).  Every
 rank trains its shards through spotlight_amd.factorization.sharded.ShardedBilinearTrainer;
 rank 0 then reassembles the tables and compares them with (a) the CPU oracle and (b) the
 single-device engine run on the same minibatches and negatives."""
@@ -34,6 +35,15 @@ def main():
         dev = torch.device('cpu')
         eng = _native.Engine(0, lib=emu_lib())
         stream = 0
+    elif backend == 'hipgloo':
+        # every rank on the ONE GPU of the box, the collectives over gloo (device tensors staged through the host by
+        # ProcessGroupGloo): the real gfx950 kernels of the shard phases against a real REMOTE peer -- RCCL refuses two ranks on one
+        # device, and the GPU boxes have one
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('gloo')
+        eng = _native.Engine(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
     else:
         torch.cuda.set_device(rank)
         dev = torch.device('cuda', rank)

@@ -1488,6 +1488,125 @@ def check_bias_shadow_is_bit_neutral(be, loss, D, U, I, N, B, nn=1, seed=43, opt
     assert not np.array_equal(results[0][4].ravel(), params[3].astype(np.float32).ravel())  # (the biases did train)
 
 
+def check_user_pingpong_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=53, options=None, with_bias_shadow=False, calls=2):
+    """Training inside a user-row ping-pong scope (slk_user_pingpong_begin / _end: the user table doubled in the ctx, the user
+    pass writes updated rows to the other copy and no record, the item pass gathers pre-step rows where they still stand)
+    against plain training: losses, every table and state tensor bit for bit.  Inside the scope the caller's user table is a MIX
+    of rows (some current rows live in the ctx's copy); the scope's end makes it whole.  `calls` training calls per scope: a
+    user's current copy alternates with every minibatch that touches it."""
+    eng = be.engine
+    rs = np.random.RandomState(seed)
+    users = rs.randint(0, U, N).astype(np.int64)
+    items = rs.randint(0, I, N).astype(np.int64)
+    sc = min(0.3, 1.0 / np.sqrt(D))
+    params = [rs.normal(0, sc, (U, D)), rs.normal(0, sc, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    state = np.random.RandomState(seed + 1).get_state()
+    n_mb = (N + B - 1) // B
+    results = []
+    saved = {k: eng.get_option(k) for k in (options or {})}
+    for pingpong in (False, True):
+        for k, v in (options or {}).items():
+            eng.set_option(k, v)
+        try:
+            dev = be.model(params, opt=opt, lr=0.05)
+            eng.rng_set_state(state)
+            d_users, d_items = be.alloc(users), be.alloc(items)
+            mb_loss = be.alloc(np.zeros(calls * n_mb, dtype=np.float32))
+            n0 = eng.get_stat('pingpong_calls')
+            with eng.bias_shadow(dev.tables, dev.optim, stream=be.stream, enabled=with_bias_shadow):
+                with eng.user_pingpong(dev.tables, dev.optim, stream=be.stream, enabled=pingpong):
+                    for rep in range(calls):
+                        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
+                                           be.ptr(mb_loss) + 4 * rep * n_mb, stream=be.stream)
+                    if pingpong:
+                        assert eng.get_stat('pingpong_calls') == n0 + calls  # every call of the scope ran on the two copies
+                        mixed = be.get(dev.p[0]).copy()
+            results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
+        finally:
+            for k, v in saved.items():
+                eng.set_option(k, v)
+    for k, (a, b) in enumerate(zip(*results)):
+        if k == 0:  # the minibatch losses: the scope's user pass is another kernel (its own occupancy, hence its own grid: the fp32
+            # per-thread loss sums associate differently; small minibatches take the persistent kernel outside the scope)
+            assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (a, b)
+            continue
+        assert np.array_equal(a, b), ('tensor %d differs between ping-ponged and plain user rows' % k)
+    # inside the scope the caller's array holds the current row of exactly the users that were updated an EVEN number of times
+    # (a user's current copy alternates with every minibatch that touches it); the others' current rows were in the ctx's copy
+    times = np.zeros(U, dtype=np.int64)
+    for m in range(n_mb):
+        times[np.unique(users[m * B:(m + 1) * B])] += calls
+    home = times % 2 == 0
+    assert np.array_equal(mixed[home], results[1][1][home])
+    if (~home).any():
+        assert not np.array_equal(mixed[~home], results[1][1][~home])
+    assert not np.array_equal(results[0][1], params[0].astype(np.float32))  # (the user rows did train)
+
+
+def check_user_pingpong_contract(be):
+    """include/spotlight_hip.h, slk_user_pingpong_begin: what the scope covers and refuses, and its lifetime rules -- one scope per
+    ctx, plain tables + row-sparse optimizers; calls that would read the caller's (mixed) user table are refused inside it; so
+    are adaptive hinge, explicit feedback and another model's tables; _end makes the table whole, _abort does not."""
+    import pytest
+    from spotlight_amd import _native
+    rs = np.random.RandomState(5)
+    U, I, D, N, B = 40, 30, 8, 600, 128
+    params = [rs.normal(0, 0.1, (U, D)), rs.normal(0, 0.1, (I, D)), rs.normal(0, 0.1, U), rs.normal(0, 0.1, I)]
+    users, items = rs.randint(0, U, N).astype(np.int64), rs.randint(0, I, N).astype(np.int64)
+    d_u, d_i = be.alloc(users), be.alloc(items)
+    nmb = (N + B - 1) // B
+    loss = be.alloc(np.zeros(nmb, dtype=np.float32))
+    eng = be.engine
+
+    def train(dev, kind='bpr', nn=1):
+        eng.rng_set_state(np.random.RandomState(9).get_state())
+        eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_u), be.ptr(d_i), N, B, kind, nn, be.ptr(loss), stream=be.stream)
+
+    dense = be.model(params, opt='adam_dense', lr=0.05)
+    with pytest.raises(_native.SlkError, match='row-sparse'):
+        with eng.user_pingpong(dense.tables, dense.optim, stream=be.stream):
+            pass
+    dev = be.model(params, opt='adagrad', lr=0.05)
+    other = be.model(params, opt='adagrad', lr=0.05)
+    ref = be.model(params, opt='adagrad', lr=0.05)
+    train(ref)
+    want = be.get(ref.p[0]).copy()
+    out, one = be.alloc(np.empty(I, dtype=np.float32)), be.alloc(np.array([3], dtype=np.int64))
+    with eng.user_pingpong(dev.tables, dev.optim, stream=be.stream):
+        with pytest.raises(_native.SlkError, match='already active'):  # one scope per ctx
+            with eng.user_pingpong(dev.tables, dev.optim, stream=be.stream):
+                pass
+        train(dev)
+        # the caller's user table is a mix of rows inside the scope: a call that would read it is refused, not answered
+        with pytest.raises(_native.SlkError, match='ping-ponged'):
+            eng.bilinear_predict(dev.tables, be.ptr(one), 1, None, I, be.ptr(out), be.stream)
+        # losses the scope does not cover, on ITS tables: refused (the scope belongs to this model's pair-loss training)
+        with pytest.raises(_native.SlkError, match='ping-ponged'):
+            train(dev, 'adaptive_hinge', 3)
+        ratings = be.alloc(np.ones(N, dtype=np.float32))
+        with pytest.raises(_native.SlkError, match='ping-ponged'):
+            eng.bilinear_train_explicit(dev.tables, dev.optim, be.ptr(d_u), be.ptr(d_i), be.ptr(ratings), N, B, 'regression',
+                                        be.ptr(loss), stream=be.stream)
+        with pytest.raises(_native.SlkError, match='OTHER'):  # another model's tables while the scope is open
+            train(other)
+        eng.bilinear_reserve(other.tables, other.optim, N, B, 'bpr', 1, stream=be.stream)  # (allocating is not training)
+        assert not np.array_equal(be.get(dev.p[0]), want)  # some current rows are in the ctx's copy
+    assert np.array_equal(be.get(dev.p[0]), want)  # _end made the table whole: the plain run's table bit for bit
+    eng.bilinear_predict(dev.tables, be.ptr(one), 1, None, I, be.ptr(out), be.stream)  # (and answered again outside it)
+    assert np.isfinite(be.get(out)).all()
+    train(other)  # the ctx is free again
+    # _abort: the scope closes, nothing is copied back
+    scope = eng.user_pingpong(dev.tables, dev.optim, stream=be.stream)
+    scope.__enter__()
+    train(dev)
+    mixed = be.get(dev.p[0]).copy()
+    scope.abort()
+    assert np.array_equal(be.get(dev.p[0]), mixed)
+    with eng.user_pingpong(dev.tables, dev.optim, stream=be.stream):  # and a new scope can open
+        pass
+    scope.__exit__(None, None, None)  # (a closed scope's exit is a no-op)
+
+
 # ---------------------------------------------------------------------------------------
 # persistent epoch kernel (csrc/slk_epoch.hip) against the per-minibatch launches
 # ---------------------------------------------------------------------------------------

@@ -42,6 +42,23 @@ def test_bias_shadow_is_bit_neutral(be, loss, nn):
                                         options={'user_lat_max_batch': 0, 'item_lat_max_tiles': 0, 'item_long_gate': 0})
 
 
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('hinge', 'sparse_adam'), ('pointwise', 'sgd'), ('bpr', 'sparse_adam')])
+def test_user_pingpong_is_bit_neutral(be, loss, opt):
+    # plain passes (users recur: a row's current copy alternates); hot users AND hot items (long runs + both stitch kernels); the
+    # bandwidth-bound forms forced; together with the item-bias shadow
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 16, U=400, I=300, N=3000, B=512)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 8, U=7, I=6, N=4000, B=2048, seed=57)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 16, U=400, I=300, N=3000, B=512, seed=58,
+                                          options={'user_lat_max_batch': 0, 'item_lat_max_tiles': 0, 'item_long_gate': 0})
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 5, U=90, I=70, N=2000, B=700, seed=59, options={'chunk_interactions': 1400})
+    if opt == 'adagrad':
+        ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 16, U=400, I=300, N=3000, B=512, seed=60, with_bias_shadow=True)
+
+
+def test_user_pingpong_contract(be):
+    ec.check_user_pingpong_contract(be)
+
+
 def test_bias_shadow_refuses_what_it_does_not_cover(be):
     ec.check_bias_shadow_refusals(be)
 

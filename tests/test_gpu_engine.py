@@ -40,6 +40,21 @@ def test_bias_shadow_is_bit_neutral(be, loss, nn):
     ec.check_bias_shadow_is_bit_neutral(be, loss, 64, U=5000, I=40, N=200000, B=1 << 17, nn=nn, seed=48)  # hot items: long runs + stitch
 
 
+@pytest.mark.parametrize('loss,opt', [('bpr', 'adagrad'), ('hinge', 'sparse_adam'), ('pointwise', 'sgd')])
+def test_user_pingpong_is_bit_neutral(be, loss, opt):
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 64, U=200000, I=100000, N=600000, B=1 << 18, calls=3)  # the bandwidth-bound forms
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 32, U=943, I=1682, N=20000, B=4096, seed=57)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 64, U=50, I=40, N=400000, B=1 << 18, seed=58)  # hot users and items: long runs + both stitch kernels
+    ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 64, U=300000, I=50000, N=3000000, B=1 << 18, seed=59,
+                                          options={'chunk_interactions': 1 << 20, 'overlap_prep': 1})  # several chunks, prep beside the passes
+    if opt == 'adagrad':
+        ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 64, U=200000, I=100000, N=300000, B=65536, seed=60, with_bias_shadow=True)
+
+
+def test_user_pingpong_contract(be):
+    ec.check_user_pingpong_contract(be)
+
+
 def test_bias_shadow_refuses_what_it_does_not_cover(be):
     ec.check_bias_shadow_refusals(be)
 

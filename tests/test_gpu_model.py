@@ -293,6 +293,16 @@ def test_bias_shadowed_fit_is_value_neutral_on_gpu():
     check_bias_shadowed_fit_is_value_neutral(engine, use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
 
 
+def test_user_pingponged_fit_is_value_neutral_on_gpu():
+    """fit() on the doubled user table (large minibatches; forced here) against the one-table layout: tables, optimizer state,
+    predictions and RandomState bit for bit."""
+    import torch
+    from spotlight_amd.factorization import implicit as host
+    from test_host_model import check_user_pingponged_fit_is_value_neutral
+    engine = host._engine_for(torch.device('cuda', 0))
+    check_user_pingponged_fit_is_value_neutral(engine, use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())
+
+
 def test_pipelined_seq_fit_is_value_neutral_on_gpu():
     from test_host_seq_model import check_pipelined_seq_fit_is_value_neutral
     check_pipelined_seq_fit_is_value_neutral(use_cuda=True, to_numpy=lambda w: w.detach().cpu().numpy())

@@ -368,6 +368,86 @@ def test_bias_shadowed_fit_is_value_neutral(emu_device):
     check_bias_shadowed_fit_is_value_neutral(emu_device)
 
 
+def check_user_pingponged_fit_is_value_neutral(engine, use_cuda=False, to_numpy=lambda w: w.detach().numpy()):
+    """Large minibatches train on a doubled user table for the duration of fit() (slk_user_pingpong_begin; host:
+    _USER_PINGPONG_MIN_BATCH).  Forced on small minibatches, against the one-table layout: tables, optimizer state, predictions and
+    RandomState bit for bit, over two fit() calls (the second starts from the table the first made whole), for the optimizers the
+    scope covers -- with the adaptive-hinge model on the side, whose loss it does not cover and whose fit() never opens one."""
+    rs = np.random.RandomState(15)
+    inter = Interactions(rs.randint(0, 90, 12000).astype(np.int32), rs.randint(0, 60, 12000).astype(np.int32), num_users=90, num_items=60)
+    results = []
+    old = host._PIPELINE_MAX_DRAWS, host._USER_PINGPONG_MIN_BATCH
+    saved = {k: engine.get_option(k) for k in ('chunk_interactions', 'overlap_min_batch')}
+    engine.set_option('chunk_interactions', 4096)
+    engine.set_option('overlap_min_batch', 0)
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        for floor in (1, 1 << 40):
+            host._USER_PINGPONG_MIN_BATCH = floor
+            before = engine.get_stat('pingpong_calls')
+            for loss, kw in (('bpr', dict(optimizer_func=_adagrad)), ('adaptive_hinge', dict(num_negative_samples=3, optimizer_func=_adagrad)),
+                             ('pointwise', dict(sparse=True, optimizer_func=lambda p: torch.optim.SparseAdam(list(p), lr=0.01))),
+                             ('hinge', dict(optimizer_func=lambda p: torch.optim.SGD(list(p), lr=0.05)))):
+                model = ImplicitFactorizationModel(loss=loss, embedding_dim=16, n_iter=2, batch_size=4096, use_cuda=use_cuda,
+                                                   random_state=np.random.RandomState(7), **kw)
+                model.fit(inter)
+                scores = model.predict(3).copy()  # (refused with "ping-ponged" if fit() had left the scope open)
+                model.fit(inter)
+                st = model._random_state.get_state()
+                opt_state = [to_numpy(v[k]).copy() for v in model._optimizer.state.values() for k in ('sum', 'exp_avg', 'exp_avg_sq') if k in v]
+                results.append([to_numpy(w).copy() for w in model._net.tables()] + opt_state + [scores, st[1].copy(), np.array(st[2])])
+            # three covered models x two fit() calls x two epochs (one training call each) ran on the doubled table; nothing else did
+            assert engine.get_stat('pingpong_calls') - before == (3 * 2 * 2 if floor == 1 else 0)
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._USER_PINGPONG_MIN_BATCH = old
+        for k, v in saved.items():
+            engine.set_option(k, v)
+    half = len(results) // 2
+    for a, b in zip(results[:half], results[half:]):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_user_pingponged_fit_is_value_neutral(emu_device):
+    check_user_pingponged_fit_is_value_neutral(emu_device)
+
+
+def test_exception_inside_a_pingponged_fit_makes_the_user_table_whole(emu_device, monkeypatch):
+    """A fit() that dies between two epochs while its user table is doubled (slk_user_pingpong_begin) leaves on its way out what
+    the one-table layout leaves: the user rows of the epochs that ran, no open scope on the shared engine."""
+    rs = np.random.RandomState(16)
+    inter = Interactions(rs.randint(0, 90, 12000).astype(np.int32), rs.randint(0, 60, 12000).astype(np.int32), num_users=90, num_items=60)
+    old = host._PIPELINE_MAX_DRAWS, host._USER_PINGPONG_MIN_BATCH
+    real_check = emu_device.check
+    left = []
+    try:
+        host._PIPELINE_MAX_DRAWS = 0
+        for floor in (1, 1 << 40):
+            host._USER_PINGPONG_MIN_BATCH = floor
+            model = ImplicitFactorizationModel(loss='bpr', embedding_dim=16, n_iter=3, batch_size=4096, optimizer_func=_adagrad,
+                                               random_state=np.random.RandomState(7))
+            calls = []
+
+            def failing_check():
+                calls.append(1)
+                if len(calls) == 2:
+                    raise RuntimeError('injected: epoch 1 failed')
+                return real_check()
+            monkeypatch.setattr(emu_device, 'check', failing_check)
+            with pytest.raises(RuntimeError, match='injected'):
+                model.fit(inter)
+            monkeypatch.setattr(emu_device, 'check', real_check)
+            scores = model.predict(3)  # (refused with "ping-ponged" if the scope were still open)
+            acc = [v['sum'].numpy().copy() for v in model._optimizer.state.values() if 'sum' in v]
+            left.append([w.detach().numpy().copy() for w in model._net.tables()] + acc + [scores])
+            model.fit(inter)  # ... and the engine takes the next fit(), on a doubled table again or not
+        for x, y in zip(left[0], left[1]):
+            assert np.array_equal(x, y)
+    finally:
+        host._PIPELINE_MAX_DRAWS, host._USER_PINGPONG_MIN_BATCH = old
+
+
 def test_fit_without_epochs_and_failed_epochs_leave_the_random_state_consistent(emu_device):
     """n_iter = 0 is a no-op on both epoch loops (the large-epoch loop raised UnboundLocalError); a degenerate epoch
     leaves the RandomState behind that epoch's negatives -- not behind the shuffle already prepared for the next one."""

@@ -193,3 +193,30 @@ def test_gpu_sharded_whole_chunk_with_slices_world1_nccl():
 @pytest.mark.gpu
 def test_gpu_sharded_world1_device_sampled_negatives():
     run_world(1, ['bpr', 'adagrad', 16, 'sample'], backend='hip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,args', [(2, ['bpr', 'adagrad', 64]), (2, ['bpr', 'adagrad', 64, 'chunk', 3]),
+                                        (3, ['hinge', 'sparse_adam', 32, 'chunk', 2]), (2, ['bpr', 'adagrad', 16, 'train', 2]),
+                                        (2, ['adaptive_hinge', 'adagrad', 64, 'chunk', 2]), (3, ['bpr', 'adagrad', 16, 'sample'])])
+def test_gpu_sharded_remote_peers_on_one_gpu_over_gloo(world, args):
+    """the N > 1 path had never run a HIP kernel against a REMOTE peer (gloo + emulator, or RCCL world 1).
+    Here `world` processes share the box's one GPU and exchange over gloo (device tensors; RCCL refuses two ranks per device):
+    the gfx950 kernels of slk_shard.hip on real remote ids, rows and gradient slots, against the oracle and the one-GPU engine."""
+    run_world(world, args, backend='hipgloo')
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_remote_peers_long_runs_and_bias_shadow_over_gloo(monkeypatch, tmp_path):
+    """... with 4 items in all (runs of ~800 gradient slots per owner: partials + stitch in the exchange-slot mode), plain and on
+    the item-bias shadow: every rank's shards bit for bit."""
+    import numpy as np
+    monkeypatch.setenv('SHARD_TEST_SHAPE', '300,4,1600,1')
+    for tag in ('plain', 'shadow'):
+        monkeypatch.setenv('SHARD_TEST_SHADOW', '1' if tag == 'shadow' else '0')
+        monkeypatch.setenv('SHARD_TEST_DUMP', str(tmp_path / tag))
+        run_world(2, ['bpr', 'adagrad', 64, 'chunk', 2], backend='hipgloo')
+    for r in range(2):
+        a, b = (np.load(str(tmp_path / tag) + '.rank%d.npz' % r) for tag in ('plain', 'shadow'))
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (r, k)
