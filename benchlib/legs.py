@@ -49,6 +49,8 @@ def _compact(kind, rec):
         layout = rec.get('config', {}).get('item_bias_layout', '')
         if layout and not layout.startswith('two arrays'):
             out['item_bias_layout'] = 'interleaved with its Adagrad accumulator for the run (slk_bias_shadow_begin, outside the timed region)'
+        if rec.get('config', {}).get('user_row_layout', '').startswith('the user table doubled'):
+            out['user_row_layout'] = 'doubled for the run (slk_user_pingpong_begin, outside the timed region): no pre-step-row record'
         if roof.get('persistent_epoch_kernel'):
             out['persistent_us_per_minibatch'] = round(roof['persistent_epoch_kernel']['us_per_minibatch'], 2)
     elif kind == 'step':

@@ -57,6 +57,8 @@
 #ifndef SLK_PP_PIPE
 #define SLK_PP_PIPE 2  // software pipeline of the bandwidth-bound ping-pong user pass (below): 0 none, 1 keys + flag, 2 + item pair, 3 + early state.  Same box, C2 user pass: one-table form 0.3135 ms, 0: 0.306, 1: 0.289, 2: 0.284, 3: 0.295 (profiles/r06_p_*)
 #endif
+// (Holding the pipelined form to the one-table form's occupancy -- amdgpu_waves_per_eu 8: 64 VGPRs instead of 65, SparseAdam 7: 72
+// instead of 81 -- spills two to eight dwords and LOSES: user pass 0.283 -> 0.289 ms, SparseAdam 0.422 -> 0.467, profiles/r06_t_ab_occ.txt.)
 template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false, bool PP = false>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     static_assert(!LAT || (UMODE == 0 && !BLOOM), "LAT is the pair mode over plain tables");

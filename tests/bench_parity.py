@@ -92,10 +92,12 @@ def _changed_rows(after, before):
 def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1, scale=None, trained=False,
                               bloom_rows=0, n_hash=4, seed=0, check_grads=True, tables=None, state=None,
                               users=None, items=None, rng_state=None, lr=1e-2, opt='adagrad', state2=None, step0=0,
-                              bias_scale=0.1):
+                              bias_scale=0.1, pingpong=False, bias_shadow=False):
     """One minibatch of B interactions over U x I tables of dim D (item layer: BloomEmbedding with `bloom_rows`
     compressed rows when > 0), Adagrad(lr) or SparseAdam(lr) (`opt`; `step0` minibatches already taken).  Tables /
-    optimizer state / ids / RNG state are generated here on the device unless given.  Returns a dict of diagnostics."""
+    optimizer state / ids / RNG state are generated here on the device unless given.  `pingpong` / `bias_shadow`: the real step
+    runs inside a user-row ping-pong scope / an item-bias shadow (slk_user_pingpong_begin, slk_bias_shadow_begin: what fit() and
+    bench.py open for minibatches / item tables this large), closed before anything is compared.  Returns a dict of diagnostics."""
     assert opt in ('adagrad', 'sparse_adam')
     betas = (0.9, 0.999)
     gen = torch.Generator(device=dev)
@@ -199,9 +201,13 @@ def bilinear_minibatch_parity(engine, dev, stream, U, I, D, B, loss='bpr', nn=1,
     before = [t.clone() for t in tables] + [s.clone() for s in state] + ([s.clone() for s in state2] if state2 else [])
     op = _native.make_optim(opt, [s.data_ptr() for s in state], [s.data_ptr() for s in state2] if state2 else None, lr=lr,
                             betas=betas, step=step0)
-    engine.rng_set_state(rng_state)
-    engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), B, B, loss, nn, mb_loss.data_ptr(),
-                          d_neg_out=neg_out.data_ptr(), stream=stream)
+    calls0 = engine.get_stat('pingpong_calls')
+    with engine.bias_shadow(tb, op, stream=stream, enabled=bias_shadow):
+        with engine.user_pingpong(tb, op, stream=stream, enabled=pingpong):
+            engine.rng_set_state(rng_state)
+            engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), B, B, loss, nn, mb_loss.data_ptr(),
+                                  d_neg_out=neg_out.data_ptr(), stream=stream)
+    assert engine.get_stat('pingpong_calls') - calls0 == (1 if pingpong else 0)
     assert np.array_equal(_np(neg_out), want_neg), 'negatives differ from numpy randint'
     got_rng = engine.rng_get_state()
     assert (got_rng[1] == want_rng[1]).all() and got_rng[2] == want_rng[2], 'RNG state after the draw'
@@ -333,7 +339,8 @@ def poolnet_minibatch_parity(engine, dev, stream, I, D, B, L, loss='bpr', nn=1, 
                 **{'elements_beyond_1e-5_but_within_conditioned_bound': cond})
 
 
-def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2, expect_route=None, loss='bpr', n_neg=1):
+def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, seed=0, lr=1e-2, expect_route=None, loss='bpr', n_neg=1,
+                       pingpong=False):
     """One slk_bilinear_train call over n_full * B + tail interactions (more than one prep chunk), bpr + Adagrad:
       * every negative of the call and the RNG state afterwards: bit-exact against numpy (one contiguous stream);
       * for every k in `check_at`: minibatch k is checked against the oracle by teacher forcing -- a second run
@@ -368,9 +375,10 @@ def multi_chunk_parity(engine, dev, stream, U, I, D, B, n_full, tail, check_at, 
         k = (n_inter + B - 1) // B
         mb = torch.zeros(k, device=dev)
         neg = torch.full((n_inter * nn,), -1, device=dev, dtype=torch.int64)
-        engine.rng_set_state(rng0)
-        engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), n_inter, B, loss, nn, mb.data_ptr(),
-                              d_neg_out=neg.data_ptr(), stream=stream)
+        with engine.user_pingpong(tb, op, stream=stream, enabled=pingpong):  # (the whole call inside a user-row ping-pong scope)
+            engine.rng_set_state(rng0)
+            engine.bilinear_train(tb, op, users.data_ptr(), items.data_ptr(), n_inter, B, loss, nn, mb.data_ptr(),
+                                  d_neg_out=neg.data_ptr(), stream=stream)
         return t, s, _np(mb), neg, engine.rng_get_state(), op.step
 
     if expect_route is not None:  # 'epoch' (the persistent kernel) / 'launch': the route the call takes is part of what is tested

@@ -20,14 +20,16 @@ def hip():
     eng.close()
 
 
+@pytest.mark.parametrize('pingpong', [True, False])
 @pytest.mark.parametrize('trained', [False, True])
-def test_c2_minibatch_at_bench_size(hip, trained):
+def test_c2_minibatch_at_bench_size(hip, trained, pingpong):
     """BASELINE.json configs[1] = bench.py's default workload: 10M users x 1M items, dim 64, bpr, Adagrad(1e-2),
     minibatch 2^20.  trained=False is bench.py's exact initial state (N(0, 1/D) rows, zero biases, zero
-    accumulators); trained=True has O(1) scores, non-zero biases and accumulators."""
+    accumulators); trained=True has O(1) scores, non-zero biases and accumulators.  pingpong=True: on the doubled user table, as
+    bench.py and fit() run minibatches this large (slk_user_pingpong_begin); False: the one-table layout with records."""
     eng, dev, stream = hip
     out = bp.bilinear_minibatch_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, loss='bpr', trained=trained,
-                                       scale=None if not trained else 0.5 / 8.0, seed=int(trained))
+                                       scale=None if not trained else 0.5 / 8.0, seed=int(trained), pingpong=pingpong)
     print('C2 parity', out)
 
 
@@ -50,13 +52,15 @@ def test_c4_minibatch_at_bench_size(hip, pad_frac):
     print('C4 parity', out)
 
 
-def test_c5_shard_minibatch_at_bench_size(hip):
+@pytest.mark.parametrize('scopes', [True, False])
+def test_c5_shard_minibatch_at_bench_size(hip, scopes):
     """configs[4], the per-GPU shard bench.py --workload c5 runs: 12.5M users x 125M items (32 GB item table +
     32 GB accumulators), dim 64, bpr, minibatch 2^20.  Every touched row is compared; the other 120M+ rows must
-    come back bit-identical."""
+    come back bit-identical.  scopes=True: as bench.py and fit() train a shard this large -- item biases shadowed, user table
+    doubled; False: the plain layouts."""
     eng, dev, stream = hip
     out = bp.bilinear_minibatch_parity(eng, dev, stream, 12_500_000, 125_000_000, 64, 1 << 20, loss='bpr', seed=5,
-                                       check_grads=False)
+                                       check_grads=False, pingpong=scopes, bias_shadow=scopes)
     print('C5-shard parity', out)
     torch.cuda.empty_cache()
 
@@ -71,7 +75,8 @@ def test_multi_chunk_call_at_bench_size(hip, overlap):
     eng.set_option('overlap_prep', overlap)
     try:
         out = bp.multi_chunk_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, n_full=10, tail=300_001,
-                                    check_at=(8, 10))
+                                    check_at=(8, 10), pingpong=True)  # (on the doubled user table, as fit() and bench.py run it:
+        # after 8 and 10 minibatches a user's current copy is whichever its update count left it in)
     finally:
         eng.set_option('overlap_prep', 0)
     print('multi-chunk parity, overlap', overlap, out)
@@ -86,7 +91,7 @@ def test_c2_minibatch_saturated_pairs(hip):
     U, I, D, B = 10_000_000, 1_000_000, 64, 1 << 20
     tables, state, users, items = bp.saturated_problem(dev, U, I, D, B, seed=1)
     out = bp.bilinear_minibatch_parity(eng, dev, stream, U, I, D, B, loss='bpr', tables=tables, state=state, users=users,
-                                       items=items, seed=11)
+                                       items=items, seed=11, pingpong=True)  # (on the doubled user table, as bench.py runs C2)
     print('C2 saturated parity', out)
     assert out['loss'] < 0.4, out  # not the linear-sigmoid regime
 
@@ -98,7 +103,7 @@ def test_c2_minibatch_sparse_adam(hip, trained):
     eng, dev, stream = hip
     out = bp.bilinear_minibatch_parity(eng, dev, stream, 10_000_000, 1_000_000, 64, 1 << 20, loss='bpr', trained=trained,
                                        scale=None if not trained else 0.35, bias_scale=0.5, seed=20 + int(trained),
-                                       opt='sparse_adam', step0=100 if trained else 0)
+                                       opt='sparse_adam', step0=100 if trained else 0, pingpong=trained)  # (one of the two on the doubled table)
     print('C2 SparseAdam parity', out)
 
 
