@@ -29,6 +29,9 @@ def pmc_traffic(args, kernel):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
+    # (the committed passes ran bench.py's defaults: the user table doubled for the run -- a --no-user-pingpong run has no match)
+    if getattr(args, 'no_user_pingpong', False) or getattr(args, 'user_pingpong_min_batch', 1 << 17) != 1 << 17:
+        return None
     for r in [rec] + list(rec.get('others', [])):  # the headline configuration first, then the other measured ones
         cfg = r.get('config', {})
         if all(cfg.get(k) == getattr(args, k) for k in ('users', 'items', 'dim', 'batch', 'loss', 'opt')):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Memory-safety fuzz of the engine through the GPU-less harness (test infrastructure): random shapes -- odd embedding dims, one-row
 tables, minibatches of 1 / 63 / 65 / 1025 / 3000, every loss and optimizer -- through training, PoolNet, bloom layers, explicit
-feedback, the shuffle, the sampler and the fused ranks.  Meant to run under AddressSanitizer:
+feedback, the user-row ping-pong scope, the shuffle, the sampler and the fused ranks.  Meant to run under AddressSanitizer:
 
     SLK_EMU_CXXFLAGS="-fsanitize=address -fno-omit-frame-pointer" LD_PRELOAD="<libasan.so> <libstdc++.so.6>" \
         ASAN_OPTIONS=detect_leaks=0 python scripts/emu_fuzz.py <seed> <seconds>
@@ -28,7 +28,7 @@ t0 = time.time(); n = 0; errs = 0
 Ds = [1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128, 192, 256]
 pick = lambda xs: xs[rs.randint(len(xs))]
 while time.time() - t0 < budget:
-    kind = rs.randint(9)
+    kind = rs.randint(11)
     seed = int(rs.randint(1 << 30))
     cfg = None
     try:
@@ -55,6 +55,16 @@ while time.time() - t0 < budget:
             cfg = ('explicit', loss, opt, D)
             ec.check_explicit_train_matches_oracle(be, loss, opt, D, U=int(pick([1, 37, 500])), I=int(pick([1, 29, 700])), N=int(pick([1, 63, 300, 2000])),
                                                    B=int(pick([1, 64, 257, 1025])), epochs=1, seed=seed)
+        elif kind >= 9:
+            # training inside a user-row ping-pong scope (two copies of the user table, flag bytes, {g, src} pairs), with and
+            # without the item-bias shadow: hot users / items (long runs + both stitch kernels), several chunks, odd dims
+            loss, opt, D = pick(['pointwise', 'bpr', 'hinge']), pick(['adagrad', 'sparse_adam', 'sgd']), pick(Ds)
+            U, I = int(pick([1, 2, 7, 37, 100, 1000])), int(pick([1, 2, 5, 29, 300, 2000]))
+            B = int(pick([1, 2, 63, 64, 65, 100, 256, 257, 1000, 1025, 3000])); N = int(max(1, min(pick([1, B, B + 1, 2 * B + 7, 3 * B - 1]), 6000)))
+            opts = pick([None, {'user_lat_max_batch': 0, 'item_lat_max_tiles': 0}, {'item_long_gate': 0}, {'chunk_interactions': max(B, 300)}])
+            cfg = ('pingpong', loss, opt, D, U, I, N, B, opts)
+            ec.check_user_pingpong_is_bit_neutral(be, loss, opt, D, U=U, I=I, N=N, B=B, seed=seed, options=opts,
+                                                  with_bias_shadow=(opt == 'adagrad' and bool(rs.randint(2))), calls=int(pick([1, 2, 3])))
         elif kind == 4:
             n_ids = int(pick([1, 2, 5, 100, 4095, 4096, 4097, 10000, 70000]))
             cfg = ('shuffle', n_ids)

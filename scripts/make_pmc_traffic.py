@@ -20,7 +20,7 @@ def entry(cfg):
     rec = json.load(open(src))
     kern = {k: {'hbm_bytes_per_launch': v['hbm_bytes_per_launch'], 'FETCH_SIZE_KiB': v['FETCH_SIZE'], 'WRITE_SIZE_KiB': v['WRITE_SIZE']}
             for k, v in rec.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v}
-    return {'config': dict(CFG[cfg], dim=64, batch=1 << 20, loss='bpr', opt='adagrad'),
+    return {'config': dict(CFG[cfg], dim=64, batch=1 << 20, loss='bpr', opt='adagrad', user_rows='doubled (slk_user_pingpong_begin): bench.py\'s default'),
             'source': 'profiles/%s_pmc_%s.md (%s)' % (tag, cfg, WHAT % ('' if cfg == 'c2' else ' --workload ' + cfg)), 'kernels': kern}
 
 
