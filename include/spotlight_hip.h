@@ -184,7 +184,11 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         192 MB: they would fill the 256 MB Infinity Cache) stores them non-temporally, as "nt" bit 16 does for
  *                         every size; 0: never (profiles/r06_mall_ab.jsonl)
  *   "user_bias_zero_hint" 1 (default): slk_tables::flags' SLK_TABLES_USER_BIAS_ZERO is honoured; 0: the user biases are fetched
- *                         regardless (A/B and test switch: same results) */
+ *                         regardless (A/B and test switch: same results)
+ *   "user_grid_own_occ"   0 (default): the user pass launches at most as many workgroups per CU as the form with the most registers
+ *                         (plain, latency-bound, long runs, ping-pong) holds resident; 1: as the form it launches does (measured:
+ *                         no gain at C2, -12 % on the C5 shard, profiles/r06_w_*; same tables, the fp32 loss sums associate by
+ *                         workgroup) */
 int slk_ctx_set_option(slk_ctx *ctx, const char *name, int64_t value);
 /* The current value of an option (ABI 9): lets a caller change an option for one piece of work and restore it afterwards --
  * a ctx is shared by every model of a process on its device (spotlight_amd/_native.py: `with engine.options(...)`). */

@@ -28,7 +28,7 @@ t0 = time.time(); n = 0; errs = 0
 Ds = [1, 2, 3, 4, 5, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128, 192, 256]
 pick = lambda xs: xs[rs.randint(len(xs))]
 while time.time() - t0 < budget:
-    kind = rs.randint(11)
+    kind = rs.randint(11) if len(sys.argv) < 4 else int(sys.argv[3])  # (third argument: one kind only)
     seed = int(rs.randint(1 << 30))
     cfg = None
     try:
@@ -64,7 +64,7 @@ while time.time() - t0 < budget:
             opts = pick([None, {'user_lat_max_batch': 0, 'item_lat_max_tiles': 0}, {'item_long_gate': 0}, {'chunk_interactions': max(B, 300)}])
             cfg = ('pingpong', loss, opt, D, U, I, N, B, opts)
             ec.check_user_pingpong_is_bit_neutral(be, loss, opt, D, U=U, I=I, N=N, B=B, seed=seed, options=opts,
-                                                  with_bias_shadow=(opt == 'adagrad' and bool(rs.randint(2))), calls=int(pick([1, 2, 3])))
+                                                  with_bias_shadow=(opt == 'adagrad' and bool(rs.randint(2))), calls=int(pick([1, 2, 3])), sanity=False)
         elif kind == 4:
             n_ids = int(pick([1, 2, 5, 100, 4095, 4096, 4097, 10000, 70000]))
             cfg = ('shuffle', n_ids)
@@ -93,8 +93,10 @@ while time.time() - t0 < budget:
             D = pick([4, 8, 24, 64, 128])
             cfg = ('ranks', D)
             ec.check_fused_ranks(be, D=D, U=int(pick([40, 90, 400])), I=int(pick([33, 333, 1500])), n_rows=int(pick([8, 9, 150])), seed=seed)
-    except AssertionError:
+    except AssertionError as e:
         errs += 1
+        if cfg and cfg[0] == 'pingpong':  # bit-neutrality is well-posed at ANY shape: a failed assert here is a bug, not an ill-posed bound
+            print('BITDIFF', cfg, seed, repr(e)[:300], flush=True)
     except Exception as e:  # an engine refusal (SlkError) for an unsupported combination is fine; anything else is printed
         print('EXC', cfg, repr(e)[:200], flush=True)
     n += 1

@@ -244,6 +244,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("nt", opt_nt, 0, 63),
     SLK_OPT("record_nt_min_bytes", opt_record_nt_min_bytes, 0, SLK_OPT_MAX),
     SLK_OPT("user_bias_zero_hint", opt_user_bias_zero_hint, 0, 1),
+    SLK_OPT("user_grid_own_occ", opt_user_grid_own_occ, 0, 1),
 };
 #undef SLK_OPT
 const slk_opt_desc *slk_find_option(const char *name) {

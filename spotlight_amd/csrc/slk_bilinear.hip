@@ -1563,6 +1563,15 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
             slk_prof_begin(ctx, SLK_K_USER_PASS, s);
             const bool lat = upass_lat && (int64_t)bm <= ctx->opt_user_lat_max_batch;
+            // Option "user_grid_own_occ" (off): the grid of the form that is launched capped at THAT form's occupancy instead of the
+            // smallest of the four forms' -- measured in round 6 and not kept (slk_common.h)
+            const pass_fn uform = user_may_long ? (lat ? upass_lat_long : upass_long) : (lat ? upass_lat : upass);
+            unsigned ugrid_form = ugrid;
+            if (ctx->opt_user_grid_own_occ) {
+                const int occ_form = slk_occupancy_of(ctx, uform);
+                ugrid_form = slk_grid_for(ctx, bm, gpb, ugm < occ_form ? ugm : occ_form);
+                if (!pre || (expl && ctx->opt_explicit_fused)) a.n_loss_partial = (int)ugrid_form;  // (the pass writes one loss partial per workgroup)
+            }
             if (user_may_long) {
                 if (ctx->upart_gen >= 0x0ffffffeu) {  // the 28-bit stamp wraps: forget every old partial
                     SLK_HIP(ctx, hipMemsetAsync(ctx->upart_meta.p, 0, ctx->upart_meta.cap, s));
@@ -1575,13 +1584,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
                 a.upart_gen = ctx->upart_gen;
                 a.UPS = UPS;
                 SLK_HIP(ctx, hipMemsetAsync(a.upart_count, 0, 4, s));
-                hipLaunchKernelGGL(lat ? upass_lat_long : upass_long, dim3(ugrid), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(uform, dim3(ugrid_form), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_user_pass<ULONG>");
                 ++ctx->stat_user_long;
                 hipLaunchKernelGGL(ustitch, dim3(slk_grid_for(ctx, ((size_t)bm + SLK_USER_TILE - 1) / SLK_USER_TILE, gpb)), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_user_stitch");
             } else {
-                hipLaunchKernelGGL(lat ? upass_lat : upass, dim3(ugrid), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(uform, dim3(ugrid_form), dim3(256), 0, s, a);
                 SLK_LAUNCH_CHECK(ctx, "k_user_pass");
             }
             slk_prof_end(ctx, s);

@@ -182,6 +182,10 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured); bit 4 the user
                                    // pass's record stores, bit 5 the item pass's record loads (round 6: the Infinity-Cache A/B,
                                    // profiles/r06_mall_ab.*)
+    int opt_user_grid_own_occ = 0;    // 1: the user pass's grid is capped at the occupancy of the FORM it launches; 0 (default): at the smallest of
+                                      // the four forms' -- measured, profiles/r06_w_*: 7 instead of 6 workgroups per CU buys the C2 pass nothing
+                                      // (0.285-0.287 against 0.283 ms) and costs the C5 shard's 12 % (0.393 against 0.350: more rows in flight
+                                      // over a 64-GB working set = more translation misses)
     int opt_user_bias_zero_hint = 1;  // 1: honour SLK_TABLES_USER_BIAS_ZERO (0: fetch the user biases regardless -- A/B and test switch)
     int64_t opt_record_nt_min_bytes = (int64_t)192 << 20;  // records of a minibatch from this size on are stored non-temporally
                                    // (slk_bilinear.hip::do_passes; 0: never)

@@ -590,6 +590,10 @@ class ImplicitFactorizationModel(object):
             shadowed = True
             pingpong.__enter__()  # (... and the user-embedding tensor holds only some of the current rows)
             pingponged = True
+            if pingpong.active:  # the scope's {dL/dscore, src} pairs are wider than the one-table layout's side array: grown now,
+                # not inside the first training call
+                engine.bilinear_reserve(tables, binding.as_struct(), n, self._batch_size, self._loss, self._num_negative_samples,
+                                        stream=stream)
             if _PREFETCH:
                 engine.bilinear_prefetch(tables, binding.as_struct(), bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), n, self._batch_size,
                                          self._loss, self._num_negative_samples, state=state, stream=stream)

@@ -1488,12 +1488,13 @@ def check_bias_shadow_is_bit_neutral(be, loss, D, U, I, N, B, nn=1, seed=43, opt
     assert not np.array_equal(results[0][4].ravel(), params[3].astype(np.float32).ravel())  # (the biases did train)
 
 
-def check_user_pingpong_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=53, options=None, with_bias_shadow=False, calls=2):
+def check_user_pingpong_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=53, options=None, with_bias_shadow=False, calls=2, sanity=True):
     """Training inside a user-row ping-pong scope (slk_user_pingpong_begin / _end: the user table doubled in the ctx, the user
     pass writes updated rows to the other copy and no record, the item pass gathers pre-step rows where they still stand)
     against plain training: losses, every table and state tensor bit for bit.  Inside the scope the caller's user table is a MIX
     of rows (some current rows live in the ctx's copy); the scope's end makes it whole.  `calls` training calls per scope: a
-    user's current copy alternates with every minibatch that touches it."""
+    user's current copy alternates with every minibatch that touches it.  `sanity=False` (the fuzz: one-item tables, single
+    interactions): the "something did train" asserts are skipped, the bit-for-bit ones are not."""
     eng = be.engine
     rs = np.random.RandomState(seed)
     users = rs.randint(0, U, N).astype(np.int64)
@@ -1519,28 +1520,29 @@ def check_user_pingpong_is_bit_neutral(be, loss, opt, D, U, I, N, B, seed=53, op
                         eng.bilinear_train(dev.tables, dev.optim, be.ptr(d_users), be.ptr(d_items), N, B, loss, 1,
                                            be.ptr(mb_loss) + 4 * rep * n_mb, stream=be.stream)
                     if pingpong:
-                        assert eng.get_stat('pingpong_calls') == n0 + calls  # every call of the scope ran on the two copies
+                        assert eng.get_stat('pingpong_calls') == n0 + calls, 'a call of the scope did not run on the two copies'
                         mixed = be.get(dev.p[0]).copy()
             results.append([be.get(mb_loss)] + [be.get(x) for x in dev.p + dev.s1 + dev.s2])
         finally:
             for k, v in saved.items():
                 eng.set_option(k, v)
-    for k, (a, b) in enumerate(zip(*results)):
-        if k == 0:  # the minibatch losses: the scope's user pass is another kernel (its own occupancy, hence its own grid: the fp32
-            # per-thread loss sums associate differently; small minibatches take the persistent kernel outside the scope)
-            assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (a, b)
-            continue
+    for k, (a, b) in list(enumerate(zip(*results)))[1:]:
         assert np.array_equal(a, b), ('tensor %d differs between ping-ponged and plain user rows' % k)
+    # the minibatch losses: the scope's user pass is another kernel (its own occupancy, hence its own grid: the fp32 per-thread
+    # loss sums associate differently -- a hot user's thousand terms by 2-3e-6; small minibatches take the persistent kernel
+    # outside the scope): the path's 1e-5 loss tolerance
+    assert np.abs(results[0][0] - results[1][0]).max() <= 1e-5 * np.abs(results[0][0]).max(), (results[0][0], results[1][0])
     # inside the scope the caller's array holds the current row of exactly the users that were updated an EVEN number of times
     # (a user's current copy alternates with every minibatch that touches it); the others' current rows were in the ctx's copy
     times = np.zeros(U, dtype=np.int64)
     for m in range(n_mb):
         times[np.unique(users[m * B:(m + 1) * B])] += calls
     home = times % 2 == 0
-    assert np.array_equal(mixed[home], results[1][1][home])
-    if (~home).any():
+    assert np.array_equal(mixed[home], results[1][1][home]), 'a user updated an even number of times is not at home in the caller\'s table'
+    if sanity and (~home).any():
         assert not np.array_equal(mixed[~home], results[1][1][~home])
-    assert not np.array_equal(results[0][1], params[0].astype(np.float32))  # (the user rows did train)
+    if sanity:
+        assert not np.array_equal(results[0][1], params[0].astype(np.float32))  # (the user rows did train)
 
 
 def check_user_pingpong_contract(be):
@@ -1867,6 +1869,7 @@ OPTION_VALUES = {
     'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
     'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
     'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63), 'record_nt_min_bytes': (0, 1), 'user_bias_zero_hint': (0,),
+    'user_grid_own_occ': (1,),
 }
 OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
 # adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the
