@@ -324,7 +324,8 @@ int slk_bias_shadow_abort(slk_ctx *ctx);
  *     through it; _end closes the scope on every return; slk_user_pingpong_abort closes it without writing (the training of
  *     the scope is lost: the caller's table is left a mix of rows); slk_ctx_destroy with an open scope says so on stderr.
  *   - _begin, the training calls and _end are ordered by the caller (same stream, or events).  One scope per ctx; may be open
- *     together with an item-bias shadow.  SLK_ENOMEM when the second copy does not fit: train without it.
+ *     together with an item-bias shadow.  SLK_ENOMEM when the second copy does not fit: train without it.  The second copy's
+ *     storage stays with the ctx for the next scope (as all ctx scratch does; slk_ctx_destroy frees it).
  * What this package's fit() does for minibatches of >= 2^17 interactions ("statistic" pingpong_calls counts the calls). */
 int slk_user_pingpong_begin(slk_ctx *ctx, const slk_tables *tables, const slk_optim *optim, void *stream);
 int slk_user_pingpong_end(slk_ctx *ctx, void *stream);
