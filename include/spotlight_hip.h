@@ -185,6 +185,12 @@ const char *slk_last_error(const slk_ctx *ctx); /* ctx may be NULL: last create 
  *                         every size; 0: never (profiles/r06_mall_ab.jsonl)
  *   "user_bias_zero_hint" 1 (default): slk_tables::flags' SLK_TABLES_USER_BIAS_ZERO is honoured; 0: the user biases are fetched
  *                         regardless (A/B and test switch: same results)
+ *   "item_single_min_items"  slk_bilinear_train inside a user-row ping-pong scope, row-sparse Adagrad, item tables of at least this
+ *                         many rows (default 2^24; 0: never): an item that occurs ONCE in its minibatch -- on a catalogue far larger
+ *                         than a minibatch nearly every one -- is updated by the user pass, which already holds its row, dL/dscore
+ *                         and the pre-step user row; the item pass skips it (no re-read of the row, no gather of the user row).
+ *                         Same operations in the same order: bit-identical tables.  Minibatches that take the latency-bound or
+ *                         the long-run form of the user pass leave every item to the item pass.
  *   "user_grid_own_occ"   0 (default): the user pass launches at most as many workgroups per CU as the form with the most registers
  *                         (plain, latency-bound, long runs, ping-pong) holds resident; 1: as the form it launches does (measured:
  *                         no gain at C2, -12 % on the C5 shard, profiles/r06_w_*; same tables, the fp32 loss sums associate by
@@ -200,6 +206,7 @@ int slk_ctx_get_option(slk_ctx *ctx, const char *name, int64_t *value);
  * "prefetched_chunks" (first chunks prepared ahead by slk_bilinear_prefetch that a training call took over),
  * "shadowed_calls" (slk_bilinear_train calls that ran on the item-bias shadow of slk_bias_shadow_begin),
  * "pingpong_calls" (slk_bilinear_train calls that ran on the user-row ping-pong of slk_user_pingpong_begin),
+ * "single_minibatches" (minibatches whose once-only items were updated by the user pass: option "item_single_min_items"),
  * "prefetch_pending" (what the last slk_bilinear_prefetch left for the next training call: 0 nothing -- it was a no-op --,
  * 1 the first chunk, 2 the first chunk and the negatives of the whole call). */
 int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value);

@@ -181,7 +181,7 @@ SLK_EXPORT void slk_ctx_destroy(slk_ctx *ctx) {
     for (slk_prep_bufs &pb : ctx->pb) {
         slk_buf *pbs[] = {&pb.neg32, &pb.ukey[0], &pb.ukey[1], &pb.uval[0], &pb.uval[1], &pb.uit, &pb.ikey[0],
                           &pb.ikey[1], &pb.ipay[0], &pb.ipay[1], &pb.bik[0], &pb.bik[1], &pb.bip[0], &pb.bip[1],
-                          &pb.buk[0], &pb.buk[1], &pb.bup[0], &pb.bup[1], &pb.lflags};
+                          &pb.buk[0], &pb.buk[1], &pb.bup[0], &pb.bup[1], &pb.lflags, &pb.mflag, &pb.msorted};
         for (slk_buf *b : pbs)
             if (b->p) (void)hipFree(b->p);
         if (pb.ev_lflags) (void)hipEventDestroy(pb.ev_lflags);
@@ -245,6 +245,7 @@ const slk_opt_desc slk_options[] = {
     SLK_OPT("record_nt_min_bytes", opt_record_nt_min_bytes, 0, SLK_OPT_MAX),
     SLK_OPT("user_bias_zero_hint", opt_user_bias_zero_hint, 0, 1),
     SLK_OPT("user_grid_own_occ", opt_user_grid_own_occ, 0, 1),
+    SLK_OPT("item_single_min_items", opt_item_single_min_items, 0, SLK_OPT_MAX),
 };
 #undef SLK_OPT
 const slk_opt_desc *slk_find_option(const char *name) {
@@ -283,6 +284,7 @@ SLK_EXPORT int slk_ctx_get_stat(slk_ctx *ctx, const char *name, int64_t *value) 
     else if (!strcmp(name, "prefetched_chunks")) *value = ctx->stat_prefetched;
     else if (!strcmp(name, "shadowed_calls")) *value = ctx->stat_shadowed;
     else if (!strcmp(name, "pingpong_calls")) *value = ctx->stat_pingpong;
+    else if (!strcmp(name, "single_minibatches")) *value = ctx->stat_single;
     else if (!strcmp(name, "lds_per_block")) *value = (int64_t)ctx->lds_per_block;
     else if (!strcmp(name, "lds_per_cu")) *value = (int64_t)ctx->lds_per_cu;
     else if (!strcmp(name, "prefetch_pending")) *value = !ctx->pf.valid ? 0 : (ctx->pf.all ? 2 : 1);

@@ -59,10 +59,16 @@
 #endif
 // (Holding the pipelined form to the one-table form's occupancy -- amdgpu_waves_per_eu 8: 64 VGPRs instead of 65, SparseAdam 7: 72
 // instead of 81 -- spills two to eight dwords and LOSES: user pass 0.283 -> 0.289 ms, SparseAdam 0.422 -> 0.467, profiles/r06_t_ab_occ.txt.)
-template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false, bool PP = false>
+// SGL (the bandwidth-bound ping-pong form, Adagrad): the single-occurrence fast path (slk_pass_args::mflag) -- an item that occurs
+// ONCE in the minibatch is updated HERE: the pass holds its pre-step row (read for the score), dL/dscore and the pre-step user row,
+// so the item pass's re-read of the row and its gather of the user row are spared (catalogues far larger than a minibatch: 98 % of
+// the occurrences at the C5 shard's shape).  The same operations in the same order as the item pass applies to a run of length
+// one (0 + g * u, then slk_apply_vec_pre): bit-identical tables.  Nobody else reads or writes such a row in this minibatch.
+template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false, bool PP = false, bool SGL = false>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     static_assert(!LAT || (UMODE == 0 && !BLOOM), "LAT is the pair mode over plain tables");
     static_assert(!PP || (UMODE == 0 && !BLOOM), "PP is the pair mode over plain tables");
+    static_assert(!SGL || (PP && !LAT && !ULONG && UPD == SLK_UPD_ADAGRAD), "SGL: the plain ping-pong form, Adagrad");
     static_assert(!ULONG || !BLOOM, "long user runs: plain tables");
     constexpr uint32_t S = SLK_USER_TILE;
     constexpr bool PRE = UMODE != 0;
@@ -94,6 +100,8 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     constexpr bool PIPE_IDS = PIPE && SLK_PP_PIPE >= 2;
     uint32_t pk_key = 0u, pk_prev = 0u, pk_flag = 0u, pn_key = 0u, pn_prev = 0u;
     uint32_t pk_ip = 0u, pk_in = 0u, pn_ip = 0u, pn_in = 0u;
+    uint32_t pk_mf = 0u, pn_mf = 0u;  // SGL: the turn's two "occurs more than once" bytes (positive | negative << 8)
+    auto ld_mf = [&](uint32_t pos) -> uint32_t { return (uint32_t)*reinterpret_cast<const uint16_t *>(a.mflag + 2 * (size_t)pos); };
     if (PIPE) {
         const uint32_t t0 = blockIdx.x * GPB + grp;
         if (t0 < n_turns) {
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 pk_ip = a.uit[2 * (size_t)(a.begin + t0)];
                 pk_in = a.uit[2 * (size_t)(a.begin + t0) + 1];
             }
+            if (SGL) pk_mf = ld_mf(a.begin + t0);
             pk_flag = (uint32_t)a.uflag[pk_key & a.umask];
         }
         if (t0 + stride < n_turns) {
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                 pn_ip = a.uit[2 * (size_t)(a.begin + t0 + stride)];
                 pn_in = a.uit[2 * (size_t)(a.begin + t0 + stride) + 1];
             }
+            if (SGL) pn_mf = ld_mf(a.begin + t0 + stride);
         }
     }
     for (uint32_t turn = blockIdx.x * GPB + grp; turn < n_turns; turn += stride) {
@@ -122,12 +132,14 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         const uint32_t key = PIPE ? pk_key : slk_ld_u32(a.ukey + p, nt_keys);
         uint32_t lat_ip = 0u, lat_in = 0u;
         bool is_head;
-        uint32_t cur_piped = 0u;
+        uint32_t cur_piped = 0u, mf_piped = 0u;
         if (PIPE) {
             is_head = !(p > a.begin && pk_prev == key);
             cur_piped = pk_flag;
             lat_ip = pk_ip;
             lat_in = pk_in;
+            mf_piped = pk_mf;
+            pk_mf = pn_mf;
             pk_key = pn_key;
             pk_prev = pn_prev;
             pk_ip = pn_ip;
@@ -140,6 +152,7 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     pn_ip = a.uit[2 * (size_t)(p + 2u * stride)];
                     pn_in = a.uit[2 * (size_t)(p + 2u * stride) + 1];
                 }
+                if (SGL) pn_mf = ld_mf(p + 2u * stride);
             }
         } else if (LAT) {
             const uint32_t prev = p > a.begin ? a.ukey[p - 1] : ~key;
@@ -185,12 +198,14 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
         // starts with a dependent round trip of TWO more rows per user behind the loss (the pass ran at 0.45 of the roofline
         // against Adagrad's 0.63, profiles/r03_final_bench_sparse_adam.json)
         constexpr bool EARLY_ADAM = !BLOOM && UPD == SLK_UPD_SPARSE_ADAM && !ULONG;
-        constexpr bool EARLY_STATE = ((EXPL || LAT || (PIPE && SLK_PP_PIPE >= 3)) && !BLOOM && UPD == SLK_UPD_ADAGRAD) || EARLY_ADAM;
+        // (SGL: the pass is one round trip per position -- user row, both item rows AND every optimizer-state row the position will
+        // update -- then arithmetic and stores; loaded one after the other behind the loss the three state rows cost it three more)
+        constexpr bool EARLY_STATE = ((EXPL || LAT || SGL || (PIPE && SLK_PP_PIPE >= 3)) && !BLOOM && UPD == SLK_UPD_ADAGRAD) || EARLY_ADAM;
         slk_vec<VEC> su = slk_vzero<VEC>(), su2 = slk_vzero<VEC>();
         if (EARLY_STATE && on) su = slk_vload_if_nt<VEC>(a.S1[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
         if (EARLY_ADAM && on) su2 = slk_vload_if_nt<VEC>(a.S2[0] + uoff, (SLK_NT_OF(a) & 1) != 0);
         float sbu = 0.0f, sbu2 = 0.0f;
-        if (EARLY_STATE) sbu = a.S1[2][user];
+        if (EARLY_STATE && !(SGL && a.ubz)) sbu = a.S1[2][user];  // (SLK_TABLES_USER_BIAS_ZERO: the user-bias gradient is exactly zero, its state is never used)
         if (EARLY_ADAM) sbu2 = a.S2[2][user];
         slk_vec<VEC> gu = slk_vzero<VEC>();
         float gbu = 0.0f;
@@ -228,6 +243,22 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                     vj = on ? slk_vload<VEC>(a.P[1] + (size_t)in * D + d0) : slk_vzero<VEC>();
                 }
                 const float bip = a.P[3][SLK_B3(a, ip)], bin = a.P[3][SLK_B3(a, in)];  // issued with the rows, not behind the dots' shuffles
+                // SGL: the optimizer state of the once-only items of this position, with their rows
+                uint32_t mf = 0xffffu;
+                slk_vec<VEC> svi = slk_vzero<VEC>(), svj = slk_vzero<VEC>();
+                float sbi = 0.0f, sbj = 0.0f;
+                if (SGL) {
+                    mf = (q == p) ? mf_piped : ld_mf(q);
+                    const bool nt_rows = (SLK_NT_OF(a) & 2) != 0;
+                    if (!(mf & 0xffu)) {
+                        if (on) svi = slk_vload_if_nt<VEC>(a.S1[1] + (size_t)ip * D + d0, nt_rows);
+                        if (lane == 0) sbi = a.S1[3][SLK_B3(a, ip)];
+                    }
+                    if (!(mf >> 8)) {
+                        if (on) svj = slk_vload_if_nt<VEC>(a.S1[1] + (size_t)in * D + d0, nt_rows);
+                        if (lane == 0) sbj = a.S1[3][SLK_B3(a, in)];
+                    }
+                }
                 const float sp = slk_group_sum<G>(slk_vdot<VEC>(u, vi)) + bu + bip;
                 const float sn = slk_group_sum<G>(slk_vdot<VEC>(u, vj)) + bu + bin;
                 float l, gp, gn;
@@ -247,6 +278,31 @@ __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
                         gq[1] = gn;
                     }
                     loss_acc += l;
+                }
+                if (SGL) {
+                    // once-only items of this position: their whole update, as the item pass applies it to a run of length one --
+                    // nothing for dL/dscore == 0 (Adagrad: the item pass leaves an untouched-gradient row alone), else the summed
+                    // gradient 0 + g * u_old and 0 + g, then the row / bias update in place (the rows and biases are this pass's own
+                    // pre-step loads)
+                    const bool nt_rows = (SLK_NT_OF(a) & 2) != 0;
+                    auto once = [&](uint32_t item, slk_vec<VEC> &v, slk_vec<VEC> &sv, float g, float b, float bs) {
+                        const size_t voff = (size_t)item * D + d0;
+                        if (on) {
+                            slk_vec<VEC> gv;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) gv.v[i] = 0.0f + g * u.v[i];
+                            slk_apply_vec_pre<VEC, UPD>(a, 1, voff, v, sv, gv, nullptr, nt_rows);
+                        }
+                        if (lane == 0) {
+                            slk_vec<1> bpv, bsv, gbv;
+                            bpv.v[0] = b;
+                            bsv.v[0] = bs;
+                            gbv.v[0] = 0.0f + g;
+                            slk_apply_vec_pre<1, UPD>(a, 3, SLK_B3(a, item), bpv, bsv, gbv);
+                        }
+                    };
+                    if (!(mf & 0xffu) && gp != 0.0f) once(ip, vi, svi, gp, bip, sbi);
+                    if (!(mf >> 8) && gn != 0.0f) once(in, vj, svj, gn, bin, sbj);
                 }
             } else if (EXPL) {
                 // explicit feedback (one pair per interaction): score, loss and dL/dscore formed here
@@ -774,6 +830,17 @@ static pass_fn user_pass_pp_fn(int upd) {
     if (upd == SLK_UPD_SPARSE_ADAM) return k_user_pass<VEC, G, SLK_UPD_SPARSE_ADAM, 0, false, LAT, ULONG, true>;
     return k_user_pass<VEC, G, SLK_UPD_SGD, 0, false, LAT, ULONG, true>;
 }
+// ... with the single-occurrence fast path (Adagrad, the bandwidth-bound form) and the item pass that skips what it covered
+template <int VEC, int G>
+static pass_fn user_pass_sgl_fn() {
+    return k_user_pass<VEC, G, SLK_UPD_ADAGRAD, 0, false, false, false, true, true>;
+}
+template <int VEC, int G>
+static slk_item_fns item_pass_sgl_fn() {
+    return {k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPPS>, k_item_stitch<VEC, G, SLK_UPD_ADAGRAD, SLK_PART_BOTH>,
+            k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPPS, SLK_PART_BOTH, false>,
+            k_item_pass<VEC, G, SLK_UPD_ADAGRAD, SLK_ITEM_SNAPPPS, SLK_PART_BOTH, false, 4>};
+}
 template <int VEC, int G>
 static pass_fn user_stitch_pp_fn(int upd) {
     if (upd == SLK_UPD_ADAGRAD) return k_user_stitch<VEC, G, SLK_UPD_ADAGRAD, true>;
@@ -1127,6 +1194,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     // the next chunk's prep instead of idling (a bubble of ~40 us per chunk of 8 minibatches in rounds 1-5).
     const bool side = ctx->opt_overlap_prep && n_chunks > 1 && bsz >= ctx->opt_overlap_min_batch;
     const int nsets = n_chunks > 1 ? 2 : 1;
+    // (the single-occurrence flags of a chunk, when the call may take that path: decided below, sized here)
+    const bool sgl_maybe = ctx->pp_active && ctx->pp_src_u == tables->d_param[0] && !pre && !bloom && !dense &&
+                           optim->kind == SLK_OPT_ADAGRAD && ctx->opt_item_single_min_items > 0 &&
+                           tables->num_items >= ctx->opt_item_single_min_items;
     for (int st = 0; st < nsets; ++st) {
         slk_prep_bufs &pb = ctx->pb[st];
         if ((rc = slk_ensure(ctx, pb.neg32, nc_max * nn * 4))) return rc;
@@ -1143,6 +1214,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             if (Hu && (rc = slk_ensure(ctx, pb.bup[b], nc_max * Hu * 4))) return rc;
         }
         if (pre && (rc = slk_ensure(ctx, pb.uit, nc_max * NP * 4))) return rc;
+        if (sgl_maybe && (rc = slk_ensure(ctx, pb.mflag, nc_max * NP + 16))) return rc;   // "occurs more than once" per occurrence: by payload,
+        if (sgl_maybe && (rc = slk_ensure(ctx, pb.msorted, nc_max * NP + 16))) return rc; //   in item-sorted order
         if ((rc = slk_ensure(ctx, pb.lflags, 2 * (size_t)mb_per_chunk * 4))) return rc;  // long-run flags of a chunk: items, users
     }
     enum { BL_UREC = 16, BL_LIVE, BL_LK0, BL_LK1, BL_LV0, BL_LV1, BL_GSN, BL_UPART, BL_LATE_SORT = 38 };  // ctx->extra slots (24, 25: slk_eval.hip; the user-partial metas, which keep launch stamps across calls, have a buffer of their own: ctx->upart_meta)
@@ -1158,6 +1231,11 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
     if (pingpong && (pre || bloom || dense || tables->num_users != ctx->pp_rows || D != ctx->pp_dim))
         return slk_fail(ctx, SLK_EINVAL, "slk_bilinear_train: the user rows are ping-ponged (slk_user_pingpong_begin): only the pair losses "
                                          "(pointwise, bpr, hinge) over plain tables of the scope's shape with a row-sparse optimizer train inside the scope");
+    // The single-occurrence fast path (k_user_pass<..., SGL>): inside a ping-pong scope, row-sparse Adagrad, item tables of at
+    // least "item_single_min_items" rows (default 2^24: a catalogue far larger than a minibatch, where nearly every occurrence is
+    // the only one of its item; at C2 -- two occurrences per item on average -- 12 % qualify and the flags would cost more)
+    const bool sgl_on = pingpong && optim->kind == SLK_OPT_ADAGRAD && ctx->opt_item_single_min_items > 0 &&
+                        tables->num_items >= ctx->opt_item_single_min_items;
     // dL/dscore per (position, pair); ping-pong: {dL/dscore, src} per (position, pair)
     if ((rc = slk_ensure(ctx, ctx->extra[BL_GSN], (size_t)bsz * NP * (pingpong ? 8 : 4)))) return rc;
     const unsigned max_grid = (unsigned)ctx->num_cus * (unsigned)(ctx->opt_user_grid_mult > 8 ? ctx->opt_user_grid_mult : 8);
@@ -1266,7 +1344,8 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
 
     const int upd = slk_upd_for(optim->kind);
     pass_fn upass = nullptr, spass = nullptr, upass_lat = nullptr, upass_long = nullptr, upass_lat_long = nullptr, ustitch = nullptr;
-    slk_item_fns ipass = {nullptr, nullptr}, ipass_rows = ipass, ipass_bias = ipass, rpass_rows = ipass;
+    pass_fn upass_sgl = nullptr;
+    slk_item_fns ipass = {nullptr, nullptr}, ipass_rows = ipass, ipass_bias = ipass, rpass_rows = ipass, ipass_sgl = ipass;
     const int umode = (expl && ctx->opt_explicit_fused) ? 2 : (pre ? 1 : 0);
 #define SLK_PICK(V_, G_)                                                                  \
     do {                                                                                  \
@@ -1284,6 +1363,10 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             upass_lat_long = user_pass_pp_fn<V_, G_, true, true>(upd);                    \
             ustitch = user_stitch_pp_fn<V_, G_>(upd);                                     \
             ipass = item_pass_pp_fn<V_, G_>(upd);                                         \
+            if (sgl_on) {                                                                 \
+                upass_sgl = user_pass_sgl_fn<V_, G_>();                                   \
+                ipass_sgl = item_pass_sgl_fn<V_, G_>();                                   \
+            }                                                                             \
         }                                                                                 \
         if (bloom) {                                                                      \
             ipass_rows = slk_item_pass_fn<V_, G_, SLK_ITEM_SNAP, SLK_PART_ROWS>(upd);     \
@@ -1369,6 +1452,13 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             uint32_t *const ikeys[2] = {(uint32_t *)pb.ikey[0].p, (uint32_t *)pb.ikey[1].p};
             uint32_t *const ivals[2] = {(uint32_t *)pb.ipay[0].p, (uint32_t *)pb.ipay[1].p};
             if ((rc = slk_sort_item_occ(ctx, uit, nocc, (size_t)bsz, NP, ibits, mbbits, ikeys, ivals, s))) return rc;
+            if (sgl_on) {  // which occurrences are NOT the only one of their item in their minibatch (ids only)
+                SLK_HIP(ctx, hipMemsetAsync(pb.mflag.p, 0, (size_t)nocc, s));
+                hipLaunchKernelGGL(k_item_multi_flags, dim3(slk_grid_for(ctx, nocc, 256)), dim3(256), 0, s, (const uint32_t *)pb.ikey[1].p,
+                                   (const uint32_t *)pb.ipay[1].p, nocc, (uint32_t)bsz * (uint32_t)NP, (uint8_t *)pb.msorted.p,
+                                   (uint8_t *)pb.mflag.p);
+                SLK_LAUNCH_CHECK(ctx, "k_item_multi_flags");
+            }
         }
         // which minibatches hold a LONG run (an item run that wholly covers a tile of the item pass, [0, n_mb); a user run that
         // wholly covers a tile of the user pass, [n_mb, 2 n_mb)): ids only, so the answer is fetched once per chunk and the usual
@@ -1565,9 +1655,17 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             const bool lat = upass_lat && (int64_t)bm <= ctx->opt_user_lat_max_batch;
             // Option "user_grid_own_occ" (off): the grid of the form that is launched capped at THAT form's occupancy instead of the
             // smallest of the four forms' -- measured in round 6 and not kept (slk_common.h)
-            const pass_fn uform = user_may_long ? (lat ? upass_lat_long : upass_long) : (lat ? upass_lat : upass);
+            // the single-occurrence fast path rides on the plain (bandwidth-bound) form only: a minibatch that takes the latency-bound
+            // or the long-run form leaves every item to the item pass
+            const bool sgl = sgl_on && upass_sgl && !user_may_long && !lat;
+            if (sgl) {
+                a.mflag = (const uint8_t *)pb.mflag.p;
+                a.msorted = (const uint8_t *)pb.msorted.p;
+                ++ctx->stat_single;
+            }
+            const pass_fn uform = sgl ? upass_sgl : (user_may_long ? (lat ? upass_lat_long : upass_long) : (lat ? upass_lat : upass));
             unsigned ugrid_form = ugrid;
-            if (ctx->opt_user_grid_own_occ) {
+            if (ctx->opt_user_grid_own_occ || sgl) {  // (the single-occurrence form holds more registers than the four whose smallest occupancy caps the others)
                 const int occ_form = slk_occupancy_of(ctx, uform);
                 ugrid_form = slk_grid_for(ctx, bm, gpb, ugm < occ_form ? ugm : occ_form);
                 if (!pre || (expl && ctx->opt_explicit_fused)) a.n_loss_partial = (int)ugrid_form;  // (the pass writes one loss partial per workgroup)
@@ -1596,7 +1694,7 @@ static int bilinear_train_impl(slk_ctx *ctx, const slk_tables *tables, slk_optim
             slk_prof_end(ctx, s);
             slk_prof_begin(ctx, SLK_K_ITEM_PASS, s);
             if (!Hi) {
-                if ((rc = slk_launch_item_pass(ctx, ipass, a, g, s, "k_item_pass", item_may_long))) return rc;
+                if ((rc = slk_launch_item_pass(ctx, sgl ? ipass_sgl : ipass, a, g, s, "k_item_pass", item_may_long))) return rc;
             } else {
                 // item biases are indexed by the item id: plain occurrence list, bias only ...
                 if ((rc = slk_launch_item_pass(ctx, ipass_bias, a, g, s, "k_item_pass<BIAS>", item_may_long))) return rc;

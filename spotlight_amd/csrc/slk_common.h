@@ -83,6 +83,7 @@ struct slk_rng_dev {
 struct slk_prep_bufs {
     slk_buf neg32, ukey[2], uval[2], uit, ikey[2], ipay[2];
     slk_buf bik[2], bip[2], buk[2], bup[2];  // BloomEmbedding hashed-row occurrence lists
+    slk_buf mflag, msorted;         // single-occurrence fast path: "the item occurs more than once in its minibatch" per occurrence
     slk_buf lflags;                 // per minibatch of the chunk: does a run of the item-sorted list wholly cover a tile?
     int *h_lflags = nullptr;        //   (k_item_long_flags; read back once per chunk into PINNED host memory -- a pageable
     size_t h_lflags_cap = 0;        //   destination makes the copy wait for the stream -- see slk_launch_item_pass)
@@ -182,6 +183,7 @@ struct slk_ctx {
                                    // (streamed once per pass); bit 3 key/payload streams (no gain measured); bit 4 the user
                                    // pass's record stores, bit 5 the item pass's record loads (round 6: the Infinity-Cache A/B,
                                    // profiles/r06_mall_ab.*)
+    int64_t opt_item_single_min_items = (int64_t)1 << 24;  // item rows from which a ping-pong scope's Adagrad calls take the single-occurrence fast path (0: never)
     int opt_user_grid_own_occ = 0;    // 1: the user pass's grid is capped at the occupancy of the FORM it launches; 0 (default): at the smallest of
                                       // the four forms' -- measured, profiles/r06_w_*: 7 instead of 6 workgroups per CU buys the C2 pass nothing
                                       // (0.285-0.287 against 0.283 ms) and costs the C5 shard's 12 % (0.393 against 0.350: more rows in flight
@@ -232,6 +234,7 @@ struct slk_ctx {
     int64_t stat_prefetched = 0;    // chunks prepared ahead that a training call took over (slk_ctx_get_stat)
     int64_t stat_shadowed = 0;      // training calls that ran on the item-bias shadow (slk_bias_shadow_begin)
     int64_t stat_pingpong = 0;      // training calls that ran on the user-row ping-pong (slk_user_pingpong_begin)
+    int64_t stat_single = 0;        // minibatches whose once-only items were updated by the user pass (k_user_pass<..., SGL>)
     int last_pipe_set = -1;         // buffer set of the last chunk of the last pipelined training call (-1: none yet)
     uint32_t ipart_gen = 0;         // item pass: stamp of the last launch's partials (slk_launch_item_pass)
     uint32_t upart_gen = 0;         // user pass, long runs: likewise (slk_bilinear.hip)

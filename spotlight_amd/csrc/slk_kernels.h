@@ -158,6 +158,12 @@ struct slk_pass_args {
     // {dL/dscore, src}: src = user | (copy that holds the pre-step row) << 31.  uflag == nullptr: no ping-pong.
     float *P0alt;
     uint8_t *uflag;
+    // single-occurrence fast path inside a ping-pong scope (catalogues far larger than a minibatch; slk_bilinear.hip): an item that
+    // occurs ONCE in the minibatch is updated by the user pass, which holds everything the update needs; the item pass skips it.
+    // mflag[r] (r = the occurrence's payload pos * 2 + s) / msorted[e] (item-sorted order): 1 = the item occurs more than once
+    // in its minibatch and is the item pass's.  nullptr: every occurrence is the item pass's.
+    const uint8_t *mflag;
+    const uint8_t *msorted;
 };
 
 enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_UPD_SGD = 3 };
@@ -174,8 +180,10 @@ enum { SLK_UPD_ADAGRAD = 0, SLK_UPD_SPARSE_ADAM = 1, SLK_UPD_GRAD_ONLY = 2, SLK_
 //   BLK   r = slot of an exchange buffer (slk_blk_row / slk_blk_scalar): vec, bias grad  (row-sharded)
 //   SNAPPP  as SNAP with NP == 2 inside a user-row ping-pong scope: no record; gsn[r - begin*2] = {g_s, src} (8 bytes),
 //         u_old = the row of user (src & 0x7fffffff) in the copy (src >> 31) of the user table (slk_pass_args::P0alt)
-enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2, SLK_ITEM_BLK = 3, SLK_ITEM_SNAPPP = 4 };
-#define SLK_ITEM_IS_SNAP(MODE) ((MODE) == SLK_ITEM_SNAP || (MODE) == SLK_ITEM_SNAPPP)
+//   SNAPPPS as SNAPPP; occurrences whose item occurs once in the minibatch (msorted[e] == 0) are skipped: the user pass updated them
+enum slk_item_mode { SLK_ITEM_SNAP = 0, SLK_ITEM_SEQ = 1, SLK_ITEM_ROW = 2, SLK_ITEM_BLK = 3, SLK_ITEM_SNAPPP = 4, SLK_ITEM_SNAPPPS = 5 };
+#define SLK_ITEM_IS_PP(MODE) ((MODE) == SLK_ITEM_SNAPPP || (MODE) == SLK_ITEM_SNAPPPS)
+#define SLK_ITEM_IS_SNAP(MODE) ((MODE) == SLK_ITEM_SNAP || SLK_ITEM_IS_PP(MODE))
 
 // Exchange buffers of the row-sharded path (slk_shard.hip): slots come in blocks of 64, a block is 64 rows of D floats
 // followed by the 64 scalars (bias / bias gradient) of those rows.  Every row of a D = 64 table is then one aligned
@@ -307,7 +315,7 @@ __device__ __forceinline__ void slk_item_contrib(const slk_pass_args &a, uint32_
         const uint32_t pos = (NP == 2) ? (r >> 1) : (r / NP);
         const uint32_t s = r - pos * NP;
         const float *rec = a.snap + (size_t)(pos - a.begin) * a.RS;
-        if (MODE == SLK_ITEM_SNAPPP) {
+        if (SLK_ITEM_IS_PP(MODE)) {
             // user-row ping-pong: {dL/dscore, src} in one 8-byte load, then the pre-step user row from the copy the user pass
             // left untouched (no record was written)
             const uint2 t = reinterpret_cast<const uint2 *>(a.gsn)[r - a.begin * 2u];
@@ -481,6 +489,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
     __shared__ uint32_t s_pay[T];
     __shared__ float s_g[T];
     __shared__ uint32_t s_src[T];      // SNAPPP: where the position's pre-step user row stands (GSPF below)
+    __shared__ uint8_t s_multi[T];     // SNAPPPS: 0 = the position's item occurs once in the minibatch (the user pass updated it)
     __shared__ uint8_t s_live[T];
     __shared__ uint16_t s_head[T];
     __shared__ int s_nheads;
@@ -505,6 +514,8 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
     // KEYPF: thread i holds key i - 1 (i <= tn + 1) and payload i (i < tn) of the NEXT tile, threads 64 / 65 its far keys
     constexpr bool KEYPF = SLK_ITEM_KEYPF != 0 && T + 2 <= 256;
     uint32_t pf_key = 0u, pf_pay = 0u, pf_far = 0u, pf_far2 = 0u;
+    constexpr bool SKIP1 = MODE == SLK_ITEM_SNAPPPS;
+    uint32_t pf_multi = 1u;
     auto tile_fetch = [&](uint32_t tile) {
         const uint32_t tb = ibegin + tile * T;
         const int tn = (iend - tb < (uint32_t)T) ? (int)(iend - tb) : T;
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
         else if (i <= tn) pf_key = slk_ld_u32(a.ikey + (tb - 1 + i), nt_keys);
         else if (LONG && i == tn + 1 && has_next) pf_key = slk_ld_u32(a.ikey + (tb + tn), nt_keys);
         if (i < tn) pf_pay = slk_ld_u32(a.ipay + (tb + i), nt_keys);
+        if (SKIP1 && i < tn) pf_multi = (uint32_t)a.msorted[tb + i];
         if (LONG && i == 64) pf_far = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - T), nt_keys);
         if (LONG && i == 65) {
             const bool next_full = has_next && iend - (tb + (uint32_t)tn) >= (uint32_t)T;
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
     // GSPF (ping-pong): a position's {dL/dscore, src} pair is fetched by the thread that holds its payload at the TOP of the tile --
     // in flight while wave 0 compacts the heads -- and handed to the row groups through LDS, so that the gather of the pre-step user
     // rows goes out WITH the head's row + state loads instead of one dependent round trip behind them
-    constexpr bool GSPF = MODE == SLK_ITEM_SNAPPP && KEYPF && SLK_ITEM_GSPF != 0;
+    constexpr bool GSPF = SLK_ITEM_IS_PP(MODE) && KEYPF && SLK_ITEM_GSPF != 0;
     if (KEYPF && blockIdx.x < ntiles) tile_fetch(blockIdx.x);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tb = ibegin + tile * T;
@@ -535,11 +547,12 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
         const bool has_next = tb + (uint32_t)tn < iend;
         __syncthreads();  // LDS of the previous tile no longer in use
         uint2 gs_pf = make_uint2(0u, 0u);
-        if (GSPF && (int)threadIdx.x < tn) gs_pf = reinterpret_cast<const uint2 *>(a.gsn)[pf_pay - a.begin * 2u];
+        if (GSPF && (int)threadIdx.x < tn && (!SKIP1 || pf_multi)) gs_pf = reinterpret_cast<const uint2 *>(a.gsn)[pf_pay - a.begin * 2u];
         if (KEYPF) {
             const int i = (int)threadIdx.x;
             if (i <= tn + (LONG ? 1 : 0)) s_key[i] = pf_key;
             if (i < tn) s_pay[i] = pf_pay;
+            if (SKIP1 && i < tn) s_multi[i] = (uint8_t)pf_multi;
             if (LONG && i == 64) s_far[0] = pf_far;
             if (LONG && i == 65) {
                 s_far[1] = pf_far;
@@ -554,6 +567,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
             s_key[i] = kv;
         }
         for (int i = threadIdx.x; i < tn; i += 256) s_pay[i] = slk_ld_u32(a.ipay + (tb + i), nt_keys);
+        for (int i = threadIdx.x; SKIP1 && i < tn; i += 256) s_multi[i] = a.msorted[tb + i];
         if (LONG && threadIdx.x == 64) s_far[0] = first_tile ? 0u : slk_ld_u32(a.ikey + (tb - T), nt_keys);
         if (LONG && threadIdx.x == 65) {
             // the next tile's last key -- if the next tile is a full one (only full tiles make a run long)
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                     const uint32_t item = key & a.imask;
                     // padding_idx rows receive no gradient: they never become heads
                     f = (((j == 0 && (first_tile || inherits_long)) || key != s_key[j]) && item != a.pad_item &&
-                         item != a.pad_item2) ? 1 : 0;
+                         item != a.pad_item2 && (!SKIP1 || s_multi[j])) ? 1 : 0;  // (a once-only item is not a head: nothing to do)
                 }
                 int incl = f;
 #pragma unroll
@@ -650,7 +664,7 @@ __global__ __launch_bounds__(256) SLK_WAVES_PER_EU(NPRE_ > SLK_ITEM_NPRE ? 4 : S
                 // never-updated keys (padding_idx rows, the dead entries of a live list) have no
                 // record worth reading -- a dead entry's payload is not even a valid reference
                 const uint32_t item = s_key[j + 1] & a.imask;
-                mine = item != a.pad_item && item != a.pad_item2;
+                mine = item != a.pad_item && item != a.pad_item2 && (!SKIP1 || s_multi[j]);
             }
             if (mine && GSPF) {
                 g[it] = s_g[j];
@@ -1008,6 +1022,21 @@ static __global__ __launch_bounds__(256) void k_item_long_flags(const uint32_t *
         const uint32_t k0 = ikey[t0], k1 = ikey[t1 - 1];
         const uint32_t item = k0 & imask;
         if (k0 == k1 && item != pad_item && item != pad_item2) flags[mb] = 1;
+    }
+}
+
+// msorted[e] = 1 iff occurrence e of the item-sorted list shares its key with a neighbour inside its minibatch's window (the
+// item occurs more than once in the minibatch), and for those mflag[payload] = 1 (mflag zeroed by the caller: on a catalogue far
+// larger than a minibatch nearly every occurrence is the only one of its item and nothing is scattered for it).  Ids only: once
+// per chunk, with the sorts.
+static __global__ __launch_bounds__(256) void k_item_multi_flags(const uint32_t *ikey, const uint32_t *ipay, uint32_t n, uint32_t per_mb,
+                                                          uint8_t *msorted, uint8_t *mflag) {
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint32_t w0 = e / per_mb * per_mb, w1 = (n - w0 < per_mb) ? n : w0 + per_mb;
+        const uint32_t key = ikey[e];
+        const bool multi = (e > w0 && ikey[e - 1] == key) || (e + 1 < w1 && ikey[e + 1] == key);
+        msorted[e] = multi ? 1 : 0;
+        if (multi) mflag[ipay[e]] = 1;
     }
 }
 

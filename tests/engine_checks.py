@@ -1869,7 +1869,7 @@ OPTION_VALUES = {
     'epoch_adaptive': (0,), 'epoch_adaptive_max_batch': (1, 1 << 20), 'epoch_max_batch': (1, 1 << 20), 'epoch_max_grid': (1, 3, 64),
     'epoch_barrier': (0, 1), 'epoch_cooperative': (1,), 'epoch_dense_elems': (0, 1 << 40), 'user_lat_max_batch': (0, 1 << 30),
     'item_long_gate': (0,), 'shuffle_band': (0, 64), 'nt': (1, 6, 15, 48, 63), 'record_nt_min_bytes': (0, 1), 'user_bias_zero_hint': (0,),
-    'user_grid_own_occ': (1,),
+    'user_grid_own_occ': (1,), 'item_single_min_items': (0, 1),
 }
 OPTIONS_NOT_RESULT_NEUTRAL = ('sort_debug', 'epoch_debug')
 # adaptive hinge's item side in its two forms (all 1 + n occurrences sorted per chunk / the live ones re-sorted per minibatch): the

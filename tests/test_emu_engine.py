@@ -55,6 +55,27 @@ def test_user_pingpong_is_bit_neutral(be, loss, opt):
         ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 16, U=400, I=300, N=3000, B=512, seed=60, with_bias_shadow=True)
 
 
+@pytest.mark.parametrize('loss', ['bpr', 'hinge', 'pointwise'])
+def test_single_occurrence_fast_path_is_bit_neutral(be, loss):
+    # inside a ping-pong scope, Adagrad, option item_single_min_items forced to 1: items that occur once in a minibatch are updated by
+    # the user pass (k_user_pass<..., SGL>), the item pass skips them (SLK_ITEM_SNAPPPS).  Against plain training, bit for bit:
+    # a catalogue far larger than the minibatch (nearly every occurrence single), one in which singles and runs mix, hot items
+    # (long runs + stitch beside the skipped singles), several chunks, the bias shadow, odd dims; B > user_lat_max_batch so that the
+    # bandwidth-bound form (the one that carries the path) is launched
+    opts = {'item_single_min_items': 1, 'user_lat_max_batch': 0}
+    n0 = be.engine.get_stat('single_minibatches')
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 16, U=400, I=40000, N=3000, B=512, seed=61, options=opts)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 16, U=400, I=700, N=3000, B=512, seed=62, options=opts)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 8, U=300, I=6, N=4000, B=2048, seed=63, options=opts)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 5, U=90, I=900, N=2000, B=700, seed=64, options=dict(opts, chunk_interactions=1400))
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 16, U=400, I=5000, N=3000, B=512, seed=65, options=opts, with_bias_shadow=True)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 64, U=50, I=3000, N=1500, B=500, seed=66, options=dict(opts, item_long_gate=0))
+    assert be.engine.get_stat('single_minibatches') > n0  # (the path did run)
+    n1 = be.engine.get_stat('single_minibatches')
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'sparse_adam', 16, U=400, I=40000, N=3000, B=512, seed=67, options=opts)
+    assert be.engine.get_stat('single_minibatches') == n1  # (Adagrad only)
+
+
 def test_user_pingpong_contract(be):
     ec.check_user_pingpong_contract(be)
 

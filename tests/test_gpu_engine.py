@@ -51,6 +51,23 @@ def test_user_pingpong_is_bit_neutral(be, loss, opt):
         ec.check_user_pingpong_is_bit_neutral(be, loss, opt, 64, U=200000, I=100000, N=300000, B=65536, seed=60, with_bias_shadow=True)
 
 
+@pytest.mark.parametrize('loss', ['bpr', 'hinge', 'pointwise'])
+def test_single_occurrence_fast_path_is_bit_neutral(be, loss):
+    # the ping-pong scope's single-occurrence fast path (option item_single_min_items forced to 1) against plain training, bit for bit:
+    # a catalogue far larger than the minibatch, one where singles and runs mix, hot items beside singles, several chunks with the prep
+    # beside the passes, the bias shadow
+    opts = {'item_single_min_items': 1}
+    n0 = be.engine.get_stat('single_minibatches')
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 64, U=200000, I=20000000, N=600000, B=1 << 18, seed=61, options=opts, calls=3)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 64, U=200000, I=300000, N=600000, B=1 << 18, seed=62, options=opts)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 32, U=5000, I=40, N=600000, B=1 << 18, seed=63, options=opts)
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 64, U=300000, I=5000000, N=3000000, B=1 << 18, seed=64,
+                                          options=dict(opts, chunk_interactions=1 << 20, overlap_prep=1))
+    ec.check_user_pingpong_is_bit_neutral(be, loss, 'adagrad', 64, U=200000, I=3000000, N=600000, B=1 << 18, seed=65, options=opts,
+                                          with_bias_shadow=True)
+    assert be.engine.get_stat('single_minibatches') > n0
+
+
 def test_user_pingpong_contract(be):
     ec.check_user_pingpong_contract(be)
 
