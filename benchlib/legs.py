@@ -51,6 +51,9 @@ def _compact(kind, rec):
             out['item_bias_layout'] = 'interleaved with its Adagrad accumulator for the run (slk_bias_shadow_begin, outside the timed region)'
         if rec.get('config', {}).get('user_row_layout', '').startswith('the user table doubled'):
             out['user_row_layout'] = 'doubled for the run (slk_user_pingpong_begin, outside the timed region): no pre-step-row record'
+        if roof.get('single_occurrence_fast_path'):
+            out['single_occurrence_fast_path'] = ('once-only items updated by the user pass (option item_single_min_items): frac = the user pass '
+                                                  'on the whole step\'s algorithmic bytes')
         if roof.get('persistent_epoch_kernel'):
             out['persistent_us_per_minibatch'] = round(roof['persistent_epoch_kernel']['us_per_minibatch'], 2)
     elif kind == 'step':

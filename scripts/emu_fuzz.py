@@ -62,6 +62,8 @@ while time.time() - t0 < budget:
             U, I = int(pick([1, 2, 7, 37, 100, 1000])), int(pick([1, 2, 5, 29, 300, 2000]))
             B = int(pick([1, 2, 63, 64, 65, 100, 256, 257, 1000, 1025, 3000])); N = int(max(1, min(pick([1, B, B + 1, 2 * B + 7, 3 * B - 1]), 6000)))
             opts = pick([None, {'user_lat_max_batch': 0, 'item_lat_max_tiles': 0}, {'item_long_gate': 0}, {'chunk_interactions': max(B, 300)}])
+            if rs.randint(2):  # ... and with the single-occurrence fast path forced (Adagrad takes it, the others ignore the option)
+                opts = dict(opts or {}, item_single_min_items=1, user_lat_max_batch=int(pick([0, 1 << 17])))
             cfg = ('pingpong', loss, opt, D, U, I, N, B, opts)
             ec.check_user_pingpong_is_bit_neutral(be, loss, opt, D, U=U, I=I, N=N, B=B, seed=seed, options=opts,
                                                   with_bias_shadow=(opt == 'adagrad' and bool(rs.randint(2))), calls=int(pick([1, 2, 3])), sanity=False)
