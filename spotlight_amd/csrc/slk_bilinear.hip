@@ -64,6 +64,8 @@
 // so the item pass's re-read of the row and its gather of the user row are spared (catalogues far larger than a minibatch: 98 % of
 // the occurrences at the C5 shard's shape).  The same operations in the same order as the item pass applies to a run of length
 // one (0 + g * u, then slk_apply_vec_pre): bit-identical tables.  Nobody else reads or writes such a row in this minibatch.
+// (The form compiles to 102 VGPRs = 4 waves per SIMD.  Held to 5 -- amdgpu_waves_per_eu: 96 VGPRs, 28 B of scratch -- it LOSES: C5 shard
+// user pass 0.683-0.689 -> 0.721-0.724 ms, profiles/r06_z3_ab_sgl_waves.txt.)
 template <int VEC, int G, int UPD, int UMODE, bool BLOOM, bool LAT = false, bool ULONG = false, bool PP = false, bool SGL = false>
 __global__ __launch_bounds__(256) void k_user_pass(slk_pass_args a) {
     static_assert(!LAT || (UMODE == 0 && !BLOOM), "LAT is the pair mode over plain tables");
